@@ -1,0 +1,31 @@
+import os
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle_small():
+    """Small ring (N=2^10, 4 x 60-bit SEAL-style primes): O(N^2) definitions stay cheap."""
+    from oracle.oracle import Oracle
+
+    return Oracle(10, 4)
+
+
+@pytest.fixture(scope="session")
+def oracle_mid():
+    """N=2^12, 5 primes, with keys: homomorphic identities in seconds."""
+    from oracle.oracle import Oracle
+
+    o = Oracle(12, 5)
+    o.keygen(seed=0x4845564D)
+    return o

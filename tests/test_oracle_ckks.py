@@ -1,0 +1,197 @@
+"""Pins the oracle's CKKS layer (Galois, rescale, key switch, encoder, encrypt/decrypt, every HEVM opcode)
+through closed forms on canonical representatives and decrypt(op(enc x)) ~= op(x).  No GPU."""
+import math
+
+import numpy as np
+import pytest
+
+from oracle.oracle import Ciphertext, Oracle, Plaintext, splitmix_fill
+
+
+def _rand_poly(o, ell, seed):
+    return np.stack([splitmix_fill(seed + i, o.N) % np.uint64(q) for i, q in enumerate(o.primes[:ell])])
+
+
+def _crt(residues, mods):
+    M = math.prod(mods)
+    x = 0
+    for r, m in zip(residues, mods):
+        Mi = M // m
+        x += int(r) * Mi * pow(Mi, -1, m)
+    return x % M, M
+
+
+def test_galois_elements_and_naf(oracle_small):
+    o = oracle_small
+    N, m = o.N, 2 * o.N
+    assert o.elt_from_step(1) == 3 and o.elt_from_step(0) == m - 1
+    assert o.elt_from_step(-1) == pow(3, N // 2 - 1, m)
+    assert o.elt_from_step(5) * o.elt_from_step(-5) % m == 1
+    with pytest.raises(ValueError):
+        o.elt_from_step(N // 2)
+    elts = o.default_galois_elts()
+    assert len(elts) == 2 * (o.logN - 1) + 1 and elts[0] == m - 1
+    want = {m - 1} | {pow(3, 1 << i, m) for i in range(o.logN - 1)} | {pow(3, -(1 << i), m) for i in range(o.logN - 1)}
+    assert set(elts) == want
+    # naf: least-significant digit first, digits sum to the value, no two adjacent non-zeros
+    assert o.naf(33) == [1, 32] and o.naf(-33) == [-1, -32] and o.naf(7) == [-1, 8] and o.naf(3) == [-1, 4]
+    for v in list(range(-300, 300)) + [12285, -15360]:
+        d = o.naf(v)
+        assert sum(d) == v
+        bits = sorted(int(math.log2(abs(x))) for x in d)
+        assert all(b2 - b1 >= 2 for b1, b2 in zip(bits, bits[1:]))
+
+
+def test_galois_ntt_table_equals_coefficient_automorphism(oracle_small):
+    o = oracle_small
+    for elt in [3, pow(3, 5, 2 * o.N), 2 * o.N - 1, o.elt_from_step(-7)]:
+        for p in (0, 1):
+            a = splitmix_fill(40 + p, o.N) % np.uint64(o.primes[p])
+            want = o.ntt_fwd(o.galois_coeff(a, elt, p)[None], [p])[0]
+            got = o.galois_ntt(o.ntt_fwd(a[None], [p]), elt)[0]
+            assert (got == want).all()
+        t = o.galois_table(elt)
+        assert sorted(t.tolist()) == list(range(o.N))  # a permutation
+        # block locality used by the HIP gather: aligned 64-blocks map to aligned 64-blocks
+        assert ((t.reshape(-1, 64) >> 6) == (t.reshape(-1, 64)[:, :1] >> 6)).all()
+
+
+def test_rescale_closed_form(oracle_small):
+    """out_i = floor((x + floor(p/2)) / p) mod q_i, x the non-centred CRT representative."""
+    o = oracle_small
+    ell = 4
+    a = _rand_poly(o, ell, 50)
+    coef = np.stack([o.ntt_inv(a[i][None], [i])[0] for i in range(ell)])
+    got = o.rescale_poly(a)
+    got_coef = np.stack([o.ntt_inv(got[i][None], [i])[0] for i in range(ell - 1)])
+    mods = o.primes[:ell]
+    p = mods[-1]
+    for n in list(range(8)) + [o.N - 1]:
+        x, _ = _crt(coef[:, n], mods)
+        want = (x + p // 2) // p
+        assert [int(v) for v in got_coef[:, n]] == [want % q for q in mods[:-1]]
+    # generic basis form used by the key-switch mod-down: basis {q0, q1, P}
+    idx = [0, 1, o.K - 1]
+    b = np.stack([splitmix_fill(60 + i, o.N) % np.uint64(o.primes[j]) for i, j in enumerate(idx)])
+    bc = np.stack([o.ntt_inv(b[i][None], [j])[0] for i, j in enumerate(idx)])
+    r = o.divide_round_last(b, idx)
+    rc = np.stack([o.ntt_inv(r[i][None], [j])[0] for i, j in enumerate(idx[:-1])])
+    ms = [o.primes[j] for j in idx]
+    for n in range(6):
+        x, _ = _crt(bc[:, n], ms)
+        assert [int(v) for v in rc[:, n]] == [((x + ms[-1] // 2) // ms[-1]) % q for q in ms[:-1]]
+
+
+def test_keyswitch_matches_simple_and_closed_form(oracle_mid):
+    o = oracle_mid
+    for ell in (1, 2, o.K - 1):
+        target = _rand_poly(o, ell, 70 + ell)
+        inner = o.keyswitch_inner_simple(target, o.relin)  # [2][ell+1][N], everything with %
+        out0 = np.zeros((ell, o.N), dtype=np.uint64)
+        out1 = np.zeros((ell, o.N), dtype=np.uint64)
+        o.keyswitch(target, o.relin, out0, out1)
+        idx = list(range(ell)) + [o.K - 1]
+        for kc, out in enumerate((out0, out1)):
+            want = o.divide_round_last(inner[kc], idx)
+            assert (out == want).all()
+        # accumulates into the destination
+        o.keyswitch(target, o.relin, out0, out1)
+        once = o.divide_round_last(inner[0], idx)
+        assert (out0 == o.poly_add(once, once)).all()
+
+
+def test_keyswitch_key_equation(oracle_mid):
+    """digit j of a key for s': c0 + c1*s = e + [limb j](P mod q_j) s'  (small e everywhere else)."""
+    o = oracle_mid
+    K, N = o.K, o.N
+    sk2 = o.poly_mul(o.sk, o.sk)
+    for j in (0, K - 2):
+        d = o.poly_add(o.relin[j, 0], o.poly_mul(o.relin[j, 1], o.sk))  # [K][N]
+        for i in range(K):
+            q = o.primes[i]
+            v = d[i].copy()
+            if i == j:
+                pmod = o.primes[K - 1] % q
+                v = np.array([(int(a) - int(b) * pmod) % q for a, b in zip(v, sk2[i])], dtype=np.uint64)
+            e = o.ntt_inv(v[None], [i])[0].astype(object)
+            e = np.array([x - q if x > q // 2 else x for x in e])
+            assert np.abs(e).max() <= 21  # centred binomial, 21 coin pairs
+
+
+def test_encode_decode_roundtrip(oracle_mid):
+    o = oracle_mid
+    rng = np.random.default_rng(1)
+    x = rng.uniform(-1, 1, o.slots)
+    for ell, bits in ((1, 40), (3, 40), (4, 80), (2, 100)):
+        pt = o.encode(x, 2.0**bits, ell)
+        assert (pt.data < np.array(o.primes[:ell], dtype=np.uint64)[:, None]).all()
+        if 60 * ell - 2 > bits:
+            assert np.abs(o.decode(pt) - x).max() < max(2.0 ** (-bits + 14), 1e-12)
+    # tiling semantics of SEAL_HEVM::encode_internal: src[i % len]
+    pt = o.encode([0.25, -0.5], 2.0**40, 2)
+    d = o.decode(pt)
+    assert np.allclose(d[0::2], 0.25, atol=1e-8) and np.allclose(d[1::2], -0.5, atol=1e-8)
+    # all-ones "upscale" constant (lhs == 0xFFFF): a constant polynomial
+    one = o.encode(np.ones(1), 2.0**30, 2)
+    c = o.ntt_inv(one.data, [0, 1])
+    assert int(c[0, 0]) == 1 << 30 and not c[:, 1:].any()
+
+
+def test_slot_order_is_rotation_orbit(oracle_mid):
+    """rotate(k) then decode == np.roll(x, -k): the Galois/encoder conventions agree."""
+    o = oracle_mid
+    x = np.arange(o.slots, dtype=np.float64) / o.slots
+    pt = o.encode(x, 2.0**40, 2)
+    for k in (1, 5, -3):
+        rot = Plaintext(o.galois_ntt(pt.data, o.elt_from_step(k)), pt.scale)
+        assert np.abs(o.decode(rot) - np.roll(x, -k)).max() < 1e-7
+
+
+@pytest.fixture(scope="module")
+def enc(oracle_mid):
+    o = oracle_mid
+    rng = np.random.default_rng(2)
+    x, y = rng.uniform(-1, 1, o.slots), rng.uniform(-1, 1, o.slots)
+    ell = o.K - 1
+    return x, y, o.encrypt(o.encode(x, 2.0**50, ell)), o.encrypt(o.encode(y, 2.0**50, ell))
+
+
+def _dec(o, ct):
+    return o.decode(o.decrypt(ct))
+
+
+def test_encrypt_decrypt(oracle_mid, enc):
+    o = oracle_mid
+    x, y, cx, cy = enc
+    assert cx.data.shape == (2, o.K - 1, o.N)
+    assert np.abs(_dec(o, cx) - x).max() < 1e-6
+    low = o.encrypt(o.encode(x, 2.0**40, 2))  # encryption below the top level
+    assert low.ell == 2 and np.abs(_dec(o, low) - x).max() < 1e-6
+
+
+def test_homomorphic_opcodes(oracle_mid, enc):
+    o = oracle_mid
+    x, y, cx, cy = enc
+    tol = 1e-5
+    assert np.abs(_dec(o, o.negate(cx)) + x).max() < tol  # opcode 2
+    assert np.abs(_dec(o, o.add(cx, cy)) - (x + y)).max() < tol  # opcode 6
+    pt = o.encode(y, 2.0**50, cx.ell)
+    assert np.abs(_dec(o, o.add_plain(cx, pt)) - (x + y)).max() < tol  # opcode 7
+    m = o.mul_plain(cx, pt)  # opcode 9
+    assert m.scale == 2.0**100 and np.abs(_dec(o, m) - x * y).max() < tol
+    mm = o.mul_relin(cx, cy)  # opcode 8
+    assert np.abs(_dec(o, mm) - x * y).max() < tol
+    r = o.rescale(mm)  # opcode 3
+    assert r.ell == mm.ell - 1 and r.scale == mm.scale / o.primes[mm.ell - 1]
+    assert np.abs(_dec(o, r) - x * y).max() < tol
+    ms = o.modswitch(cx, 2)  # opcode 4
+    assert ms.ell == cx.ell - 2 and np.abs(_dec(o, ms) - x).max() < tol
+    assert o.modswitch(cx, 0) is None
+    for k in (1, -2, 3, 37, -100):  # opcode 1: direct keys and NAF multi-hop
+        assert np.abs(_dec(o, o.rotate(cx, k)) - np.roll(x, -k)).max() < tol, k
+    assert len(o.rotate_hops(37)) == 3 and len(o.rotate_hops(4)) == 1 and len(o.rotate_hops(3)) == 2
+    b = o.bootstrap(r, 2)  # opcode 10 (SEAL VM: decrypt -> re-encode -> encrypt)
+    assert b.ell == 2 and np.abs(_dec(o, b) - x * y).max() < tol
+    # chained: ((x*y rescaled) rotated + itself) at a lower level
+    z = o.add(o.rotate(r, 4), r)
+    assert np.abs(_dec(o, z) - (np.roll(x * y, -4) + x * y)).max() < tol
