@@ -1,0 +1,15 @@
+"""dacapo_amd -- MI355X-native HEVM runtime: a drop-in for the reference's libSEAL_HEVM.so.
+
+The product is the shared library dacapo_amd/lib/libSEAL_HEVM.so (HIP kernels + C++ host, built from
+dacapo_amd/csrc by `__graft_entry__.build()`); this package only holds ctypes bindings:
+
+  * dacapo_amd.runner   -- mirror of the reference's python/hecate/hecate/runner.py (class HEVM)
+  * dacapo_amd.lowlevel -- the kernel-level C ABI of include/dacapo_ckks.h
+  * dacapo_amd.hevm_asm -- .hevm/.cst writer (the reference's emitter is an MLIR pass we cannot run here)
+
+There is no CPU fallback: importing the bindings without the built library, or creating a context without
+a GPU, fails loudly.
+"""
+from pathlib import Path
+
+LIB_PATH = Path(__file__).resolve().parent / "lib" / "libSEAL_HEVM.so"

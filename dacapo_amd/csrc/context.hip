@@ -1,0 +1,171 @@
+// Context construction: SEAL-style prime chain + minimal primitive roots + twiddle tables uploaded to HBM.
+// Reference behaviour being reproduced: SEAL_HEVM.cpp:46-59 (create_context) / :93-99 (loadSEAL) build a
+// SEALContext whose NTT tables use the numerically smallest primitive 2N-th root of each prime, powers
+// stored in bit-reversed order [SEAL-upstream numth.cpp, ntt.cpp].
+#include "context.hpp"
+
+namespace dacapo {
+
+u64 h_mulmod(u64 a, u64 b, u64 q) { return (u64)(((u128)a * b) % q); }
+
+u64 h_powmod(u64 a, u64 e, u64 q)
+{
+    u64 r = 1;
+    a %= q;
+    for (; e; e >>= 1) {
+        if (e & 1) r = h_mulmod(r, a, q);
+        a = h_mulmod(a, a, q);
+    }
+    return r;
+}
+
+u64 h_invmod(u64 a, u64 q) { return h_powmod(a % q, q - 2, q); }
+
+bool h_is_prime(u64 n)
+{
+    if (n < 2) return false;
+    const u64 small[] = { 2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37 };
+    for (u64 p : small) {
+        if (n == p) return true;
+        if (n % p == 0) return false;
+    }
+    u64 d = n - 1;
+    int r = 0;
+    while ((d & 1) == 0) d >>= 1, r++;
+    for (u64 a : small) { // these 12 witnesses are exact below 2^64
+        u64 x = h_powmod(a, d, n);
+        if (x == 1 || x == n - 1) continue;
+        bool witness = true;
+        for (int i = 1; i < r && witness; i++) {
+            x = h_mulmod(x, x, n);
+            if (x == n - 1) witness = false;
+        }
+        if (witness) return false;
+    }
+    return true;
+}
+
+bool h_seal_prime_chain(int logN, int bits, int count, std::vector<u64> &out)
+{
+    const u64 step = 2ull << logN;
+    u64 cand = ((1ull << bits) - 1) / step * step + 1;
+    const u64 floor_ = 1ull << (bits - 1);
+    std::vector<u64> found;
+    for (; (int)found.size() < count && cand > floor_; cand -= step)
+        if (h_is_prime(cand)) found.push_back(cand);
+    if ((int)found.size() != count) return false;
+    out.assign(found.rbegin(), found.rend());
+    return true;
+}
+
+u64 h_min_primitive_root(u64 degree, u64 q)
+{
+    if ((q - 1) % degree) return 0;
+    u64 g = 0;
+    for (u64 x = 2; x < 4096 && !g; x++) {
+        u64 c = h_powmod(x, (q - 1) / degree, q);
+        if (h_powmod(c, degree >> 1, q) == q - 1) g = c;
+    }
+    if (!g) return 0;
+    const u64 g2 = h_mulmod(g, g, q);
+    u64 best = g;
+    for (u64 i = 1, cur = g; i < degree / 2; i++) {
+        cur = h_mulmod(cur, g2, q);
+        if (cur < best) best = cur;
+    }
+    return best;
+}
+
+Context::Context(int logN_, int K_, int bits, const u64 *primes_or_null) : logN(logN_), N(1ull << logN_), K(K_)
+{
+    if (logN < 12 || logN > 17) {
+        fprintf(stderr, "[dacapo_amd] ring degree 2^%d unsupported (12..17)\n", logN);
+        abort();
+    }
+    k1 = logN / 2;
+    k2 = logN - k1;
+    if (primes_or_null)
+        primes.assign(primes_or_null, primes_or_null + K);
+    else if (!h_seal_prime_chain(logN, bits, K, primes)) {
+        fprintf(stderr, "[dacapo_amd] cannot build a %d x %d-bit prime chain for N=2^%d\n", K, bits, logN);
+        abort();
+    }
+    h_mods.resize(K);
+    psi.resize(K);
+    std::vector<u64> tw((size_t)K * N), itw((size_t)K * N);
+    for (int i = 0; i < K; i++) {
+        const u64 q = primes[i];
+        const u64 delta = (1ull << kQBits) - q;
+        if (q >= (1ull << kQBits) || delta >= kMaxDelta || (q - 1) % (2 * N) || !h_is_prime(q)) {
+            fprintf(stderr,
+                    "[dacapo_amd] prime %d (0x%llx) is not of the HEVM form 2^60 - delta (delta < 2^28), = 1 mod 2N\n", i,
+                    (unsigned long long)q);
+            abort();
+        }
+        psi[i] = h_min_primitive_root(2 * N, q);
+        const u64 ipsi = h_invmod(psi[i], q);
+        u64 pw = 1, ipw = 1;
+        u64 *t = tw.data() + (size_t)i * N, *it = itw.data() + (size_t)i * N;
+        for (size_t k = 0; k < N; k++) {
+            const u32 r = h_bitrev((u32)k, logN);
+            t[r] = pw;
+            it[r] = ipw;
+            pw = h_mulmod(pw, psi[i], q);
+            ipw = h_mulmod(ipw, ipsi, q);
+        }
+        DModulus &m = h_mods[i];
+        m.q = q;
+        m.delta = (u32)delta;
+        m.pad_ = 0;
+        m.inv_n = h_invmod((u64)N, q);
+        m.inv_n_w = h_mulmod(m.inv_n, it[1], q);
+    }
+    DC_HIP_CHECK(hipMalloc(&d_mods, sizeof(DModulus) * K));
+    DC_HIP_CHECK(hipMemcpy(d_mods, h_mods.data(), sizeof(DModulus) * K, hipMemcpyHostToDevice));
+    DC_HIP_CHECK(hipMalloc(&d_tw, tw.size() * 8));
+    DC_HIP_CHECK(hipMalloc(&d_itw, itw.size() * 8));
+    DC_HIP_CHECK(hipMemcpy(d_tw, tw.data(), tw.size() * 8, hipMemcpyHostToDevice));
+    DC_HIP_CHECK(hipMemcpy(d_itw, itw.data(), itw.size() * 8, hipMemcpyHostToDevice));
+
+    // divide-and-round constants for every (dropped prime l, remaining prime i) pair
+    std::vector<u64> inv_last((size_t)K * K, 0), half_mod((size_t)K * K, 0);
+    for (int l = 0; l < K; l++)
+        for (int i = 0; i < K; i++) {
+            if (i == l) continue;
+            inv_last[(size_t)l * K + i] = h_invmod(primes[l] % primes[i], primes[i]);
+            half_mod[(size_t)l * K + i] = (primes[l] >> 1) % primes[i];
+        }
+    DC_HIP_CHECK(hipMalloc(&d_inv_last, inv_last.size() * 8));
+    DC_HIP_CHECK(hipMalloc(&d_half_mod, half_mod.size() * 8));
+    DC_HIP_CHECK(hipMemcpy(d_inv_last, inv_last.data(), inv_last.size() * 8, hipMemcpyHostToDevice));
+    DC_HIP_CHECK(hipMemcpy(d_half_mod, half_mod.data(), half_mod.size() * 8, hipMemcpyHostToDevice));
+}
+
+void Context::ensure_scratch()
+{
+    if (d_ks_digits) return;
+    const size_t L = max_level();
+    DC_HIP_CHECK(hipMalloc(&d_ks_digits, L * N * 8));
+    DC_HIP_CHECK(hipMalloc(&d_ks_ext, L * (L + 1) * N * 8));
+    DC_HIP_CHECK(hipMalloc(&d_ks_acc, 2 * (L + 1) * N * 8));
+    DC_HIP_CHECK(hipMalloc(&d_ks_tmp, 2 * L * N * 8));
+    DC_HIP_CHECK(hipMalloc(&d_ct_tmp, 3 * L * N * 8));
+    std::vector<int> pidx;
+    ks_pidx_off.assign(L + 2, 0);
+    for (int ell = 1; ell <= (int)L; ell++) {
+        ks_pidx_off[ell] = (int)pidx.size();
+        for (int j = 0; j < ell; j++)
+            for (int e = 0; e < ell; e++) pidx.push_back(ks_other_prime(j, e, ell, K - 1));
+    }
+    DC_HIP_CHECK(hipMalloc(&d_ks_pidx, pidx.size() * sizeof(int)));
+    DC_HIP_CHECK(hipMemcpy(d_ks_pidx, pidx.data(), pidx.size() * sizeof(int), hipMemcpyHostToDevice));
+}
+
+Context::~Context()
+{
+    for (void *p : { (void *)d_mods, (void *)d_tw, (void *)d_itw, (void *)d_ks_digits, (void *)d_ks_ext, (void *)d_ks_acc,
+                     (void *)d_ks_tmp, (void *)d_ct_tmp, (void *)d_inv_last, (void *)d_half_mod, (void *)d_ks_pidx })
+        if (p) (void)hipFree(p);
+}
+
+} // namespace dacapo

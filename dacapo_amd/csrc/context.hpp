@@ -1,0 +1,80 @@
+// Host-side CKKS context of the MI355X HEVM runtime: prime chain, roots, twiddle tables resident in HBM,
+// per-level scratch for key switching.  Mirrors what SEAL builds in SEALContext / NTTTables for
+// SEAL_HEVM.cpp:46-59,93-99 (parameters N = 2^15, CoeffModulus::Create(N, {60 x 14})).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <vector>
+
+#include "modarith.hpp"
+
+namespace dacapo {
+
+#define DC_HIP_CHECK(expr)                                                                                     \
+    do {                                                                                                       \
+        hipError_t e_ = (expr);                                                                                \
+        if (e_ != hipSuccess) {                                                                                \
+            fprintf(stderr, "[dacapo_amd] HIP error %s at %s:%d: %s\n", hipGetErrorName(e_), __FILE__, __LINE__, \
+                    hipGetErrorString(e_));                                                                    \
+            abort();                                                                                           \
+        }                                                                                                      \
+    } while (0)
+
+typedef unsigned __int128 u128;
+
+// ---- host number theory (setup only; every polynomial operation runs on the GPU) -----------------------
+u64 h_mulmod(u64 a, u64 b, u64 q);
+u64 h_powmod(u64 a, u64 e, u64 q);
+u64 h_invmod(u64 a, u64 q);
+bool h_is_prime(u64 n);
+// CoeffModulus::Create(2^logN, {bits x count}) ordering: out[0] = last prime found ... out[count-1] = first
+bool h_seal_prime_chain(int logN, int bits, int count, std::vector<u64> &out);
+u64 h_min_primitive_root(u64 degree, u64 q);
+inline u32 h_bitrev(u32 x, int bits)
+{
+    u32 r = 0;
+    for (int i = 0; i < bits; i++) r |= ((x >> i) & 1u) << (bits - 1 - i);
+    return r;
+}
+
+// prime index of the e-th "other" modulus of digit j at level ell: moduli {0..ell-1} \ {j}, then the special
+// prime sp.  e in [0, ell).
+__host__ __device__ inline int ks_other_prime(int j, int e, int ell, int sp)
+{
+    int m = e < j ? e : e + 1;
+    return m == ell ? sp : m;
+}
+
+struct Context {
+    int logN = 0;
+    size_t N = 0;
+    int K = 0; // primes in the key-level chain; data levels use primes 0..ell-1, special prime = K-1
+    int k1 = 0, k2 = 0; // NTT split: COLS phase runs k1 stages, ROWS phase k2 = logN - k1
+    std::vector<u64> primes, psi;
+    std::vector<DModulus> h_mods;
+    DModulus *d_mods = nullptr;
+    u64 *d_tw = nullptr;  // [K][N] psi^bitrev(k)
+    u64 *d_itw = nullptr; // [K][N] inverse of the above, same index
+    // key-switch / rescale scratch (allocated lazily for max level)
+    u64 *d_ks_digits = nullptr; // [Lmax][N]        coefficient-domain digits
+    u64 *d_ks_ext = nullptr;    // [Lmax][Lmax+1][N] digits lifted to every modulus (NTT under way)
+    u64 *d_ks_acc = nullptr;    // [2][Lmax+1][N]    inner products
+    u64 *d_ks_tmp = nullptr;    // [2][Lmax][N]      mod-down correction terms
+    u64 *d_ct_tmp = nullptr;    // [3][Lmax][N]      tensor product / galois scratch
+    std::vector<u64> h_inv_p_mod; // P^{-1} mod q_i
+    u64 *d_inv_last = nullptr;  // [K][K] : inv_last[l*K + i] = q_l^{-1} mod q_i (i != l)
+    u64 *d_half_mod = nullptr;  // [K][K] : floor(q_l/2) mod q_i
+    int *d_ks_pidx = nullptr;   // per level: prime index of every (digit j, other-modulus e) limb of d_ks_ext
+    std::vector<int> ks_pidx_off;
+    const int *ks_prime_idx(int ell) const { return d_ks_pidx + ks_pidx_off[ell]; }
+
+    Context(int logN, int K, int bits, const u64 *primes_or_null);
+    ~Context();
+    int max_level() const { return K - 1; }
+    void ensure_scratch();
+};
+
+} // namespace dacapo

@@ -1,0 +1,60 @@
+// Batched negacyclic NTT / inverse NTT over RNS limbs: two launches per transform (see ntt_tile.hpp).
+// Replaces SEAL's ntt_negacyclic_harvey / inverse_ntt_negacyclic_harvey [SEAL-upstream ntt.cpp], which
+// SEAL_HEVM.cpp reaches through every rotate (:273), rescale (:283), relinearize (:316) and encode (:262).
+#include "kernels.hpp"
+#include "ntt_tile.hpp"
+
+namespace dacapo {
+
+template <int K, bool COLS, bool INV, bool CANON>
+__global__ __launch_bounds__(kTileThreads) void ntt_phase_kernel(u64 *__restrict__ data, long limb_stride,
+                                                                  const int *__restrict__ prime_idx, int prime_base,
+                                                                  int prime_period, const DModulus *__restrict__ mods,
+                                                                  const u64 *__restrict__ tw, int logN)
+{
+    __shared__ __attribute__((aligned(16))) u64 lds[kTileLdsElems];
+    const int limb = blockIdx.y;
+    const int p = prime_idx ? prime_idx[limb] : prime_base + (limb % prime_period);
+    u64 *a = data + (long)limb * limb_stride;
+    const DModulus M = mods[p];
+    ntt_tile<K, COLS, INV, CANON>(
+        M, tw + ((size_t)p << logN), logN, blockIdx.x, [=](int i) { return a[i]; }, [=](int i, u64 v) { a[i] = v; }, lds);
+}
+
+template <int K, bool COLS, bool INV, bool CANON>
+static void launch_phase(const Context &c, u64 *data, long limb_stride, int count, const int *d_prime_idx, int prime_base,
+                         int prime_period, hipStream_t s)
+{
+    dim3 grid((unsigned)(c.N >> kTileLog), (unsigned)count);
+    hipLaunchKernelGGL((ntt_phase_kernel<K, COLS, INV, CANON>), grid, dim3(kTileThreads), 0, s, data, limb_stride,
+                       d_prime_idx, prime_base, prime_period, c.d_mods, INV ? c.d_itw : c.d_tw, c.logN);
+}
+
+template <bool COLS, bool INV, bool CANON>
+static void launch_phase_k(int K, const Context &c, u64 *data, long limb_stride, int count, const int *d_prime_idx,
+                           int prime_base, int prime_period, hipStream_t s)
+{
+    switch (K) {
+    case 6: launch_phase<6, COLS, INV, CANON>(c, data, limb_stride, count, d_prime_idx, prime_base, prime_period, s); break;
+    case 7: launch_phase<7, COLS, INV, CANON>(c, data, limb_stride, count, d_prime_idx, prime_base, prime_period, s); break;
+    case 8: launch_phase<8, COLS, INV, CANON>(c, data, limb_stride, count, d_prime_idx, prime_base, prime_period, s); break;
+    case 9: launch_phase<9, COLS, INV, CANON>(c, data, limb_stride, count, d_prime_idx, prime_base, prime_period, s); break;
+    default: fprintf(stderr, "[dacapo_amd] unsupported NTT phase size 2^%d\n", K); abort();
+    }
+}
+
+void launch_ntt(const Context &c, bool inverse, u64 *data, long limb_stride, int count, const int *d_prime_idx,
+                int prime_base, int prime_period, hipStream_t s)
+{
+    if (count <= 0) return;
+    if (prime_period <= 0) prime_period = 1 << 30;
+    if (!inverse) {
+        launch_phase_k<true, false, false>(c.k1, c, data, limb_stride, count, d_prime_idx, prime_base, prime_period, s);
+        launch_phase_k<false, false, true>(c.k2, c, data, limb_stride, count, d_prime_idx, prime_base, prime_period, s);
+    } else {
+        launch_phase_k<false, true, false>(c.k2, c, data, limb_stride, count, d_prime_idx, prime_base, prime_period, s);
+        launch_phase_k<true, true, true>(c.k1, c, data, limb_stride, count, d_prime_idx, prime_base, prime_period, s);
+    }
+}
+
+} // namespace dacapo

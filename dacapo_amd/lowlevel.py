@@ -1,0 +1,125 @@
+"""ctypes binding of the kernel-level C ABI (include/dacapo_ckks.h).  Device memory is handled through the
+ABI's own dc_malloc/dc_memcpy_*: no torch types cross the boundary."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import LIB_PATH
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise RuntimeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(there is no CPU fallback for the HEVM hot path)")
+        L = C.CDLL(str(LIB_PATH))
+        vp, u64p, i32, lng = C.c_void_p, C.c_void_p, C.c_int, C.c_long
+        L.dc_context_create.restype = vp
+        L.dc_context_create.argtypes = [i32, i32, i32, vp]
+        L.dc_context_destroy.argtypes = [vp]
+        L.dc_context_logn.argtypes = [vp]
+        L.dc_context_num_primes.argtypes = [vp]
+        L.dc_context_primes.argtypes = [vp, vp]
+        L.dc_context_roots.argtypes = [vp, vp]
+        L.dc_malloc.restype = vp
+        L.dc_malloc.argtypes = [C.c_size_t]
+        L.dc_free.argtypes = [vp]
+        L.dc_memcpy_h2d.argtypes = [vp, vp, C.c_size_t]
+        L.dc_memcpy_d2h.argtypes = [vp, vp, C.c_size_t]
+        L.dc_memset.argtypes = [vp, i32, C.c_size_t]
+        L.dc_stream_sync.argtypes = [vp]
+        L.dc_event_create.restype = vp
+        L.dc_event_destroy.argtypes = [vp]
+        L.dc_event_record.argtypes = [vp, vp]
+        L.dc_event_elapsed_ms.restype = C.c_float
+        L.dc_event_elapsed_ms.argtypes = [vp, vp]
+        for f in (L.dc_ntt_forward, L.dc_ntt_inverse):
+            f.argtypes = [vp, u64p, lng, i32, vp, i32, i32, vp]
+        L.dc_ct_negate.argtypes = [vp, u64p, lng, u64p, lng, i32, vp]
+        L.dc_ct_add.argtypes = [vp, u64p, lng, u64p, lng, u64p, lng, i32, vp]
+        L.dc_ct_add_plain.argtypes = [vp, u64p, lng, u64p, lng, u64p, i32, vp]
+        L.dc_ct_mul_plain.argtypes = [vp, u64p, lng, u64p, lng, u64p, i32, vp]
+        L.dc_ct_mul_relin.argtypes = [vp, u64p, lng, u64p, lng, u64p, lng, u64p, i32, vp]
+        L.dc_ct_rotate_hop.argtypes = [vp, u64p, lng, u64p, lng, C.c_uint32, u64p, i32, vp]
+        L.dc_ct_rescale.argtypes = [vp, u64p, lng, u64p, lng, i32, vp]
+        L.dc_ct_modswitch.argtypes = [vp, u64p, lng, u64p, lng, i32, i32, vp]
+        L.dc_keyswitch.argtypes = [vp, u64p, lng, u64p, u64p, u64p, u64p, i32, vp]
+        L.dc_galois_ntt.argtypes = [vp, u64p, lng, u64p, lng, C.c_uint32, i32, i32, vp]
+        L.dc_poly_mul.argtypes = [vp, u64p, u64p, u64p, i32, vp]
+        L.dc_poly_add.argtypes = [vp, u64p, u64p, u64p, i32, vp]
+        L.dc_galois_elt_from_step.restype = C.c_uint32
+        L.dc_galois_elt_from_step.argtypes = [vp, i32]
+        _lib = L
+    return _lib
+
+
+class DeviceBuffer:
+    """A uint64 array in HBM owned through dc_malloc/dc_free."""
+
+    def __init__(self, shape, dtype=np.uint64):
+        self.shape = tuple(int(x) for x in np.atleast_1d(shape))
+        self.dtype = np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape)) * self.dtype.itemsize
+        self.ptr = lib().dc_malloc(max(self.nbytes, 16))
+
+    @classmethod
+    def from_host(cls, a: np.ndarray):
+        a = np.ascontiguousarray(a)
+        d = cls(a.shape, a.dtype)
+        lib().dc_memcpy_h2d(d.ptr, a.ctypes.data, a.nbytes)
+        return d
+
+    def to_host(self) -> np.ndarray:
+        out = np.empty(self.shape, dtype=self.dtype)
+        lib().dc_memcpy_d2h(out.ctypes.data, self.ptr, self.nbytes)
+        return out
+
+    def at(self, elem_offset: int) -> int:
+        return self.ptr + int(elem_offset) * self.dtype.itemsize
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                lib().dc_free(self.ptr)
+                self.ptr = None
+        except Exception:
+            pass
+
+
+class Context:
+    def __init__(self, logN=15, num_primes=14, bit_size=60, primes=None):
+        L = lib()
+        arr = None
+        if primes is not None:
+            arr = (C.c_uint64 * len(primes))(*[int(p) for p in primes])
+            num_primes = len(primes)
+        self.h = L.dc_context_create(logN, num_primes, bit_size, arr)
+        self.logN, self.N, self.K = logN, 1 << logN, num_primes
+        out = np.zeros(num_primes, dtype=np.uint64)
+        L.dc_context_primes(self.h, out.ctypes.data)
+        self.primes = [int(x) for x in out]
+        L.dc_context_roots(self.h, out.ctypes.data)
+        self.roots = [int(x) for x in out]
+
+    def __del__(self):
+        try:
+            lib().dc_context_destroy(self.h)
+        except Exception:
+            pass
+
+    def sync(self, stream=None):
+        lib().dc_stream_sync(stream)
+
+    def ntt(self, buf: DeviceBuffer, count, inverse=False, prime_idx: DeviceBuffer | None = None, prime_base=0,
+            prime_period=0, limb_stride=None, offset=0, stream=None):
+        f = lib().dc_ntt_inverse if inverse else lib().dc_ntt_forward
+        f(self.h, buf.at(offset), self.N if limb_stride is None else limb_stride, count,
+          prime_idx.ptr if prime_idx is not None else None, prime_base, prime_period, stream)
+
+    def elt_from_step(self, step: int) -> int:
+        return int(lib().dc_galois_elt_from_step(self.h, step))
