@@ -1,0 +1,231 @@
+#!/usr/bin/env python3
+"""bench.py -- HEVM hot-path benchmark on MI355X (contract: see the task statement / DESIGN.md "Measurement").
+
+step      = one run() of the ResNet-shaped HEVM program (nt = 2^14 slots, N = 2^15, 14 x 60-bit primes: the
+            parameters SEAL_HEVM.cpp:39-53 hard-codes) on ciphertexts already resident in HBM; the timed region is
+            run() only, exactly what examples/tests/ResNet.py:109-111 times.
+value     = NTT-equivalents per second over the whole job (all ranks): (l+1)(l+2) per key switch, 2l per rescale
+            (SURVEY.md 3.4 / BASELINE.md 1) divided by the max-over-ranks wall time of K steps.
+roofline  = the dominant kernel pair (forward negacyclic NTT = COLS phase + ROWS phase launch) on a 4096-limb batch,
+            timed with HIP events on the launch stream; algorithmic bytes = 2 * N * 8 per limb.
+cpu_baseline = the CPU oracle (C restatement of SEAL 4.0's algorithms, 1 thread like the reference) on a bounded
+            prefix of the same program, rank 0, N = 1 only.
+Launch: python bench.py [--gpus N --steps K --warmup W]   (N > 1: via torch.distributed.run, one rank per GPU).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
+
+
+def ntt_equivalents(stats_or_counts):
+    return stats_or_counts["ntts"]
+
+
+def roofline_leg(ll, ctx, limbs=4096, iters=10):
+    """forward NTT over `limbs` limbs of N = 2^15: two launches (COLS phase, ROWS phase) per transform"""
+    L = ll.lib()
+    N = ctx.N
+    buf = ll.DeviceBuffer((limbs, N))
+    host = (np.arange(limbs * N, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)) >> np.uint64(5)
+    L.dc_memcpy_h2d(buf.ptr, host.ctypes.data, host.nbytes)
+    for _ in range(2):
+        ctx.ntt(buf, limbs, prime_base=0, prime_period=ctx.K)
+    e0, e1 = L.dc_event_create(), L.dc_event_create()
+    L.dc_event_record(e0, None)
+    for _ in range(iters):
+        ctx.ntt(buf, limbs, prime_base=0, prime_period=ctx.K)
+    L.dc_event_record(e1, None)
+    ms = L.dc_event_elapsed_ms(e0, e1) / iters
+    alg_bytes = 2.0 * limbs * N * 8
+    gbs = alg_bytes / (ms * 1e-3) / 1e9
+    del buf
+    return {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+            "traffic": None, "kernel": "ntt_phase_kernel<7,COLS,fwd> + ntt_phase_kernel<8,ROWS,fwd> (one forward NTT = both launches)",
+            "launch": {"limbs": limbs, "N": N, "algorithmic_bytes": alg_bytes, "avg_us": round(ms * 1e3, 2),
+                       "ntt_per_s": round(limbs / (ms * 1e-3))}}
+
+
+def ntt_micro_leg(ll, iters=200):
+    """BASELINE config 2: single forward NTT, N = 2^14, 1 limb (latency-bound)"""
+    L = ll.lib()
+    ctx = ll.Context(14, 2)
+    buf = ll.DeviceBuffer((1, ctx.N))
+    L.dc_memset(buf.ptr, 1, buf.nbytes)
+    for _ in range(5):
+        ctx.ntt(buf, 1)
+    e0, e1 = L.dc_event_create(), L.dc_event_create()
+    L.dc_event_record(e0, None)
+    for _ in range(iters):
+        ctx.ntt(buf, 1)
+    L.dc_event_record(e1, None)
+    us = L.dc_event_elapsed_ms(e0, e1) / iters * 1e3
+    return {"workload": "single forward NTT, N=2^14, 1 limb", "us_per_ntt_back_to_back": round(us, 2)}
+
+
+def cpu_baseline_leg(cst: bytes, hv: bytes, budget_s=18.0):
+    """oracle VM (1 thread) on a prefix of the same program; returns NTT-equivalents/s"""
+    import tempfile
+
+    from oracle.oracle import Oracle, OracleVM
+
+    t0 = time.time()
+    o = Oracle(15, 14)
+    o.keygen(seed=0x4845564D)
+    with tempfile.TemporaryDirectory() as d:
+        (Path(d) / "p.cst").write_bytes(cst)
+        (Path(d) / "p.hevm").write_bytes(hv)
+        vm = OracleVM(o)
+        vm.load(Path(d) / "p.cst", Path(d) / "p.hevm")
+    rng = np.random.default_rng(100)
+    vm.encrypt(0, rng.uniform(-0.5, 0.5, o.slots))
+    setup_s = time.time() - t0
+    ntts, n_ops, spent, ks = 0, 0, 0.0, 0
+    for op in vm.prog.ops:
+        opcode, dst, lhs, rhs = (int(x) for x in op)
+        if opcode == 0:  # encode lazily, untimed (preprocess is untimed in the reference)
+            src = np.ones(1) if lhs == 0xFFFF else vm.consts[lhs]
+            vm.plains[dst] = vm.encode_internal(src, rhs >> 10, rhs & 0x3FF)
+            continue
+        if opcode == 10:
+            break  # the sample stops at the first re-encryption
+        lvl = vm.ciphers[lhs].ell
+        t = time.perf_counter()
+        vm.step(op)
+        spent += time.perf_counter() - t
+        n_ops += 1
+        if opcode == 1:
+            off = rhs - 65536 if rhs >= 32768 else rhs
+            h = len(o.rotate_hops(off))
+            ntts += h * (lvl + 1) * (lvl + 2)
+            ks += h
+        elif opcode == 8:
+            ntts += (lvl + 1) * (lvl + 2)
+            ks += 1
+        elif opcode == 3:
+            ntts += 2 * lvl
+        if spent > budget_s:
+            break
+    return {"value": round(ntts / spent, 1), "unit": "NTT/s", "cores": 1, "kind": "port",
+            "sample": f"first {n_ops} run-time ops ({ks} key switches) of the same ResNet-shaped program, "
+                      f"{spent:.1f} s of single-thread work (+{setup_s:.0f} s untimed keygen/encrypt)",
+            "seconds": round(spent, 2), "ntt_equivalents": ntts,
+            "reference_published": "README.md:176-188: 53.73 s for the DaCapo-compiled ResNet-20 on SEAL CPU (hardware unstated)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--layers", type=int, default=20, help="ResNet-shaped program depth (20 = the traced op mix)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist_mod
+
+        torch.cuda.set_device(local_rank)
+        dist_mod.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist = dist_mod
+
+    from dacapo_amd import hevm_asm as ha
+    from dacapo_amd import lowlevel as ll
+    from dacapo_amd import runner
+
+    L = ll.lib()
+    L.dc_set_device(local_rank)
+
+    def barrier_sync():
+        if dist is not None:
+            dist.barrier()
+            import torch
+
+            torch.cuda.synchronize()
+        L.dc_device_sync()
+
+    # ---- set-up (untimed, like hc-test: context/keys, load, preprocess, encrypt) ---------------------------------
+    t_setup = time.time()
+    hevm = runner.HEVM(seed=0x4845564D + rank, logN=15, num_primes=14)
+    prog = ha.resnet_shaped(seed=100, layers=args.layers)  # independent stream per rank: same program, own keys/inputs
+    cst, hv, info = prog.assemble()
+    hevm.load_mem(cst, hv)
+    rng = np.random.default_rng(100 + rank)
+    image = rng.uniform(-0.5, 0.5, hevm.slots)
+    hevm.setInput(0, image)
+    t_setup = time.time() - t_setup
+
+    for _ in range(args.warmup):
+        hevm.run()
+    barrier_sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        hevm.run()  # synchronous: returns when the program has finished on the device
+    barrier_sync()
+    elapsed = time.perf_counter() - t0
+    stats = hevm.stats()
+
+    if dist is not None:
+        import torch
+
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank != 0:
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    ms_per_step = elapsed / args.steps * 1e3
+    ntts_per_step = ntt_equivalents(stats)
+    value = world * ntts_per_step * args.steps / elapsed
+    ctx = ll.Context(15, 14)
+    roof = roofline_leg(ll, ctx)
+    micro = ntt_micro_leg(ll)
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline_leg(cst, hv)
+
+    line = {
+        "metric": "NTT/s (NTT-equivalents over one run() of the ResNet-shaped HEVM program, nt=2^14)",
+        "value": round(value, 1), "unit": "NTT/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u64", "data": "synthetic",
+        "config": {"workload": "ResNet-shaped HEVM program (SURVEY App. C op mix), nt=2^14 slots, N=2^15, 14 x 60-bit primes "
+                               "(SEAL_HEVM.cpp:39-53); one independent ciphertext stream per GPU",
+                   "ops": info["op_mix"], "key_switches_per_step": stats["keyswitches"], "ntt_equivalents_per_step": ntts_per_step,
+                   "parallelism": f"replicas x{world} (no collective in the op path)"},
+        "hevm_wall_s": round(ms_per_step / 1e3, 4),
+        "setup_s_untimed": round(t_setup, 1),
+        "roofline": roof,
+        "ntt_micro": micro,
+        "cpu_baseline": cpu,
+    }
+    if cpu:
+        line["speedup_vs_cpu_port"] = round(value / cpu["value"], 1)
+    print(json.dumps(line))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

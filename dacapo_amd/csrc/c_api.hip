@@ -5,10 +5,7 @@
 
 using namespace dacapo;
 
-struct dc_context {
-    Context impl;
-    dc_context(int logN, int K, int bits, const u64 *primes) : impl(logN, K, bits, primes) {}
-};
+#include "c_api_types.hpp"
 
 static inline hipStream_t S(void *s) { return (hipStream_t)s; }
 static inline CtView V(const uint64_t *p, long stride) { return CtView{ const_cast<u64 *>(p), stride }; }
@@ -26,18 +23,22 @@ dc_context *dc_context_create(int logN, int num_primes, int bit_size, const uint
         fprintf(stderr, "[dacapo_amd] only the 60-bit HEVM prime chain is supported (asked for %d bits)\n", bit_size);
         abort();
     }
-    return new dc_context(logN, num_primes, bit_size, primes);
+    return new dc_context{ new Context(logN, num_primes, bit_size, primes), true };
 }
-void dc_context_destroy(dc_context *ctx) { delete ctx; }
-int dc_context_logn(const dc_context *ctx) { return ctx->impl.logN; }
-int dc_context_num_primes(const dc_context *ctx) { return ctx->impl.K; }
+void dc_context_destroy(dc_context *ctx)
+{
+    if (ctx && ctx->owned) delete ctx->c;
+    delete ctx;
+}
+int dc_context_logn(const dc_context *ctx) { return ctx->c->logN; }
+int dc_context_num_primes(const dc_context *ctx) { return ctx->c->K; }
 void dc_context_primes(const dc_context *ctx, uint64_t *out)
 {
-    for (int i = 0; i < ctx->impl.K; i++) out[i] = ctx->impl.primes[i];
+    for (int i = 0; i < ctx->c->K; i++) out[i] = ctx->c->primes[i];
 }
 void dc_context_roots(const dc_context *ctx, uint64_t *out)
 {
-    for (int i = 0; i < ctx->impl.K; i++) out[i] = ctx->impl.psi[i];
+    for (int i = 0; i < ctx->c->K; i++) out[i] = ctx->c->psi[i];
 }
 
 void *dc_malloc(size_t bytes)
@@ -51,6 +52,14 @@ void dc_memcpy_h2d(void *dst, const void *src, size_t bytes) { DC_HIP_CHECK(hipM
 void dc_memcpy_d2h(void *dst, const void *src, size_t bytes) { DC_HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost)); }
 void dc_memset(void *dst, int value, size_t bytes) { DC_HIP_CHECK(hipMemset(dst, value, bytes)); }
 void dc_stream_sync(void *stream) { DC_HIP_CHECK(hipStreamSynchronize(S(stream))); }
+
+void dc_set_device(int device) { DC_HIP_CHECK(hipSetDevice(device)); }
+void dc_device_sync(void) { DC_HIP_CHECK(hipDeviceSynchronize()); }
+int dc_device_count(void)
+{
+    int n = 0;
+    return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
 
 void *dc_event_create(void)
 {
@@ -71,76 +80,76 @@ float dc_event_elapsed_ms(void *start, void *stop)
 void dc_ntt_forward(dc_context *ctx, uint64_t *data, long limb_stride, int count, const int32_t *d_prime_idx, int prime_base,
                     int prime_period, void *stream)
 {
-    launch_ntt(ctx->impl, false, data, limb_stride, count, d_prime_idx, prime_base, prime_period, S(stream));
+    launch_ntt(*ctx->c, false, data, limb_stride, count, d_prime_idx, prime_base, prime_period, S(stream));
 }
 void dc_ntt_inverse(dc_context *ctx, uint64_t *data, long limb_stride, int count, const int32_t *d_prime_idx, int prime_base,
                     int prime_period, void *stream)
 {
-    launch_ntt(ctx->impl, true, data, limb_stride, count, d_prime_idx, prime_base, prime_period, S(stream));
+    launch_ntt(*ctx->c, true, data, limb_stride, count, d_prime_idx, prime_base, prime_period, S(stream));
 }
 
 void dc_ct_negate(dc_context *ctx, uint64_t *dst, long dst_stride, const uint64_t *a, long a_stride, int ell, void *stream)
 {
-    launch_ew(ctx->impl, EwOp::Neg, V(dst, dst_stride), V(a, a_stride), V(a, a_stride), 2, 2, ell, S(stream));
+    launch_ew(*ctx->c, EwOp::Neg, V(dst, dst_stride), V(a, a_stride), V(a, a_stride), 2, 2, ell, S(stream));
 }
 void dc_ct_add(dc_context *ctx, uint64_t *dst, long dst_stride, const uint64_t *a, long a_stride, const uint64_t *b,
                long b_stride, int ell, void *stream)
 {
-    launch_ew(ctx->impl, EwOp::Add, V(dst, dst_stride), V(a, a_stride), V(b, b_stride), 2, 2, ell, S(stream));
+    launch_ew(*ctx->c, EwOp::Add, V(dst, dst_stride), V(a, a_stride), V(b, b_stride), 2, 2, ell, S(stream));
 }
 void dc_ct_add_plain(dc_context *ctx, uint64_t *dst, long dst_stride, const uint64_t *a, long a_stride, const uint64_t *plain,
                      int ell, void *stream)
 {
-    launch_add_plain(ctx->impl, V(dst, dst_stride), V(a, a_stride), plain, ell, S(stream));
+    launch_add_plain(*ctx->c, V(dst, dst_stride), V(a, a_stride), plain, ell, S(stream));
 }
 void dc_ct_mul_plain(dc_context *ctx, uint64_t *dst, long dst_stride, const uint64_t *a, long a_stride, const uint64_t *plain,
                      int ell, void *stream)
 {
-    launch_ew(ctx->impl, EwOp::Mul, V(dst, dst_stride), V(a, a_stride), V(plain, 0), 2, 1, ell, S(stream));
+    launch_ew(*ctx->c, EwOp::Mul, V(dst, dst_stride), V(a, a_stride), V(plain, 0), 2, 1, ell, S(stream));
 }
 void dc_ct_mul_relin(dc_context *ctx, uint64_t *dst, long dst_stride, const uint64_t *a, long a_stride, const uint64_t *b,
                      long b_stride, const uint64_t *relin_key, int ell, void *stream)
 {
-    mul_relin(ctx->impl, V(dst, dst_stride), V(a, a_stride), V(b, b_stride), relin_key, ell, S(stream));
+    mul_relin(*ctx->c, V(dst, dst_stride), V(a, a_stride), V(b, b_stride), relin_key, ell, S(stream));
 }
 void dc_ct_rotate_hop(dc_context *ctx, uint64_t *dst, long dst_stride, const uint64_t *src, long src_stride,
                       uint32_t galois_elt, const uint64_t *galois_key, int ell, void *stream)
 {
-    rotate_hop(ctx->impl, V(dst, dst_stride), V(src, src_stride), galois_elt, galois_key, ell, S(stream));
+    rotate_hop(*ctx->c, V(dst, dst_stride), V(src, src_stride), galois_elt, galois_key, ell, S(stream));
 }
 void dc_ct_rescale(dc_context *ctx, uint64_t *dst, long dst_stride, const uint64_t *src, long src_stride, int ell, void *stream)
 {
-    rescale(ctx->impl, V(dst, dst_stride), V(src, src_stride), ell, S(stream));
+    rescale(*ctx->c, V(dst, dst_stride), V(src, src_stride), ell, S(stream));
 }
 void dc_ct_modswitch(dc_context *ctx, uint64_t *dst, long dst_stride, const uint64_t *src, long src_stride, int ell, int down,
                      void *stream)
 {
     if (down <= 0 || (dst == src && dst_stride == src_stride)) return; // dropping limbs in place moves nothing
-    launch_ew(ctx->impl, EwOp::Copy, V(dst, dst_stride), V(src, src_stride), V(src, src_stride), 2, 2, ell - down, S(stream));
+    launch_ew(*ctx->c, EwOp::Copy, V(dst, dst_stride), V(src, src_stride), V(src, src_stride), 2, 2, ell - down, S(stream));
 }
 
 void dc_keyswitch(dc_context *ctx, uint64_t *out, long out_stride, const uint64_t *base0, const uint64_t *base1,
                   const uint64_t *target, const uint64_t *key, int ell, void *stream)
 {
-    keyswitch(ctx->impl, V(out, out_stride), base0, base1, target, key, ell, S(stream));
+    keyswitch(*ctx->c, V(out, out_stride), base0, base1, target, key, ell, S(stream));
 }
 void dc_galois_ntt(dc_context *ctx, uint64_t *dst, long dst_stride, const uint64_t *src, long src_stride, uint32_t galois_elt,
                    int polys, int ell, void *stream)
 {
-    launch_galois(ctx->impl, V(dst, dst_stride), V(src, src_stride), galois_elt, polys, ell, S(stream));
+    launch_galois(*ctx->c, V(dst, dst_stride), V(src, src_stride), galois_elt, polys, ell, S(stream));
 }
 void dc_poly_mul(dc_context *ctx, uint64_t *dst, const uint64_t *a, const uint64_t *b, int ell, void *stream)
 {
-    launch_ew(ctx->impl, EwOp::Mul, V(dst, 0), V(a, 0), V(b, 0), 1, 1, ell, S(stream));
+    launch_ew(*ctx->c, EwOp::Mul, V(dst, 0), V(a, 0), V(b, 0), 1, 1, ell, S(stream));
 }
 void dc_poly_add(dc_context *ctx, uint64_t *dst, const uint64_t *a, const uint64_t *b, int ell, void *stream)
 {
-    launch_ew(ctx->impl, EwOp::Add, V(dst, 0), V(a, 0), V(b, 0), 1, 1, ell, S(stream));
+    launch_ew(*ctx->c, EwOp::Add, V(dst, 0), V(a, 0), V(b, 0), 1, 1, ell, S(stream));
 }
 
 uint32_t dc_galois_elt_from_step(const dc_context *ctx, int step)
 {
-    const uint32_t n = (uint32_t)ctx->impl.N, m = 2 * n;
+    const uint32_t n = (uint32_t)ctx->c->N, m = 2 * n;
     if (step == 0) return m - 1;
     const uint32_t pos = (uint32_t)(step < 0 ? -step : step);
     if (pos >= (n >> 1)) return 0;

@@ -1,0 +1,8 @@
+// The kernel-level handle of include/dacapo_ckks.h: a (possibly borrowed) Context.
+#pragma once
+#include "context.hpp"
+
+struct dc_context {
+    dacapo::Context *c;
+    bool owned; // false when the context belongs to an HEVM (hevm_context())
+};

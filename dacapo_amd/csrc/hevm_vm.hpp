@@ -1,0 +1,123 @@
+// HEVM virtual machine on the MI355X: state and host-side helpers behind the 18-symbol ABI of
+// include/hevm_abi.h.  Mirrors struct SEAL_HEVM (/root/reference/lib/Runtime/SEAL_HEVM.cpp:15-402) with the
+// SEAL objects replaced by HBM-resident limb arrays and HIP launches.
+#pragma once
+#include <complex>
+#include <deque>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/hevm_abi.h"
+#include "kernels.hpp"
+
+namespace dacapo {
+
+// wire format of include/hecate/Support/HEVMHeader.h:10-35 (little endian, natural alignment)
+struct WireHeader {
+    uint32_t magic_number;
+    uint32_t hevm_header_size;
+    uint64_t arg_length;
+    uint64_t res_length;
+};
+struct WireConfigBody {
+    uint64_t config_body_length;
+    uint64_t num_operations;
+    uint64_t num_ctxt_buffer;
+    uint64_t num_ptxt_buffer;
+    uint64_t init_level;
+};
+struct WireOp {
+    uint16_t opcode, dst, lhs, rhs;
+};
+static_assert(sizeof(WireHeader) == 24 && sizeof(WireConfigBody) == 40 && sizeof(WireOp) == 8, "HEVM wire format");
+
+// CKKSEncoder restated on the host (encode/decode are untimed set-up work in the reference: SEAL_HEVM.cpp:242-267,
+// :439-455); the RNS lift and every NTT run on the GPU.
+class HostEncoder {
+  public:
+    HostEncoder(int logN);
+    // values tiled over N/2 slots as src[i % len] (SEAL_HEVM.cpp:259-261); returns round(coefficients) as int128
+    void encode(const double *src, size_t len, double scale, std::vector<__int128> &coeffs) const;
+    // coeffs: N real coefficients already divided by the scale -> N/2 slot values (real parts)
+    void decode(std::vector<std::complex<double>> &coeffs, double *out) const;
+    size_t N, slots;
+    int logN;
+
+  private:
+    std::vector<std::complex<double>> root_; // exp(2 pi i bitrev(k) / 2N)
+    std::vector<uint32_t> slot_map_;         // CKKSEncoder::matrix_reps_index_map_
+};
+
+struct Plain {
+    u64 *d = nullptr;
+    int level = 0;
+    double scale = 1.0;
+};
+
+struct KeySet {
+    u64 *sk = nullptr;    // [K][N]
+    u64 *pk = nullptr;    // [2][K][N]
+    u64 *relin = nullptr; // [K-1][2][K][N]
+    std::map<u32, u64 *> galois;
+};
+
+class HEVM {
+  public:
+    std::unique_ptr<Context> ctx;
+    std::unique_ptr<HostEncoder> encoder;
+    KeySet keys;
+    hipStream_t stream = nullptr;
+    bool debug = false;
+    u64 seed = 0, enc_counter = 0;
+
+    // program
+    std::vector<std::vector<double>> buffer; // constants of the .cst file
+    WireHeader header{};
+    WireConfigBody config{};
+    std::vector<WireOp> ops;
+    std::vector<uint64_t> arg_scale, arg_level, res_scale, res_level, res_dst;
+    std::deque<hevm_ctxt> ciphers; // deque: growing it never invalidates references to registers
+    std::vector<Plain> plains;
+
+    // statistics of the last run()
+    int64_t op_counts[11] = { 0 };
+    int64_t n_keyswitch = 0, n_ntt = 0;
+
+    HEVM() = default;
+    size_t key_elems() const { return (size_t)(ctx->K - 1) * 2 * ctx->K * ctx->N; }
+    void init_context(int logN, int K, const u64 *primes);
+    void generate_keys(u64 seed, bool secret, bool pub, bool eval);
+    void gen_kswitch_key(u64 *key, const u64 *new_key, u64 stream_id);
+    void add_galois_key(u32 elt);
+    void save_keys(const std::string &dir);
+    void load_keys(const std::string &dir, bool need_secret, bool need_public, bool need_eval);
+
+    void load_constants(const void *data, size_t len);
+    void load_program(const void *data, size_t len, bool header_only);
+    void reset_res_dst();
+    void preprocess();
+    void encode_internal(Plain &dst, const double *src, size_t len, int level, int scale_bits);
+    hevm_ctxt &reg(size_t i);
+    void encrypt_plain(hevm_ctxt &dst, const Plain &pt);
+    void encrypt(int64_t i, const double *dat, int len);
+    void decrypt(int64_t i, double *out);
+    void run();
+
+    // opcode handlers (SEAL_HEVM.cpp:268-334)
+    void op_rotate(int dst, int src, int offset);
+    void op_negate(int dst, int src);
+    void op_rescale(int dst, int src);
+    void op_modswitch(int dst, int src, int down);
+    void op_addcc(int dst, int lhs, int rhs);
+    void op_addcp(int dst, int lhs, int rhs);
+    void op_mulcc(int dst, int lhs, int rhs);
+    void op_mulcp(int dst, int lhs, int rhs);
+    void op_bootstrap(int dst, int src, int target_level);
+    std::vector<u32> rotate_hops(int steps) const;
+
+    CtView view(const hevm_ctxt &c) const { return CtView{ c.data, (long)c.poly_stride }; }
+};
+
+} // namespace dacapo

@@ -1,0 +1,403 @@
+"""HEVM program assembler: writes the reference's `.hevm` bytecode and `.cst` constant files.
+
+The reference produces these files with an MLIR pass pipeline (`hecate-opt ... --emit-hevm`,
+/root/reference/lib/Dialect/CKKS/Transforms/EmitHEVM.cpp:28-120 and
+lib/Dialect/Earth/Transforms/ElideConstant.cpp:40-53) that cannot be built here (no MLIR).  This module writes
+the same wire format (include/hecate/Support/HEVMHeader.h:10-35) from a small tracing builder so that the
+runtime can be exercised with real programs:
+
+  * operand encoding follows include/hecate/Dialect/CKKS/IR/CKKSOps.td:69-222 (opcode numbers, rhs packing
+    `(level << 10) + scale` for encode, int16 rotation offsets, 0xFFFF = all-ones "upscale" constant);
+  * scale management is a minimal EVA-style waterline policy (rescale once the scale would stay >= the waterline,
+    modswitch to equalise levels, upscale = mulcp by the all-ones constant: lib/Conversion/.../UpscaleToMulcp.cpp:52-72);
+  * cipher registers are re-used once dead, arguments first, like ReuseBuffer.cpp:27-55 / EmitHEVM.cpp:45-52.
+
+Every value also carries its plaintext slot vector (numpy), so the expected result of a program is known when it
+is built (the examples/tests/*.py scripts recompute it the same way).
+"""
+from __future__ import annotations
+
+import struct
+from dataclasses import dataclass, field
+from pathlib import Path
+
+import numpy as np
+
+MAGIC = 0x4845564D
+OP_ENCODE, OP_ROTATE, OP_NEGATE, OP_RESCALE, OP_MODSWITCH, OP_UPSCALE = 0, 1, 2, 3, 4, 5
+OP_ADDCC, OP_ADDCP, OP_MULCC, OP_MULCP, OP_BOOTSTRAP = 6, 7, 8, 9, 10
+OP_NAMES = ["encode", "rotate", "negate", "rescale", "modswitch", "upscale", "addcc", "addcp", "mulcc", "mulcp", "bootstrap"]
+
+
+def write_cst(path, constants):
+    """ElideConstant.cpp:40-53: i64 count; {i64 len; f64 data[len]} * count."""
+    with open(path, "wb") as f:
+        f.write(struct.pack("<q", len(constants)))
+        for c in constants:
+            c = np.ascontiguousarray(c, dtype="<f8").ravel()
+            f.write(struct.pack("<q", len(c)))
+            f.write(c.tobytes())
+
+
+def pack_cst(constants) -> bytes:
+    out = [struct.pack("<q", len(constants))]
+    for c in constants:
+        c = np.ascontiguousarray(c, dtype="<f8").ravel()
+        out += [struct.pack("<q", len(c)), c.tobytes()]
+    return b"".join(out)
+
+
+def pack_hevm(arg_scale, arg_level, res_scale, res_level, res_dst, num_ctxt, num_ptxt, init_level, ops) -> bytes:
+    """EmitHEVM.cpp:31-37,94-119."""
+    na, nr = len(arg_scale), len(res_scale)
+    ops = np.ascontiguousarray(ops, dtype="<u2").reshape(-1, 4)
+    body_len = 40 + 8 * (2 * na + 3 * nr)
+    out = [struct.pack("<IIQQ", MAGIC, 24, na, nr), struct.pack("<5Q", body_len, len(ops), num_ctxt, num_ptxt, init_level)]
+    for arr in (arg_scale, arg_level, res_scale, res_level, res_dst):
+        out.append(struct.pack(f"<{len(arr)}Q", *[int(x) for x in arr]))
+    out.append(ops.tobytes())
+    return b"".join(out)
+
+
+@dataclass
+class Value:
+    """An SSA ciphertext value of the traced program."""
+    id: int
+    level: int
+    scale_bits: int
+    plain: np.ndarray | None  # expected slot values (None when plaintext shadowing is off)
+    last_use: int = -1
+
+
+@dataclass
+class _Op:
+    opcode: int
+    dst: int | None  # value id (cipher) or plain register (encode)
+    lhs: int
+    rhs: int
+    lhs_is_value: bool = True
+    rhs_is_value: bool = False
+
+
+class Builder:
+    def __init__(self, slots=1 << 14, waterline=40, init_level=13, rescale_bits=60, min_level=1, shadow=True):
+        self.slots, self.waterline, self.init_level, self.rescale_bits = slots, waterline, init_level, rescale_bits
+        self.min_level, self.shadow = min_level, shadow
+        self.values: list[Value] = []
+        self.ops: list[_Op] = []
+        self.constants: list[np.ndarray] = []
+        self._const_index = {}
+        self.num_plain = 0
+        self.args: list[Value] = []
+        self.results: list[Value] = []
+
+    # ---- helpers ----------------------------------------------------------------------------------------------
+    def _new(self, level, scale_bits, plain):
+        v = Value(len(self.values), level, scale_bits, plain if self.shadow else None)
+        self.values.append(v)
+        return v
+
+    def _emit(self, opcode, dst: Value, lhs: Value, rhs=0, rhs_is_value=False):
+        idx = len(self.ops)
+        lhs.last_use = idx
+        if rhs_is_value:
+            self.values[rhs].last_use = idx
+        self.ops.append(_Op(opcode, dst.id, lhs.id, rhs, True, rhs_is_value))
+
+    def _tile(self, vec):
+        vec = np.asarray(vec, dtype=np.float64).ravel()
+        return vec[np.arange(self.slots) % len(vec)]
+
+    def _const(self, vec) -> int:
+        vec = np.ascontiguousarray(vec, dtype=np.float64).ravel()
+        key = vec.tobytes()
+        if key not in self._const_index:
+            self._const_index[key] = len(self.constants)
+            self.constants.append(vec)
+        return self._const_index[key]
+
+    def _encode(self, const_idx: int, level: int, scale_bits: int) -> int:
+        """opcode 0: dst = plain register, lhs = constant index (0xFFFF = ones), rhs = (level << 10) + scale."""
+        assert 0 < scale_bits < 1024 and 0 < level < 64
+        reg = self.num_plain
+        self.num_plain += 1
+        self.ops.append(_Op(OP_ENCODE, reg, const_idx, (level << 10) + scale_bits, False, False))
+        return reg
+
+    # ---- program inputs / outputs ---------------------------------------------------------------------------------
+    def input(self, plain=None, level=None, scale_bits=None) -> Value:
+        assert not self.ops, "arguments occupy the first registers: declare them before any op"
+        p = self._tile(plain) if (plain is not None and self.shadow) else None
+        v = self._new(self.init_level if level is None else level, self.waterline if scale_bits is None else scale_bits, p)
+        self.args.append(v)
+        return v
+
+    def output(self, v: Value):
+        v.last_use = 1 << 60
+        self.results.append(v)
+
+    # ---- ciphertext ops ------------------------------------------------------------------------------------------
+    def rotate(self, x: Value, offset: int) -> Value:
+        assert -(1 << 15) <= offset < (1 << 15)
+        out = self._new(x.level, x.scale_bits, np.roll(x.plain, -offset) if self.shadow else None)
+        self._emit(OP_ROTATE, out, x, offset & 0xFFFF)
+        return out
+
+    def negate(self, x: Value) -> Value:
+        out = self._new(x.level, x.scale_bits, -x.plain if self.shadow else None)
+        self._emit(OP_NEGATE, out, x)
+        return out
+
+    def rescale(self, x: Value) -> Value:
+        assert x.level > 1, "out of levels: bootstrap first"
+        out = self._new(x.level - 1, x.scale_bits - self.rescale_bits, x.plain)
+        self._emit(OP_RESCALE, out, x)
+        return out
+
+    def modswitch(self, x: Value, down: int) -> Value:
+        if down <= 0:
+            return x
+        assert x.level - down >= 1
+        out = self._new(x.level - down, x.scale_bits, x.plain)
+        self._emit(OP_MODSWITCH, out, x, down)
+        return out
+
+    def upscale(self, x: Value, bits: int) -> Value:
+        """UpscaleToMulcp: multiply by the all-ones plaintext encoded at scale 2^bits (constant index -1)."""
+        if bits <= 0:
+            return x
+        reg = self._encode(0xFFFF, x.level, bits)
+        out = self._new(x.level, x.scale_bits + bits, x.plain)
+        self._emit(OP_MULCP, out, x, reg)
+        return out
+
+    def bootstrap(self, x: Value, target_level=None) -> Value:
+        t = self.init_level if target_level is None else target_level
+        out = self._new(t, x.scale_bits, x.plain)
+        self._emit(OP_BOOTSTRAP, out, x, t)
+        return out
+
+    def _normalise(self, x: Value) -> Value:
+        while x.scale_bits - self.rescale_bits >= self.waterline and x.level > self.min_level:
+            x = self.rescale(x)
+        return x
+
+    def _match(self, x: Value, y: Value, scales: bool):
+        lv = min(x.level, y.level)
+        x, y = self.modswitch(x, x.level - lv), self.modswitch(y, y.level - lv)
+        if scales and x.scale_bits != y.scale_bits:
+            s = max(x.scale_bits, y.scale_bits)
+            x, y = self.upscale(x, s - x.scale_bits), self.upscale(y, s - y.scale_bits)
+        return x, y
+
+    def add(self, x: Value, y: Value) -> Value:
+        x, y = self._match(x, y, True)
+        out = self._new(x.level, y.scale_bits, x.plain + y.plain if self.shadow else None)
+        self._emit(OP_ADDCC, out, x, y.id, True)
+        return out
+
+    def sub(self, x: Value, y: Value) -> Value:
+        return self.add(x, self.negate(y))
+
+    def add_plain(self, x: Value, vec) -> Value:
+        reg = self._encode(self._const(vec), x.level, x.scale_bits)
+        out = self._new(x.level, x.scale_bits, x.plain + self._tile(vec) if self.shadow else None)
+        self._emit(OP_ADDCP, out, x, reg)
+        return out
+
+    def mul_plain(self, x: Value, vec, scale_bits=None, normalise=True) -> Value:
+        sb = self.waterline if scale_bits is None else scale_bits
+        reg = self._encode(self._const(vec), x.level, sb)
+        out = self._new(x.level, x.scale_bits + sb, x.plain * self._tile(vec) if self.shadow else None)
+        self._emit(OP_MULCP, out, x, reg)
+        return self._normalise(out) if normalise else out
+
+    def normalise(self, x: Value) -> Value:
+        """rescale while the scale stays at or above the waterline (what WaterlineRescaling does after a sum)"""
+        return self._normalise(x)
+
+    def mul(self, x: Value, y: Value) -> Value:
+        x, y = self._match(x, y, False)
+        out = self._new(x.level, x.scale_bits + y.scale_bits, x.plain * y.plain if self.shadow else None)
+        self._emit(OP_MULCC, out, x, y.id, True)
+        return self._normalise(out)
+
+    # ---- register allocation + serialisation -----------------------------------------------------------------------
+    def assemble(self, preserve_args=True):
+        """Returns (cst_bytes, hevm_bytes, info).  Cipher registers: arguments first, then greedy reuse of dead ones.
+        preserve_args keeps the argument registers out of the recycling pool, so a loaded program can be run()
+        repeatedly on the same encrypted inputs (every other register is written before it is read)."""
+        reg_of: dict[int, int] = {}
+        free: list[int] = []
+        next_reg = 0
+        for a in self.args:
+            reg_of[a.id] = next_reg
+            next_reg += 1
+        wire = np.zeros((len(self.ops), 4), dtype=np.uint16)
+        for idx, op in enumerate(self.ops):
+            if op.opcode == OP_ENCODE:
+                wire[idx] = (OP_ENCODE, op.dst, op.lhs, op.rhs)
+                continue
+            lhs_reg = reg_of[op.lhs]
+            rhs = reg_of[op.rhs] if op.rhs_is_value else op.rhs
+            # sources that die here can be recycled as the destination (kernels are alias-safe)
+            dying = [v for v in ({op.lhs} | ({op.rhs} if op.rhs_is_value else set())) if self.values[v].last_use == idx]
+            for v in dying:
+                if not (preserve_args and reg_of[v] < len(self.args)):
+                    free.append(reg_of[v])
+            if free:
+                dst_reg = free.pop()
+            else:
+                dst_reg = next_reg
+                next_reg += 1
+            reg_of[op.dst] = dst_reg
+            if self.values[op.dst].last_use < 0:  # never read: dead immediately
+                free.append(dst_reg)
+            assert max(dst_reg, lhs_reg) < 0xFFFF
+            wire[idx] = (op.opcode, dst_reg, lhs_reg, rhs & 0xFFFF)
+        hevm = pack_hevm([a.scale_bits for a in self.args], [a.level for a in self.args],
+                         [r.scale_bits for r in self.results], [r.level for r in self.results],
+                         [reg_of[r.id] for r in self.results], next_reg, self.num_plain, self.init_level, wire)
+        info = {"num_ctxt": next_reg, "num_ptxt": self.num_plain, "num_ops": len(self.ops),
+                "op_mix": {OP_NAMES[k]: int((wire[:, 0] == k).sum()) for k in range(11)}}
+        return pack_cst(self.constants), hevm, info
+
+    def write(self, cst_path, hevm_path):
+        cst, hevm, info = self.assemble()
+        Path(cst_path).write_bytes(cst)
+        Path(hevm_path).write_bytes(hevm)
+        return info
+
+    def expected(self):
+        return [r.plain for r in self.results]
+
+
+# ---- programs of the reference's example suite, hand-assembled ------------------------------------------------------
+def sobel_filter(image64: np.ndarray, **kw) -> Builder:
+    """examples/benchmarks/SobelFilter.py:9-26 (expected result: examples/tests/SobelFilter.py:17-35)."""
+    b = Builder(**kw)
+    x = b.input(image64)
+    F = [[-1, 0, 1], [-2, 0, 2], [-1, 0, 1]]
+    Ix = Iy = None
+    for i in range(3):
+        for j in range(3):
+            rot = b.rotate(x, i * 64 + j)
+            for coef, which in ((F[i][j], "x"), (F[j][i], "y")):
+                if coef == 0:
+                    continue
+                h = b.mul_plain(rot, [float(coef)])
+                if which == "x":
+                    Ix = h if Ix is None else b.add(Ix, h)
+                else:
+                    Iy = h if Iy is None else b.add(Iy, h)
+    c = b.add(b.mul(Ix, Ix), b.mul(Iy, Iy))
+    c2 = b.mul(c, c)
+    c3 = b.mul(c2, c)
+    d = b.add(b.sub(b.mul_plain(c3, [0.173]), b.mul_plain(c2, [1.098])), b.mul_plain(c, [2.214]))
+    b.output(d)
+    return b
+
+
+def linear_regression(xs: np.ndarray, ys: np.ndarray, epochs=2, lr=0.01, logn_data=12, **kw) -> Builder:
+    """examples/benchmarks/LinearRegression.py:5-36: gradient descent with rotate-and-add reductions."""
+    b = Builder(**kw)
+    x, y = b.input(xs), b.input(ys)
+    n = 1 << logn_data
+
+    def reduce_sum(v):
+        for k in range(logn_data):
+            v = b.add(v, b.rotate(v, 1 << k))
+        return v
+
+    w = bias = None
+    for _ in range(epochs):
+        pred = x if w is None else b.mul(x, w)
+        if w is None:
+            pred = b.mul_plain(x, [0.0])
+        if bias is not None:
+            pred = b.add(pred, bias)
+        err = b.sub(pred, y)
+        gw = b.mul_plain(reduce_sum(b.mul(err, x)), [lr * 2.0 / n])
+        gb = b.mul_plain(reduce_sum(err), [lr * 2.0 / n])
+        w = b.negate(gw) if w is None else b.sub(w, gw)
+        bias = b.negate(gb) if bias is None else b.sub(bias, gb)
+    b.output(w)
+    b.output(bias)
+    return b
+
+
+def offset_with_naf_weight(rng, weight: int, max_bit=12) -> int:
+    """A rotation offset whose non-adjacent form has exactly `weight` non-zero digits, i.e. that costs `weight`
+    key-switch hops under SEAL's default power-of-two Galois keys (Evaluator::rotate_internal)."""
+    while True:
+        bits = sorted(int(v) for v in rng.choice(np.arange(0, max_bit + 1), size=weight, replace=False))
+        if all(b2 - b1 >= 2 for b1, b2 in zip(bits, bits[1:])):
+            break
+    signs = rng.choice([-1, 1], size=weight)
+    off = int(sum(int(sg) * (1 << b) for sg, b in zip(signs, bits)))
+    return off if off != 0 else 1
+
+
+# hop histogram of the traced ResNet: 1 hop 1 769, 2: 286, 3: 185, 4: 144, 5: 66, 6: 18 of 2 510
+RESNET_TAP_HOPS = [1] * 75 + [2] * 14 + [3] * 9 + [4] * 7 + [5] * 3 + [6] * 1
+
+
+def resnet_shaped(seed=100, slots=1 << 14, layers=20, init_level=13, waterline=40, shadow=False, mulcp_per_tap=2,
+                  mulcc_per_layer=18, addcp_per_layer=30, neg_per_layer=7, tap_hops=None, reduce_steps=13, conv_level=3,
+                  act_level=5, min_level=2) -> Builder:
+    """A synthetic program with the traced op mix of examples/benchmarks/ResNet.py at nt = 2^14 (SURVEY.md App. C:
+    2 510 rotates = 3 910 key-switch hops, 4 822 ct*pt, 361 ct*ct, ~5.9 k ct+ct, 591 ct+pt, 133 negates).
+
+    Level schedule: the reference's own numbers (README.md:176-188: 53.7 s over ~4.3 k key switches = 12.6 ms each,
+    against profiled_SEAL_CPU.json's 8.0 ms at 2 primes / 13.6 ms at 3) say the DaCapo-compiled program keeps its
+    ciphertexts at 2-3 primes -- cheap because the SEAL VM's "bootstrap" is a decrypt/re-encrypt -- so every layer
+    here runs its convolution rotations at `conv_level` primes and its ct*ct chain between `act_level` and
+    `min_level` (= the config's levelLowerBound 2), re-encrypting (opcode 10) whenever it runs out of levels.
+    Each "layer" = multiplexed convolution (rotate, weight multiply, accumulate), rotate-and-sum channel reduction,
+    bias adds, polynomial activation.  No compiled ResNet .hevm can be produced here (needs hecate-opt); if one is
+    supplied the runtime runs it unchanged."""
+    rng = np.random.default_rng(seed)
+    b = Builder(slots=slots, waterline=waterline, init_level=init_level, shadow=shadow, min_level=1)
+    x = b.input(rng.uniform(-0.5, 0.5, slots) if shadow else None)
+    tap_hops = RESNET_TAP_HOPS if tap_hops is None else tap_hops
+    max_bit = int(np.log2(slots)) - 2
+    w = lambda s=0.1: rng.uniform(-s, s, slots if shadow else 16)  # noqa: E731
+
+    def at_level(v, lvl):  # bring a value to exactly `lvl` primes
+        if v.level < lvl:
+            return b.bootstrap(v, lvl)
+        return b.modswitch(v, v.level - lvl)
+
+    for layer in range(layers):
+        x = at_level(x, conv_level)
+        acc = None
+        for h in tap_hops:
+            r = b.rotate(x, offset_with_naf_weight(rng, h, max_bit))
+            for _ in range(mulcp_per_tap):  # products are summed first and rescaled once, as the compiler schedules it
+                term = b.mul_plain(r, w(0.02), normalise=False)
+                acc = term if acc is None else b.add(acc, term)
+        acc = b.normalise(acc)
+        acc = b.normalise(b.mul_plain(acc, [2.0 ** -min(reduce_steps, 6)], scale_bits=60 - acc.scale_bits if acc.scale_bits < 60
+                                      else 20, normalise=False))
+        for k in range(reduce_steps):  # rotate-and-sum reduction across packed channels
+            acc = b.add(acc, b.rotate(acc, 1 << (k % (max_bit + 1))))
+        for _ in range(addcp_per_layer):
+            acc = b.add_plain(acc, w(0.01))
+        for _ in range(neg_per_layer // 2):
+            acc = b.negate(b.negate(acc))
+        if neg_per_layer % 2:
+            acc = b.negate(acc)
+        # activation: a chain of mulcc_per_layer ct*ct products, one level each
+        t = at_level(acc, act_level)
+        base = {act_level: t}
+        for i in range(mulcc_per_layer):
+            if t.level <= min_level:
+                t = b.bootstrap(t, act_level)
+            if t.level not in base:
+                base[t.level] = b.modswitch(base[act_level], act_level - t.level)
+            t = b.mul(t, base[t.level])
+            if i % 6 == 5 and t.level > min_level:
+                t = b.mul_plain(t, w(0.5), scale_bits=60)
+        x = t
+    b.output(x)
+    return b

@@ -33,6 +33,7 @@ def lib():
         L.dc_memcpy_d2h.argtypes = [vp, vp, C.c_size_t]
         L.dc_memset.argtypes = [vp, i32, C.c_size_t]
         L.dc_stream_sync.argtypes = [vp]
+        L.dc_set_device.argtypes = [i32]
         L.dc_event_create.restype = vp
         L.dc_event_destroy.argtypes = [vp]
         L.dc_event_record.argtypes = [vp, vp]
@@ -89,6 +90,13 @@ class DeviceBuffer:
                 self.ptr = None
         except Exception:
             pass
+
+
+def read_device(ptr: int, shape, dtype=np.uint64) -> np.ndarray:
+    """copy a raw device pointer range to a new host array"""
+    out = np.empty(shape, dtype=dtype)
+    lib().dc_memcpy_d2h(out.ctypes.data, ptr, out.nbytes)
+    return out
 
 
 class Context:

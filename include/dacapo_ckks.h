@@ -43,6 +43,9 @@ void dc_memcpy_h2d(void *dst, const void *src, size_t bytes);
 void dc_memcpy_d2h(void *dst, const void *src, size_t bytes);
 void dc_memset(void *dst, int value, size_t bytes);
 void dc_stream_sync(void *stream);
+void dc_set_device(int device);  /* hipSetDevice: one process per GPU, call before creating contexts/VMs */
+void dc_device_sync(void);       /* hipDeviceSynchronize */
+int dc_device_count(void);
 /* HIP events on `stream`, for timing the kernels where they are launched (bench.py) */
 void *dc_event_create(void);
 void dc_event_destroy(void *event);

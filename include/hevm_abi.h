@@ -1,0 +1,91 @@
+/*
+ * hevm_abi.h -- the drop-in boundary: the 18 extern "C" symbols that the reference's libSEAL_HEVM.so exports
+ * (/root/reference/lib/Runtime/SEAL_HEVM.cpp:404-504) and that python/hecate/hecate/runner.py:28-71 binds with
+ * ctypes.  dacapo_amd/lib/libSEAL_HEVM.so exports exactly these names with these signatures; dropping it into
+ * $HECATE/build/lib makes `hc-test <mode> <wl> <bench> SEAL CPU` run on the MI355X.
+ *
+ * Contract kept from the reference: opaque VM handle allocated with `new` and never freed (no destroy symbol);
+ * no error returns -- failures abort the process (SEAL_HEVM.cpp:295,327,496); caller owns every double*;
+ * not thread-safe; `run` returns only when the program has finished ON THE DEVICE (the caller stops its timer on
+ * return, examples/tests/ResNet.py:109-111).
+ */
+#ifndef HEVM_ABI_H
+#define HEVM_ABI_H
+
+#include <stdbool.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* SEAL_HEVM.cpp:405  -- runner.py:35 declares and passes (char*, bool); the 2nd argument is accepted and ignored */
+void *initFullVM(char *dir, bool device);
+/* SEAL_HEVM.cpp:410 */
+void *initClientVM(char *dir);
+/* SEAL_HEVM.cpp:415 */
+void *initServerVM(char *dir);
+/* SEAL_HEVM.cpp:421  -- writes parm/pub/sec/relin/gal ".seal" files (this runtime's own raw-limb container,
+ * not SEAL's serialization: SURVEY.md 8f row f1) */
+void create_context(char *dir);
+/* SEAL_HEVM.cpp:424 */
+void load(void *vm, char *constant, char *vmfile);
+/* SEAL_HEVM.cpp:431  -- the reference takes a std::istream*; runner.py:213 passes a path string (broken upstream).
+ * Here `is` is treated as a NUL-terminated path to the .hevm file whose header is read. */
+void loadClient(void *vm, void *is);
+/* SEAL_HEVM.cpp:439 */
+void encrypt(void *vm, int64_t i, double *dat, int len);
+/* SEAL_HEVM.cpp:446  -- writes N/2 doubles */
+void decrypt(void *vm, int64_t i, double *dat);
+/* SEAL_HEVM.cpp:458 */
+void decrypt_result(void *vm, int64_t i, double *dat);
+/* SEAL_HEVM.cpp:464 */
+int64_t getResIdx(void *vm, int64_t i);
+/* SEAL_HEVM.cpp:470  -- pointer to this runtime's ciphertext register descriptor (struct hevm_ctxt below) */
+void *getCtxt(void *vm, int64_t id);
+/* SEAL_HEVM.cpp:475 */
+void preprocess(void *vm);
+/* SEAL_HEVM.cpp:479 */
+void run(void *vm);
+/* SEAL_HEVM.cpp:483 */
+int64_t getArgLen(void *vm);
+/* SEAL_HEVM.cpp:487 */
+int64_t getResLen(void *vm);
+/* SEAL_HEVM.cpp:491 */
+void setDebug(void *vm, bool enable);
+/* SEAL_HEVM.cpp:495  -- the reference asserts; here the VM is always on the GPU and the call is a no-op */
+void setToGPU(void *vm, bool ongpu);
+/* SEAL_HEVM.cpp:498 */
+void printMem(void *vm);
+
+/* What getCtxt returns (the reference returns seal::Ciphertext*): a ciphertext register resident in HBM. */
+struct hevm_ctxt {
+    uint64_t *data;     /* device pointer: [2][capacity][N] uint64 limbs, NTT domain */
+    int64_t poly_stride; /* elements between the two polynomials */
+    int32_t level;      /* number of RNS primes currently in the ciphertext (HEVM "level") */
+    int32_t reserved;
+    double scale;
+};
+
+/* ---- extensions (not in the reference) used by this repo's tests and bench ------------------------------- */
+/* Generate parameters + the reference's key set in HBM without touching disk.  logN/num_primes = 0 take the
+ * reference's hard-coded N = 2^15, 14 primes (SEAL_HEVM.cpp:39-40). */
+void *hevm_init_seeded(int logN, int num_primes, uint64_t seed);
+/* the kernel-level context (dc_context*, include/dacapo_ckks.h) behind a VM */
+void *hevm_context(void *vm);
+/* device pointers to key material: relin key, galois key for `elt` (NULL if absent), secret/public key */
+const uint64_t *hevm_relin_key(void *vm);
+const uint64_t *hevm_galois_key(void *vm, uint32_t elt);
+const uint64_t *hevm_secret_key(void *vm);
+const uint64_t *hevm_public_key(void *vm);
+/* device pointer + level + scale of plaintext register i after preprocess() */
+const uint64_t *hevm_plain(void *vm, int64_t i, int32_t *level, double *scale);
+/* load a program from memory images of the .cst / .hevm files */
+void hevm_load_mem(void *vm, const void *cst, uint64_t cst_len, const void *hevm, uint64_t hevm_len);
+/* per-opcode launch statistics of the last run(): counts[11], NTT-equivalents executed */
+void hevm_last_run_stats(void *vm, int64_t *op_counts /*[11]*/, int64_t *keyswitches, int64_t *ntts);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

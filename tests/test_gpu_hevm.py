@@ -1,0 +1,205 @@
+"""GPU: the HEVM drop-in boundary (include/hevm_abi.h) end to end -- runner-style call sequence on assembled
+programs, checked (a) bit-exactly against the oracle VM fed with the same key/plaintext/input limbs and
+(b) numerically (RMS) against the plaintext computation, as examples/tests/*.py do."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle.oracle import Ciphertext, Oracle, OracleVM, Plaintext, read_cst, read_hevm
+
+
+def _import_keys(o: Oracle, hevm, ll):
+    """pull the GPU VM's key material into the oracle so both interpret the program on identical limbs"""
+    from dacapo_amd import runner
+
+    lw = runner.lw
+    K, N = o.K, o.N
+    o.sk = ll.read_device(lw.hevm_secret_key(hevm.vm), (K, N))
+    o.pk = ll.read_device(lw.hevm_public_key(hevm.vm), (2, K, N))
+    o.relin = ll.read_device(lw.hevm_relin_key(hevm.vm), (K - 1, 2, K, N))
+    o.galois = {}
+    for elt in o.default_galois_elts():
+        p = lw.hevm_galois_key(hevm.vm, elt)
+        assert p, f"default Galois key {elt} missing"
+        o.galois[elt] = ll.read_device(p, (K - 1, 2, K, N))
+
+
+def _get_ct(hevm, ll, reg):
+    c = hevm.getCtxt(reg)
+    full = ll.read_device(c.data, (2, c.poly_stride // hevm.N, hevm.N))
+    return Ciphertext(np.ascontiguousarray(full[:, : c.level]), c.scale)
+
+
+def _mirror_vm(hevm, ll, o, cst, hv, tmp_path):
+    import ctypes
+
+    from dacapo_amd import runner
+
+    (tmp_path / "p.cst").write_bytes(cst)
+    (tmp_path / "p.hevm").write_bytes(hv)
+    ovm = OracleVM(o)
+    ovm.load(tmp_path / "p.cst", tmp_path / "p.hevm")
+    for i in range(ovm.prog.num_ptxt):
+        lvl, sc = ctypes.c_int32(), ctypes.c_double()
+        p = runner.lw.hevm_plain(hevm.vm, i, ctypes.byref(lvl), ctypes.byref(sc))
+        if p:
+            ovm.plains[i] = Plaintext(ll.read_device(p, (lvl.value, o.N)), sc.value)
+    return ovm
+
+
+@pytest.fixture(scope="module")
+def vm13():
+    from dacapo_amd import lowlevel as ll
+    from dacapo_amd import runner
+
+    hevm = runner.HEVM(seed=0x4845564D, logN=13, num_primes=6)
+    o = Oracle(13, 6)
+    _import_keys(o, hevm, ll)
+    return hevm, o, ll
+
+
+def test_generated_keys_satisfy_key_equations(vm13):
+    hevm, o, ll = vm13
+    K, N = o.K, o.N
+    # secret is ternary; pk decrypts to small noise
+    s = o.ntt_inv(o.sk, list(range(K)))
+    for i, q in enumerate(o.primes):
+        assert set(np.unique(s[i]).tolist()) <= {0, 1, q - 1}
+    e = o.ntt_inv(o.poly_add(o.pk[0], o.poly_mul(o.pk[1], o.sk)), list(range(K)))
+    cent = np.where(e[0] > o.primes[0] // 2, e[0].astype(np.int64) - np.int64(o.primes[0]), e[0].astype(np.int64))
+    assert np.abs(cent).max() <= 21 and cent.std() > 2.0
+    # relin digit j: c0 + c1 s - [i==j] (P mod q_j) s^2 is small
+    sk2 = o.poly_mul(o.sk, o.sk)
+    for j in (0, K - 2):
+        d = o.poly_add(o.relin[j, 0], o.poly_mul(o.relin[j, 1], o.sk))
+        fac = np.zeros((K, N), dtype=np.uint64)
+        fac[j, :] = o.primes[K - 1] % o.primes[j]
+        d = o.poly_sub(d, o.poly_mul(sk2, fac))
+        e = o.ntt_inv(d, list(range(K)))
+        for i in (0, j, K - 1):
+            q = o.primes[i]
+            c = np.where(e[i] > q // 2, e[i].astype(np.int64) - np.int64(q), e[i].astype(np.int64))
+            assert np.abs(c).max() <= 21
+
+
+def test_sobel_program_bit_exact_and_rms(vm13, tmp_path):
+    from dacapo_amd import hevm_asm as ha
+
+    hevm, o, ll = vm13
+    rng = np.random.default_rng(100)
+    img = rng.uniform(0, 1, 4096)
+    b = ha.sobel_filter(img, slots=o.slots, init_level=5)
+    cst, hv, info = b.assemble()
+    hevm.load_mem(cst, hv)
+    assert hevm.arglen == 1 and hevm.reslen == 1
+    ovm = _mirror_vm(hevm, ll, o, cst, hv, tmp_path)
+    # encoder parity: GPU-VM plaintext limbs vs oracle encode of the same constants (FP contraction may differ by 1 ulp)
+    ovm2 = OracleVM(o)
+    ovm2.load(tmp_path / "p.cst", tmp_path / "p.hevm")
+    ovm2.preprocess()
+    for i, (a, bb) in enumerate(zip(ovm.plains, ovm2.plains)):
+        ca = o.ntt_inv(a.data, list(range(a.ell))).astype(np.int64)
+        cb = o.ntt_inv(bb.data, list(range(bb.ell))).astype(np.int64)
+        assert a.scale == bb.scale and np.abs(ca - cb).max() <= 1
+    hevm.setInput(0, img)
+    ovm.ciphers[0] = _get_ct(hevm, ll, 0)
+    assert ovm.ciphers[0].ell == 5 and ovm.ciphers[0].scale == 2.0**40
+    # fresh encryption decrypts correctly under the oracle too
+    assert np.abs(o.decode(o.decrypt(ovm.ciphers[0])) - img[np.arange(o.slots) % 4096]).max() < 1e-6
+    hevm.run()
+    ovm.run()
+    got = _get_ct(hevm, ll, ovm.prog.res_dst[0])
+    want = ovm.ciphers[ovm.prog.res_dst[0]]
+    assert got.ell == want.ell and got.scale == want.scale
+    assert (got.data == want.data).all()  # program-level bit-exactness
+    res = hevm.getOutput()
+    ref = b.expected()[0]
+    rms = np.sqrt(np.mean((res[0] - ref) ** 2))
+    assert rms < 1e-4, rms
+    assert np.abs(ovm.decrypt_result(0) - res[0]).max() < 1e-9  # host decoder == oracle decoder
+    st = hevm.stats()
+    assert st["op_counts"][1] == 9 and st["op_counts"][8] == 4 and st["keyswitches"] >= 4 + 8
+
+
+def test_linear_regression_two_inputs_two_outputs(vm13):
+    from dacapo_amd import hevm_asm as ha
+
+    hevm, o, ll = vm13
+    rng = np.random.default_rng(100)
+    xs = rng.uniform(-1, 1, 4096)
+    ys = 0.7 * xs + 0.2 + rng.normal(0, 0.01, 4096)
+    b = ha.linear_regression(xs, ys, epochs=2, logn_data=12, slots=o.slots, init_level=5, min_level=1)
+    cst, hv, info = b.assemble()
+    hevm.load_mem(cst, hv)
+    assert hevm.arglen == 2 and hevm.reslen == 2
+    hevm.setInput(0, xs)
+    hevm.setInput(1, ys)
+    hevm.run()
+    res = hevm.getOutput()
+    for r, e in zip(res, b.expected()):
+        assert np.sqrt(np.mean((r - e) ** 2)) < 1e-4
+
+
+def test_rotation_by_arbitrary_offsets_and_bootstrap_opcode(vm13, tmp_path):
+    from dacapo_amd import hevm_asm as ha
+
+    hevm, o, ll = vm13
+    rng = np.random.default_rng(7)
+    x = rng.uniform(-1, 1, o.slots)
+    b = ha.Builder(slots=o.slots, init_level=5)
+    v = b.input(x)
+    acc = b.rotate(v, 37)          # NAF: 3 hops
+    acc = b.add(acc, b.rotate(v, -100))
+    acc = b.add(acc, b.rotate(v, 4))
+    m = b.mul(acc, acc)            # scale 80
+    m = b.mul_plain(m, [0.5])      # 120 -> rescale
+    z = b.bootstrap(m, 5)          # SEAL VM's decrypt/re-encrypt
+    z = b.add_plain(z, [0.25])
+    b.output(z)
+    cst, hv, info = b.assemble()
+    hevm.load_mem(cst, hv)
+    hevm.setInput(0, x)
+    hevm.run()
+    res = hevm.getOutput()[0]
+    assert np.sqrt(np.mean((res - b.expected()[0]) ** 2)) < 1e-4
+    c = hevm.getCtxt(int(read_hevm_bytes(hv).res_dst[0]))
+    assert c.level == 5
+
+
+def read_hevm_bytes(hv):
+    import tempfile
+
+    with tempfile.NamedTemporaryFile(suffix=".hevm") as f:
+        f.write(hv)
+        f.flush()
+        return read_hevm(f.name)
+
+
+def test_file_based_runner_sequence(tmp_path, monkeypatch):
+    """the reference's call sequence through files: create_context -> initFullVM -> load -> encrypt -> run -> decrypt"""
+    from dacapo_amd import hevm_asm as ha
+    from dacapo_amd import runner
+
+    monkeypatch.setenv("DACAPO_HEVM_LOGN", "12")
+    monkeypatch.setenv("DACAPO_HEVM_PRIMES", "4")
+    keydir = tmp_path / "keys"
+    hevm = runner.HEVM(path=str(keydir))
+    assert sorted(p.name for p in keydir.iterdir()) == ["gal.seal", "parm.seal", "pub.seal", "relin.seal", "sec.seal"]
+    assert hevm.logN == 12 and hevm.K == 4
+    rng = np.random.default_rng(3)
+    x = rng.uniform(-1, 1, hevm.slots)
+    b = ha.Builder(slots=hevm.slots, init_level=3)
+    v = b.input(x)
+    y = b.add(b.mul(v, b.rotate(v, 1)), b.mul_plain(v, [2.0]))
+    b.output(y)
+    info = b.write(tmp_path / "_hecate_t.cst", tmp_path / "t.40._hecate_t.hevm")
+    hevm.load(str(tmp_path / "_hecate_t.cst"), str(tmp_path / "t.40._hecate_t.hevm"))
+    hevm.setInput(0, x)
+    hevm.run()
+    res = hevm.getOutput()[0]
+    assert np.sqrt(np.mean((res - b.expected()[0]) ** 2)) < 1e-4
+    # a second VM instance loading the same key directory decrypts what the first one produced? (server/client split)
+    client = runner.HEVM(path=str(keydir), option="client")
+    client.load(str(tmp_path / "_hecate_t.cst"), str(tmp_path / "t.40._hecate_t.hevm"))
+    assert client.arglen == 1 and client.reslen == 1

@@ -1,0 +1,69 @@
+"""CPU-only: wire formats, assembler, C-ABI export check."""
+import ctypes
+import re
+import struct
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def test_hevm_wire_format_roundtrip(tmp_path):
+    from dacapo_amd import hevm_asm as ha
+    from oracle.oracle import read_cst, read_hevm
+
+    b = ha.Builder(slots=1 << 11, init_level=4)
+    x = b.input(np.arange(8.0))
+    y = b.add(b.rotate(x, -3), b.mul_plain(x, [1.0, 2.0]))
+    y = b.mul(y, y)
+    b.output(y)
+    info = b.write(tmp_path / "a.cst", tmp_path / "a.hevm")
+    raw = (tmp_path / "a.hevm").read_bytes()
+    magic, hsize, na, nr = struct.unpack_from("<IIQQ", raw, 0)
+    assert (magic, hsize, na, nr) == (0x4845564D, 24, 1, 1)  # HEVMHeader.h:10-17
+    body_len, nops, nct, npt, init_level = struct.unpack_from("<5Q", raw, 24)
+    assert body_len == 40 + 8 * (2 * na + 3 * nr) and init_level == 4 and nops == info["num_ops"]
+    assert len(raw) == 24 + body_len + 8 * nops
+    p = read_hevm(tmp_path / "a.hevm")
+    assert p.arg_scale == [40] and p.arg_level == [4]
+    rot = [op for op in p.ops if op[0] == 1][0]
+    assert np.int16(rot[3]) == -3  # CKKSOps.td:96 : rhs carries the signed offset
+    enc = [op for op in p.ops if op[0] == 0][0]
+    assert enc[3] == (4 << 10) + 40  # CKKSOps.td:75
+    consts = read_cst(tmp_path / "a.cst")
+    assert len(consts) == 1 and consts[0].tolist() == [1.0, 2.0]
+    # registers: argument 0 first, destination registers recycled
+    assert p.num_ctxt <= 3 and p.res_dst[0] < p.num_ctxt
+    assert np.allclose(b.expected()[0][:8], ((np.roll(np.arange(8.0)[np.arange(2048) % 8], 3) + np.arange(8.0)[np.arange(2048) % 8] * np.array([1.0, 2.0])[np.arange(2048) % 2]) ** 2)[:8])
+
+
+def test_resnet_shaped_program_has_the_traced_op_mix():
+    from dacapo_amd import hevm_asm as ha
+
+    b = ha.resnet_shaped()
+    cst, hv, info = b.assemble()
+    mix = info["op_mix"]
+    # SURVEY.md App. C targets: 2510 rotates, 4822 mulcp, 361 mulcc, ~5940 addcc, 591 addcp, 133 negates
+    assert 2300 <= mix["rotate"] <= 2700 and 4200 <= mix["mulcp"] <= 5200 and 340 <= mix["mulcc"] <= 380
+    assert 4000 <= mix["addcc"] <= 6500 and 550 <= mix["addcp"] <= 650 and 120 <= mix["negate"] <= 150
+    assert 10 <= mix["bootstrap"] <= 25 and info["num_ctxt"] < 32
+
+
+def test_library_exports_every_declared_symbol():
+    """the C-ABI library loads without a GPU and exports everything include/*.h declares"""
+    from dacapo_amd import LIB_PATH
+
+    lib = ctypes.CDLL(str(LIB_PATH))
+    names = set()
+    for h in ("hevm_abi.h", "dacapo_ckks.h"):
+        text = (ROOT / "include" / h).read_text()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        names |= set(re.findall(r"\b(\w+)\s*\([^;{]*\)\s*;", text))
+    names -= {"defined"}
+    reference_18 = {"initFullVM", "initClientVM", "initServerVM", "create_context", "load", "loadClient", "encrypt", "decrypt",
+                    "decrypt_result", "getResIdx", "getCtxt", "preprocess", "run", "getArgLen", "getResLen", "setDebug",
+                    "setToGPU", "printMem"}
+    assert reference_18 <= names and len(names) >= 18 + 25
+    for n in sorted(names):
+        assert hasattr(lib, n), n
