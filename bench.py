@@ -74,7 +74,7 @@ def ntt_micro_leg(ll, iters=200):
     return {"workload": "single forward NTT, N=2^14, 1 limb", "us_per_ntt_back_to_back": round(us, 2)}
 
 
-def cpu_baseline_leg(cst: bytes, hv: bytes, budget_s=18.0):
+def cpu_baseline_leg(cst: bytes, hv: bytes, budget_s=15.0):
     """oracle VM (1 thread) on a prefix of the same program; returns NTT-equivalents/s"""
     import tempfile
 
@@ -98,8 +98,6 @@ def cpu_baseline_leg(cst: bytes, hv: bytes, budget_s=18.0):
             src = np.ones(1) if lhs == 0xFFFF else vm.consts[lhs]
             vm.plains[dst] = vm.encode_internal(src, rhs >> 10, rhs & 0x3FF)
             continue
-        if opcode == 10:
-            break  # the sample stops at the first re-encryption
         lvl = vm.ciphers[lhs].ell
         t = time.perf_counter()
         vm.step(op)

@@ -93,6 +93,11 @@ class Builder:
 
     # ---- helpers ----------------------------------------------------------------------------------------------
     def _new(self, level, scale_bits, plain):
+        if self.shadow and plain is not None:
+            # CKKS capacity: |value| * scale must stay below Q_level / 2 or decryption wraps around
+            peak = float(np.max(np.abs(plain))) if len(plain) else 0.0
+            if peak > 0 and np.log2(peak) + scale_bits > self.rescale_bits * level - 2:
+                raise OverflowError(f"value of magnitude {peak:.3g} at scale 2^{scale_bits} does not fit {level} prime(s)")
         v = Value(len(self.values), level, scale_bits, plain if self.shadow else None)
         self.values.append(v)
         return v

@@ -53,8 +53,8 @@ def vm13():
     from dacapo_amd import lowlevel as ll
     from dacapo_amd import runner
 
-    hevm = runner.HEVM(seed=0x4845564D, logN=13, num_primes=6)
-    o = Oracle(13, 6)
+    hevm = runner.HEVM(seed=0x4845564D, logN=13, num_primes=7)
+    o = Oracle(13, 7)
     _import_keys(o, hevm, ll)
     return hevm, o, ll
 
@@ -89,7 +89,7 @@ def test_sobel_program_bit_exact_and_rms(vm13, tmp_path):
     hevm, o, ll = vm13
     rng = np.random.default_rng(100)
     img = rng.uniform(0, 1, 4096)
-    b = ha.sobel_filter(img, slots=o.slots, init_level=5)
+    b = ha.sobel_filter(img, slots=o.slots, init_level=6)
     cst, hv, info = b.assemble()
     hevm.load_mem(cst, hv)
     assert hevm.arglen == 1 and hevm.reslen == 1
@@ -104,7 +104,7 @@ def test_sobel_program_bit_exact_and_rms(vm13, tmp_path):
         assert a.scale == bb.scale and np.abs(ca - cb).max() <= 1
     hevm.setInput(0, img)
     ovm.ciphers[0] = _get_ct(hevm, ll, 0)
-    assert ovm.ciphers[0].ell == 5 and ovm.ciphers[0].scale == 2.0**40
+    assert ovm.ciphers[0].ell == 6 and ovm.ciphers[0].scale == 2.0**40
     # fresh encryption decrypts correctly under the oracle too
     assert np.abs(o.decode(o.decrypt(ovm.ciphers[0])) - img[np.arange(o.slots) % 4096]).max() < 1e-6
     hevm.run()
@@ -116,7 +116,7 @@ def test_sobel_program_bit_exact_and_rms(vm13, tmp_path):
     res = hevm.getOutput()
     ref = b.expected()[0]
     rms = np.sqrt(np.mean((res[0] - ref) ** 2))
-    assert rms < 1e-4, rms
+    assert rms < 1e-4 * max(1.0, np.abs(ref).max()), rms
     assert np.abs(ovm.decrypt_result(0) - res[0]).max() < 1e-9  # host decoder == oracle decoder
     st = hevm.stats()
     assert st["op_counts"][1] == 9 and st["op_counts"][8] == 4 and st["keyswitches"] >= 4 + 8
@@ -129,7 +129,7 @@ def test_linear_regression_two_inputs_two_outputs(vm13):
     rng = np.random.default_rng(100)
     xs = rng.uniform(-1, 1, 4096)
     ys = 0.7 * xs + 0.2 + rng.normal(0, 0.01, 4096)
-    b = ha.linear_regression(xs, ys, epochs=2, logn_data=12, slots=o.slots, init_level=5, min_level=1)
+    b = ha.linear_regression(xs, ys, epochs=2, logn_data=12, slots=o.slots, init_level=6, min_level=1)
     cst, hv, info = b.assemble()
     hevm.load_mem(cst, hv)
     assert hevm.arglen == 2 and hevm.reslen == 2
@@ -147,7 +147,7 @@ def test_rotation_by_arbitrary_offsets_and_bootstrap_opcode(vm13, tmp_path):
     hevm, o, ll = vm13
     rng = np.random.default_rng(7)
     x = rng.uniform(-1, 1, o.slots)
-    b = ha.Builder(slots=o.slots, init_level=5)
+    b = ha.Builder(slots=o.slots, init_level=6)
     v = b.input(x)
     acc = b.rotate(v, 37)          # NAF: 3 hops
     acc = b.add(acc, b.rotate(v, -100))
