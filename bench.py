@@ -212,6 +212,7 @@ def main():
                    "ops": info["op_mix"], "key_switches_per_step": stats["keyswitches"], "ntt_equivalents_per_step": ntts_per_step,
                    "parallelism": f"replicas x{world} (no collective in the op path)"},
         "hevm_wall_s": round(ms_per_step / 1e3, 4),
+        "hevm_bootstrap_s_per_step": round(stats["bootstrap_s"], 4),
         "setup_s_untimed": round(t_setup, 1),
         "roofline": roof,
         "ntt_micro": micro,

@@ -10,6 +10,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <fstream>
 #include <iostream>
 
@@ -133,6 +134,85 @@ __global__ __launch_bounds__(kVmThreads) void decrypt_kernel(u64 *__restrict__ o
 #pragma unroll
     for (int t = 0; t < 2; t++) r[t] = addmod(c0[t], mulmod(c1[t], s[t], M), M.q);
     *reinterpret_cast<u64x2 *>(out + (size_t)i * N + off) = r;
+}
+
+
+// ---- opcode 10 on the device -----------------------------------------------------------------------------------
+// The SEAL VM's "bootstrap" (SEAL_HEVM.cpp:328-333) is decrypt -> decode -> encode(scale 2^floor(log2 scale),
+// target level) -> encrypt.  decode keeps the REAL part of every slot and encode re-embeds it, so on the
+// plaintext polynomial m (centred integer coefficients) the pair computes
+//        m' = round( (m + m(X^-1)) / 2 * new_scale / old_scale ),     m(X^-1)_j = -m_{N-j}, m(X^-1)_0 = m_0,
+// (the conjugate automorphism X -> X^{2N-1} is complex conjugation of the slots).  This kernel evaluates exactly that
+// in one pass -- no FFT, no host round trip: CRT-compose each coefficient to a centred double with Garner's
+// mixed-radix digits taken relative to the digits of floor(Q/2) (so small values cancel digit-wise instead of
+// catastrophically), project, scale, round (half away from zero, like std::round in CKKSEncoder::encode) and emit
+// the 128-bit two's-complement integer that lift_i128_kernel reduces into the target primes.
+struct CrtDev {
+    const u64 *inv;  // [ell]       (q_0...q_{k-1})^{-1} mod q_k
+    const u64 *mmod; // [ell][ell]  (q_0...q_{i-1}) mod q_k at [i*ell+k]
+    const u64 *hmod; // [ell]       floor(Q/2) mod q_k
+    const u64 *hdig; // [ell]       mixed-radix digits of floor(Q/2)
+    const double *mdbl; // [ell]    (double)(q_0...q_{k-1})
+};
+constexpr int kMaxCrt = 32;
+
+__device__ inline double crt_centered(const u64 *__restrict__ coef, size_t n, int ell, size_t N,
+                                      const DModulus *__restrict__ mods, const CrtDev c)
+{
+    u64 v[kMaxCrt];
+    double acc = 0.0;
+    for (int k = 0; k < ell; k++) {
+        const DModulus M = mods[k];
+        u64 s = 0;
+        for (int i = 0; i < k; i++) s = addmod(s, mulmod(v[i], c.mmod[i * ell + k], M), M.q);
+        const u64 y = addmod(coef[(size_t)k * N + n], c.hmod[k], M.q);
+        v[k] = mulmod(submod(y, s, M.q), c.inv[k], M);
+    }
+    for (int k = ell - 1; k >= 0; k--) acc += (double)((long long)v[k] - (long long)c.hdig[k]) * c.mdbl[k];
+    return acc;
+}
+
+__device__ inline void store_i128(u64 *lo, u64 *hi, size_t idx, double x)
+{ // x is integral, |x| < 2^120
+    const bool neg = x < 0.0;
+    const double a = fabs(x);
+    u64 l, h;
+    if (a < 0x1p63) {
+        l = (u64)a;
+        h = 0;
+    } else {
+        int e;
+        const double fr = frexp(a, &e); // a = fr * 2^e, fr in [0.5, 1)
+        const u64 mant = (u64)ldexp(fr, 53);
+        const int sh = e - 53; // > 9
+        l = sh < 64 ? mant << sh : 0;
+        h = sh < 64 ? mant >> (64 - sh) : mant << (sh - 64);
+    }
+    if (neg) {
+        l = ~l + 1;
+        h = ~h + (l == 0);
+    }
+    lo[idx] = l;
+    hi[idx] = h;
+}
+
+// grid = (N/2 + 1 threads).  coef: [ell][N] coefficient domain, canonical.
+__global__ __launch_bounds__(kVmThreads) void reencode_kernel(u64 *__restrict__ lo, u64 *__restrict__ hi,
+                                                               const u64 *__restrict__ coef, int ell, size_t N,
+                                                               const DModulus *__restrict__ mods, const CrtDev c, double ratio)
+{
+    const size_t i = (size_t)blockIdx.x * kVmThreads + threadIdx.x;
+    if (i > N / 2) return;
+    if (i == 0) {
+        store_i128(lo, hi, 0, round(crt_centered(coef, 0, ell, N, mods, c) * ratio));
+    } else if (i == N / 2) {
+        store_i128(lo, hi, i, 0.0);
+    } else {
+        const double a = crt_centered(coef, i, ell, N, mods, c), b = crt_centered(coef, N - i, ell, N, mods, c);
+        const double r = round((a - b) * 0.5 * ratio);
+        store_i128(lo, hi, i, r);
+        store_i128(lo, hi, N - i, -r);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -839,23 +919,122 @@ void HEVM::op_mulcp(int dst, int lhs, int rhs)
     const double sc = a.scale * p.scale;
     d.level = a.level, d.scale = sc;
 }
+// host-side constants of the device CRT for level ell (built once per level)
+const HEVM::CrtTables &HEVM::crt_tables(int ell)
+{
+    auto it = crt_.find(ell);
+    if (it != crt_.end()) return it->second;
+    const Context &c = *ctx;
+    if (ell > kMaxCrt || ell > 16) {
+        fprintf(stderr, "[dacapo_amd] device CRT supports up to 16 primes (Q must fit a double's range)\n");
+        abort();
+    }
+    std::vector<u64> inv(ell), mmod((size_t)ell * ell, 0), hmod(ell), hdig(ell);
+    std::vector<double> mdbl(ell);
+    long double prod = 1.0L;
+    for (int k = 0; k < ell; k++) {
+        const u64 qk = c.primes[k];
+        u64 acc = 1;
+        for (int i = 0; i <= k; i++) {
+            mmod[(size_t)i * ell + k] = acc;
+            if (i < k) acc = h_mulmod(acc, c.primes[i] % qk, qk);
+        }
+        inv[k] = h_invmod(acc, qk);
+        mdbl[k] = (double)prod;
+        prod *= (long double)qk;
+    }
+    // h = floor(Q/2) as a multiword integer, then its residues and mixed-radix digits
+    std::vector<u64> Q(ell + 1, 0);
+    Q[0] = 1;
+    for (int k = 0; k < ell; k++) {
+        u128 carry = 0;
+        for (int w = 0; w <= ell; w++) {
+            u128 t = (u128)Q[w] * c.primes[k] + (u64)carry;
+            Q[w] = (u64)t;
+            carry = t >> 64;
+        }
+    }
+    std::vector<u64> h(ell + 1);
+    for (int w = 0; w <= ell; w++) h[w] = (Q[w] >> 1) | (w < ell ? (Q[w + 1] << 63) : 0);
+    for (int k = 0; k < ell; k++) {
+        u128 r = 0;
+        for (int w = ell; w >= 0; w--) r = ((r << 64) | h[w]) % c.primes[k];
+        hmod[k] = (u64)r;
+    }
+    std::vector<u64> t = h;
+    for (int k = 0; k < ell; k++) { // digit k = t mod q_k ; t /= q_k
+        u128 r = 0;
+        for (int w = ell; w >= 0; w--) {
+            u128 cur = (r << 64) | t[w];
+            t[w] = (u64)(cur / c.primes[k]);
+            r = cur % c.primes[k];
+        }
+        hdig[k] = (u64)r;
+    }
+    CrtTables tb;
+    auto up = [&](const void *src, size_t bytes) {
+        void *d = nullptr;
+        DC_HIP_CHECK(hipMalloc(&d, bytes));
+        DC_HIP_CHECK(hipMemcpy(d, src, bytes, hipMemcpyHostToDevice));
+        return d;
+    };
+    tb.inv = (u64 *)up(inv.data(), inv.size() * 8);
+    tb.mmod = (u64 *)up(mmod.data(), mmod.size() * 8);
+    tb.hmod = (u64 *)up(hmod.data(), hmod.size() * 8);
+    tb.hdig = (u64 *)up(hdig.data(), hdig.size() * 8);
+    tb.mdbl = (double *)up(mdbl.data(), mdbl.size() * 8);
+    return crt_.emplace(ell, tb).first->second;
+}
+
 void HEVM::op_bootstrap(int dst, int src, int target_level)
-{ // the SEAL VM's stand-in: decrypt -> decode -> re-encode at `target_level` primes -> encrypt (SEAL_HEVM.cpp:328-333)
+{ // the SEAL VM's stand-in: decrypt -> decode -> re-encode at `target_level` primes -> encrypt (SEAL_HEVM.cpp:328-333),
+  // evaluated on the device (see reencode_kernel)
+    const auto t0 = std::chrono::steady_clock::now();
+    struct Tick {
+        decltype(t0) t;
+        double &acc;
+        ~Tick() { acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); }
+    } tick{ t0, t_bootstrap };
+    Context &c = *ctx;
+    const size_t N = c.N;
     hevm_ctxt &s = reg(src);
     if (debug) std::cout << std::log2(s.scale) << std::endl;
-    std::vector<double> vals(ctx->N >> 1);
-    decrypt(src, vals.data());
-    Plain pt;
-    encode_internal(pt, vals.data(), vals.size(), target_level, (int)(int64_t)std::log2(s.scale));
-    encrypt_plain(reg(dst), pt);
-    DC_HIP_CHECK(hipStreamSynchronize(stream));
-    (void)hipFree(pt.d);
+    const int ell = s.level;
+    if (!keys.sk || !keys.pk || ell < 1 || target_level < 1 || target_level > c.max_level()) {
+        fprintf(stderr, "[dacapo_amd] bootstrap: needs a full VM (secret + public key) and a valid target level\n");
+        abort();
+    }
+    const double new_scale = pow(2.0, (double)(int64_t)std::log2(s.scale)); // SEAL_HEVM.cpp:332 -> :262
+    const CrtTables &tb = crt_tables(ell);
+    u64 *pt = c.d_ks_tmp;      // [ell][N]
+    u64 *lohi = c.d_ks_digits; // [2][N]
+    hipLaunchKernelGGL(decrypt_kernel, dim3((unsigned)(N / (2 * kVmThreads)), (unsigned)ell), dim3(kVmThreads), 0, stream, pt,
+                       view(s), keys.sk, N, c.d_mods);
+    launch_ntt(c, true, pt, (long)N, ell, nullptr, 0, 0, stream);
+    const CrtDev cd{ tb.inv, tb.mmod, tb.hmod, tb.hdig, tb.mdbl };
+    hipLaunchKernelGGL(reencode_kernel, dim3((unsigned)((N / 2 + kVmThreads) / kVmThreads)), dim3(kVmThreads), 0, stream, lohi,
+                       lohi + N, pt, ell, N, c.d_mods, cd, new_scale / s.scale);
+    if (boot_plain.d && boot_plain.level < target_level) {
+        DC_HIP_CHECK(hipStreamSynchronize(stream));
+        (void)hipFree(boot_plain.d);
+        boot_plain.d = nullptr;
+    }
+    if (!boot_plain.d) {
+        boot_plain.d = dalloc((size_t)c.max_level() * N);
+        boot_plain.level = c.max_level();
+    }
+    Plain ptx{ boot_plain.d, target_level, new_scale };
+    hipLaunchKernelGGL(lift_i128_kernel, dim3((unsigned)(N / kVmThreads), (unsigned)target_level), dim3(kVmThreads), 0, stream,
+                       ptx.d, lohi, lohi + N, N, c.d_mods);
+    launch_ntt(c, false, ptx.d, (long)N, target_level, nullptr, 0, 0, stream);
+    encrypt_plain(reg(dst), ptx);
 }
 
 void HEVM::run()
 {
     memset(op_counts, 0, sizeof(op_counts));
     n_keyswitch = n_ntt = 0;
+    t_bootstrap = 0.0;
     int i = (int)((header.hevm_header_size + config.config_body_length) / 8), j = 0;
     for (const WireOp &op : ops) {
         if (debug) {
@@ -1016,6 +1195,7 @@ void hevm_load_mem(void *vm, const void *cst, uint64_t cst_len, const void *hevm
     h->load_constants(cst, cst_len);
     h->load_program(hevm, hevm_len, false);
 }
+double hevm_last_run_bootstrap_seconds(void *vm) { return static_cast<HEVM *>(vm)->t_bootstrap; }
 void hevm_last_run_stats(void *vm, int64_t *op_counts, int64_t *keyswitches, int64_t *ntts)
 {
     auto h = static_cast<HEVM *>(vm);

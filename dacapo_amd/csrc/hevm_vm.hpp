@@ -81,9 +81,19 @@ class HEVM {
     std::deque<hevm_ctxt> ciphers; // deque: growing it never invalidates references to registers
     std::vector<Plain> plains;
 
+    // device CRT tables per level + staging plaintext of opcode 10
+    struct CrtTables {
+        u64 *inv, *mmod, *hmod, *hdig;
+        double *mdbl;
+    };
+    std::map<int, CrtTables> crt_;
+    const CrtTables &crt_tables(int ell);
+    Plain boot_plain;
+
     // statistics of the last run()
     int64_t op_counts[11] = { 0 };
     int64_t n_keyswitch = 0, n_ntt = 0;
+    double t_bootstrap = 0.0; // host wall time spent inside opcode 10
 
     HEVM() = default;
     size_t key_elems() const { return (size_t)(ctx->K - 1) * 2 * ctx->K * ctx->N; }

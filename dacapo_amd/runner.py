@@ -67,6 +67,8 @@ def reinit_lw():  # runner.py:73-117
     lw.hevm_load_mem.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_char_p, ctypes.c_uint64]
     lw.hevm_last_run_stats.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64),
                                        ctypes.POINTER(ctypes.c_int64)]
+    lw.hevm_last_run_bootstrap_seconds.argtypes = [ctypes.c_void_p]
+    lw.hevm_last_run_bootstrap_seconds.restype = ctypes.c_double
     return lw
 
 
@@ -170,7 +172,8 @@ class HEVM:
         counts = (ctypes.c_int64 * 11)()
         ks, ntt = ctypes.c_int64(), ctypes.c_int64()
         lw.hevm_last_run_stats(self.vm, counts, ctypes.byref(ks), ctypes.byref(ntt))
-        return {"op_counts": list(counts), "keyswitches": ks.value, "ntts": ntt.value}
+        return {"op_counts": list(counts), "keyswitches": ks.value, "ntts": ntt.value,
+                "bootstrap_s": float(lw.hevm_last_run_bootstrap_seconds(self.vm))}
 
     def printer(self, latency, rms, mem_usage=0.0):  # runner.py:256-271
         bench = re.search(r"optimized/(.*)/(.*)\.(.*)\._", self.hevm_path)
