@@ -23,7 +23,9 @@ dc_context *dc_context_create(int logN, int num_primes, int bit_size, const uint
         fprintf(stderr, "[dacapo_amd] only the 60-bit HEVM prime chain is supported (asked for %d bits)\n", bit_size);
         abort();
     }
-    return new dc_context{ new Context(logN, num_primes, bit_size, primes), true };
+    Context *c = new Context(logN, num_primes, bit_size, primes);
+    c->ensure_scratch();
+    return new dc_context{ c, true };
 }
 void dc_context_destroy(dc_context *ctx)
 {
@@ -110,16 +112,16 @@ void dc_ct_mul_plain(dc_context *ctx, uint64_t *dst, long dst_stride, const uint
 void dc_ct_mul_relin(dc_context *ctx, uint64_t *dst, long dst_stride, const uint64_t *a, long a_stride, const uint64_t *b,
                      long b_stride, const uint64_t *relin_key, int ell, void *stream)
 {
-    mul_relin(*ctx->c, V(dst, dst_stride), V(a, a_stride), V(b, b_stride), relin_key, ell, S(stream));
+    mul_relin(*ctx->c, ctx->c->ws0, V(dst, dst_stride), V(a, a_stride), V(b, b_stride), relin_key, ell, S(stream));
 }
 void dc_ct_rotate_hop(dc_context *ctx, uint64_t *dst, long dst_stride, const uint64_t *src, long src_stride,
                       uint32_t galois_elt, const uint64_t *galois_key, int ell, void *stream)
 {
-    rotate_hop(*ctx->c, V(dst, dst_stride), V(src, src_stride), galois_elt, galois_key, ell, S(stream));
+    rotate_hop(*ctx->c, ctx->c->ws0, V(dst, dst_stride), V(src, src_stride), galois_elt, galois_key, ell, S(stream));
 }
 void dc_ct_rescale(dc_context *ctx, uint64_t *dst, long dst_stride, const uint64_t *src, long src_stride, int ell, void *stream)
 {
-    rescale(*ctx->c, V(dst, dst_stride), V(src, src_stride), ell, S(stream));
+    rescale(*ctx->c, ctx->c->ws0, V(dst, dst_stride), V(src, src_stride), ell, S(stream));
 }
 void dc_ct_modswitch(dc_context *ctx, uint64_t *dst, long dst_stride, const uint64_t *src, long src_stride, int ell, int down,
                      void *stream)
@@ -131,7 +133,7 @@ void dc_ct_modswitch(dc_context *ctx, uint64_t *dst, long dst_stride, const uint
 void dc_keyswitch(dc_context *ctx, uint64_t *out, long out_stride, const uint64_t *base0, const uint64_t *base1,
                   const uint64_t *target, const uint64_t *key, int ell, void *stream)
 {
-    keyswitch(*ctx->c, V(out, out_stride), base0, base1, target, key, ell, S(stream));
+    keyswitch(*ctx->c, ctx->c->ws0, V(out, out_stride), base0, base1, target, key, ell, S(stream));
 }
 void dc_galois_ntt(dc_context *ctx, uint64_t *dst, long dst_stride, const uint64_t *src, long src_stride, uint32_t galois_elt,
                    int polys, int ell, void *stream)

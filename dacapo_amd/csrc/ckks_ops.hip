@@ -128,67 +128,64 @@ __global__ __launch_bounds__(kOpThreads) void copy_limbs_kernel(u64 *__restrict_
         *reinterpret_cast<const u64x2 *>(src + blockIdx.y * src_stride + k);
 }
 
-void keyswitch(Context &c, CtView out, const u64 *base0, const u64 *base1, const u64 *target, const u64 *key, int ell,
-               hipStream_t s)
+void keyswitch(Context &c, const Workspace &w, CtView out, const u64 *base0, const u64 *base1, const u64 *target,
+               const u64 *key, int ell, hipStream_t s)
 {
-    c.ensure_scratch();
     const size_t N = c.N;
     const int K = c.K, sp = K - 1;
     const unsigned gx = (unsigned)(N / (2 * kOpThreads));
     // (1) digits = iNTT(target)
-    hipLaunchKernelGGL(copy_limbs_kernel, dim3(gx, ell), dim3(kOpThreads), 0, s, c.d_ks_digits, (long)N, target, (long)N);
-    launch_ntt(c, true, c.d_ks_digits, (long)N, ell, nullptr, 0, 0, s);
+    hipLaunchKernelGGL(copy_limbs_kernel, dim3(gx, ell), dim3(kOpThreads), 0, s, w.ks_digits, (long)N, target, (long)N);
+    launch_ntt(c, true, w.ks_digits, (long)N, ell, nullptr, 0, 0, s);
     // (2) lift every digit to every other modulus, forward NTT there
-    hipLaunchKernelGGL(ks_lift_kernel, dim3(gx, ell, ell), dim3(kOpThreads), 0, s, c.d_ks_ext, c.d_ks_digits, ell, sp, N,
+    hipLaunchKernelGGL(ks_lift_kernel, dim3(gx, ell, ell), dim3(kOpThreads), 0, s, w.ks_ext, w.ks_digits, ell, sp, N,
                        c.d_mods);
-    launch_ntt(c, false, c.d_ks_ext, (long)N, ell * ell, c.ks_prime_idx(ell), 0, 0, s);
+    launch_ntt(c, false, w.ks_ext, (long)N, ell * ell, c.ks_prime_idx(ell), 0, 0, s);
     // (3) inner products with the key
-    hipLaunchKernelGGL(ks_mac_kernel, dim3(gx, ell + 1), dim3(kOpThreads), 0, s, c.d_ks_acc, c.d_ks_ext, target, key, ell, K, N,
+    hipLaunchKernelGGL(ks_mac_kernel, dim3(gx, ell + 1), dim3(kOpThreads), 0, s, w.ks_acc, w.ks_ext, target, key, ell, K, N,
                        c.d_mods);
     // (4) mod-down by the special prime
-    u64 *acc_last = c.d_ks_acc + (size_t)ell * N;
+    u64 *acc_last = w.ks_acc + (size_t)ell * N;
     const long acc_ps = (long)(ell + 1) * (long)N;
     launch_ntt(c, true, acc_last, acc_ps, 2, nullptr, sp, 1, s);
-    hipLaunchKernelGGL(dr_lift_kernel, dim3(gx, ell, 2), dim3(kOpThreads), 0, s, c.d_ks_tmp, (long)ell * (long)N, acc_last,
+    hipLaunchKernelGGL(dr_lift_kernel, dim3(gx, ell, 2), dim3(kOpThreads), 0, s, w.ks_tmp, (long)ell * (long)N, acc_last,
                        acc_ps, sp, K, N, c.d_mods, c.d_half_mod);
-    launch_ntt(c, false, c.d_ks_tmp, (long)N, 2 * ell, nullptr, 0, ell, s);
-    hipLaunchKernelGGL(dr_final_kernel, dim3(gx, ell, 2), dim3(kOpThreads), 0, s, out, c.d_ks_acc, acc_ps, c.d_ks_tmp,
+    launch_ntt(c, false, w.ks_tmp, (long)N, 2 * ell, nullptr, 0, ell, s);
+    hipLaunchKernelGGL(dr_final_kernel, dim3(gx, ell, 2), dim3(kOpThreads), 0, s, out, w.ks_acc, acc_ps, w.ks_tmp,
                        (long)ell * (long)N, base0, base1, sp, K, N, c.d_mods, c.d_inv_last);
 }
 
-void rescale(Context &c, CtView dst, CtView src, int ell, hipStream_t s)
+void rescale(Context &c, const Workspace &w, CtView dst, CtView src, int ell, hipStream_t s)
 {
-    c.ensure_scratch();
     const size_t N = c.N;
     const int l = ell - 1;
     const unsigned gx = (unsigned)(N / (2 * kOpThreads));
-    u64 *last = c.d_ks_digits; // [2][N]
+    u64 *last = w.ks_digits; // [2][N]
     hipLaunchKernelGGL(copy_limbs_kernel, dim3(gx, 2), dim3(kOpThreads), 0, s, last, (long)N, src.limb(0, l, N),
                        src.poly_stride);
     launch_ntt(c, true, last, (long)N, 2, nullptr, l, 1, s);
     if (l == 0) return;
-    hipLaunchKernelGGL(dr_lift_kernel, dim3(gx, l, 2), dim3(kOpThreads), 0, s, c.d_ks_tmp, (long)l * (long)N, last, (long)N, l,
+    hipLaunchKernelGGL(dr_lift_kernel, dim3(gx, l, 2), dim3(kOpThreads), 0, s, w.ks_tmp, (long)l * (long)N, last, (long)N, l,
                        c.K, N, c.d_mods, c.d_half_mod);
-    launch_ntt(c, false, c.d_ks_tmp, (long)N, 2 * l, nullptr, 0, l, s);
-    hipLaunchKernelGGL(dr_final_kernel, dim3(gx, l, 2), dim3(kOpThreads), 0, s, dst, src.p, src.poly_stride, c.d_ks_tmp,
+    launch_ntt(c, false, w.ks_tmp, (long)N, 2 * l, nullptr, 0, l, s);
+    hipLaunchKernelGGL(dr_final_kernel, dim3(gx, l, 2), dim3(kOpThreads), 0, s, dst, src.p, src.poly_stride, w.ks_tmp,
                        (long)l * (long)N, (const u64 *)nullptr, (const u64 *)nullptr, l, c.K, N, c.d_mods, c.d_inv_last);
 }
 
-void mul_relin(Context &c, CtView dst, CtView a, CtView b, const u64 *relin_key, int ell, hipStream_t s)
+void mul_relin(Context &c, const Workspace &w, CtView dst, CtView a, CtView b, const u64 *relin_key, int ell, hipStream_t s)
 {
-    c.ensure_scratch();
-    u64 *c2 = c.d_ct_tmp;
+    u64 *c2 = w.ct_tmp;
     launch_tensor(c, dst, c2, a, b, ell, s);
-    keyswitch(c, dst, dst.limb(0, 0, c.N), dst.limb(1, 0, c.N), c2, relin_key, ell, s);
+    keyswitch(c, w, dst, dst.limb(0, 0, c.N), dst.limb(1, 0, c.N), c2, relin_key, ell, s);
 }
 
-void rotate_hop(Context &c, CtView dst, CtView src, u32 galois_elt, const u64 *galois_key, int ell, hipStream_t s)
+void rotate_hop(Context &c, const Workspace &w, CtView dst, CtView src, u32 galois_elt, const u64 *galois_key, int ell,
+                hipStream_t s)
 {
-    c.ensure_scratch();
     // permuted (c0, c1) -> scratch [2][ell][N]; c1' is the key-switch target, c0' the base of output poly 0
-    CtView tmp{ c.d_ct_tmp, (long)ell * (long)c.N };
+    CtView tmp{ w.ct_tmp, (long)ell * (long)c.N };
     launch_galois(c, tmp, src, galois_elt, 2, ell, s);
-    keyswitch(c, dst, tmp.limb(0, 0, c.N), nullptr, tmp.limb(1, 0, c.N), galois_key, ell, s);
+    keyswitch(c, w, dst, tmp.limb(0, 0, c.N), nullptr, tmp.limb(1, 0, c.N), galois_key, ell, s);
 }
 
 } // namespace dacapo

@@ -4,6 +4,8 @@
 // stored in bit-reversed order [SEAL-upstream numth.cpp, ntt.cpp].
 #include "context.hpp"
 
+#include <algorithm>
+
 namespace dacapo {
 
 u64 h_mulmod(u64 a, u64 b, u64 q) { return (u64)(((u128)a * b) % q); }
@@ -141,15 +143,24 @@ Context::Context(int logN_, int K_, int bits, const u64 *primes_or_null) : logN(
     DC_HIP_CHECK(hipMemcpy(d_half_mod, half_mod.data(), half_mod.size() * 8, hipMemcpyHostToDevice));
 }
 
+Workspace Context::new_workspace()
+{
+    const size_t L = max_level();
+    Workspace w;
+    DC_HIP_CHECK(hipMalloc(&w.ks_digits, std::max<size_t>(L, 2) * N * 8));
+    DC_HIP_CHECK(hipMalloc(&w.ks_ext, std::max<size_t>(L * L, K) * N * 8));
+    DC_HIP_CHECK(hipMalloc(&w.ks_acc, 2 * (L + 1) * N * 8));
+    DC_HIP_CHECK(hipMalloc(&w.ks_tmp, 2 * std::max<size_t>(L, 1) * N * 8));
+    DC_HIP_CHECK(hipMalloc(&w.ct_tmp, 3 * std::max<size_t>(L, 1) * N * 8));
+    workspaces.push_back(w);
+    return w;
+}
+
 void Context::ensure_scratch()
 {
-    if (d_ks_digits) return;
+    if (ws0.ks_digits) return;
     const size_t L = max_level();
-    DC_HIP_CHECK(hipMalloc(&d_ks_digits, L * N * 8));
-    DC_HIP_CHECK(hipMalloc(&d_ks_ext, L * (L + 1) * N * 8));
-    DC_HIP_CHECK(hipMalloc(&d_ks_acc, 2 * (L + 1) * N * 8));
-    DC_HIP_CHECK(hipMalloc(&d_ks_tmp, 2 * L * N * 8));
-    DC_HIP_CHECK(hipMalloc(&d_ct_tmp, 3 * L * N * 8));
+    ws0 = new_workspace();
     std::vector<int> pidx;
     ks_pidx_off.assign(L + 2, 0);
     for (int ell = 1; ell <= (int)L; ell++) {
@@ -157,15 +168,17 @@ void Context::ensure_scratch()
         for (int j = 0; j < ell; j++)
             for (int e = 0; e < ell; e++) pidx.push_back(ks_other_prime(j, e, ell, K - 1));
     }
-    DC_HIP_CHECK(hipMalloc(&d_ks_pidx, pidx.size() * sizeof(int)));
+    DC_HIP_CHECK(hipMalloc(&d_ks_pidx, std::max<size_t>(pidx.size(), 1) * sizeof(int)));
     DC_HIP_CHECK(hipMemcpy(d_ks_pidx, pidx.data(), pidx.size() * sizeof(int), hipMemcpyHostToDevice));
 }
 
 Context::~Context()
 {
-    for (void *p : { (void *)d_mods, (void *)d_tw, (void *)d_itw, (void *)d_ks_digits, (void *)d_ks_ext, (void *)d_ks_acc,
-                     (void *)d_ks_tmp, (void *)d_ct_tmp, (void *)d_inv_last, (void *)d_half_mod, (void *)d_ks_pidx })
+    for (void *p : { (void *)d_mods, (void *)d_tw, (void *)d_itw, (void *)d_inv_last, (void *)d_half_mod, (void *)d_ks_pidx })
         if (p) (void)hipFree(p);
+    for (Workspace &w : workspaces)
+        for (void *p : { (void *)w.ks_digits, (void *)w.ks_ext, (void *)w.ks_acc, (void *)w.ks_tmp, (void *)w.ct_tmp })
+            if (p) (void)hipFree(p);
 }
 
 } // namespace dacapo

@@ -48,6 +48,16 @@ __host__ __device__ inline int ks_other_prime(int j, int e, int ell, int sp)
     return m == ell ? sp : m;
 }
 
+// Scratch of one in-flight composite op (key switch / rescale / rotate / mulcc).  Ops running concurrently on
+// different HIP streams each own one.
+struct Workspace {
+    u64 *ks_digits = nullptr; // [Lmax][N]        coefficient-domain digits (also [2][N] staging)
+    u64 *ks_ext = nullptr;    // [Lmax][Lmax][N]  digits lifted to every other modulus
+    u64 *ks_acc = nullptr;    // [2][Lmax+1][N]   inner products
+    u64 *ks_tmp = nullptr;    // [2][Lmax][N]     mod-down correction terms
+    u64 *ct_tmp = nullptr;    // [3][Lmax][N]     tensor product / galois scratch
+};
+
 struct Context {
     int logN = 0;
     size_t N = 0;
@@ -58,13 +68,8 @@ struct Context {
     DModulus *d_mods = nullptr;
     u64 *d_tw = nullptr;  // [K][N] psi^bitrev(k)
     u64 *d_itw = nullptr; // [K][N] inverse of the above, same index
-    // key-switch / rescale scratch (allocated lazily for max level)
-    u64 *d_ks_digits = nullptr; // [Lmax][N]        coefficient-domain digits
-    u64 *d_ks_ext = nullptr;    // [Lmax][Lmax+1][N] digits lifted to every modulus (NTT under way)
-    u64 *d_ks_acc = nullptr;    // [2][Lmax+1][N]    inner products
-    u64 *d_ks_tmp = nullptr;    // [2][Lmax][N]      mod-down correction terms
-    u64 *d_ct_tmp = nullptr;    // [3][Lmax][N]      tensor product / galois scratch
-    std::vector<u64> h_inv_p_mod; // P^{-1} mod q_i
+    Workspace ws0;                     // default workspace (kernel-level C ABI, set-up work)
+    std::vector<Workspace> workspaces; // everything ever handed out, for the destructor
     u64 *d_inv_last = nullptr;  // [K][K] : inv_last[l*K + i] = q_l^{-1} mod q_i (i != l)
     u64 *d_half_mod = nullptr;  // [K][K] : floor(q_l/2) mod q_i
     int *d_ks_pidx = nullptr;   // per level: prime index of every (digit j, other-modulus e) limb of d_ks_ext
@@ -75,6 +80,7 @@ struct Context {
     ~Context();
     int max_level() const { return K - 1; }
     void ensure_scratch();
+    Workspace new_workspace();
 };
 
 } // namespace dacapo

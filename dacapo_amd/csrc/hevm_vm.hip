@@ -29,7 +29,7 @@ __host__ __device__ inline u64 sm64(u64 z)
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
     return z ^ (z >> 31);
 }
-// counter-based generator: (seed, stream, index, attempt) -> 64 random bits
+// counter-based generator: (seed, S(), index, attempt) -> 64 random bits
 __host__ __device__ inline u64 prng(u64 seed, u64 stream, u64 idx, u64 attempt)
 {
     return sm64(sm64(sm64(seed ^ (stream * 0xD1342543DE82EF95ull)) + idx) + attempt * 0xA0761D6478BD642Full);
@@ -51,12 +51,14 @@ __global__ __launch_bounds__(kVmThreads) void sample_uniform_kernel(u64 *__restr
 // one small signed polynomial (ternary: sample_poly_ternary; cbd: sample_poly_cbd, 21-21 coin pairs) lifted to the
 // first `limbs` primes.  grid = (N/256, limbs)
 __global__ __launch_bounds__(kVmThreads) void sample_small_kernel(u64 *__restrict__ out, size_t N, int cbd, u64 seed,
-                                                                   u64 stream, const DModulus *__restrict__ mods)
+                                                                   u64 stream, const DModulus *__restrict__ mods,
+                                                                   const u64 *__restrict__ epoch)
 {
     const int i = blockIdx.y;
     const u64 q = mods[i].q;
     const size_t k = (size_t)blockIdx.x * kVmThreads + threadIdx.x;
-    const u64 r = prng(seed, stream, k, 0);
+    // `epoch` lives in HBM and is bumped once per run(): a replayed HIP graph still draws fresh encryption randomness
+    const u64 r = prng(seed, stream + (epoch ? (*epoch << 32) : 0), k, 0);
     int v;
     if (cbd)
         v = __popcll(r & 0x1FFFFF) - __popcll((r >> 21) & 0x1FFFFF);
@@ -66,6 +68,8 @@ __global__ __launch_bounds__(kVmThreads) void sample_small_kernel(u64 *__restric
 }
 
 // signed 128-bit integer coefficients (two's complement, |x| < 2^120) -> residues.  grid = (N/256, ell)
+__global__ void bump_epoch_kernel(u64 *epoch) { *epoch += 1; }
+
 __global__ __launch_bounds__(kVmThreads) void lift_i128_kernel(u64 *__restrict__ out, const u64 *__restrict__ lo,
                                                                 const u64 *__restrict__ hi, size_t N,
                                                                 const DModulus *__restrict__ mods)
@@ -311,6 +315,18 @@ void HEVM::init_context(int logN, int K, const u64 *primes)
     ctx.reset(new Context(logN, K, kQBits, primes));
     ctx->ensure_scratch();
     encoder.reset(new HostEncoder(logN));
+    if (const char *e = getenv("DACAPO_HEVM_STREAMS")) n_lanes = std::max(1, atoi(e));
+    if (const char *e = getenv("DACAPO_HEVM_GRAPH")) use_graph = atoi(e) != 0;
+    lanes.resize((size_t)n_lanes);
+    for (int i = 0; i < n_lanes; i++) {
+        DC_HIP_CHECK(hipStreamCreateWithFlags(&lanes[i].stream, hipStreamNonBlocking));
+        lanes[i].ws = i == 0 ? ctx->ws0 : ctx->new_workspace();
+        lanes[i].boot_plain.d = dalloc((size_t)ctx->max_level() * ctx->N);
+        lanes[i].boot_plain.level = ctx->max_level();
+    }
+    DC_HIP_CHECK(hipMalloc(&d_epoch, 8));
+    DC_HIP_CHECK(hipMemset(d_epoch, 0, 8));
+    cur = 0;
 }
 
 // KeyGenerator::generate_one_kswitch_key for every digit: key[j] = (-(a_j s + e_j) + [limb j](P mod q_j) s', a_j)
@@ -322,12 +338,12 @@ void HEVM::gen_kswitch_key(u64 *key, const u64 *new_key, u64 stream_id)
     const dim3 g1((unsigned)(N / kVmThreads), (unsigned)K), g2((unsigned)(N / (2 * kVmThreads)), (unsigned)K);
     for (int j = 0; j < K - 1; j++) {
         u64 *c0 = key + (size_t)j * 2 * K * N, *c1 = c0 + (size_t)K * N;
-        hipLaunchKernelGGL(sample_uniform_kernel, g1, dim3(kVmThreads), 0, stream, c1, N, seed, stream_id * 4096 + 2 * j, c.d_mods);
-        hipLaunchKernelGGL(sample_small_kernel, g1, dim3(kVmThreads), 0, stream, c0, N, 1, seed, stream_id * 4096 + 2 * j + 1,
-                           c.d_mods);
-        launch_ntt(c, false, c0, (long)N, K, nullptr, 0, 0, stream);
+        hipLaunchKernelGGL(sample_uniform_kernel, g1, dim3(kVmThreads), 0, S(), c1, N, seed, stream_id * 4096 + 2 * j, c.d_mods);
+        hipLaunchKernelGGL(sample_small_kernel, g1, dim3(kVmThreads), 0, S(), c0, N, 1, seed, stream_id * 4096 + 2 * j + 1,
+                           c.d_mods, (const u64 *)nullptr);
+        launch_ntt(c, false, c0, (long)N, K, nullptr, 0, 0, S());
         const u64 factor = c.primes[K - 1] % c.primes[j];
-        hipLaunchKernelGGL(ezs_final_kernel, g2, dim3(kVmThreads), 0, stream, c0, c1, keys.sk, new_key, j, factor, N, c.d_mods);
+        hipLaunchKernelGGL(ezs_final_kernel, g2, dim3(kVmThreads), 0, S(), c0, c1, keys.sk, new_key, j, factor, N, c.d_mods);
     }
 }
 
@@ -335,8 +351,8 @@ void HEVM::add_galois_key(u32 elt)
 {
     if (keys.galois.count(elt)) return;
     Context &c = *ctx;
-    u64 *rot = c.d_ct_tmp; // [K][N] fits: scratch is 3*(K-1)*N
-    launch_galois(c, CtView{ rot, 0 }, CtView{ keys.sk, 0 }, elt, 1, c.K, stream);
+    u64 *rot = W().ct_tmp; // [K][N] fits: scratch is 3*(K-1)*N
+    launch_galois(c, CtView{ rot, 0 }, CtView{ keys.sk, 0 }, elt, 1, c.K, S());
     u64 *key = dalloc(key_elems());
     gen_kswitch_key(key, rot, 16 + (u64)elt);
     keys.galois[elt] = key;
@@ -352,20 +368,20 @@ void HEVM::generate_keys(u64 seed_, bool secret, bool pub, bool eval)
     const int K = c.K;
     const dim3 g1((unsigned)(N / kVmThreads), (unsigned)K), g2((unsigned)(N / (2 * kVmThreads)), (unsigned)K);
     keys.sk = dalloc((size_t)K * N);
-    hipLaunchKernelGGL(sample_small_kernel, g1, dim3(kVmThreads), 0, stream, keys.sk, N, 0, seed, 1, c.d_mods);
-    launch_ntt(c, false, keys.sk, (long)N, K, nullptr, 0, 0, stream);
+    hipLaunchKernelGGL(sample_small_kernel, g1, dim3(kVmThreads), 0, S(), keys.sk, N, 0, seed, 1, c.d_mods, (const u64 *)nullptr);
+    launch_ntt(c, false, keys.sk, (long)N, K, nullptr, 0, 0, S());
     if (pub) {
         keys.pk = dalloc((size_t)2 * K * N);
         u64 *c0 = keys.pk, *c1 = keys.pk + (size_t)K * N;
-        hipLaunchKernelGGL(sample_uniform_kernel, g1, dim3(kVmThreads), 0, stream, c1, N, seed, 2, c.d_mods);
-        hipLaunchKernelGGL(sample_small_kernel, g1, dim3(kVmThreads), 0, stream, c0, N, 1, seed, 3, c.d_mods);
-        launch_ntt(c, false, c0, (long)N, K, nullptr, 0, 0, stream);
-        hipLaunchKernelGGL(ezs_final_kernel, g2, dim3(kVmThreads), 0, stream, c0, c1, keys.sk, (const u64 *)nullptr, -1, (u64)0, N,
+        hipLaunchKernelGGL(sample_uniform_kernel, g1, dim3(kVmThreads), 0, S(), c1, N, seed, 2, c.d_mods);
+        hipLaunchKernelGGL(sample_small_kernel, g1, dim3(kVmThreads), 0, S(), c0, N, 1, seed, 3, c.d_mods, (const u64 *)nullptr);
+        launch_ntt(c, false, c0, (long)N, K, nullptr, 0, 0, S());
+        hipLaunchKernelGGL(ezs_final_kernel, g2, dim3(kVmThreads), 0, S(), c0, c1, keys.sk, (const u64 *)nullptr, -1, (u64)0, N,
                            c.d_mods);
     }
     if (eval) {
-        u64 *sk2 = c.d_ct_tmp;
-        launch_ew(c, EwOp::Mul, CtView{ sk2, 0 }, CtView{ keys.sk, 0 }, CtView{ keys.sk, 0 }, 1, 1, K, stream);
+        u64 *sk2 = W().ct_tmp;
+        launch_ew(c, EwOp::Mul, CtView{ sk2, 0 }, CtView{ keys.sk, 0 }, CtView{ keys.sk, 0 }, 1, 1, K, S());
         keys.relin = dalloc(key_elems());
         gen_kswitch_key(keys.relin, sk2, 8);
         // GaloisTool::get_elts_all(): 2N-1, then 3^(2^i), 3^-(2^i), i < logN-1
@@ -384,7 +400,7 @@ void HEVM::generate_keys(u64 seed_, bool secret, bool pub, bool eval)
             neg = (neg * neg) & (m - 1);
         }
     }
-    DC_HIP_CHECK(hipStreamSynchronize(stream));
+    DC_HIP_CHECK(hipStreamSynchronize(S()));
 }
 
 // ---- key files: raw-limb container (NOT SEAL's serialization) -------------------------
@@ -570,6 +586,8 @@ void HEVM::load_program(const void *data, size_t len, bool header_only)
         plains.assign(config.num_ptxt_buffer, Plain{});
     }
     while (ciphers.size() < nct) ciphers.push_back(hevm_ctxt{ nullptr, 0, 0, 0, 1.0 });
+    for (size_t i = 0; i < nct; i++) reg(i); // allocate now: nothing may call hipMalloc while run() is being captured
+    invalidate_graph();
 }
 
 void HEVM::reset_res_dst()
@@ -609,25 +627,25 @@ void HEVM::encode_internal(Plain &dst, const double *src, size_t len, int level,
         lohi[j] = (u64)(unsigned __int128)coeffs[j];
         lohi[N + j] = (u64)((unsigned __int128)coeffs[j] >> 64);
     }
-    u64 *stage = c.d_ks_digits; // >= 2N elements whenever K >= 3
+    u64 *stage = W().ks_digits; // >= 2N elements whenever K >= 3
     static u64 *stage_small = nullptr;
     if (c.max_level() < 2) {
         if (!stage_small) stage_small = dalloc(2 * N);
         stage = stage_small;
     }
-    DC_HIP_CHECK(hipMemcpyAsync(stage, lohi.data(), 2 * N * 8, hipMemcpyHostToDevice, stream));
+    DC_HIP_CHECK(hipMemcpyAsync(stage, lohi.data(), 2 * N * 8, hipMemcpyHostToDevice, S()));
     if (dst.d && dst.level != level) {
-        DC_HIP_CHECK(hipStreamSynchronize(stream));
+        DC_HIP_CHECK(hipStreamSynchronize(S()));
         (void)hipFree(dst.d);
         dst.d = nullptr;
     }
     if (!dst.d) dst.d = dalloc((size_t)level * N);
     dst.level = level;
     dst.scale = scale;
-    hipLaunchKernelGGL(lift_i128_kernel, dim3((unsigned)(N / kVmThreads), (unsigned)level), dim3(kVmThreads), 0, stream, dst.d,
+    hipLaunchKernelGGL(lift_i128_kernel, dim3((unsigned)(N / kVmThreads), (unsigned)level), dim3(kVmThreads), 0, S(), dst.d,
                        stage, stage + N, N, c.d_mods);
-    launch_ntt(c, false, dst.d, (long)N, level, nullptr, 0, 0, stream);
-    DC_HIP_CHECK(hipStreamSynchronize(stream)); // `lohi` and the staging buffer are reused by the next call
+    launch_ntt(c, false, dst.d, (long)N, level, nullptr, 0, 0, S());
+    DC_HIP_CHECK(hipStreamSynchronize(S())); // `lohi` and the staging buffer are reused by the next call
 }
 
 void HEVM::preprocess()
@@ -651,20 +669,20 @@ void HEVM::encrypt_plain(hevm_ctxt &dst, const Plain &pt)
         fprintf(stderr, "[dacapo_amd] encrypt: this VM has no public key\n");
         abort();
     }
-    u64 *u = c.d_ks_ext; // [cnt][N]
+    u64 *u = W().ks_ext; // [cnt][N]
     const CtView tmp{ dst.data, (long)dst.poly_stride };
     const u64 s0 = 1000 + 4 * (enc_counter++);
     const dim3 g1((unsigned)(N / kVmThreads), (unsigned)cnt);
-    hipLaunchKernelGGL(sample_small_kernel, g1, dim3(kVmThreads), 0, stream, u, N, 0, seed, s0, c.d_mods);
-    hipLaunchKernelGGL(sample_small_kernel, g1, dim3(kVmThreads), 0, stream, tmp.limb(0, 0, N), N, 1, seed, s0 + 1, c.d_mods);
-    hipLaunchKernelGGL(sample_small_kernel, g1, dim3(kVmThreads), 0, stream, tmp.limb(1, 0, N), N, 1, seed, s0 + 2, c.d_mods);
-    launch_ntt(c, false, u, (long)N, cnt, nullptr, 0, 0, stream);
-    launch_ntt(c, false, tmp.limb(0, 0, N), (long)N, cnt, nullptr, 0, 0, stream);
-    launch_ntt(c, false, tmp.limb(1, 0, N), (long)N, cnt, nullptr, 0, 0, stream);
-    hipLaunchKernelGGL(pk_encrypt_kernel, dim3((unsigned)(N / (2 * kVmThreads)), (unsigned)cnt, 2), dim3(kVmThreads), 0, stream,
+    hipLaunchKernelGGL(sample_small_kernel, g1, dim3(kVmThreads), 0, S(), u, N, 0, seed, s0, c.d_mods, d_epoch);
+    hipLaunchKernelGGL(sample_small_kernel, g1, dim3(kVmThreads), 0, S(), tmp.limb(0, 0, N), N, 1, seed, s0 + 1, c.d_mods, d_epoch);
+    hipLaunchKernelGGL(sample_small_kernel, g1, dim3(kVmThreads), 0, S(), tmp.limb(1, 0, N), N, 1, seed, s0 + 2, c.d_mods, d_epoch);
+    launch_ntt(c, false, u, (long)N, cnt, nullptr, 0, 0, S());
+    launch_ntt(c, false, tmp.limb(0, 0, N), (long)N, cnt, nullptr, 0, 0, S());
+    launch_ntt(c, false, tmp.limb(1, 0, N), (long)N, cnt, nullptr, 0, 0, S());
+    hipLaunchKernelGGL(pk_encrypt_kernel, dim3((unsigned)(N / (2 * kVmThreads)), (unsigned)cnt, 2), dim3(kVmThreads), 0, S(),
                        tmp.p, tmp.poly_stride, keys.pk, (long)c.K * (long)N, u, N, c.d_mods);
-    rescale(c, tmp, tmp, cnt, stream);
-    launch_add_plain(c, tmp, tmp, pt.d, ell, stream);
+    rescale(c, W(), tmp, tmp, cnt, S());
+    launch_add_plain(c, tmp, tmp, pt.d, ell, S());
     dst.level = ell;
     dst.scale = pt.scale;
 }
@@ -674,7 +692,7 @@ void HEVM::encrypt(int64_t i, const double *dat, int len)
     Plain pt;
     encode_internal(pt, dat, (size_t)len, (int)arg_level.at((size_t)i), (int)arg_scale.at((size_t)i));
     encrypt_plain(reg((size_t)i), pt);
-    DC_HIP_CHECK(hipStreamSynchronize(stream));
+    DC_HIP_CHECK(hipStreamSynchronize(S()));
     (void)hipFree(pt.d);
 }
 
@@ -688,13 +706,13 @@ void HEVM::decrypt(int64_t i, double *out)
         fprintf(stderr, "[dacapo_amd] decrypt: no secret key or empty register %lld\n", (long long)i);
         abort();
     }
-    u64 *pt = c.d_ks_tmp;
-    hipLaunchKernelGGL(decrypt_kernel, dim3((unsigned)(N / (2 * kVmThreads)), (unsigned)ell), dim3(kVmThreads), 0, stream, pt,
+    u64 *pt = W().ks_tmp;
+    hipLaunchKernelGGL(decrypt_kernel, dim3((unsigned)(N / (2 * kVmThreads)), (unsigned)ell), dim3(kVmThreads), 0, S(), pt,
                        view(ct), keys.sk, N, c.d_mods);
-    launch_ntt(c, true, pt, (long)N, ell, nullptr, 0, 0, stream);
+    launch_ntt(c, true, pt, (long)N, ell, nullptr, 0, 0, S());
     std::vector<u64> coef((size_t)ell * N);
-    DC_HIP_CHECK(hipMemcpyAsync(coef.data(), pt, coef.size() * 8, hipMemcpyDeviceToHost, stream));
-    DC_HIP_CHECK(hipStreamSynchronize(stream));
+    DC_HIP_CHECK(hipMemcpyAsync(coef.data(), pt, coef.size() * 8, hipMemcpyDeviceToHost, S()));
+    DC_HIP_CHECK(hipStreamSynchronize(S()));
     // CRT-compose each coefficient (Garner), centre it, divide by the scale  [CKKSEncoder::decode_internal]
     const int W = ell;
     std::vector<u64> M((size_t)(ell + 1) * W, 0); // M[k] = q_0 ... q_{k-1}
@@ -818,11 +836,11 @@ void HEVM::op_rotate(int dst, int src, int offset)
     const int ell = s.level;
     const hevm_ctxt *cur = &s;
     for (u32 elt : hops) {
-        rotate_hop(*ctx, view(d), view(*cur), elt, keys.galois.at(elt), ell, stream);
+        rotate_hop(*ctx, W(), view(d), view(*cur), elt, keys.galois.at(elt), ell, S());
         cur = &d;
         n_keyswitch++, n_ntt += ks_ntts(ell);
     }
-    if (hops.empty() && dst != src) launch_ew(*ctx, EwOp::Copy, view(d), view(s), view(s), 2, 2, ell, stream);
+    if (hops.empty() && dst != src) launch_ew(*ctx, EwOp::Copy, view(d), view(s), view(s), 2, 2, ell, S());
     d.level = ell, d.scale = s.scale;
 }
 void HEVM::op_negate(int dst, int src)
@@ -830,7 +848,7 @@ void HEVM::op_negate(int dst, int src)
     hevm_ctxt &s = reg(src);
     hevm_ctxt &d = reg(dst);
     if (debug) std::cout << std::log2(s.scale) << std::endl;
-    launch_ew(*ctx, EwOp::Neg, view(d), view(s), view(s), 2, 2, s.level, stream);
+    launch_ew(*ctx, EwOp::Neg, view(d), view(s), view(s), 2, 2, s.level, S());
     d.level = s.level, d.scale = s.scale;
 }
 void HEVM::op_rescale(int dst, int src)
@@ -843,7 +861,7 @@ void HEVM::op_rescale(int dst, int src)
         fprintf(stderr, "[dacapo_amd] rescale: end of modulus switching chain reached\n");
         abort();
     }
-    rescale(*ctx, view(d), view(s), ell, stream);
+    rescale(*ctx, W(), view(d), view(s), ell, S());
     n_ntt += 2 * ell;
     d.scale = s.scale / (double)ctx->primes[ell - 1];
     d.level = ell - 1;
@@ -859,7 +877,7 @@ void HEVM::op_modswitch(int dst, int src, int down)
         fprintf(stderr, "[dacapo_amd] modswitch: end of modulus switching chain reached\n");
         abort();
     }
-    if (dst != src) launch_ew(*ctx, EwOp::Copy, view(d), view(s), view(s), 2, 2, ell, stream);
+    if (dst != src) launch_ew(*ctx, EwOp::Copy, view(d), view(s), view(s), 2, 2, ell, S());
     d.level = ell, d.scale = s.scale;
 }
 void HEVM::op_addcc(int dst, int lhs, int rhs)
@@ -873,7 +891,7 @@ void HEVM::op_addcc(int dst, int lhs, int rhs)
         fprintf(stderr, "[dacapo_amd] addcc: level mismatch %d vs %d\n", a.level, b.level);
         abort();
     }
-    launch_ew(*ctx, EwOp::Add, view(d), view(a), view(b), 2, 2, a.level, stream);
+    launch_ew(*ctx, EwOp::Add, view(d), view(a), view(b), 2, 2, a.level, S());
     d.level = a.level, d.scale = b.scale;
 }
 void HEVM::op_addcp(int dst, int lhs, int rhs)
@@ -887,7 +905,7 @@ void HEVM::op_addcp(int dst, int lhs, int rhs)
         fprintf(stderr, "[dacapo_amd] addcp: level mismatch %d vs %d\n", a.level, p.level);
         abort();
     }
-    launch_add_plain(*ctx, view(d), view(a), p.d, a.level, stream);
+    launch_add_plain(*ctx, view(d), view(a), p.d, a.level, S());
     d.level = a.level, d.scale = p.scale;
 }
 void HEVM::op_mulcc(int dst, int lhs, int rhs)
@@ -900,7 +918,7 @@ void HEVM::op_mulcc(int dst, int lhs, int rhs)
         fprintf(stderr, "[dacapo_amd] mulcc: level mismatch %d vs %d\n", a.level, b.level);
         abort();
     }
-    mul_relin(*ctx, view(d), view(a), view(b), keys.relin, a.level, stream);
+    mul_relin(*ctx, W(), view(d), view(a), view(b), keys.relin, a.level, S());
     n_keyswitch++, n_ntt += ks_ntts(a.level);
     const double sc = a.scale * b.scale;
     d.level = a.level, d.scale = sc;
@@ -915,7 +933,7 @@ void HEVM::op_mulcp(int dst, int lhs, int rhs)
         fprintf(stderr, "[dacapo_amd] mulcp: level mismatch %d vs %d\n", a.level, p.level);
         abort();
     }
-    launch_ew(*ctx, EwOp::Mul, view(d), view(a), CtView{ p.d, 0 }, 2, 1, a.level, stream);
+    launch_ew(*ctx, EwOp::Mul, view(d), view(a), CtView{ p.d, 0 }, 2, 1, a.level, S());
     const double sc = a.scale * p.scale;
     d.level = a.level, d.scale = sc;
 }
@@ -1006,37 +1024,71 @@ void HEVM::op_bootstrap(int dst, int src, int target_level)
     }
     const double new_scale = pow(2.0, (double)(int64_t)std::log2(s.scale)); // SEAL_HEVM.cpp:332 -> :262
     const CrtTables &tb = crt_tables(ell);
-    u64 *pt = c.d_ks_tmp;      // [ell][N]
-    u64 *lohi = c.d_ks_digits; // [2][N]
-    hipLaunchKernelGGL(decrypt_kernel, dim3((unsigned)(N / (2 * kVmThreads)), (unsigned)ell), dim3(kVmThreads), 0, stream, pt,
+    u64 *pt = W().ks_tmp;      // [ell][N]
+    u64 *lohi = W().ks_digits; // [2][N]
+    hipLaunchKernelGGL(decrypt_kernel, dim3((unsigned)(N / (2 * kVmThreads)), (unsigned)ell), dim3(kVmThreads), 0, S(), pt,
                        view(s), keys.sk, N, c.d_mods);
-    launch_ntt(c, true, pt, (long)N, ell, nullptr, 0, 0, stream);
+    launch_ntt(c, true, pt, (long)N, ell, nullptr, 0, 0, S());
     const CrtDev cd{ tb.inv, tb.mmod, tb.hmod, tb.hdig, tb.mdbl };
-    hipLaunchKernelGGL(reencode_kernel, dim3((unsigned)((N / 2 + kVmThreads) / kVmThreads)), dim3(kVmThreads), 0, stream, lohi,
+    hipLaunchKernelGGL(reencode_kernel, dim3((unsigned)((N / 2 + kVmThreads) / kVmThreads)), dim3(kVmThreads), 0, S(), lohi,
                        lohi + N, pt, ell, N, c.d_mods, cd, new_scale / s.scale);
-    if (boot_plain.d && boot_plain.level < target_level) {
-        DC_HIP_CHECK(hipStreamSynchronize(stream));
-        (void)hipFree(boot_plain.d);
-        boot_plain.d = nullptr;
-    }
-    if (!boot_plain.d) {
-        boot_plain.d = dalloc((size_t)c.max_level() * N);
-        boot_plain.level = c.max_level();
-    }
-    Plain ptx{ boot_plain.d, target_level, new_scale };
-    hipLaunchKernelGGL(lift_i128_kernel, dim3((unsigned)(N / kVmThreads), (unsigned)target_level), dim3(kVmThreads), 0, stream,
+    Plain ptx{ lanes[cur].boot_plain.d, target_level, new_scale };
+    hipLaunchKernelGGL(lift_i128_kernel, dim3((unsigned)(N / kVmThreads), (unsigned)target_level), dim3(kVmThreads), 0, S(),
                        ptx.d, lohi, lohi + N, N, c.d_mods);
-    launch_ntt(c, false, ptx.d, (long)N, target_level, nullptr, 0, 0, stream);
+    launch_ntt(c, false, ptx.d, (long)N, target_level, nullptr, 0, 0, S());
     encrypt_plain(reg(dst), ptx);
 }
 
-void HEVM::run()
+hipEvent_t HEVM::new_event()
+{
+    if (ev_next == ev_pool.size()) {
+        hipEvent_t e;
+        DC_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        ev_pool.push_back(e);
+    }
+    return ev_pool[ev_next++];
+}
+
+void HEVM::invalidate_graph()
+{
+    if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
+    if (graph) (void)hipGraphDestroy(graph);
+    graph_exec = nullptr;
+    graph = nullptr;
+}
+
+void HEVM::dispatch(const WireOp &op)
+{
+    switch (op.opcode) {
+    case 1: op_rotate(op.dst, op.lhs, (int16_t)op.rhs); break;
+    case 2: op_negate(op.dst, op.lhs); break;
+    case 3: op_rescale(op.dst, op.lhs); break;
+    case 4: op_modswitch(op.dst, op.lhs, (int16_t)op.rhs); break;
+    case 5: fprintf(stderr, "This VM does not support native upscale op\n"); abort();
+    case 6: op_addcc(op.dst, op.lhs, op.rhs); break;
+    case 7: op_addcp(op.dst, op.lhs, op.rhs); break;
+    case 8: op_mulcc(op.dst, op.lhs, op.rhs); break;
+    case 9: op_mulcp(op.dst, op.lhs, op.rhs); break;
+    case 10: op_bootstrap(op.dst, op.lhs, op.rhs); break;
+    default: break; // 0 = Encode (done in preprocess), 0xFFFF buffer marker and unknown opcodes are no-ops
+    }
+}
+
+// The dispatch loop of SEAL_HEVM::run (SEAL_HEVM.cpp:336-401).  multi_lane: ops are spread over the lanes; the
+// only ordering enforced between lanes is the program's own register dataflow (RAW, WAR and WAW on cipher
+// registers -- ReuseBuffer recycles registers, so all three occur); plaintext registers are read-only here.
+void HEVM::execute(bool multi_lane)
 {
     memset(op_counts, 0, sizeof(op_counts));
     n_keyswitch = n_ntt = 0;
     t_bootstrap = 0.0;
+    deps.assign(ciphers.size(), RegDeps{});
+    ev_next = 0;
+    for (Lane &l : lanes) l.load = 0, l.tail_op = -1;
     int i = (int)((header.hevm_header_size + config.config_body_length) / 8), j = 0;
+    int opi = -1;
     for (const WireOp &op : ops) {
+        opi++;
         if (debug) {
             std::cout << std::endl;
             std::cout << std::oct << i++ << " " << std::dec << j++ << std::endl;
@@ -1044,22 +1096,89 @@ void HEVM::run()
                       << std::endl;
         }
         if (op.opcode <= 10) op_counts[op.opcode]++;
-        switch (op.opcode) {
-        case 0: break; // Encode: done in preprocess()
-        case 1: op_rotate(op.dst, op.lhs, (int16_t)op.rhs); break;
-        case 2: op_negate(op.dst, op.lhs); break;
-        case 3: op_rescale(op.dst, op.lhs); break;
-        case 4: op_modswitch(op.dst, op.lhs, (int16_t)op.rhs); break;
-        case 5: fprintf(stderr, "This VM does not support native upscale op\n"); abort();
-        case 6: op_addcc(op.dst, op.lhs, op.rhs); break;
-        case 7: op_addcp(op.dst, op.lhs, op.rhs); break;
-        case 8: op_mulcc(op.dst, op.lhs, op.rhs); break;
-        case 9: op_mulcp(op.dst, op.lhs, op.rhs); break;
-        case 10: op_bootstrap(op.dst, op.lhs, op.rhs); break;
-        default: break; // 0xFFFF buffer-allocation marker and unknown opcodes are no-ops
+        if (op.opcode == 0 || op.opcode > 10) continue;
+        if (!multi_lane) {
+            cur = 0;
+            dispatch(op);
+            continue;
+        }
+        const bool rhs_is_reg = op.opcode == 6 || op.opcode == 8;
+        const int srcs[2] = { (int)op.lhs, rhs_is_reg ? (int)op.rhs : -1 };
+        const int dst = op.dst;
+        if ((size_t)std::max({ dst, srcs[0], srcs[1] }) >= deps.size()) deps.resize((size_t)std::max({ dst, srcs[0], srcs[1] }) + 1);
+        // lane choice: continue the producer's chain when it is still the tail of its lane, else the least loaded lane
+        int lane = -1;
+        for (int sidx = 0; sidx < 2 && lane < 0; sidx++) {
+            if (srcs[sidx] < 0) continue;
+            const Dep &w = deps[(size_t)srcs[sidx]].writer;
+            if (w.lane >= 0 && lanes[(size_t)w.lane].tail_op == w.op) lane = w.lane;
+        }
+        if (lane < 0) {
+            lane = 0;
+            for (int l = 1; l < n_lanes; l++)
+                if (lanes[(size_t)l].load < lanes[(size_t)lane].load) lane = l;
+        }
+        hipStream_t st = lanes[(size_t)lane].stream;
+        auto wait_for = [&](const Dep &d) {
+            if (d.ev && d.lane != lane) DC_HIP_CHECK(hipStreamWaitEvent(st, d.ev, 0));
+        };
+        for (int sidx = 0; sidx < 2; sidx++)
+            if (srcs[sidx] >= 0) wait_for(deps[(size_t)srcs[sidx]].writer); // RAW
+        wait_for(deps[(size_t)dst].writer);                                   // WAW
+        for (const Dep &r : deps[(size_t)dst].readers) wait_for(r);           // WAR
+        cur = lane;
+        const int64_t ntt_before = n_ntt;
+        dispatch(op);
+        lanes[(size_t)lane].load += 1 + (long)(n_ntt - ntt_before);
+        lanes[(size_t)lane].tail_op = opi;
+        Dep me{ lane, opi, new_event() };
+        DC_HIP_CHECK(hipEventRecord(me.ev, st));
+        for (int sidx = 0; sidx < 2; sidx++)
+            if (srcs[sidx] >= 0 && srcs[sidx] != dst) deps[(size_t)srcs[sidx]].readers.push_back(me);
+        deps[(size_t)dst].writer = me;
+        deps[(size_t)dst].readers.clear();
+    }
+    cur = 0;
+    if (multi_lane) { // join every lane into lane 0
+        for (int l = 1; l < n_lanes; l++) {
+            hipEvent_t e = new_event();
+            DC_HIP_CHECK(hipEventRecord(e, lanes[(size_t)l].stream));
+            DC_HIP_CHECK(hipStreamWaitEvent(lanes[0].stream, e, 0));
         }
     }
-    DC_HIP_CHECK(hipStreamSynchronize(stream)); // the caller's timer stops when run() returns
+    hipLaunchKernelGGL(bump_epoch_kernel, dim3(1), dim3(1), 0, lanes[0].stream, d_epoch);
+}
+
+void HEVM::run()
+{
+    const bool multi = n_lanes > 1 && !debug;
+    if (!use_graph || debug) {
+        execute(multi);
+        DC_HIP_CHECK(hipStreamSynchronize(lanes[0].stream)); // the caller's timer stops when run() returns
+        return;
+    }
+    if (!graph_exec) { // first run of this program: record it once ...
+        hipStream_t s0 = lanes[0].stream;
+        DC_HIP_CHECK(hipStreamBeginCapture(s0, hipStreamCaptureModeRelaxed));
+        if (multi) { // fork: the other lanes join the capture by waiting on an event of the origin stream
+            hipEvent_t fork = nullptr;
+            DC_HIP_CHECK(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
+            DC_HIP_CHECK(hipEventRecord(fork, s0));
+            for (int l = 1; l < n_lanes; l++) DC_HIP_CHECK(hipStreamWaitEvent(lanes[(size_t)l].stream, fork, 0));
+        }
+        execute(multi);
+        DC_HIP_CHECK(hipStreamEndCapture(s0, &graph));
+        DC_HIP_CHECK(hipGraphInstantiate(&graph_exec, graph, nullptr, nullptr, 0));
+        final_meta.resize(ciphers.size());
+        for (size_t r = 0; r < ciphers.size(); r++) final_meta[r] = RegMeta{ ciphers[r].level, ciphers[r].scale };
+    }
+    // ... then replay it: one launch for the whole program
+    DC_HIP_CHECK(hipGraphLaunch(graph_exec, lanes[0].stream));
+    DC_HIP_CHECK(hipStreamSynchronize(lanes[0].stream)); // the caller's timer stops when run() returns
+    for (size_t r = 0; r < final_meta.size() && r < ciphers.size(); r++) {
+        ciphers[r].level = final_meta[r].level;
+        ciphers[r].scale = final_meta[r].scale;
+    }
 }
 
 } // namespace dacapo

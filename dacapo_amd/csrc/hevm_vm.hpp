@@ -68,9 +68,47 @@ class HEVM {
     std::unique_ptr<Context> ctx;
     std::unique_ptr<HostEncoder> encoder;
     KeySet keys;
-    hipStream_t stream = nullptr;
     bool debug = false;
     u64 seed = 0, enc_counter = 0;
+    u64 *d_epoch = nullptr; // run() counter in HBM, mixed into the encryption randomness (graph replays stay fresh)
+
+    // Execution lanes: one HIP stream + one scratch workspace each.  run() spreads independent ops of the program
+    // over the lanes (register-level dependency tracking with events) and captures the result into one HIP graph.
+    struct Lane {
+        hipStream_t stream = nullptr;
+        Workspace ws;
+        Plain boot_plain; // staging plaintext of opcode 10
+        long load = 0;    // scheduled work estimate (NTT-equivalents)
+        int tail_op = -1; // index of the last op issued on this lane
+    };
+    std::vector<Lane> lanes;
+    int cur = 0; // lane the handlers currently issue to
+    hipStream_t S() const { return lanes[cur].stream; }
+    const Workspace &W() const { return lanes[cur].ws; }
+    int n_lanes = 8;
+    bool use_graph = true;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+    struct RegMeta {
+        int32_t level;
+        double scale;
+    };
+    std::vector<RegMeta> final_meta; // register metadata after a captured run
+    struct Dep {
+        int lane = -1, op = -1;
+        hipEvent_t ev = nullptr;
+    };
+    struct RegDeps {
+        Dep writer;
+        std::vector<Dep> readers;
+    };
+    std::vector<RegDeps> deps;
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_next = 0;
+    hipEvent_t new_event();
+    void invalidate_graph();
+    void execute(bool multi_lane);
+    void dispatch(const WireOp &op);
 
     // program
     std::vector<std::vector<double>> buffer; // constants of the .cst file
@@ -88,7 +126,6 @@ class HEVM {
     };
     std::map<int, CrtTables> crt_;
     const CrtTables &crt_tables(int ell);
-    Plain boot_plain;
 
     // statistics of the last run()
     int64_t op_counts[11] = { 0 };

@@ -36,13 +36,14 @@ void launch_galois(const Context &c, CtView dst, CtView src, u32 galois_elt, int
 // Evaluator::switch_key_inplace: (out0,out1) (+)= KS(target) at level ell.  key: [K-1][2][K][N].
 // base0/base1: what the switched pair is added to (nullable = 0); out may alias base.  target [ell][N] NTT form
 // (preserved).
-void keyswitch(Context &c, CtView out, const u64 *base0, const u64 *base1, const u64 *target, const u64 *key, int ell,
-               hipStream_t s);
+void keyswitch(Context &c, const Workspace &w, CtView out, const u64 *base0, const u64 *base1, const u64 *target,
+               const u64 *key, int ell, hipStream_t s);
 // Evaluator::rescale_to_next: dst(level ell-1) = round(src / q_{ell-1}).  dst may alias src.
-void rescale(Context &c, CtView dst, CtView src, int ell, hipStream_t s);
+void rescale(Context &c, const Workspace &w, CtView dst, CtView src, int ell, hipStream_t s);
 // Evaluator::multiply + relinearize_inplace
-void mul_relin(Context &c, CtView dst, CtView a, CtView b, const u64 *relin_key, int ell, hipStream_t s);
+void mul_relin(Context &c, const Workspace &w, CtView dst, CtView a, CtView b, const u64 *relin_key, int ell, hipStream_t s);
 // Evaluator::apply_galois_inplace (one key-switch hop)
-void rotate_hop(Context &c, CtView dst, CtView src, u32 galois_elt, const u64 *galois_key, int ell, hipStream_t s);
+void rotate_hop(Context &c, const Workspace &w, CtView dst, CtView src, u32 galois_elt, const u64 *galois_key, int ell,
+                hipStream_t s);
 
 } // namespace dacapo
