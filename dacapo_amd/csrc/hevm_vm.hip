@@ -1084,7 +1084,8 @@ void HEVM::execute(bool multi_lane)
     t_bootstrap = 0.0;
     deps.assign(ciphers.size(), RegDeps{});
     ev_next = 0;
-    for (Lane &l : lanes) l.load = 0, l.tail_op = -1;
+    for (Lane &l : lanes) l.load = 0, l.tail_op = -1, l.used = false, l.last_ev = nullptr;
+    lanes[0].used = true;
     int i = (int)((header.hevm_header_size + config.config_body_length) / 8), j = 0;
     int opi = -1;
     for (const WireOp &op : ops) {
@@ -1119,9 +1120,24 @@ void HEVM::execute(bool multi_lane)
                 if (lanes[(size_t)l].load < lanes[(size_t)lane].load) lane = l;
         }
         hipStream_t st = lanes[(size_t)lane].stream;
+        static const bool trace = getenv("DACAPO_HEVM_TRACE") != nullptr;
+        if (trace) fprintf(stderr, "op %d opcode %d dst %d lhs %d rhs %d -> lane %d\n", opi, op.opcode, dst, srcs[0], srcs[1], lane);
+        hipEvent_t waited[8];
+        int n_waited = 0;
         auto wait_for = [&](const Dep &d) {
-            if (d.ev && d.lane != lane) DC_HIP_CHECK(hipStreamWaitEvent(st, d.ev, 0));
+            if (!d.ev || d.lane == lane) return;
+            for (int w = 0; w < n_waited; w++)
+                if (waited[w] == d.ev) return; // one edge per producer event
+            if (n_waited < 8) waited[n_waited++] = d.ev;
+            if (trace) fprintf(stderr, "   wait lane %d op %d\n", d.lane, d.op);
+            DC_HIP_CHECK(hipStreamWaitEvent(st, d.ev, 0));
         };
+        if (!lanes[(size_t)lane].used) { // first work on this lane: branch it off lane 0 (this is what joins it to a capture)
+            lanes[(size_t)lane].used = true;
+            hipEvent_t fork = new_event();
+            DC_HIP_CHECK(hipEventRecord(fork, lanes[0].stream));
+            DC_HIP_CHECK(hipStreamWaitEvent(st, fork, 0));
+        }
         for (int sidx = 0; sidx < 2; sidx++)
             if (srcs[sidx] >= 0) wait_for(deps[(size_t)srcs[sidx]].writer); // RAW
         wait_for(deps[(size_t)dst].writer);                                   // WAW
@@ -1131,16 +1147,25 @@ void HEVM::execute(bool multi_lane)
         dispatch(op);
         lanes[(size_t)lane].load += 1 + (long)(n_ntt - ntt_before);
         lanes[(size_t)lane].tail_op = opi;
-        Dep me{ lane, opi, new_event() };
-        DC_HIP_CHECK(hipEventRecord(me.ev, st));
+        Dep me{ lane, opi, nullptr };
+        const bool metadata_only = (op.opcode == 4 && (op.dst == op.lhs || (int16_t)op.rhs <= 0)) ||
+                                   (op.opcode == 1 && op.rhs == 0 && op.dst == op.lhs);
+        if (metadata_only && lanes[(size_t)lane].last_ev) {
+            me.ev = lanes[(size_t)lane].last_ev; // metadata-only op (e.g. in-place modswitch): nothing new to wait for
+        } else {
+            me.ev = new_event();
+            DC_HIP_CHECK(hipEventRecord(me.ev, st));
+            lanes[(size_t)lane].last_ev = me.ev;
+        }
         for (int sidx = 0; sidx < 2; sidx++)
             if (srcs[sidx] >= 0 && srcs[sidx] != dst) deps[(size_t)srcs[sidx]].readers.push_back(me);
         deps[(size_t)dst].writer = me;
         deps[(size_t)dst].readers.clear();
     }
     cur = 0;
-    if (multi_lane) { // join every lane into lane 0
+    if (multi_lane) { // join every lane that received work into lane 0
         for (int l = 1; l < n_lanes; l++) {
+            if (!lanes[(size_t)l].used) continue;
             hipEvent_t e = new_event();
             DC_HIP_CHECK(hipEventRecord(e, lanes[(size_t)l].stream));
             DC_HIP_CHECK(hipStreamWaitEvent(lanes[0].stream, e, 0));
@@ -1160,14 +1185,16 @@ void HEVM::run()
     if (!graph_exec) { // first run of this program: record it once ...
         hipStream_t s0 = lanes[0].stream;
         DC_HIP_CHECK(hipStreamBeginCapture(s0, hipStreamCaptureModeRelaxed));
-        if (multi) { // fork: the other lanes join the capture by waiting on an event of the origin stream
-            hipEvent_t fork = nullptr;
-            DC_HIP_CHECK(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
-            DC_HIP_CHECK(hipEventRecord(fork, s0));
-            for (int l = 1; l < n_lanes; l++) DC_HIP_CHECK(hipStreamWaitEvent(lanes[(size_t)l].stream, fork, 0));
-        }
         execute(multi);
+        if (getenv("DACAPO_HEVM_TRACE")) fprintf(stderr, "ending capture\n");
         DC_HIP_CHECK(hipStreamEndCapture(s0, &graph));
+        if (getenv("DACAPO_HEVM_TRACE")) fprintf(stderr, "capture ended\n");
+        if (const char *dot = getenv("DACAPO_HEVM_DUMP_DOT")) {
+            size_t nn = 0;
+            (void)hipGraphGetNodes(graph, nullptr, &nn);
+            fprintf(stderr, "[dacapo_amd] captured graph: %zu nodes, dumping to %s\n", nn, dot);
+            (void)hipGraphDebugDotPrint(graph, dot, 0);
+        }
         DC_HIP_CHECK(hipGraphInstantiate(&graph_exec, graph, nullptr, nullptr, 0));
         final_meta.resize(ciphers.size());
         for (size_t r = 0; r < ciphers.size(); r++) final_meta[r] = RegMeta{ ciphers[r].level, ciphers[r].scale };

@@ -80,13 +80,18 @@ class HEVM {
         Plain boot_plain; // staging plaintext of opcode 10
         long load = 0;    // scheduled work estimate (NTT-equivalents)
         int tail_op = -1; // index of the last op issued on this lane
+        bool used = false;        // has work in the current execute()
+        hipEvent_t last_ev = nullptr; // event after the last op issued here
     };
     std::vector<Lane> lanes;
     int cur = 0; // lane the handlers currently issue to
     hipStream_t S() const { return lanes[cur].stream; }
     const Workspace &W() const { return lanes[cur].ws; }
-    int n_lanes = 8;
-    bool use_graph = true;
+    // defaults: one lane, eager.  More lanes / graph capture are opt-in (DACAPO_HEVM_STREAMS / DACAPO_HEVM_GRAPH): on
+    // ROCm 7.2 hipStreamEndCapture overflows its stack on captures with >= 3 mutually waiting streams
+    // (tools/graph_repro.hip), and eager multi-stream issue is host-bound (DESIGN.md "Scheduling").
+    int n_lanes = 1;
+    bool use_graph = false;
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
     struct RegMeta {
@@ -108,6 +113,7 @@ class HEVM {
     hipEvent_t new_event();
     void invalidate_graph();
     void execute(bool multi_lane);
+    bool capturing = false;
     void dispatch(const WireOp &op);
 
     // program
