@@ -317,6 +317,8 @@ void HEVM::init_context(int logN, int K, const u64 *primes)
     encoder.reset(new HostEncoder(logN));
     if (const char *e = getenv("DACAPO_HEVM_STREAMS")) n_lanes = std::max(1, atoi(e));
     if (const char *e = getenv("DACAPO_HEVM_GRAPH")) use_graph = atoi(e) != 0;
+    if (const char *e = getenv("DACAPO_HEVM_PLAN")) use_plan = atoi(e) != 0;
+    if (const char *e = getenv("DACAPO_HEVM_MAX_BATCH")) max_batch = std::max(1, atoi(e));
     lanes.resize((size_t)n_lanes);
     for (int i = 0; i < n_lanes; i++) {
         DC_HIP_CHECK(hipStreamCreateWithFlags(&lanes[i].stream, hipStreamNonBlocking));
@@ -588,6 +590,7 @@ void HEVM::load_program(const void *data, size_t len, bool header_only)
     while (ciphers.size() < nct) ciphers.push_back(hevm_ctxt{ nullptr, 0, 0, 0, 1.0 });
     for (size_t i = 0; i < nct; i++) reg(i); // allocate now: nothing may call hipMalloc while run() is being captured
     invalidate_graph();
+    plan.ready = false;
 }
 
 void HEVM::reset_res_dst()
@@ -598,15 +601,20 @@ void HEVM::reset_res_dst()
 hevm_ctxt &HEVM::reg(size_t i)
 {
     while (i >= ciphers.size()) ciphers.push_back(hevm_ctxt{ nullptr, 0, 0, 0, 1.0 }); // deque: references stay valid
+    while (i >= home.size()) home.push_back(nullptr);
     hevm_ctxt &r = ciphers[i];
-    if (!r.data) { // registers are allocated once at full capacity: [2][K][N] (K limbs so encryption can stage the extra prime)
+    if (!home[i]) // a register's own buffer, full capacity [2][K][N] (K limbs: encryption stages one extra prime)
+        home[i] = dalloc((size_t)2 * ctx->K * ctx->N);
+    if (!r.data) {
         r.poly_stride = (int64_t)ctx->K * (int64_t)ctx->N;
-        r.data = dalloc((size_t)2 * r.poly_stride);
+        r.data = home[i];
         r.level = 0;
         r.scale = 1.0;
     }
     return r;
 }
+
+void HEVM::bump_epoch(hipStream_t s) { hipLaunchKernelGGL(bump_epoch_kernel, dim3(1), dim3(1), 0, s, d_epoch); }
 
 // ---------------------------------------------------------------------------------------------------------
 // encode / encrypt / decrypt (SEAL_HEVM.cpp:242-267, :439-455)
@@ -691,7 +699,10 @@ void HEVM::encrypt(int64_t i, const double *dat, int len)
 {
     Plain pt;
     encode_internal(pt, dat, (size_t)len, (int)arg_level.at((size_t)i), (int)arg_scale.at((size_t)i));
-    encrypt_plain(reg((size_t)i), pt);
+    hevm_ctxt &r = reg((size_t)i);
+    r.data = home[(size_t)i]; // program inputs always live in the register's own buffer (a plan may have re-pointed it)
+    r.poly_stride = (int64_t)ctx->K * (int64_t)ctx->N;
+    encrypt_plain(r, pt);
     DC_HIP_CHECK(hipStreamSynchronize(S()));
     (void)hipFree(pt.d);
 }
@@ -1005,38 +1016,39 @@ const HEVM::CrtTables &HEVM::crt_tables(int ell)
 }
 
 void HEVM::op_bootstrap(int dst, int src, int target_level)
-{ // the SEAL VM's stand-in: decrypt -> decode -> re-encode at `target_level` primes -> encrypt (SEAL_HEVM.cpp:328-333),
-  // evaluated on the device (see reencode_kernel)
+{
     const auto t0 = std::chrono::steady_clock::now();
-    struct Tick {
-        decltype(t0) t;
-        double &acc;
-        ~Tick() { acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); }
-    } tick{ t0, t_bootstrap };
-    Context &c = *ctx;
-    const size_t N = c.N;
     hevm_ctxt &s = reg(src);
     if (debug) std::cout << std::log2(s.scale) << std::endl;
-    const int ell = s.level;
+    boot_item(view(s), s.level, s.scale, reg(dst), target_level);
+    t_bootstrap += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+
+// the SEAL VM's stand-in: decrypt -> decode -> re-encode at `target_level` primes -> encrypt (SEAL_HEVM.cpp:328-333),
+// evaluated on the device (see reencode_kernel).  dst may alias src.
+void HEVM::boot_item(CtView src, int ell, double src_scale, hevm_ctxt &dst, int target_level)
+{
+    Context &c = *ctx;
+    const size_t N = c.N;
     if (!keys.sk || !keys.pk || ell < 1 || target_level < 1 || target_level > c.max_level()) {
         fprintf(stderr, "[dacapo_amd] bootstrap: needs a full VM (secret + public key) and a valid target level\n");
         abort();
     }
-    const double new_scale = pow(2.0, (double)(int64_t)std::log2(s.scale)); // SEAL_HEVM.cpp:332 -> :262
+    const double new_scale = pow(2.0, (double)(int64_t)std::log2(src_scale)); // SEAL_HEVM.cpp:332 -> :262
     const CrtTables &tb = crt_tables(ell);
     u64 *pt = W().ks_tmp;      // [ell][N]
     u64 *lohi = W().ks_digits; // [2][N]
-    hipLaunchKernelGGL(decrypt_kernel, dim3((unsigned)(N / (2 * kVmThreads)), (unsigned)ell), dim3(kVmThreads), 0, S(), pt,
-                       view(s), keys.sk, N, c.d_mods);
+    hipLaunchKernelGGL(decrypt_kernel, dim3((unsigned)(N / (2 * kVmThreads)), (unsigned)ell), dim3(kVmThreads), 0, S(), pt, src,
+                       keys.sk, N, c.d_mods);
     launch_ntt(c, true, pt, (long)N, ell, nullptr, 0, 0, S());
     const CrtDev cd{ tb.inv, tb.mmod, tb.hmod, tb.hdig, tb.mdbl };
     hipLaunchKernelGGL(reencode_kernel, dim3((unsigned)((N / 2 + kVmThreads) / kVmThreads)), dim3(kVmThreads), 0, S(), lohi,
-                       lohi + N, pt, ell, N, c.d_mods, cd, new_scale / s.scale);
+                       lohi + N, pt, ell, N, c.d_mods, cd, new_scale / src_scale);
     Plain ptx{ lanes[cur].boot_plain.d, target_level, new_scale };
     hipLaunchKernelGGL(lift_i128_kernel, dim3((unsigned)(N / kVmThreads), (unsigned)target_level), dim3(kVmThreads), 0, S(),
                        ptx.d, lohi, lohi + N, N, c.d_mods);
     launch_ntt(c, false, ptx.d, (long)N, target_level, nullptr, 0, 0, S());
-    encrypt_plain(reg(dst), ptx);
+    encrypt_plain(dst, ptx);
 }
 
 hipEvent_t HEVM::new_event()
@@ -1176,6 +1188,10 @@ void HEVM::execute(bool multi_lane)
 
 void HEVM::run()
 {
+    if (use_plan && !debug && n_lanes == 1 && !use_graph) {
+        run_plan();
+        return;
+    }
     const bool multi = n_lanes > 1 && !debug;
     if (!use_graph || debug) {
         execute(multi);

@@ -11,6 +11,7 @@
 
 #include "../../include/hevm_abi.h"
 #include "kernels.hpp"
+#include "plan.hpp"
 
 namespace dacapo {
 
@@ -132,6 +133,60 @@ class HEVM {
     };
     std::map<int, CrtTables> crt_;
     const CrtTables &crt_tables(int ell);
+
+    // ---- batched plan (plan.hpp): built on the first run() of a loaded program -----------------------------
+    enum PopKind { P_ROT, P_MULCC, P_RESCALE, P_SUM, P_NEG, P_MULP, P_ADDP, P_COPY, P_BOOT };
+    struct Val {
+        int level = 0;
+        double scale = 1.0;
+        int root = -1;     // value whose buffer this one aliases (modswitch = a view with fewer limbs)
+        int def_step = -1; // step producing it (-1: program input)
+        int last_use = -1; // last step reading it
+        int uses = 0;
+        int def_pop = -1;
+        u64 *buf = nullptr;
+        bool external = false, pinned = false;
+    };
+    struct Pop {
+        PopKind kind;
+        int level = 0;
+        int dst = -1;
+        std::vector<int> srcs;
+        u32 elt = 0;
+        const u64 *key = nullptr;
+        int plain = -1, target_level = 0;
+        bool dead = false;
+        int wave = 0, step = -1;
+    };
+    struct Step {
+        PopKind kind;
+        int level = 0, first = 0, count = 0; // range in the kind's device item table
+        int pop = -1;                       // P_BOOT: the single pop
+    };
+    struct Plan {
+        bool ready = false;
+        std::vector<Val> vals;
+        std::vector<Pop> pops;
+        std::vector<Step> steps;
+        std::vector<int> final_val; // architectural register -> value at program end
+        KsItem *d_ks = nullptr;
+        MulItem *d_mul = nullptr;
+        RsItem *d_rs = nullptr;
+        EwItem *d_ew = nullptr;
+        SumItem *d_sum = nullptr;
+        CtView *d_sum_srcs = nullptr;
+        BatchWs ws;
+        std::vector<u64 *> pool; // every pool buffer ever allocated (reused across plans)
+        int64_t n_keyswitch = 0, n_ntt = 0;
+        size_t launches = 0, max_live = 0;
+    } plan;
+    bool use_plan = true;
+    int max_batch = 128;
+    std::vector<u64 *> home; // permanent buffer of every architectural register (program inputs live here)
+    void build_plan();
+    void run_plan();
+    void boot_item(CtView src, int src_level, double src_scale, hevm_ctxt &dst, int target_level);
+    void bump_epoch(hipStream_t s);
 
     // statistics of the last run()
     int64_t op_counts[11] = { 0 };

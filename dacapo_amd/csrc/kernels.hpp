@@ -15,8 +15,9 @@ struct CtView {
 };
 
 // ---- NTT (ntt_kernels.hip) -----------------------------------------------------------------------------
-// `count` limbs at data + b*limb_stride; limb b is modulo prime d_prime_idx[b] (device array) or, when the
-// pointer is null, prime_base + (b % prime_period).  In place.  Output canonical.
+// `count` limbs at data + b*limb_stride; limb b is modulo prime d_prime_idx[b % prime_period] (device array) or,
+// when the pointer is null, prime_base + (b % prime_period); prime_period <= 0 means "no wrap".  In place.
+// Output canonical.
 void launch_ntt(const Context &c, bool inverse, u64 *data, long limb_stride, int count, const int *d_prime_idx,
                 int prime_base, int prime_period, hipStream_t s);
 

@@ -14,7 +14,7 @@ __global__ __launch_bounds__(kTileThreads) void ntt_phase_kernel(u64 *__restrict
 {
     __shared__ __attribute__((aligned(16))) u64 lds[kTileLdsElems];
     const int limb = blockIdx.y;
-    const int p = prime_idx ? prime_idx[limb] : prime_base + (limb % prime_period);
+    const int p = prime_idx ? prime_idx[limb % prime_period] : prime_base + (limb % prime_period);
     u64 *a = data + (long)limb * limb_stride;
     const DModulus M = mods[p];
     ntt_tile<K, COLS, INV, CANON>(

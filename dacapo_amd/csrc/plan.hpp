@@ -1,0 +1,56 @@
+// Batched execution plan of an HEVM program.
+//
+// The reference interprets the bytecode one blocking SEAL call at a time (SEAL_HEVM.cpp:336-401).  On the MI355X a
+// single low-level ciphertext op (2-5 primes) is a few microseconds of work spread over a dozen dependent launches:
+// issued one by one the GPU idles between them.  HBM is plentiful (288 GB), so run() instead executes a PLAN
+// built once per loaded program:
+//   1. registers are renamed (SSA): every op result gets its own buffer from a pool, which removes the WAR/WAW
+//      hazards that ReuseBuffer.cpp's register recycling introduces and leaves only true dataflow;
+//   2. ops are levelled by dataflow depth ("waves"); all ops of one kind and level in a wave become ONE batched
+//      launch sequence (the key switches of the ~100 independent rotations of a convolution run as one batch);
+//   3. chains of ct+ct additions are summed by one n-ary kernel -- modular addition is exact, so the result limbs
+//      are bit-identical to the sequential chain.
+// Every kernel takes a device-resident table of per-item views; level/scale bookkeeping is resolved at plan time.
+#pragma once
+#include "kernels.hpp"
+
+namespace dacapo {
+
+struct KsItem {   // one key-switch hop of a rotation: dst = apply_galois(src)
+    CtView src, dst;
+    const u64 *key;
+    u32 elt, pad;
+};
+struct MulItem {  // dst = relinearize(a * b)
+    CtView a, b, dst;
+};
+struct RsItem {   // dst = rescale_to_next(src)
+    CtView src, dst;
+};
+struct EwItem {   // dst = a (op) b ; plaintext operand: b.p = limbs, b.poly_stride = 0
+    CtView dst, a, b;
+};
+struct SumItem {  // dst = sum of `count` ciphertexts srcs[first ...]
+    CtView dst;
+    int first, count;
+};
+
+// scratch of one batched step, sized for the largest batch of the plan
+struct BatchWs {
+    u64 *target = nullptr; // [B][l][N]     key-switch target, NTT form
+    u64 *digits = nullptr; // [B][l][N]     its coefficient-domain digits (rescale: [B][2][N] dropped limbs)
+    u64 *ext = nullptr;    // [B][l*l][N]   digits lifted to the other moduli
+    u64 *acc = nullptr;    // [B][2][l+1][N]
+    u64 *tmp = nullptr;    // [B][2][l][N]
+    u64 *c0perm = nullptr; // [B][l][N]     permuted c0 of a rotation
+};
+
+void b_rotate_hops(Context &c, const BatchWs &w, const KsItem *d_items, int B, int ell, hipStream_t s);
+void b_mul_relin(Context &c, const BatchWs &w, const MulItem *d_items, const u64 *relin_key, int B, int ell, hipStream_t s);
+void b_rescale(Context &c, const BatchWs &w, const RsItem *d_items, int B, int ell, hipStream_t s);
+// op: Neg / Mul (ct * plain) / Copy ; b_polys as in launch_ew
+void b_ew(Context &c, EwOp op, const EwItem *d_items, int B, int polys, int b_polys, int ell, hipStream_t s);
+void b_add_plain(Context &c, const EwItem *d_items, int B, int ell, hipStream_t s);
+void b_sum(Context &c, const SumItem *d_items, const CtView *d_srcs, int B, int ell, hipStream_t s);
+
+} // namespace dacapo

@@ -1,0 +1,405 @@
+// Plan construction and execution for the HEVM VM (see plan.hpp for the idea).  Semantics per opcode are those of
+// SEAL_HEVM.cpp:268-334 (including the scale overwrite of addcc/addcp at :301,:308 and the untouched dst of a
+// zero modswitch at :288), evaluated once at plan time in program order.
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+#include <map>
+#include <queue>
+#include <tuple>
+
+#include "hevm_vm.hpp"
+
+namespace dacapo {
+
+static inline int64_t ks_ntts(int ell) { return (int64_t)(ell + 1) * (ell + 2); }
+
+template <class T>
+static T *upload(const std::vector<T> &v)
+{
+    T *d = nullptr;
+    DC_HIP_CHECK(hipMalloc(&d, std::max<size_t>(v.size(), 1) * sizeof(T)));
+    if (!v.empty()) DC_HIP_CHECK(hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return d;
+}
+
+void HEVM::build_plan()
+{
+    Context &c = *ctx;
+    const size_t N = c.N;
+    Plan &P = plan;
+    for (void *p : { (void *)P.d_ks, (void *)P.d_mul, (void *)P.d_rs, (void *)P.d_ew, (void *)P.d_sum, (void *)P.d_sum_srcs })
+        if (p) (void)hipFree(p);
+    P.vals.clear(), P.pops.clear(), P.steps.clear();
+    P.n_keyswitch = P.n_ntt = 0;
+    const size_t nreg = ciphers.size();
+    std::vector<int> cur(nreg, -1);
+    auto new_val = [&](int level, double scale) {
+        Val v;
+        v.level = level, v.scale = scale, v.root = (int)P.vals.size();
+        P.vals.push_back(v);
+        return (int)P.vals.size() - 1;
+    };
+    auto need = [&](int r, const char *what) {
+        if (r < 0 || (size_t)r >= nreg || cur[(size_t)r] < 0) {
+            fprintf(stderr, "[dacapo_amd] %s reads cipher register %d before anything wrote it\n", what, r);
+            abort();
+        }
+        return cur[(size_t)r];
+    };
+    auto add_pop = [&](PopKind k, int level, std::vector<int> srcs, int dst) -> Pop & {
+        Pop p;
+        p.kind = k, p.level = level, p.srcs = std::move(srcs), p.dst = dst;
+        P.vals[(size_t)dst].def_pop = (int)P.pops.size();
+        P.pops.push_back(p);
+        return P.pops.back();
+    };
+    for (size_t i = 0; i < header.arg_length; i++) { // program inputs: written by encrypt() into the home buffers
+        const int v = new_val((int)arg_level[i], pow(2.0, (double)arg_scale[i]));
+        P.vals[(size_t)v].external = true;
+        P.vals[(size_t)v].buf = home.at(i);
+        cur[i] = v;
+    }
+    // ---- 1. SSA walk in program order: metadata semantics of the reference, one pseudo-op per kernel sequence ----
+    for (const WireOp &op : ops) {
+        switch (op.opcode) {
+        case 1: { // rotate: one key-switch hop per Galois element (direct key or NAF digits)
+            int v = need(op.lhs, "rotate");
+            for (u32 elt : rotate_hops((int16_t)op.rhs)) {
+                const Val s = P.vals[(size_t)v];
+                const int nv = new_val(s.level, s.scale);
+                Pop &p = add_pop(P_ROT, s.level, { v }, nv);
+                p.elt = elt, p.key = keys.galois.at(elt);
+                P.n_keyswitch++, P.n_ntt += ks_ntts(s.level);
+                v = nv;
+            }
+            cur[op.dst] = v; // zero hops: dst simply names the same value
+            break;
+        }
+        case 2: {
+            const int a = need(op.lhs, "negate");
+            const Val s = P.vals[(size_t)a];
+            const int nv = new_val(s.level, s.scale);
+            add_pop(P_NEG, s.level, { a }, nv);
+            cur[op.dst] = nv;
+            break;
+        }
+        case 3: {
+            const int a = need(op.lhs, "rescale");
+            const Val s = P.vals[(size_t)a];
+            if (s.level < 2) {
+                fprintf(stderr, "[dacapo_amd] rescale: end of modulus switching chain reached\n");
+                abort();
+            }
+            const int nv = new_val(s.level - 1, s.scale / (double)c.primes[(size_t)s.level - 1]);
+            add_pop(P_RESCALE, s.level, { a }, nv);
+            P.n_ntt += 2 * s.level;
+            cur[op.dst] = nv;
+            break;
+        }
+        case 4: { // CKKS mod_switch_to_next drops limbs: a view of the same buffer with fewer primes
+            const int down = (int16_t)op.rhs;
+            if (down <= 0) break; // dst untouched (SEAL_HEVM.cpp:288)
+            const int a = need(op.lhs, "modswitch");
+            const Val s = P.vals[(size_t)a];
+            if (s.level - down < 1) {
+                fprintf(stderr, "[dacapo_amd] modswitch: end of modulus switching chain reached\n");
+                abort();
+            }
+            const int nv = new_val(s.level - down, s.scale);
+            P.vals[(size_t)nv].root = s.root;
+            P.vals[(size_t)nv].def_pop = P.vals[(size_t)s.root].def_pop;
+            P.vals[(size_t)a].uses++; // the view keeps the original alive and observable
+            cur[op.dst] = nv;
+            break;
+        }
+        case 5: fprintf(stderr, "This VM does not support native upscale op\n"); abort();
+        case 6: {
+            const int a = need(op.lhs, "addcc"), b = need(op.rhs, "addcc");
+            P.vals[(size_t)a].scale = P.vals[(size_t)b].scale; // SEAL_HEVM.cpp:301
+            if (P.vals[(size_t)a].level != P.vals[(size_t)b].level) {
+                fprintf(stderr, "[dacapo_amd] addcc: level mismatch %d vs %d\n", P.vals[(size_t)a].level, P.vals[(size_t)b].level);
+                abort();
+            }
+            const int nv = new_val(P.vals[(size_t)a].level, P.vals[(size_t)b].scale);
+            add_pop(P_SUM, P.vals[(size_t)a].level, { a, b }, nv);
+            cur[op.dst] = nv;
+            break;
+        }
+        case 7: {
+            const int a = need(op.lhs, "addcp");
+            const Plain &pl = plains.at(op.rhs);
+            P.vals[(size_t)a].scale = pl.scale; // SEAL_HEVM.cpp:308
+            if (P.vals[(size_t)a].level != pl.level) {
+                fprintf(stderr, "[dacapo_amd] addcp: level mismatch %d vs %d\n", P.vals[(size_t)a].level, pl.level);
+                abort();
+            }
+            const int nv = new_val(pl.level, pl.scale);
+            add_pop(P_ADDP, pl.level, { a }, nv).plain = op.rhs;
+            cur[op.dst] = nv;
+            break;
+        }
+        case 8: {
+            const int a = need(op.lhs, "mulcc"), b = need(op.rhs, "mulcc");
+            const Val sa = P.vals[(size_t)a], sb = P.vals[(size_t)b];
+            if (sa.level != sb.level) {
+                fprintf(stderr, "[dacapo_amd] mulcc: level mismatch %d vs %d\n", sa.level, sb.level);
+                abort();
+            }
+            const int nv = new_val(sa.level, sa.scale * sb.scale);
+            add_pop(P_MULCC, sa.level, { a, b }, nv);
+            P.n_keyswitch++, P.n_ntt += ks_ntts(sa.level);
+            cur[op.dst] = nv;
+            break;
+        }
+        case 9: {
+            const int a = need(op.lhs, "mulcp");
+            const Val sa = P.vals[(size_t)a];
+            const Plain &pl = plains.at(op.rhs);
+            if (sa.level != pl.level) {
+                fprintf(stderr, "[dacapo_amd] mulcp: level mismatch %d vs %d\n", sa.level, pl.level);
+                abort();
+            }
+            const int nv = new_val(sa.level, sa.scale * pl.scale);
+            add_pop(P_MULP, sa.level, { a }, nv).plain = op.rhs;
+            cur[op.dst] = nv;
+            break;
+        }
+        case 10: {
+            const int a = need(op.lhs, "bootstrap");
+            const Val sa = P.vals[(size_t)a];
+            const int nv = new_val((int)op.rhs, pow(2.0, (double)(int64_t)std::log2(sa.scale))); // SEAL_HEVM.cpp:332
+            add_pop(P_BOOT, sa.level, { a }, nv).target_level = op.rhs;
+            cur[op.dst] = nv;
+            break;
+        }
+        default: break;
+        }
+    }
+    P.final_val = cur;
+    std::vector<Val> &V = P.vals;
+    std::vector<Pop> &O = P.pops;
+    for (const Pop &p : O)
+        for (int s : p.srcs) V[(size_t)s].uses++;
+    for (int v : cur)
+        if (v >= 0) V[(size_t)v].uses++, V[(size_t)V[(size_t)v].root].pinned = true;
+
+    // ---- 2. fold ct+ct chains into n-ary sums (only through intermediates nothing else observes) ------------------
+    for (Pop &p : O) {
+        if (p.kind != P_SUM) continue;
+        std::vector<int> flat;
+        for (int s : p.srcs) {
+            const Val &sv = V[(size_t)s];
+            const int dp = sv.root == s ? sv.def_pop : -1;
+            if (dp >= 0 && O[(size_t)dp].kind == P_SUM && !O[(size_t)dp].dead && sv.uses == 1 && O[(size_t)dp].dst == s) {
+                flat.insert(flat.end(), O[(size_t)dp].srcs.begin(), O[(size_t)dp].srcs.end());
+                O[(size_t)dp].dead = true;
+            } else
+                flat.push_back(s);
+        }
+        p.srcs = flat;
+    }
+
+    // ---- 3. dataflow depth ------------------------------------------------------------------------------------------
+    int max_wave = 0;
+    for (Pop &p : O) {
+        if (p.dead) continue;
+        int w = 0;
+        for (int s : p.srcs) {
+            const int dp = V[(size_t)s].def_pop;
+            if (dp >= 0) w = std::max(w, O[(size_t)dp].wave);
+        }
+        p.wave = w + 1;
+        max_wave = std::max(max_wave, p.wave);
+    }
+
+    // ---- 4. steps: per wave, one batch per (kind, level) -----------------------------------------------------------------
+    std::vector<std::vector<int>> by_wave((size_t)max_wave + 1);
+    for (size_t i = 0; i < O.size(); i++)
+        if (!O[i].dead) by_wave[(size_t)O[i].wave].push_back((int)i);
+    std::vector<KsItem> h_ks;
+    std::vector<MulItem> h_mul;
+    std::vector<RsItem> h_rs;
+    std::vector<EwItem> h_ew;
+    std::vector<SumItem> h_sum;
+    std::vector<CtView> h_srcs;
+    std::vector<std::vector<int>> step_pops;
+    for (int w = 1; w <= max_wave; w++) {
+        std::map<std::pair<int, int>, std::vector<int>> buckets; // (kind, level) -> pops
+        for (int pi : by_wave[(size_t)w]) buckets[{ (int)O[(size_t)pi].kind, O[(size_t)pi].level }].push_back(pi);
+        for (auto &kv : buckets) {
+            const PopKind kind = (PopKind)kv.first.first;
+            const bool heavy = kind == P_ROT || kind == P_MULCC || kind == P_RESCALE;
+            const size_t chunk = kind == P_BOOT ? 1 : (heavy ? (size_t)max_batch : (size_t)4096);
+            for (size_t off = 0; off < kv.second.size(); off += chunk) {
+                Step st;
+                st.kind = kind, st.level = kv.first.second;
+                st.count = (int)std::min(chunk, kv.second.size() - off);
+                std::vector<int> members(kv.second.begin() + (long)off, kv.second.begin() + (long)off + st.count);
+                for (int pi : members) O[(size_t)pi].step = (int)P.steps.size();
+                if (kind == P_BOOT) st.pop = members[0];
+                P.steps.push_back(st);
+                step_pops.push_back(members);
+            }
+        }
+    }
+    // ---- 5. lifetimes and pool buffers ---------------------------------------------------------------------------------
+    for (const Pop &p : O) {
+        if (p.dead) continue;
+        V[(size_t)V[(size_t)p.dst].root].def_step = p.step;
+        for (int s : p.srcs) {
+            Val &r = V[(size_t)V[(size_t)s].root];
+            r.last_use = std::max(r.last_use, p.step);
+        }
+    }
+    const size_t buf_elems = (size_t)2 * c.K * N;
+    std::vector<u64 *> free_list = P.pool; // every pool buffer is free at plan start
+    typedef std::pair<int, u64 *> Rel; // (last_use, buffer)
+    std::priority_queue<Rel, std::vector<Rel>, std::greater<Rel>> busy;
+    size_t live = 0;
+    P.max_live = 0;
+    std::vector<std::vector<int>> defs(P.steps.size());
+    for (size_t v = 0; v < V.size(); v++)
+        if (V[v].root == (int)v && V[v].def_step >= 0 && !V[v].external) defs[(size_t)V[v].def_step].push_back((int)v);
+    for (size_t s = 0; s < P.steps.size(); s++) {
+        while (!busy.empty() && busy.top().first < (int)s) {
+            free_list.push_back(busy.top().second);
+            busy.pop();
+            live--;
+        }
+        for (int v : defs[s]) {
+            u64 *b;
+            if (!free_list.empty()) {
+                b = free_list.back();
+                free_list.pop_back();
+            } else {
+                DC_HIP_CHECK(hipMalloc(&b, buf_elems * sizeof(u64)));
+                P.pool.push_back(b);
+            }
+            V[(size_t)v].buf = b;
+            live++;
+            P.max_live = std::max(P.max_live, live);
+            if (!V[(size_t)v].pinned) busy.push({ std::max(V[(size_t)v].last_use, (int)s), b });
+        }
+    }
+    // ---- 6. device item tables ----------------------------------------------------------------------------------------
+    const long ps = (long)c.K * (long)N;
+    auto view = [&](int v) {
+        u64 *b = V[(size_t)V[(size_t)v].root].buf;
+        if (!b) {
+            fprintf(stderr, "[dacapo_amd] plan: value %d has no buffer (internal error)\n", v);
+            abort();
+        }
+        return CtView{ b, ps };
+    };
+    size_t need_t = 0, need_d = 0, need_e = 0, need_a = 0, need_m = 0, need_c = 0;
+    P.launches = 0;
+    for (size_t s = 0; s < P.steps.size(); s++) {
+        Step &st = P.steps[s];
+        const size_t B = (size_t)st.count, l = (size_t)st.level;
+        switch (st.kind) {
+        case P_ROT:
+            st.first = (int)h_ks.size();
+            for (int pi : step_pops[s]) h_ks.push_back(KsItem{ view(O[(size_t)pi].srcs[0]), view(O[(size_t)pi].dst), O[(size_t)pi].key, O[(size_t)pi].elt, 0 });
+            break;
+        case P_MULCC:
+            st.first = (int)h_mul.size();
+            for (int pi : step_pops[s]) h_mul.push_back(MulItem{ view(O[(size_t)pi].srcs[0]), view(O[(size_t)pi].srcs[1]), view(O[(size_t)pi].dst) });
+            break;
+        case P_RESCALE:
+            st.first = (int)h_rs.size();
+            for (int pi : step_pops[s]) h_rs.push_back(RsItem{ view(O[(size_t)pi].srcs[0]), view(O[(size_t)pi].dst) });
+            break;
+        case P_SUM:
+            st.first = (int)h_sum.size();
+            for (int pi : step_pops[s]) {
+                h_sum.push_back(SumItem{ view(O[(size_t)pi].dst), (int)h_srcs.size(), (int)O[(size_t)pi].srcs.size() });
+                for (int sv : O[(size_t)pi].srcs) h_srcs.push_back(view(sv));
+            }
+            break;
+        case P_NEG:
+        case P_COPY:
+            st.first = (int)h_ew.size();
+            for (int pi : step_pops[s]) h_ew.push_back(EwItem{ view(O[(size_t)pi].dst), view(O[(size_t)pi].srcs[0]), view(O[(size_t)pi].srcs[0]) });
+            break;
+        case P_MULP:
+        case P_ADDP:
+            st.first = (int)h_ew.size();
+            for (int pi : step_pops[s])
+                h_ew.push_back(EwItem{ view(O[(size_t)pi].dst), view(O[(size_t)pi].srcs[0]), CtView{ plains.at((size_t)O[(size_t)pi].plain).d, 0 } });
+            break;
+        case P_BOOT: break;
+        }
+        if (st.kind == P_ROT || st.kind == P_MULCC) {
+            need_t = std::max(need_t, B * l), need_d = std::max(need_d, B * std::max<size_t>(l, 2)), need_e = std::max(need_e, B * l * l);
+            need_a = std::max(need_a, B * 2 * (l + 1)), need_m = std::max(need_m, B * 2 * l), need_c = std::max(need_c, B * l);
+            P.launches += 13;
+        } else if (st.kind == P_RESCALE) {
+            need_d = std::max(need_d, B * 2), need_m = std::max(need_m, B * 2 * l);
+            P.launches += 7;
+        } else
+            P.launches += st.kind == P_BOOT ? 25 : 1;
+    }
+    P.d_ks = upload(h_ks), P.d_mul = upload(h_mul), P.d_rs = upload(h_rs), P.d_ew = upload(h_ew), P.d_sum = upload(h_sum);
+    P.d_sum_srcs = upload(h_srcs);
+    for (void *p : { (void *)P.ws.target, (void *)P.ws.digits, (void *)P.ws.ext, (void *)P.ws.acc, (void *)P.ws.tmp, (void *)P.ws.c0perm })
+        if (p) (void)hipFree(p);
+    auto alloc = [&](size_t limbs) {
+        u64 *d = nullptr;
+        DC_HIP_CHECK(hipMalloc(&d, std::max<size_t>(limbs, 1) * N * sizeof(u64)));
+        return d;
+    };
+    P.ws.target = alloc(need_t), P.ws.digits = alloc(need_d), P.ws.ext = alloc(need_e);
+    P.ws.acc = alloc(need_a), P.ws.tmp = alloc(need_m), P.ws.c0perm = alloc(need_c);
+    P.ready = true;
+    if (getenv("DACAPO_HEVM_TRACE"))
+        fprintf(stderr, "[dacapo_amd] plan: %zu ops -> %zu pseudo-ops -> %zu steps in %d waves, ~%zu launches, %zu live buffers (%.1f GB pool)\n",
+                ops.size(), O.size(), P.steps.size(), max_wave, P.launches, P.max_live, (double)P.pool.size() * buf_elems * 8 / 1e9);
+}
+
+void HEVM::run_plan()
+{
+    if (!plan.ready) build_plan();
+    Context &c = *ctx;
+    Plan &P = plan;
+    cur = 0;
+    hipStream_t s = S();
+    memset(op_counts, 0, sizeof(op_counts));
+    for (const WireOp &op : ops)
+        if (op.opcode <= 10) op_counts[op.opcode]++;
+    n_keyswitch = P.n_keyswitch, n_ntt = P.n_ntt;
+    t_bootstrap = 0.0;
+    const long ps = (long)c.K * (long)c.N;
+    for (const Step &st : P.steps) {
+        switch (st.kind) {
+        case P_ROT: b_rotate_hops(c, P.ws, P.d_ks + st.first, st.count, st.level, s); break;
+        case P_MULCC: b_mul_relin(c, P.ws, P.d_mul + st.first, keys.relin, st.count, st.level, s); break;
+        case P_RESCALE: b_rescale(c, P.ws, P.d_rs + st.first, st.count, st.level, s); break;
+        case P_SUM: b_sum(c, P.d_sum + st.first, P.d_sum_srcs, st.count, st.level, s); break;
+        case P_NEG: b_ew(c, EwOp::Neg, P.d_ew + st.first, st.count, 2, 2, st.level, s); break;
+        case P_COPY: b_ew(c, EwOp::Copy, P.d_ew + st.first, st.count, 2, 2, st.level, s); break;
+        case P_MULP: b_ew(c, EwOp::Mul, P.d_ew + st.first, st.count, 2, 1, st.level, s); break;
+        case P_ADDP: b_add_plain(c, P.d_ew + st.first, st.count, st.level, s); break;
+        case P_BOOT: {
+            const Pop &p = P.pops[(size_t)st.pop];
+            const Val &sv = P.vals[(size_t)p.srcs[0]];
+            hevm_ctxt d{ P.vals[(size_t)P.vals[(size_t)p.dst].root].buf, ps, 0, 0, 1.0 };
+            boot_item(CtView{ P.vals[(size_t)sv.root].buf, ps }, sv.level, sv.scale, d, p.target_level);
+            break;
+        }
+        }
+    }
+    bump_epoch(s);
+    DC_HIP_CHECK(hipStreamSynchronize(s)); // the caller's timer stops when run() returns
+    for (size_t r = 0; r < P.final_val.size() && r < ciphers.size(); r++) {
+        const int v = P.final_val[r];
+        if (v < 0) continue;
+        ciphers[r].data = P.vals[(size_t)P.vals[(size_t)v].root].buf;
+        ciphers[r].poly_stride = ps;
+        ciphers[r].level = P.vals[(size_t)v].level;
+        ciphers[r].scale = P.vals[(size_t)v].scale;
+    }
+}
+
+} // namespace dacapo

@@ -48,21 +48,25 @@ def _mirror_vm(hevm, ll, o, cst, hv, tmp_path):
     return ovm
 
 
-@pytest.fixture(scope="module", params=["eager1", "eager4", "graph2"])
+@pytest.fixture(scope="module", params=["plan", "eager1", "eager4", "graph2"])
 def vm13(request):
-    """eager1 = default: single stream, the plain dispatch loop of the reference; eager4 = 4 lanes issued eagerly
-    (exercises the event-based register dependency tracking); graph2 = 2 lanes captured into a HIP graph and replayed."""
+    """plan   = default: the batched execution plan (SSA-renamed registers, one batched launch sequence per wave);
+    eager1 = the reference's dispatch loop, one op at a time on one stream;
+    eager4 = 4 lanes issued eagerly (event-based register dependency tracking);
+    graph2 = 2 lanes captured into a HIP graph and replayed."""
     import os
 
     from dacapo_amd import lowlevel as ll
     from dacapo_amd import runner
 
-    lanes, graph = {"graph2": ("2", "1"), "eager1": ("1", "0"), "eager4": ("4", "0")}[request.param]
-    os.environ["DACAPO_HEVM_STREAMS"], os.environ["DACAPO_HEVM_GRAPH"] = lanes, graph
+    env = {"plan": {}, "eager1": {"DACAPO_HEVM_PLAN": "0"}, "eager4": {"DACAPO_HEVM_PLAN": "0", "DACAPO_HEVM_STREAMS": "4"},
+           "graph2": {"DACAPO_HEVM_PLAN": "0", "DACAPO_HEVM_STREAMS": "2", "DACAPO_HEVM_GRAPH": "1"}}[request.param]
+    os.environ.update(env)
     try:
         hevm = runner.HEVM(seed=0x4845564D, logN=13, num_primes=7)
     finally:
-        os.environ.pop("DACAPO_HEVM_STREAMS"), os.environ.pop("DACAPO_HEVM_GRAPH")
+        for k in env:
+            os.environ.pop(k)
     o = Oracle(13, 7)
     _import_keys(o, hevm, ll)
     return hevm, o, ll
