@@ -1,0 +1,234 @@
+// Fused phase kernels of the batched key-switch / rescale pipelines (plan.hpp, batch_ops.hip).
+//
+// A key switch at level l is  iNTT(l limbs) -> lift each digit to the l other moduli -> NTT(l*l limbs) -> inner
+// products with the key -> mod-down (iNTT of the special-prime limb, lift, NTT, scale) [SEAL-upstream
+// Evaluator::switch_key_inplace, reached from SEAL_HEVM.cpp:273,316].  Launched phase by phase that is 13 dependent
+// launches; at the HEVM working levels (2-5 primes) each is microseconds of work, so the launch chain IS the latency.
+// The tile routine lets an inverse COLS phase hand its canonical output to a forward COLS phase in registers, so:
+//   L1 irows   : inverse ROWS phase, reading the operand in place (Galois gather fused into the loader)
+//   L2 icols+lift+fcols : per (digit j, other modulus e): finish the iNTT of digit j, reduce into q_e, first NTT phase
+//   L3 frows   : second NTT phase over the l*l lifted digits
+//   L4 mac     : inner products with the key (the j == m term reads the operand in place)
+//   L5 irows   : special-prime limb of both accumulators
+//   L6 icols+round+fcols : finish its iNTT, add floor(P/2), reduce into q_i, subtract, first NTT phase
+//   L7 frows+final : second NTT phase, (acc - t) * P^-1 + base, written straight into the destination
+// 7 launches instead of 13; rescale is L5'-L7' = 3 instead of 7.  L2/L6 recompute the inverse COLS phase once per
+// target modulus (it is 1/(l+1) of that kernel's work) to keep every workgroup at two phases.
+#include "ntt_tile.hpp"
+#include "plan.hpp"
+
+namespace dacapo {
+
+__device__ __forceinline__ u32 galois_idx(u32 k, u32 elt, int logN)
+{
+    const u32 r = (__brev(k) >> (32 - logN)) * 2u + 1u;
+    const u32 idx = ((elt * r) >> 1) & ((1u << logN) - 1u);
+    return __brev(idx) >> (32 - logN);
+}
+
+// ---- operand sources of the first inverse phase ----------------------------------------------------------------------
+struct SrcStrided { // limb z at base + z*stride, modulo prime prime_base + z % period
+    const u64 *base;
+    long stride;
+    int prime_base, period;
+    __device__ int prime(int z) const { return prime_base + z % period; }
+    __device__ u64 load(int z, int g, int) const { return base[(long)z * stride + g]; }
+};
+struct SrcRotC1 { // limb z = b*l + j : c1 of item b, limb j, read through the item's Galois permutation
+    const KsItem *items;
+    int ell;
+    __device__ int prime(int z) const { return z % ell; }
+    __device__ u64 load(int z, int g, int logN) const
+    {
+        const KsItem &it = items[z / ell];
+        return it.src.limb(1, z % ell, (size_t)1 << logN)[galois_idx((u32)g, it.elt, logN)];
+    }
+};
+struct SrcRsLast { // limb z = b*2 + p : the limb being dropped by a rescale
+    const RsItem *items;
+    int l;
+    __device__ int prime(int) const { return l; }
+    __device__ u64 load(int z, int g, int logN) const { return items[z >> 1].src.limb(z & 1, l, (size_t)1 << logN)[g]; }
+};
+
+// L1 / L5 / R1: inverse ROWS phase, out[z] (lazy values) = phase(src limb z)
+template <int K, class Src>
+__global__ __launch_bounds__(kTileThreads) void f_irows_kernel(Src src, u64 *__restrict__ out, long out_stride,
+                                                                const DModulus *__restrict__ mods, const u64 *__restrict__ itw,
+                                                                int logN)
+{
+    __shared__ __attribute__((aligned(16))) u64 lds[kTileLdsElems];
+    const int z = blockIdx.y, p = src.prime(z);
+    u64 *o = out + (long)z * out_stride;
+    ntt_tile<K, false, true, false>(
+        mods[p], itw + ((size_t)p << logN), logN, blockIdx.x, [=](int g) { return src.load(z, g, logN); },
+        [=](int g, u64 v) { o[g] = v; }, lds);
+}
+
+// L2: z = (b*l + j)*l + e
+template <int K>
+__global__ __launch_bounds__(kTileThreads) void f_ks_icols_lift_fcols_kernel(const u64 *__restrict__ digits, u64 *__restrict__ ext,
+                                                                              int ell, int sp, const DModulus *__restrict__ mods,
+                                                                              const u64 *__restrict__ tw, const u64 *__restrict__ itw,
+                                                                              int logN)
+{
+    __shared__ __attribute__((aligned(16))) u64 lds[kTileLdsElems];
+    const int z = blockIdx.y, e = z % ell, dj = z / ell, j = dj % ell;
+    const size_t N = (size_t)1 << logN;
+    const u64 *in = digits + (size_t)dj * N;
+    u64 *out = ext + (size_t)z * N;
+    u64 x[8];
+    auto nost = [](int, u64) {};
+    ntt_tile_x<K, true, true, true, false, true>(
+        x, mods[j], itw + ((size_t)j << logN), logN, blockIdx.x, [=](int g) { return in[g]; }, nost, lds);
+    const int pm = ks_other_prime(j, e, ell, sp);
+    const DModulus Mm = mods[pm];
+#pragma unroll
+    for (int r = 0; r < 8; r++) x[r] = x[r] >= Mm.q ? x[r] - Mm.q : x[r]; // one conditional subtraction: all primes in (2^60-2^28, 2^60)
+    __syncthreads(); // the inverse tile's last LDS image has been read by everyone
+    auto nold = [](int) -> u64 { return 0; };
+    ntt_tile_x<K, true, false, false, true, false>(
+        x, Mm, tw + ((size_t)pm << logN), logN, blockIdx.x, nold, [=](int g, u64 v) { out[g] = v; }, lds);
+}
+
+// L6 / R2: z = bp*cnt + i : finish the iNTT of the dropped limb bp (prime l), round, change base to prime i, first NTT phase
+template <int K>
+__global__ __launch_bounds__(kTileThreads) void f_dr_icols_lift_fcols_kernel(const u64 *__restrict__ last, long last_stride,
+                                                                              u64 *__restrict__ tmp, int cnt, int l, int Kp,
+                                                                              const DModulus *__restrict__ mods,
+                                                                              const u64 *__restrict__ half_mod,
+                                                                              const u64 *__restrict__ tw, const u64 *__restrict__ itw,
+                                                                              int logN)
+{
+    __shared__ __attribute__((aligned(16))) u64 lds[kTileLdsElems];
+    const int z = blockIdx.y, i = z % cnt, bp = z / cnt;
+    const size_t N = (size_t)1 << logN;
+    const u64 *in = last + (long)bp * last_stride;
+    u64 *out = tmp + (size_t)z * N;
+    u64 x[8];
+    auto nost = [](int, u64) {};
+    ntt_tile_x<K, true, true, true, false, true>(
+        x, mods[l], itw + ((size_t)l << logN), logN, blockIdx.x, [=](int g) { return in[g]; }, nost, lds);
+    const DModulus Mi = mods[i];
+    const u64 ql = mods[l].q, qi = Mi.q, half = ql >> 1;
+    const u64 neg_half = qi - half_mod[(size_t)l * Kp + i];
+#pragma unroll
+    for (int r = 0; r < 8; r++) { // RNSTool::divide_and_round_q_last_ntt_inplace, coefficient-domain part
+        u64 y = x[r] + half;
+        y = y >= ql ? y - ql : y;
+        y = y >= qi ? y - qi : y;
+        y += neg_half;
+        x[r] = y >= qi ? y - qi : y;
+    }
+    __syncthreads();
+    auto nold = [](int) -> u64 { return 0; };
+    ntt_tile_x<K, true, false, false, true, false>(
+        x, Mi, tw + ((size_t)i << logN), logN, blockIdx.x, nold, [=](int g, u64 v) { out[g] = v; }, lds);
+}
+
+// L7 / R3: z = bp*cnt + i.  MODE 0 rotation, 1 relinearisation, 2 rescale
+template <int K, int MODE>
+__global__ __launch_bounds__(kTileThreads) void f_frows_final_kernel(const u64 *__restrict__ tmp, const void *__restrict__ items_,
+                                                                      const u64 *__restrict__ acc, int cnt, int l, int Kp,
+                                                                      const DModulus *__restrict__ mods,
+                                                                      const u64 *__restrict__ inv_last, const u64 *__restrict__ tw,
+                                                                      int logN)
+{
+    __shared__ __attribute__((aligned(16))) u64 lds[kTileLdsElems];
+    const int z = blockIdx.y, i = z % cnt, bp = z / cnt, b = bp >> 1, p = bp & 1;
+    const size_t N = (size_t)1 << logN;
+    const DModulus M = mods[i];
+    const u64 inv = inv_last[(size_t)l * Kp + i];
+    const u64 *in = tmp + (size_t)z * N;
+    if (MODE == 0) {
+        const KsItem it = reinterpret_cast<const KsItem *>(items_)[b];
+        const u64 *x = acc + (((size_t)bp) * (cnt + 1) + i) * N;
+        const u64 *c0 = it.src.limb(0, i, N);
+        u64 *o = it.dst.limb(p, i, N);
+        ntt_tile<K, false, false, true>(
+            M, tw + ((size_t)i << logN), logN, blockIdx.x, [=](int g) { return in[g]; },
+            [=](int g, u64 v) {
+                const u64 base = p == 0 ? c0[galois_idx((u32)g, it.elt, logN)] : 0;
+                o[g] = addmod(base, mulmod(submod(x[g], v, M.q), inv, M), M.q);
+            },
+            lds);
+    } else if (MODE == 1) {
+        const MulItem it = reinterpret_cast<const MulItem *>(items_)[b];
+        const u64 *x = acc + (((size_t)bp) * (cnt + 1) + i) * N;
+        u64 *o = it.dst.limb(p, i, N);
+        ntt_tile<K, false, false, true>(
+            M, tw + ((size_t)i << logN), logN, blockIdx.x, [=](int g) { return in[g]; },
+            [=](int g, u64 v) { o[g] = addmod(o[g], mulmod(submod(x[g], v, M.q), inv, M), M.q); }, lds);
+    } else {
+        const RsItem it = reinterpret_cast<const RsItem *>(items_)[b];
+        const u64 *x = it.src.limb(p, i, N);
+        u64 *o = it.dst.limb(p, i, N);
+        ntt_tile<K, false, false, true>(
+            M, tw + ((size_t)i << logN), logN, blockIdx.x, [=](int g) { return in[g]; },
+            [=](int g, u64 v) { o[g] = mulmod(submod(x[g], v, M.q), inv, M); }, lds);
+    }
+}
+
+// ---- launchers (K dispatch) -----------------------------------------------------------------------------------------------
+#define DC_K_SWITCH(Kval, CALL)                                                                           \
+    switch (Kval) {                                                                                       \
+    case 6: { constexpr int KK = 6; CALL; } break;                                                        \
+    case 7: { constexpr int KK = 7; CALL; } break;                                                        \
+    case 8: { constexpr int KK = 8; CALL; } break;                                                        \
+    case 9: { constexpr int KK = 9; CALL; } break;                                                        \
+    default: fprintf(stderr, "[dacapo_amd] unsupported NTT phase size 2^%d\n", Kval); abort();             \
+    }
+
+template <class Src>
+static void launch_irows(const Context &c, Src src, u64 *out, long out_stride, int count, hipStream_t s)
+{
+    dim3 grid((unsigned)(c.N >> kTileLog), (unsigned)count);
+    DC_K_SWITCH(c.k2, hipLaunchKernelGGL((f_irows_kernel<KK, Src>), grid, dim3(kTileThreads), 0, s, src, out, out_stride, c.d_mods,
+                                         c.d_itw, c.logN));
+}
+
+void f_irows_strided(const Context &c, const u64 *base, long stride, int prime_base, int period, u64 *out, long out_stride, int count,
+                     hipStream_t s)
+{
+    launch_irows(c, SrcStrided{ base, stride, prime_base, period }, out, out_stride, count, s);
+}
+void f_irows_rot_c1(const Context &c, const KsItem *items, int ell, u64 *out, int B, hipStream_t s)
+{
+    launch_irows(c, SrcRotC1{ items, ell }, out, (long)c.N, B * ell, s);
+}
+void f_irows_rs_last(const Context &c, const RsItem *items, int l, u64 *out, int B, hipStream_t s)
+{
+    launch_irows(c, SrcRsLast{ items, l }, out, (long)c.N, 2 * B, s);
+}
+
+void f_ks_icols_lift_fcols(const Context &c, const u64 *digits, u64 *ext, int B, int ell, hipStream_t s)
+{
+    dim3 grid((unsigned)(c.N >> kTileLog), (unsigned)(B * ell * ell));
+    DC_K_SWITCH(c.k1, hipLaunchKernelGGL((f_ks_icols_lift_fcols_kernel<KK>), grid, dim3(kTileThreads), 0, s, digits, ext, ell, c.K - 1,
+                                         c.d_mods, c.d_tw, c.d_itw, c.logN));
+}
+
+void f_dr_icols_lift_fcols(const Context &c, const u64 *last, long last_stride, u64 *tmp, int polys, int cnt, int l, hipStream_t s)
+{
+    dim3 grid((unsigned)(c.N >> kTileLog), (unsigned)(polys * cnt));
+    DC_K_SWITCH(c.k1, hipLaunchKernelGGL((f_dr_icols_lift_fcols_kernel<KK>), grid, dim3(kTileThreads), 0, s, last, last_stride, tmp, cnt, l,
+                                         c.K, c.d_mods, c.d_half_mod, c.d_tw, c.d_itw, c.logN));
+}
+
+void f_frows_final(const Context &c, int mode, const u64 *tmp, const void *items, const u64 *acc, int polys, int cnt, int l,
+                   hipStream_t s)
+{
+    dim3 grid((unsigned)(c.N >> kTileLog), (unsigned)(polys * cnt));
+    if (mode == 0) {
+        DC_K_SWITCH(c.k2, hipLaunchKernelGGL((f_frows_final_kernel<KK, 0>), grid, dim3(kTileThreads), 0, s, tmp, items, acc, cnt, l, c.K,
+                                             c.d_mods, c.d_inv_last, c.d_tw, c.logN));
+    } else if (mode == 1) {
+        DC_K_SWITCH(c.k2, hipLaunchKernelGGL((f_frows_final_kernel<KK, 1>), grid, dim3(kTileThreads), 0, s, tmp, items, acc, cnt, l, c.K,
+                                             c.d_mods, c.d_inv_last, c.d_tw, c.logN));
+    } else {
+        DC_K_SWITCH(c.k2, hipLaunchKernelGGL((f_frows_final_kernel<KK, 2>), grid, dim3(kTileThreads), 0, s, tmp, items, acc, cnt, l, c.K,
+                                             c.d_mods, c.d_inv_last, c.d_tw, c.logN));
+    }
+}
+
+} // namespace dacapo

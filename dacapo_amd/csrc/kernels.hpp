@@ -21,6 +21,10 @@ struct CtView {
 void launch_ntt(const Context &c, bool inverse, u64 *data, long limb_stride, int count, const int *d_prime_idx,
                 int prime_base, int prime_period, hipStream_t s);
 
+// second (ROWS) phase of a forward NTT only: the input holds the output of a COLS phase (fused_ks.hip)
+void launch_ntt_rows_fwd(const Context &c, u64 *data, long limb_stride, int count, const int *d_prime_idx, int prime_base,
+                         int prime_period, hipStream_t s);
+
 // ---- limb-wise kernels (poly_kernels.hip) -----------------------------------------------------------------
 enum class EwOp : int { Add = 0, Sub = 1, Neg = 2, Mul = 3, Copy = 4 };
 // dst[p][i] = a[p][i] (op) b[pb][i] for p < polys, i < ell (limb i modulo prime i).  b_polys == 1 broadcasts

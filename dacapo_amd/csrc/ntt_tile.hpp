@@ -79,9 +79,13 @@ __device__ __forceinline__ void gs_bfly(u64 &x, u64 &y, u64 w, const DModulus &M
 
 // Ld: u64 operator()(int gidx)            coefficient gidx (0..N-1) of this limb, value < 2^62
 // St: void operator()(int gidx, u64 v)    v canonical if CANON else lazy (< 2^63)
-template <int K, bool COLS, bool INV, bool CANON, class Ld, class St>
-__device__ __forceinline__ void ntt_tile(const DModulus M, const u64 *__restrict__ tw, int logN, int tile, Ld ld, St st,
-                                         u64 *__restrict__ lds)
+// PRELOADED: x[] already holds the first pass's coefficients (register j <-> idx_of(first pass, s, j)); ld unused.
+// KEEP     : leave the result in x[] (canonical if CANON) instead of calling st.  The last pass of an inverse phase and
+//            the first pass of a forward phase of the same shape use the same thread<->coefficient map, so an inverse
+//            tile can hand its output to a forward tile in registers (the fused iNTT -> base change -> NTT kernels).
+template <int K, bool COLS, bool INV, bool CANON, bool PRELOADED, bool KEEP, class Ld, class St>
+__device__ __forceinline__ void ntt_tile_x(u64 (&x)[8], const DModulus M, const u64 *__restrict__ tw, int logN, int tile, Ld ld,
+                                           St st, u64 *__restrict__ lds)
 {
     constexpr int n = 1 << K, LOGB = kTileLog - K, B = 1 << LOGB, T = kTileThreads, SUBT = n / 8;
     constexpr int NP = num_passes(K);
@@ -99,7 +103,6 @@ __device__ __forceinline__ void ntt_tile(const DModulus M, const u64 *__restrict
     const u32 twroot = COLS ? 1u : ((1u << sh) + (u32)lane_id);
     auto gidx = [&](int idx) -> int { return COLS ? ((idx << sh) + lane_id) : ((lane_id << K) + idx); };
 
-    u64 x[8];
 #pragma unroll
     for (int pp = 0; pp < NP; pp++) {
         const int p = INV ? (NP - 1 - pp) : pp;
@@ -107,8 +110,10 @@ __device__ __forceinline__ void ntt_tile(const DModulus M, const u64 *__restrict
         const bool first = (pp == 0), last = (pp == NP - 1);
         // ---- load
         if (first) {
+            if (!PRELOADED) {
 #pragma unroll
-            for (int j = 0; j < 8; j++) x[j] = ld(gidx(PassMap<K>::idx_of(p, s, j)));
+                for (int j = 0; j < 8; j++) x[j] = ld(gidx(PassMap<K>::idx_of(p, s, j)));
+            }
         } else {
             const int stride = T + lds_pad<K, COLS>(p, INV);
 #pragma unroll
@@ -146,8 +151,15 @@ __device__ __forceinline__ void ntt_tile(const DModulus M, const u64 *__restrict
         }
         // ---- store
         if (last) {
+            if (KEEP) {
+                if (CANON) {
 #pragma unroll
-            for (int j = 0; j < 8; j++) st(gidx(PassMap<K>::idx_of(p, s, j)), CANON ? canon(x[j], M) : x[j]);
+                    for (int j = 0; j < 8; j++) x[j] = canon(x[j], M);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; j++) st(gidx(PassMap<K>::idx_of(p, s, j)), CANON ? canon(x[j], M) : x[j]);
+            }
         } else {
             const int pn = INV ? p - 1 : p + 1;
             const int stride = T + lds_pad<K, COLS>(pn, INV);
@@ -162,6 +174,26 @@ __device__ __forceinline__ void ntt_tile(const DModulus M, const u64 *__restrict
             __syncthreads();
         }
     }
+}
+
+template <int K, bool COLS, bool INV, bool CANON, class Ld, class St>
+__device__ __forceinline__ void ntt_tile(const DModulus M, const u64 *__restrict__ tw, int logN, int tile, Ld ld, St st,
+                                         u64 *__restrict__ lds)
+{
+    u64 x[8];
+    ntt_tile_x<K, COLS, INV, CANON, false, false>(x, M, tw, logN, tile, ld, st, lds);
+}
+
+// polynomial index of register j of this thread in the first pass of a forward tile (= last pass of an inverse tile)
+template <int K, bool COLS>
+__device__ __forceinline__ int tile_first_pass_gidx(int logN, int tile, int j)
+{
+    constexpr int LOGB = kTileLog - K, B = 1 << LOGB, SUBT = (1 << K) / 8;
+    const int t = threadIdx.x;
+    const int b = COLS ? (t & (B - 1)) : (t / SUBT), s = COLS ? (t >> LOGB) : (t & (SUBT - 1));
+    const int idx = PassMap<K>::idx_of(0, s, j);
+    const int lane_id = tile * B + b;
+    return COLS ? ((idx << (logN - K)) + lane_id) : ((lane_id << K) + idx);
 }
 
 // Pads found with tools/lds_conflicts.py (0 = already conflict-free).  Max pad bounds the LDS allocation.
