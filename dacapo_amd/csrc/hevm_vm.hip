@@ -318,6 +318,7 @@ void HEVM::init_context(int logN, int K, const u64 *primes)
     if (const char *e = getenv("DACAPO_HEVM_STREAMS")) n_lanes = std::max(1, atoi(e));
     if (const char *e = getenv("DACAPO_HEVM_GRAPH")) use_graph = atoi(e) != 0;
     if (const char *e = getenv("DACAPO_HEVM_PLAN")) use_plan = atoi(e) != 0;
+    if (const char *e = getenv("DACAPO_HEVM_PLAN_GRAPH")) plan_graph = atoi(e) != 0;
     if (const char *e = getenv("DACAPO_HEVM_MAX_BATCH")) max_batch = std::max(1, atoi(e));
     lanes.resize((size_t)n_lanes);
     for (int i = 0; i < n_lanes; i++) {

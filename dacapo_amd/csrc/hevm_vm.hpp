@@ -179,7 +179,11 @@ class HEVM {
         std::vector<u64 *> pool; // every pool buffer ever allocated (reused across plans)
         int64_t n_keyswitch = 0, n_ntt = 0;
         size_t launches = 0, max_live = 0;
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t graph_exec = nullptr;
     } plan;
+    bool plan_graph = false; // DACAPO_HEVM_PLAN_GRAPH=1: replay the plan's launch sequence as one HIP graph
+    void issue_plan(hipStream_t s);
     bool use_plan = true;
     int max_batch = 128;
     std::vector<u64 *> home; // permanent buffer of every architectural register (program inputs live here)

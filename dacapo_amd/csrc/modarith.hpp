@@ -33,8 +33,20 @@ struct DModulus {
 };
 
 __device__ __forceinline__ u64 mad32(u32 a, u32 b, u64 c) { return (u64)a * (u64)b + c; } // v_mad_u64_u32
+__device__ __forceinline__ u32 lo32(u64 x) { return (u32)x; }
+__device__ __forceinline__ u32 hi32(u64 x) { return (u32)(x >> 32); }
+__device__ __forceinline__ u64 pack64(u32 lo, u32 hi) { return ((u64)hi << 32) | (u64)lo; }
+// ({hi,lo} >> s) & 0xffffffff for 0 < s < 32 : one v_alignbit_b32
+__device__ __forceinline__ u32 shr_pair(u32 hi, u32 lo, u32 s) { return __builtin_amdgcn_alignbit(hi, lo, s); }
+// Optimisation fence: hipcc otherwise re-associates the mad chains below (factoring out delta, splitting a 64-bit
+// addend into a later v_lshl_add_u64) and spends 6-8 extra moves/adds per modular multiply.  Emits no instruction.
+__device__ __forceinline__ u64 opaque(u64 x)
+{
+    asm("" : "+v"(x));
+    return x;
+}
 
-// full 64x64 -> 128 product, 4 x v_mad_u64_u32
+// full 64x64 -> 128 product, 4 x v_mad_u64_u32 (any operands)
 __device__ __forceinline__ void mul_wide(u64 a, u64 b, u64 &hi, u64 &lo)
 {
     u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
@@ -47,7 +59,10 @@ __device__ __forceinline__ void mul_wide(u64 a, u64 b, u64 &hi, u64 &lo)
 }
 
 // x (any 64-bit value) -> congruent value < 2^60 + 15*delta < 2q.   1 mad
-__device__ __forceinline__ u64 fold60(u64 x, u32 delta) { return mad32((u32)(x >> kQBits), delta, x & kQMask); }
+__device__ __forceinline__ u64 fold60(u64 x, u32 delta)
+{
+    return mad32(hi32(x) >> 28, delta, pack64(lo32(x), hi32(x) & 0x0FFFFFFFu));
+}
 
 // any 64-bit value -> canonical residue
 __device__ __forceinline__ u64 canon(u64 x, const DModulus &m)
@@ -56,24 +71,29 @@ __device__ __forceinline__ u64 canon(u64 x, const DModulus &m)
     return r >= m.q ? r - m.q : r;
 }
 
-// (hi:lo) < 2^124  ->  congruent value < 2^62.   3 mads
-__device__ __forceinline__ u64 reduce128_lazy(u64 hi, u64 lo, u32 delta)
+// T = hi*2^64 + w1*2^32 + w0 < 2^124  ->  congruent value < 2^62.   3 mads, 5 other VALU ops
+__device__ __forceinline__ u64 reduce_words(u64 hi, u32 w1, u32 w0, u32 delta)
 {
-    u64 H = (hi << 4) | (lo >> kQBits); // floor(T / 2^60) < 2^64
-    u64 L = lo & kQMask;
-    u64 A = mad32((u32)H, delta, L);        // < 2^60 + 2^60
-    u64 Bv = (u64)(u32)(H >> 32) * delta;   // weight 2^32, < 2^60
+    const u32 H0 = shr_pair(lo32(hi), w1, 28);       // floor(T / 2^60), low word
+    const u32 H1 = shr_pair(hi32(hi), lo32(hi), 28);  //                   high word (hi < 2^60)
+    const u64 A = opaque(mad32(H0, delta, pack64(w0, w1 & 0x0FFFFFFFu))); // < 2^60 + 2^60
+    const u64 Bv = opaque((u64)H1 * delta);           // weight 2^32, < 2^60
     // Bv * 2^32 = (Bv >> 28) * 2^60 + (Bv & (2^28-1)) * 2^32
-    u64 C = mad32((u32)(Bv >> 28), delta, A); // < 2^61 + 2^60
-    return C + ((Bv & 0x0FFFFFFFull) << 32);  // < 2^62
+    const u64 C = opaque(mad32(shr_pair(hi32(Bv), lo32(Bv), 28), delta, A)); // < 2^61 + 2^60
+    return pack64(lo32(C), hi32(C) + (lo32(Bv) & 0x0FFFFFFFu));       // < 2^62
 }
+__device__ __forceinline__ u64 reduce128_lazy(u64 hi, u64 lo, u32 delta) { return reduce_words(hi, hi32(lo), lo32(lo), delta); }
 
-// a*b must be < 2^124 (e.g. a < 2^60, b < 2^64).  Result congruent to a*b, < 2^62.   7 mads
+// a < 2^60 (a twiddle, a key limb, a canonical residue), b < 2^63.  Result congruent to a*b, < 2^62.   7 mads.
+// The middle term a0*b1 + a1*b0 (+ carry word) stays below 2^63 + 2^60 + 2^32, so it is one chained pair of mads
+// with no 64-bit add and no carry handling.
 __device__ __forceinline__ u64 mulmod_lazy(u64 a, u64 b, u32 delta)
 {
-    u64 hi, lo;
-    mul_wide(a, b, hi, lo);
-    return reduce128_lazy(hi, lo, delta);
+    const u32 a0 = lo32(a), a1 = hi32(a), b0 = lo32(b), b1 = hi32(b);
+    const u64 p00 = opaque((u64)a0 * b0);
+    const u64 mid = opaque(mad32(a1, b0, opaque(mad32(a0, b1, opaque((u64)hi32(p00))))));
+    const u64 hi = opaque(mad32(a1, b1, opaque((u64)hi32(mid))));
+    return reduce_words(hi, lo32(mid), lo32(p00), delta);
 }
 
 __device__ __forceinline__ u64 mulmod(u64 a, u64 b, const DModulus &m) { return canon(mulmod_lazy(a, b, m.delta), m); }

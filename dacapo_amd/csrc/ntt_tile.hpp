@@ -68,13 +68,14 @@ __device__ __forceinline__ void ct_bfly(u64 &x, u64 &y, u64 w, const DModulus &M
     x = xf + t;                             // < 2^63
     y = xf + (M.q << 2) - t;                // 4q > t : < 2^60 + 2^31 + 2^62
 }
-// Gentleman-Sande butterfly, values < 2^62 in and out:  (x, y) -> (x + y, (x - y) w)
+// Gentleman-Sande butterfly, values < 4q (< 2^62) in and out:  (x, y) -> (x + y, (x - y) w)
+// (every value here is a canonical input, a fold60 result or a mulmod_lazy result, all < 4q = 2^62 - 4 delta)
 __device__ __forceinline__ void gs_bfly(u64 &x, u64 &y, u64 w, const DModulus &M)
 {
     u64 s = x + y;                          // < 2^63
-    u64 d = x + (M.q << 3) - y;             // 8q > y ; < 2^62 + 2^63
+    u64 d = x + (M.q << 2) - y;             // 4q > y ; < 2^62 + 2^62 = 2^63
     x = fold60(s, M.delta);
-    y = mulmod_lazy(w, d, M.delta);         // w*d < 2^60 * 2^63.6 < 2^124 ; result < 2^62
+    y = mulmod_lazy(w, d, M.delta);         // w < 2^60, d < 2^63 ; result < 4q
 }
 
 // Ld: u64 operator()(int gidx)            coefficient gidx (0..N-1) of this limb, value < 2^62
@@ -140,7 +141,7 @@ __device__ __forceinline__ void ntt_tile_x(u64 (&x)[8], const DModulus M, const 
                             ct_bfly(x[j0], x[j1], w, M);
                         else if (COLS && gs == 0) { // very last inverse stage: fold N^{-1} in
                             u64 sv = x[j0] + x[j1];
-                            u64 d = x[j0] + (M.q << 3) - x[j1];
+                            u64 d = x[j0] + (M.q << 2) - x[j1];
                             x[j0] = mulmod_lazy(M.inv_n, sv, M.delta);
                             x[j1] = mulmod_lazy(M.inv_n_w, d, M.delta);
                         } else

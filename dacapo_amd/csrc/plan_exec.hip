@@ -31,6 +31,9 @@ void HEVM::build_plan()
     Plan &P = plan;
     for (void *p : { (void *)P.d_ks, (void *)P.d_mul, (void *)P.d_rs, (void *)P.d_ew, (void *)P.d_sum, (void *)P.d_sum_srcs })
         if (p) (void)hipFree(p);
+    if (P.graph_exec) (void)hipGraphExecDestroy(P.graph_exec);
+    if (P.graph) (void)hipGraphDestroy(P.graph);
+    P.graph_exec = nullptr, P.graph = nullptr;
     P.vals.clear(), P.pops.clear(), P.steps.clear();
     P.n_keyswitch = P.n_ntt = 0;
     const size_t nreg = ciphers.size();
@@ -171,6 +174,7 @@ void HEVM::build_plan()
             const Val sa = P.vals[(size_t)a];
             const int nv = new_val((int)op.rhs, pow(2.0, (double)(int64_t)std::log2(sa.scale))); // SEAL_HEVM.cpp:332
             add_pop(P_BOOT, sa.level, { a }, nv).target_level = op.rhs;
+            (void)crt_tables(sa.level); // device CRT constants are uploaded now, never during a (captured) run
             cur[op.dst] = nv;
             break;
         }
@@ -358,18 +362,10 @@ void HEVM::build_plan()
                 ops.size(), O.size(), P.steps.size(), max_wave, P.launches, P.max_live, (double)P.pool.size() * buf_elems * 8 / 1e9);
 }
 
-void HEVM::run_plan()
+void HEVM::issue_plan(hipStream_t s)
 {
-    if (!plan.ready) build_plan();
     Context &c = *ctx;
     Plan &P = plan;
-    cur = 0;
-    hipStream_t s = S();
-    memset(op_counts, 0, sizeof(op_counts));
-    for (const WireOp &op : ops)
-        if (op.opcode <= 10) op_counts[op.opcode]++;
-    n_keyswitch = P.n_keyswitch, n_ntt = P.n_ntt;
-    t_bootstrap = 0.0;
     const long ps = (long)c.K * (long)c.N;
     for (const Step &st : P.steps) {
         switch (st.kind) {
@@ -391,6 +387,31 @@ void HEVM::run_plan()
         }
     }
     bump_epoch(s);
+}
+
+void HEVM::run_plan()
+{
+    if (!plan.ready) build_plan();
+    Context &c = *ctx;
+    Plan &P = plan;
+    cur = 0;
+    hipStream_t s = S();
+    memset(op_counts, 0, sizeof(op_counts));
+    for (const WireOp &op : ops)
+        if (op.opcode <= 10) op_counts[op.opcode]++;
+    n_keyswitch = P.n_keyswitch, n_ntt = P.n_ntt;
+    t_bootstrap = 0.0;
+    const long ps = (long)c.K * (long)c.N;
+    if (plan_graph) { // the plan is a fixed launch sequence on one stream: record it once, replay it as one graph launch
+        if (!P.graph_exec) {
+            DC_HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
+            issue_plan(s);
+            DC_HIP_CHECK(hipStreamEndCapture(s, &P.graph));
+            DC_HIP_CHECK(hipGraphInstantiate(&P.graph_exec, P.graph, nullptr, nullptr, 0));
+        }
+        DC_HIP_CHECK(hipGraphLaunch(P.graph_exec, s));
+    } else
+        issue_plan(s);
     DC_HIP_CHECK(hipStreamSynchronize(s)); // the caller's timer stops when run() returns
     for (size_t r = 0; r < P.final_val.size() && r < ciphers.size(); r++) {
         const int v = P.final_val[r];
