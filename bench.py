@@ -131,17 +131,10 @@ def main():
     ap.add_argument("--layers", type=int, default=20, help="ResNet-shaped program depth (20 = the traced op mix)")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
-    if world > 1:
-        import torch
-        import torch.distributed as dist_mod
+    from dacapo_amd.dist import Group
 
-        torch.cuda.set_device(local_rank)
-        dist_mod.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        dist = dist_mod
+    grp = Group(backend="nccl")
+    rank, local_rank, world = grp.rank, grp.local_rank, grp.world
 
     from dacapo_amd import hevm_asm as ha
     from dacapo_amd import lowlevel as ll
@@ -151,11 +144,7 @@ def main():
     L.dc_set_device(local_rank)
 
     def barrier_sync():
-        if dist is not None:
-            dist.barrier()
-            import torch
-
-            torch.cuda.synchronize()
+        grp.barrier()  # dist.barrier() + torch.cuda.synchronize() when world > 1
         L.dc_device_sync()
 
     # ---- set-up (untimed, like hc-test: context/keys, load, preprocess, encrypt) ---------------------------------
@@ -179,22 +168,15 @@ def main():
     elapsed = time.perf_counter() - t0
     stats = hevm.stats()
 
-    if dist is not None:
-        import torch
-
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    ntts_per_step = ntt_equivalents(stats)
+    elapsed, total_ntts = grp.job_totals(elapsed, float(ntts_per_step) * args.steps)  # max time, summed work over ranks
 
     if rank != 0:
-        if dist is not None:
-            dist.barrier()
-            dist.destroy_process_group()
+        grp.close()
         return
 
     ms_per_step = elapsed / args.steps * 1e3
-    ntts_per_step = ntt_equivalents(stats)
-    value = world * ntts_per_step * args.steps / elapsed
+    value = total_ntts / elapsed
     ctx = ll.Context(15, 14)
     roof = roofline_leg(ll, ctx)
     micro = ntt_micro_leg(ll)
@@ -221,9 +203,7 @@ def main():
     if cpu:
         line["speedup_vs_cpu_port"] = round(value / cpu["value"], 1)
     print(json.dumps(line))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    grp.close()
 
 
 if __name__ == "__main__":

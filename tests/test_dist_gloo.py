@@ -1,0 +1,51 @@
+"""CPU, world_size 2, gloo: the multi-GPU path of bench.py (stream sharding + whole-job aggregation)."""
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+
+WORKER = r"""
+import sys, json
+sys.path.insert(0, %r)
+from dacapo_amd.dist import Group, streams_of_rank
+g = Group(backend="gloo")
+mine = streams_of_rank(5, g.rank, g.world)
+g.barrier()
+# rank r "ran" len(mine) streams of 1000 work units each in (1 + r) seconds
+elapsed, work = g.job_totals(1.0 + g.rank, 1000.0 * len(mine))
+print(json.dumps({"rank": g.rank, "mine": mine, "elapsed": elapsed, "work": work}), flush=True)
+g.close()
+"""
+
+
+def test_two_rank_gloo_sharding_and_aggregation(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % str(ROOT))
+    import socket
+
+    with socket.socket() as sk:  # a free rendezvous port
+        sk.bind(("127.0.0.1", 0))
+        port = str(sk.getsockname()[1])
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+                          "127.0.0.1", "--master-port", port, str(script)], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    import json
+
+    rows = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(rows) == 2
+    by_rank = {r["rank"]: r for r in rows}
+    assert by_rank[0]["mine"] == [0, 2, 4] and by_rank[1]["mine"] == [1, 3]  # stream s -> rank s mod world
+    for r in rows:  # every rank sees the job totals: max time, summed work
+        assert r["elapsed"] == 2.0 and r["work"] == 5000.0
+
+
+def test_single_process_group_is_a_noop():
+    from dacapo_amd.dist import Group
+
+    g = Group()
+    assert g.world == 1 and g.job_totals(0.5, 7.0) == (0.5, 7.0)
+    g.barrier()
+    g.close()

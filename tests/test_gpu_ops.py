@@ -141,3 +141,31 @@ def test_homomorphic_roundtrip_on_gpu(env):
     res = Ciphertext(dy.to_host()[:, : cap - 1].copy(), 2.0**100 / o.primes[cap - 1])
     got = o.decode(o.decrypt(res))
     assert np.abs(got - np.roll(x * y, -1)).max() < 1e-5
+
+
+def test_baseline_config3_mul_relin_n65536_l24():
+    """BASELINE.json config 3: ct x ct multiply + relinearize at N = 2^16 with 24 data primes + 1 special prime
+    (25 x 60-bit, the same CoeffModulus::Create rule).  SEAL itself cannot run this size; it is the same algorithm."""
+    from dacapo_amd import lowlevel as ll
+
+    logN, K = 16, 25
+    o = Oracle(logN, K)
+    o.keygen(seed=0x4845564D, galois_elts=[])
+    ctx = ll.Context(logN, K)
+    assert ctx.primes == o.primes
+    L, N, ell = ll.lib(), o.N, K - 1
+    a, b = _rand_ct(o, ell, 31), _rand_ct(o, ell, 32)
+    da, db, dd = ll.DeviceBuffer.from_host(a), ll.DeviceBuffer.from_host(b), ll.DeviceBuffer((2, ell, N))
+    drel = ll.DeviceBuffer.from_host(o.relin)
+    st = ell * N
+    L.dc_ct_mul_relin(ctx.h, dd.ptr, st, da.ptr, st, db.ptr, st, drel.ptr, ell, None)
+    want = o.mul_relin(Ciphertext(a, 2.0**40), Ciphertext(b, 2.0**40)).data
+    assert (dd.to_host() == want).all()
+    # encrypt -> multiply -> decrypt round trip at this size
+    rng = np.random.default_rng(5)
+    x, y = rng.uniform(-1, 1, o.slots), rng.uniform(-1, 1, o.slots)
+    cx, cy = o.encrypt(o.encode(x, 2.0**40, ell)), o.encrypt(o.encode(y, 2.0**40, ell))
+    dx, dy = ll.DeviceBuffer.from_host(cx.data), ll.DeviceBuffer.from_host(cy.data)
+    L.dc_ct_mul_relin(ctx.h, dd.ptr, st, dx.ptr, st, dy.ptr, st, drel.ptr, ell, None)
+    got = o.decode(o.decrypt(Ciphertext(dd.to_host(), 2.0**80)))
+    assert np.abs(got - x * y).max() < 1e-6
