@@ -51,8 +51,14 @@ def roofline_leg(ll, ctx, limbs=4096, iters=10):
     alg_bytes = 2.0 * limbs * N * 8
     gbs = alg_bytes / (ms * 1e-3) / 1e9
     del buf
+    # HBM bytes per forward NTT of this batch from the PMC passes committed under profiles/ (FETCH_SIZE doubled per the
+    # gfx950 correction + WRITE_SIZE, separate rocprofv3 --pmc runs of tools/ntt_only.py); bench.py cannot read counters itself
+    traffic = None
+    tf = ROOT / "profiles" / "r01_ntt_hbm_traffic.json"
+    if tf.exists() and limbs == 4096 and N == 32768:
+        traffic = json.loads(tf.read_text()).get("forward_ntt_hbm_bytes")
     return {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-            "traffic": None, "kernel": "ntt_phase_kernel<7,COLS,fwd> + ntt_phase_kernel<8,ROWS,fwd> (one forward NTT = both launches)",
+            "traffic": traffic, "kernel": "ntt_phase_kernel<7,COLS,fwd> + ntt_phase_kernel<8,ROWS,fwd> (one forward NTT = both launches)",
             "launch": {"limbs": limbs, "N": N, "algorithmic_bytes": alg_bytes, "avg_us": round(ms * 1e3, 2),
                        "ntt_per_s": round(limbs / (ms * 1e-3))}}
 
