@@ -100,16 +100,6 @@ __global__ __launch_bounds__(kBT) void b_ks_mac_kernel(u64 *__restrict__ acc, co
     *reinterpret_cast<u64x2 *>(ac + ((size_t)1 * (ell + 1) + m) * N + k) = o1;
 }
 
-// fused phase launchers (fused_ks.hip)
-void f_irows_strided(const Context &c, const u64 *base, long stride, int prime_base, int period, u64 *out, long out_stride, int count,
-                     hipStream_t s);
-void f_irows_rot_c1(const Context &c, const KsItem *items, int ell, u64 *out, int B, hipStream_t s);
-void f_irows_rs_last(const Context &c, const RsItem *items, int l, u64 *out, int B, hipStream_t s);
-void f_ks_icols_lift_fcols(const Context &c, const u64 *digits, u64 *ext, int B, int ell, hipStream_t s);
-void f_dr_icols_lift_fcols(const Context &c, const u64 *last, long last_stride, u64 *tmp, int polys, int cnt, int l, hipStream_t s);
-void f_frows_final(const Context &c, int mode, const u64 *tmp, const void *items, const u64 *acc, int polys, int cnt, int l,
-                   hipStream_t s);
-
 // L2..L7 of the key-switch pipeline (fused_ks.hip) once the digits' inverse ROWS phase (L1) has been issued
 template <int MODE>
 static void b_ks_tail(Context &c, const BatchWs &w, const KsItem *items, const void *final_items, const u64 *shared_key, int B, int ell,
@@ -149,6 +139,15 @@ void b_rescale(Context &c, const BatchWs &w, const RsItem *d_items, int B, int e
     f_irows_rs_last(c, d_items, l, last, B, s);
     f_dr_icols_lift_fcols(c, last, (long)c.N, w.tmp, 2 * B, l, l, s);
     f_frows_final(c, 2, w.tmp, d_items, nullptr, 2 * B, l, l, s);
+}
+
+void rescale_fused(Context &c, const Workspace &w, CtView dst, CtView src, int ell, const u64 *plain, hipStream_t s)
+{
+    const int l = ell - 1;
+    u64 *last = w.ks_digits; // [2][N]
+    f_irows_rs_single(c, src, l, last, s);
+    f_dr_icols_lift_fcols(c, last, (long)c.N, w.ks_tmp, 2, l, l, s);
+    f_frows_final(c, 3, w.ks_tmp, nullptr, nullptr, 2, l, l, s, RsItem{ src, dst }, plain);
 }
 
 // ---- limb-wise batched kernels ---------------------------------------------------------------------------------

@@ -148,7 +148,7 @@ Workspace Context::new_workspace()
     const size_t L = max_level();
     Workspace w;
     DC_HIP_CHECK(hipMalloc(&w.ks_digits, std::max<size_t>(L, 2) * N * 8));
-    DC_HIP_CHECK(hipMalloc(&w.ks_ext, std::max<size_t>(L * L, K) * N * 8));
+    DC_HIP_CHECK(hipMalloc(&w.ks_ext, std::max<size_t>(L * L, 3 * (size_t)K) * N * 8)); // also [3][K][N] encryption staging
     DC_HIP_CHECK(hipMalloc(&w.ks_acc, 2 * (L + 1) * N * 8));
     DC_HIP_CHECK(hipMalloc(&w.ks_tmp, 2 * std::max<size_t>(L, 1) * N * 8));
     DC_HIP_CHECK(hipMalloc(&w.ct_tmp, 3 * std::max<size_t>(L, 1) * N * 8));

@@ -51,6 +51,25 @@ struct SrcRsLast { // limb z = b*2 + p : the limb being dropped by a rescale
     __device__ u64 load(int z, int g, int logN) const { return items[z >> 1].src.limb(z & 1, l, (size_t)1 << logN)[g]; }
 };
 
+struct SrcRsLast1 { // single rescale without a device item table (encryption's divide-and-round)
+    CtView src;
+    int l;
+    __device__ int prime(int) const { return l; }
+    __device__ u64 load(int z, int g, int logN) const { return src.limb(z & 1, l, (size_t)1 << logN)[g]; }
+};
+struct SrcDecrypt { // limb z of c0 + c1*s  (Decryptor::decrypt fused into the first inverse phase)
+    CtView ct;
+    const u64 *sk;
+    const DModulus *mods;
+    __device__ int prime(int z) const { return z; }
+    __device__ u64 load(int z, int g, int logN) const
+    {
+        const size_t N = (size_t)1 << logN;
+        const DModulus M = mods[z];
+        return addmod(ct.limb(0, z, N)[g], mulmod(ct.limb(1, z, N)[g], sk[(size_t)z * N + g], M), M.q);
+    }
+};
+
 // L1 / L5 / R1: inverse ROWS phase, out[z] (lazy values) = phase(src limb z)
 template <int K, class Src>
 __global__ __launch_bounds__(kTileThreads) void f_irows_kernel(Src src, u64 *__restrict__ out, long out_stride,
@@ -129,6 +148,7 @@ __global__ __launch_bounds__(kTileThreads) void f_dr_icols_lift_fcols_kernel(con
 // L7 / R3: z = bp*cnt + i.  MODE 0 rotation, 1 relinearisation, 2 rescale
 template <int K, int MODE>
 __global__ __launch_bounds__(kTileThreads) void f_frows_final_kernel(const u64 *__restrict__ tmp, const void *__restrict__ items_,
+                                                                      RsItem single, const u64 *__restrict__ plain,
                                                                       const u64 *__restrict__ acc, int cnt, int l, int Kp,
                                                                       const DModulus *__restrict__ mods,
                                                                       const u64 *__restrict__ inv_last, const u64 *__restrict__ tw,
@@ -159,6 +179,17 @@ __global__ __launch_bounds__(kTileThreads) void f_frows_final_kernel(const u64 *
         ntt_tile<K, false, false, true>(
             M, tw + ((size_t)i << logN), logN, blockIdx.x, [=](int g) { return in[g]; },
             [=](int g, u64 v) { o[g] = addmod(o[g], mulmod(submod(x[g], v, M.q), inv, M), M.q); }, lds);
+    } else if (MODE == 3) { // one rescale given by value, optionally followed by "+ plaintext" on c0 (Encryptor::encrypt)
+        const u64 *x = single.src.limb(p, i, N);
+        u64 *o = single.dst.limb(p, i, N);
+        const u64 *pl = (plain && p == 0) ? plain + (size_t)i * N : nullptr;
+        ntt_tile<K, false, false, true>(
+            M, tw + ((size_t)i << logN), logN, blockIdx.x, [=](int g) { return in[g]; },
+            [=](int g, u64 v) {
+                const u64 r = mulmod(submod(x[g], v, M.q), inv, M);
+                o[g] = pl ? addmod(r, pl[g], M.q) : r;
+            },
+            lds);
     } else {
         const RsItem it = reinterpret_cast<const RsItem *>(items_)[b];
         const u64 *x = it.src.limb(p, i, N);
@@ -201,6 +232,15 @@ void f_irows_rs_last(const Context &c, const RsItem *items, int l, u64 *out, int
     launch_irows(c, SrcRsLast{ items, l }, out, (long)c.N, 2 * B, s);
 }
 
+void f_irows_rs_single(const Context &c, CtView src, int l, u64 *out, hipStream_t s)
+{
+    launch_irows(c, SrcRsLast1{ src, l }, out, (long)c.N, 2, s);
+}
+void f_irows_decrypt(const Context &c, CtView ct, const u64 *sk, int ell, u64 *out, hipStream_t s)
+{
+    launch_irows(c, SrcDecrypt{ ct, sk, c.d_mods }, out, (long)c.N, ell, s);
+}
+
 void f_ks_icols_lift_fcols(const Context &c, const u64 *digits, u64 *ext, int B, int ell, hipStream_t s)
 {
     dim3 grid((unsigned)(c.N >> kTileLog), (unsigned)(B * ell * ell));
@@ -216,18 +256,23 @@ void f_dr_icols_lift_fcols(const Context &c, const u64 *last, long last_stride, 
 }
 
 void f_frows_final(const Context &c, int mode, const u64 *tmp, const void *items, const u64 *acc, int polys, int cnt, int l,
-                   hipStream_t s)
+                   hipStream_t s, RsItem single, const u64 *plain)
 {
     dim3 grid((unsigned)(c.N >> kTileLog), (unsigned)(polys * cnt));
+    if (mode == 3) {
+        DC_K_SWITCH(c.k2, hipLaunchKernelGGL((f_frows_final_kernel<KK, 3>), grid, dim3(kTileThreads), 0, s, tmp, items, single, plain, acc,
+                                             cnt, l, c.K, c.d_mods, c.d_inv_last, c.d_tw, c.logN));
+        return;
+    }
     if (mode == 0) {
-        DC_K_SWITCH(c.k2, hipLaunchKernelGGL((f_frows_final_kernel<KK, 0>), grid, dim3(kTileThreads), 0, s, tmp, items, acc, cnt, l, c.K,
-                                             c.d_mods, c.d_inv_last, c.d_tw, c.logN));
+        DC_K_SWITCH(c.k2, hipLaunchKernelGGL((f_frows_final_kernel<KK, 0>), grid, dim3(kTileThreads), 0, s, tmp, items, single, plain, acc, cnt, l,
+                                             c.K, c.d_mods, c.d_inv_last, c.d_tw, c.logN));
     } else if (mode == 1) {
-        DC_K_SWITCH(c.k2, hipLaunchKernelGGL((f_frows_final_kernel<KK, 1>), grid, dim3(kTileThreads), 0, s, tmp, items, acc, cnt, l, c.K,
-                                             c.d_mods, c.d_inv_last, c.d_tw, c.logN));
+        DC_K_SWITCH(c.k2, hipLaunchKernelGGL((f_frows_final_kernel<KK, 1>), grid, dim3(kTileThreads), 0, s, tmp, items, single, plain, acc, cnt, l,
+                                             c.K, c.d_mods, c.d_inv_last, c.d_tw, c.logN));
     } else {
-        DC_K_SWITCH(c.k2, hipLaunchKernelGGL((f_frows_final_kernel<KK, 2>), grid, dim3(kTileThreads), 0, s, tmp, items, acc, cnt, l, c.K,
-                                             c.d_mods, c.d_inv_last, c.d_tw, c.logN));
+        DC_K_SWITCH(c.k2, hipLaunchKernelGGL((f_frows_final_kernel<KK, 2>), grid, dim3(kTileThreads), 0, s, tmp, items, single, plain, acc, cnt, l,
+                                             c.K, c.d_mods, c.d_inv_last, c.d_tw, c.logN));
     }
 }
 

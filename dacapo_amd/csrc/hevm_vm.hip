@@ -67,6 +67,19 @@ __global__ __launch_bounds__(kVmThreads) void sample_small_kernel(u64 *__restric
     out[(size_t)i * N + k] = v < 0 ? q - (u64)(-v) : (u64)v;
 }
 
+// Encryptor::encrypt randomness in one launch: out[0] = ternary u, out[1], out[2] = centred-binomial e0, e1, each lifted
+// to `cnt` primes.  grid = (N/256, cnt, 3)
+__global__ __launch_bounds__(kVmThreads) void sample_enc_kernel(u64 *__restrict__ out, size_t N, int cnt, u64 seed, u64 stream,
+                                                                 const DModulus *__restrict__ mods, const u64 *__restrict__ epoch)
+{
+    const int i = blockIdx.y, z = blockIdx.z;
+    const u64 q = mods[i].q;
+    const size_t k = (size_t)blockIdx.x * kVmThreads + threadIdx.x;
+    const u64 r = prng(seed, stream + (u64)z + (epoch ? (*epoch << 32) : 0), k, 0);
+    const int v = z ? (__popcll(r & 0x1FFFFF) - __popcll((r >> 21) & 0x1FFFFF)) : ((int)(r % 3) - 1);
+    out[((size_t)z * cnt + i) * N + k] = v < 0 ? q - (u64)(-v) : (u64)v;
+}
+
 // signed 128-bit integer coefficients (two's complement, |x| < 2^120) -> residues.  grid = (N/256, ell)
 __global__ void bump_epoch_kernel(u64 *epoch) { *epoch += 1; }
 
@@ -111,13 +124,13 @@ __global__ __launch_bounds__(kVmThreads) void ezs_final_kernel(u64 *__restrict__
 
 // encrypt_zero_asymmetric body: tmp[p][i] = pk[p][i]*u[i] + e[p][i].  grid = (N/512, limbs, 2)
 __global__ __launch_bounds__(kVmThreads) void pk_encrypt_kernel(u64 *__restrict__ tmp, long tmp_ps, const u64 *__restrict__ pk,
-                                                                 long pk_ps, const u64 *__restrict__ u, size_t N,
-                                                                 const DModulus *__restrict__ mods)
+                                                                 long pk_ps, const u64 *__restrict__ u, const u64 *__restrict__ e01,
+                                                                 long e_ps, size_t N, const DModulus *__restrict__ mods)
 {
     const int i = blockIdx.y, p = blockIdx.z;
     const DModulus M = mods[i];
     const size_t k = (size_t)i * N + ((size_t)blockIdx.x * kVmThreads + threadIdx.x) * 2;
-    const u64x2 e = *reinterpret_cast<const u64x2 *>(tmp + p * tmp_ps + k), a = *reinterpret_cast<const u64x2 *>(pk + p * pk_ps + k),
+    const u64x2 e = *reinterpret_cast<const u64x2 *>(e01 + p * e_ps + k), a = *reinterpret_cast<const u64x2 *>(pk + p * pk_ps + k),
                 uu = *reinterpret_cast<const u64x2 *>(u + k);
     u64x2 r;
 #pragma unroll
@@ -678,20 +691,15 @@ void HEVM::encrypt_plain(hevm_ctxt &dst, const Plain &pt)
         fprintf(stderr, "[dacapo_amd] encrypt: this VM has no public key\n");
         abort();
     }
-    u64 *u = W().ks_ext; // [cnt][N]
+    u64 *ue = W().ks_ext; // [3][cnt][N]: u, e0, e1
     const CtView tmp{ dst.data, (long)dst.poly_stride };
     const u64 s0 = 1000 + 4 * (enc_counter++);
-    const dim3 g1((unsigned)(N / kVmThreads), (unsigned)cnt);
-    hipLaunchKernelGGL(sample_small_kernel, g1, dim3(kVmThreads), 0, S(), u, N, 0, seed, s0, c.d_mods, d_epoch);
-    hipLaunchKernelGGL(sample_small_kernel, g1, dim3(kVmThreads), 0, S(), tmp.limb(0, 0, N), N, 1, seed, s0 + 1, c.d_mods, d_epoch);
-    hipLaunchKernelGGL(sample_small_kernel, g1, dim3(kVmThreads), 0, S(), tmp.limb(1, 0, N), N, 1, seed, s0 + 2, c.d_mods, d_epoch);
-    launch_ntt(c, false, u, (long)N, cnt, nullptr, 0, 0, S());
-    launch_ntt(c, false, tmp.limb(0, 0, N), (long)N, cnt, nullptr, 0, 0, S());
-    launch_ntt(c, false, tmp.limb(1, 0, N), (long)N, cnt, nullptr, 0, 0, S());
+    hipLaunchKernelGGL(sample_enc_kernel, dim3((unsigned)(N / kVmThreads), (unsigned)cnt, 3), dim3(kVmThreads), 0, S(), ue, N, cnt, seed,
+                       s0, c.d_mods, d_epoch);
+    launch_ntt(c, false, ue, (long)N, 3 * cnt, nullptr, 0, cnt, S());
     hipLaunchKernelGGL(pk_encrypt_kernel, dim3((unsigned)(N / (2 * kVmThreads)), (unsigned)cnt, 2), dim3(kVmThreads), 0, S(),
-                       tmp.p, tmp.poly_stride, keys.pk, (long)c.K * (long)N, u, N, c.d_mods);
-    rescale(c, W(), tmp, tmp, cnt, S());
-    launch_add_plain(c, tmp, tmp, pt.d, ell, S());
+                       tmp.p, tmp.poly_stride, keys.pk, (long)c.K * (long)N, ue, ue + (size_t)cnt * N, (long)cnt * (long)N, N, c.d_mods);
+    rescale_fused(c, W(), tmp, tmp, cnt, pt.d, S()); // divide-and-round by the extra prime, then + plaintext on c0
     dst.level = ell;
     dst.scale = pt.scale;
 }
@@ -1039,9 +1047,8 @@ void HEVM::boot_item(CtView src, int ell, double src_scale, hevm_ctxt &dst, int 
     const CrtTables &tb = crt_tables(ell);
     u64 *pt = W().ks_tmp;      // [ell][N]
     u64 *lohi = W().ks_digits; // [2][N]
-    hipLaunchKernelGGL(decrypt_kernel, dim3((unsigned)(N / (2 * kVmThreads)), (unsigned)ell), dim3(kVmThreads), 0, S(), pt, src,
-                       keys.sk, N, c.d_mods);
-    launch_ntt(c, true, pt, (long)N, ell, nullptr, 0, 0, S());
+    f_irows_decrypt(c, src, keys.sk, ell, pt, S()); // c0 + c1*s fused into the first inverse phase
+    launch_ntt_cols_inv(c, pt, (long)N, ell, nullptr, 0, 0, S());
     const CrtDev cd{ tb.inv, tb.mmod, tb.hmod, tb.hdig, tb.mdbl };
     hipLaunchKernelGGL(reencode_kernel, dim3((unsigned)((N / 2 + kVmThreads) / kVmThreads)), dim3(kVmThreads), 0, S(), lohi,
                        lohi + N, pt, ell, N, c.d_mods, cd, new_scale / src_scale);

@@ -25,6 +25,10 @@ void launch_ntt(const Context &c, bool inverse, u64 *data, long limb_stride, int
 void launch_ntt_rows_fwd(const Context &c, u64 *data, long limb_stride, int count, const int *d_prime_idx, int prime_base,
                          int prime_period, hipStream_t s);
 
+// second (COLS) phase of an inverse NTT only: the input holds the output of an inverse ROWS phase
+void launch_ntt_cols_inv(const Context &c, u64 *data, long limb_stride, int count, const int *d_prime_idx, int prime_base,
+                         int prime_period, hipStream_t s);
+
 // ---- limb-wise kernels (poly_kernels.hip) -----------------------------------------------------------------
 enum class EwOp : int { Add = 0, Sub = 1, Neg = 2, Mul = 3, Copy = 4 };
 // dst[p][i] = a[p][i] (op) b[pb][i] for p < polys, i < ell (limb i modulo prime i).  b_polys == 1 broadcasts

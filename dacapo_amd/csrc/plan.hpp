@@ -53,4 +53,19 @@ void b_ew(Context &c, EwOp op, const EwItem *d_items, int B, int polys, int b_po
 void b_add_plain(Context &c, const EwItem *d_items, int B, int ell, hipStream_t s);
 void b_sum(Context &c, const SumItem *d_items, const CtView *d_srcs, int B, int ell, hipStream_t s);
 
+// fused phase launchers (fused_ks.hip)
+void f_irows_strided(const Context &c, const u64 *base, long stride, int prime_base, int period, u64 *out, long out_stride, int count,
+                     hipStream_t s);
+void f_irows_rot_c1(const Context &c, const KsItem *items, int ell, u64 *out, int B, hipStream_t s);
+void f_irows_rs_last(const Context &c, const RsItem *items, int l, u64 *out, int B, hipStream_t s);
+void f_irows_rs_single(const Context &c, CtView src, int l, u64 *out, hipStream_t s);
+void f_irows_decrypt(const Context &c, CtView ct, const u64 *sk, int ell, u64 *out, hipStream_t s);
+void f_ks_icols_lift_fcols(const Context &c, const u64 *digits, u64 *ext, int B, int ell, hipStream_t s);
+void f_dr_icols_lift_fcols(const Context &c, const u64 *last, long last_stride, u64 *tmp, int polys, int cnt, int l, hipStream_t s);
+// mode 0 rotation / 1 relinearisation / 2 rescale items / 3 one rescale by value (+ optional plaintext added to c0)
+void f_frows_final(const Context &c, int mode, const u64 *tmp, const void *items, const u64 *acc, int polys, int cnt, int l,
+                   hipStream_t s, RsItem single = RsItem{}, const u64 *plain = nullptr);
+// a single rescale_to_next of `src` (level ell) into dst, optionally adding a level-(ell-1) plaintext to c0: 3 launches
+void rescale_fused(Context &c, const Workspace &w, CtView dst, CtView src, int ell, const u64 *plain, hipStream_t s);
+
 } // namespace dacapo
