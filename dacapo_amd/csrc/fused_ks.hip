@@ -71,47 +71,47 @@ struct SrcDecrypt { // limb z of c0 + c1*s  (Decryptor::decrypt fused into the f
 };
 
 // L1 / L5 / R1: inverse ROWS phase, out[z] (lazy values) = phase(src limb z)
-template <int K, class Src>
+template <int K, int LOGE, class Src>
 __global__ __launch_bounds__(kTileThreads) void f_irows_kernel(Src src, u64 *__restrict__ out, long out_stride,
                                                                 const DModulus *__restrict__ mods, const u64 *__restrict__ itw,
                                                                 int logN)
 {
-    __shared__ __attribute__((aligned(16))) u64 lds[kTileLdsElems];
+    __shared__ __attribute__((aligned(16))) u64 lds[TileGeo<LOGE>::LDS_ELEMS];
     const int z = blockIdx.y, p = src.prime(z);
     u64 *o = out + (long)z * out_stride;
-    ntt_tile<K, false, true, false>(
+    ntt_tile<K, LOGE, false, true, false>(
         mods[p], itw + ((size_t)p << logN), logN, blockIdx.x, [=](int g) { return src.load(z, g, logN); },
         [=](int g, u64 v) { o[g] = v; }, lds);
 }
 
 // L2: z = (b*l + j)*l + e
-template <int K>
+template <int K, int LOGE>
 __global__ __launch_bounds__(kTileThreads) void f_ks_icols_lift_fcols_kernel(const u64 *__restrict__ digits, u64 *__restrict__ ext,
                                                                               int ell, int sp, const DModulus *__restrict__ mods,
                                                                               const u64 *__restrict__ tw, const u64 *__restrict__ itw,
                                                                               int logN)
 {
-    __shared__ __attribute__((aligned(16))) u64 lds[kTileLdsElems];
+    __shared__ __attribute__((aligned(16))) u64 lds[TileGeo<LOGE>::LDS_ELEMS];
     const int z = blockIdx.y, e = z % ell, dj = z / ell, j = dj % ell;
     const size_t N = (size_t)1 << logN;
     const u64 *in = digits + (size_t)dj * N;
     u64 *out = ext + (size_t)z * N;
-    u64 x[8];
+    u64 x[1 << LOGE];
     auto nost = [](int, u64) {};
-    ntt_tile_x<K, true, true, true, false, true>(
+    ntt_tile_x<K, LOGE, true, true, true, false, true>(
         x, mods[j], itw + ((size_t)j << logN), logN, blockIdx.x, [=](int g) { return in[g]; }, nost, lds);
     const int pm = ks_other_prime(j, e, ell, sp);
     const DModulus Mm = mods[pm];
 #pragma unroll
-    for (int r = 0; r < 8; r++) x[r] = x[r] >= Mm.q ? x[r] - Mm.q : x[r]; // one conditional subtraction: all primes in (2^60-2^28, 2^60)
+    for (int r = 0; r < (1 << LOGE); r++) x[r] = x[r] >= Mm.q ? x[r] - Mm.q : x[r]; // one conditional subtraction: all primes in (2^60-2^28, 2^60)
     __syncthreads(); // the inverse tile's last LDS image has been read by everyone
     auto nold = [](int) -> u64 { return 0; };
-    ntt_tile_x<K, true, false, false, true, false>(
+    ntt_tile_x<K, LOGE, true, false, false, true, false>(
         x, Mm, tw + ((size_t)pm << logN), logN, blockIdx.x, nold, [=](int g, u64 v) { out[g] = v; }, lds);
 }
 
 // L6 / R2: z = bp*cnt + i : finish the iNTT of the dropped limb bp (prime l), round, change base to prime i, first NTT phase
-template <int K>
+template <int K, int LOGE>
 __global__ __launch_bounds__(kTileThreads) void f_dr_icols_lift_fcols_kernel(const u64 *__restrict__ last, long last_stride,
                                                                               u64 *__restrict__ tmp, int cnt, int l, int Kp,
                                                                               const DModulus *__restrict__ mods,
@@ -119,20 +119,20 @@ __global__ __launch_bounds__(kTileThreads) void f_dr_icols_lift_fcols_kernel(con
                                                                               const u64 *__restrict__ tw, const u64 *__restrict__ itw,
                                                                               int logN)
 {
-    __shared__ __attribute__((aligned(16))) u64 lds[kTileLdsElems];
+    __shared__ __attribute__((aligned(16))) u64 lds[TileGeo<LOGE>::LDS_ELEMS];
     const int z = blockIdx.y, i = z % cnt, bp = z / cnt;
     const size_t N = (size_t)1 << logN;
     const u64 *in = last + (long)bp * last_stride;
     u64 *out = tmp + (size_t)z * N;
-    u64 x[8];
+    u64 x[1 << LOGE];
     auto nost = [](int, u64) {};
-    ntt_tile_x<K, true, true, true, false, true>(
+    ntt_tile_x<K, LOGE, true, true, true, false, true>(
         x, mods[l], itw + ((size_t)l << logN), logN, blockIdx.x, [=](int g) { return in[g]; }, nost, lds);
     const DModulus Mi = mods[i];
     const u64 ql = mods[l].q, qi = Mi.q, half = ql >> 1;
     const u64 neg_half = qi - half_mod[(size_t)l * Kp + i];
 #pragma unroll
-    for (int r = 0; r < 8; r++) { // RNSTool::divide_and_round_q_last_ntt_inplace, coefficient-domain part
+    for (int r = 0; r < (1 << LOGE); r++) { // RNSTool::divide_and_round_q_last_ntt_inplace, coefficient-domain part
         u64 y = x[r] + half;
         y = y >= ql ? y - ql : y;
         y = y >= qi ? y - qi : y;
@@ -141,12 +141,12 @@ __global__ __launch_bounds__(kTileThreads) void f_dr_icols_lift_fcols_kernel(con
     }
     __syncthreads();
     auto nold = [](int) -> u64 { return 0; };
-    ntt_tile_x<K, true, false, false, true, false>(
+    ntt_tile_x<K, LOGE, true, false, false, true, false>(
         x, Mi, tw + ((size_t)i << logN), logN, blockIdx.x, nold, [=](int g, u64 v) { out[g] = v; }, lds);
 }
 
 // L7 / R3: z = bp*cnt + i.  MODE 0 rotation, 1 relinearisation, 2 rescale
-template <int K, int MODE>
+template <int K, int LOGE, int MODE>
 __global__ __launch_bounds__(kTileThreads) void f_frows_final_kernel(const u64 *__restrict__ tmp, const void *__restrict__ items_,
                                                                       RsItem single, const u64 *__restrict__ plain,
                                                                       const u64 *__restrict__ acc, int cnt, int l, int Kp,
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(kTileThreads) void f_frows_final_kernel(const u64 *
                                                                       const u64 *__restrict__ inv_last, const u64 *__restrict__ tw,
                                                                       int logN)
 {
-    __shared__ __attribute__((aligned(16))) u64 lds[kTileLdsElems];
+    __shared__ __attribute__((aligned(16))) u64 lds[TileGeo<LOGE>::LDS_ELEMS];
     const int z = blockIdx.y, i = z % cnt, bp = z / cnt, b = bp >> 1, p = bp & 1;
     const size_t N = (size_t)1 << logN;
     const DModulus M = mods[i];
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(kTileThreads) void f_frows_final_kernel(const u64 *
         const u64 *x = acc + (((size_t)bp) * (cnt + 1) + i) * N;
         const u64 *c0 = it.src.limb(0, i, N);
         u64 *o = it.dst.limb(p, i, N);
-        ntt_tile<K, false, false, true>(
+        ntt_tile<K, LOGE, false, false, true>(
             M, tw + ((size_t)i << logN), logN, blockIdx.x, [=](int g) { return in[g]; },
             [=](int g, u64 v) {
                 const u64 base = p == 0 ? c0[galois_idx((u32)g, it.elt, logN)] : 0;
@@ -176,14 +176,14 @@ __global__ __launch_bounds__(kTileThreads) void f_frows_final_kernel(const u64 *
         const MulItem it = reinterpret_cast<const MulItem *>(items_)[b];
         const u64 *x = acc + (((size_t)bp) * (cnt + 1) + i) * N;
         u64 *o = it.dst.limb(p, i, N);
-        ntt_tile<K, false, false, true>(
+        ntt_tile<K, LOGE, false, false, true>(
             M, tw + ((size_t)i << logN), logN, blockIdx.x, [=](int g) { return in[g]; },
             [=](int g, u64 v) { o[g] = addmod(o[g], mulmod(submod(x[g], v, M.q), inv, M), M.q); }, lds);
     } else if (MODE == 3) { // one rescale given by value, optionally followed by "+ plaintext" on c0 (Encryptor::encrypt)
         const u64 *x = single.src.limb(p, i, N);
         u64 *o = single.dst.limb(p, i, N);
         const u64 *pl = (plain && p == 0) ? plain + (size_t)i * N : nullptr;
-        ntt_tile<K, false, false, true>(
+        ntt_tile<K, LOGE, false, false, true>(
             M, tw + ((size_t)i << logN), logN, blockIdx.x, [=](int g) { return in[g]; },
             [=](int g, u64 v) {
                 const u64 r = mulmod(submod(x[g], v, M.q), inv, M);
@@ -194,28 +194,38 @@ __global__ __launch_bounds__(kTileThreads) void f_frows_final_kernel(const u64 *
         const RsItem it = reinterpret_cast<const RsItem *>(items_)[b];
         const u64 *x = it.src.limb(p, i, N);
         u64 *o = it.dst.limb(p, i, N);
-        ntt_tile<K, false, false, true>(
+        ntt_tile<K, LOGE, false, false, true>(
             M, tw + ((size_t)i << logN), logN, blockIdx.x, [=](int g) { return in[g]; },
             [=](int g, u64 v) { o[g] = mulmod(submod(x[g], v, M.q), inv, M); }, lds);
     }
 }
 
-// ---- launchers (K dispatch) -----------------------------------------------------------------------------------------------
-#define DC_K_SWITCH(Kval, CALL)                                                                           \
+// ---- launchers (K and geometry dispatch) ---------------------------------------------------------------------------------
+#define DC_K_SWITCH(Kval, ...)                                                                            \
     switch (Kval) {                                                                                       \
-    case 6: { constexpr int KK = 6; CALL; } break;                                                        \
-    case 7: { constexpr int KK = 7; CALL; } break;                                                        \
-    case 8: { constexpr int KK = 8; CALL; } break;                                                        \
-    case 9: { constexpr int KK = 9; CALL; } break;                                                        \
+    case 6: { constexpr int KK = 6; __VA_ARGS__; } break;                                                        \
+    case 7: { constexpr int KK = 7; __VA_ARGS__; } break;                                                        \
+    case 8: { constexpr int KK = 8; __VA_ARGS__; } break;                                                        \
+    case 9: { constexpr int KK = 9; __VA_ARGS__; } break;                                                        \
     default: fprintf(stderr, "[dacapo_amd] unsupported NTT phase size 2^%d\n", Kval); abort();             \
+    }
+// CALL sees KK (phase size) and LE (log2 coefficients per thread); grid.x = tiles of that geometry
+#define DC_GEO_SWITCH(Kval, limbs, ...)                                                                   \
+    if (use_small_tiles(c.N, (limbs))) {                                                                  \
+        constexpr int LE = 2;                                                                             \
+        const dim3 grid((unsigned)(c.N >> TileGeo<LE>::LOG), (unsigned)(limbs));                          \
+        DC_K_SWITCH(Kval, __VA_ARGS__)                                                                         \
+    } else {                                                                                              \
+        constexpr int LE = 3;                                                                             \
+        const dim3 grid((unsigned)(c.N >> TileGeo<LE>::LOG), (unsigned)(limbs));                          \
+        DC_K_SWITCH(Kval, __VA_ARGS__)                                                                         \
     }
 
 template <class Src>
 static void launch_irows(const Context &c, Src src, u64 *out, long out_stride, int count, hipStream_t s)
 {
-    dim3 grid((unsigned)(c.N >> kTileLog), (unsigned)count);
-    DC_K_SWITCH(c.k2, hipLaunchKernelGGL((f_irows_kernel<KK, Src>), grid, dim3(kTileThreads), 0, s, src, out, out_stride, c.d_mods,
-                                         c.d_itw, c.logN));
+    DC_GEO_SWITCH(c.k2, count, hipLaunchKernelGGL((f_irows_kernel<KK, LE, Src>), grid, dim3(kTileThreads), 0, s, src, out, out_stride,
+                                                  c.d_mods, c.d_itw, c.logN));
 }
 
 void f_irows_strided(const Context &c, const u64 *base, long stride, int prime_base, int period, u64 *out, long out_stride, int count,
@@ -231,7 +241,6 @@ void f_irows_rs_last(const Context &c, const RsItem *items, int l, u64 *out, int
 {
     launch_irows(c, SrcRsLast{ items, l }, out, (long)c.N, 2 * B, s);
 }
-
 void f_irows_rs_single(const Context &c, CtView src, int l, u64 *out, hipStream_t s)
 {
     launch_irows(c, SrcRsLast1{ src, l }, out, (long)c.N, 2, s);
@@ -243,37 +252,29 @@ void f_irows_decrypt(const Context &c, CtView ct, const u64 *sk, int ell, u64 *o
 
 void f_ks_icols_lift_fcols(const Context &c, const u64 *digits, u64 *ext, int B, int ell, hipStream_t s)
 {
-    dim3 grid((unsigned)(c.N >> kTileLog), (unsigned)(B * ell * ell));
-    DC_K_SWITCH(c.k1, hipLaunchKernelGGL((f_ks_icols_lift_fcols_kernel<KK>), grid, dim3(kTileThreads), 0, s, digits, ext, ell, c.K - 1,
-                                         c.d_mods, c.d_tw, c.d_itw, c.logN));
+    DC_GEO_SWITCH(c.k1, B * ell * ell, hipLaunchKernelGGL((f_ks_icols_lift_fcols_kernel<KK, LE>), grid, dim3(kTileThreads), 0, s, digits, ext,
+                                                          ell, c.K - 1, c.d_mods, c.d_tw, c.d_itw, c.logN));
 }
 
 void f_dr_icols_lift_fcols(const Context &c, const u64 *last, long last_stride, u64 *tmp, int polys, int cnt, int l, hipStream_t s)
 {
-    dim3 grid((unsigned)(c.N >> kTileLog), (unsigned)(polys * cnt));
-    DC_K_SWITCH(c.k1, hipLaunchKernelGGL((f_dr_icols_lift_fcols_kernel<KK>), grid, dim3(kTileThreads), 0, s, last, last_stride, tmp, cnt, l,
-                                         c.K, c.d_mods, c.d_half_mod, c.d_tw, c.d_itw, c.logN));
+    DC_GEO_SWITCH(c.k1, polys * cnt, hipLaunchKernelGGL((f_dr_icols_lift_fcols_kernel<KK, LE>), grid, dim3(kTileThreads), 0, s, last,
+                                                        last_stride, tmp, cnt, l, c.K, c.d_mods, c.d_half_mod, c.d_tw, c.d_itw, c.logN));
 }
 
 void f_frows_final(const Context &c, int mode, const u64 *tmp, const void *items, const u64 *acc, int polys, int cnt, int l,
                    hipStream_t s, RsItem single, const u64 *plain)
 {
-    dim3 grid((unsigned)(c.N >> kTileLog), (unsigned)(polys * cnt));
-    if (mode == 3) {
-        DC_K_SWITCH(c.k2, hipLaunchKernelGGL((f_frows_final_kernel<KK, 3>), grid, dim3(kTileThreads), 0, s, tmp, items, single, plain, acc,
-                                             cnt, l, c.K, c.d_mods, c.d_inv_last, c.d_tw, c.logN));
-        return;
+#define DC_FINAL(MD)                                                                                                                   \
+    DC_GEO_SWITCH(c.k2, polys * cnt, hipLaunchKernelGGL((f_frows_final_kernel<KK, LE, MD>), grid, dim3(kTileThreads), 0, s, tmp, items, single, \
+                                                        plain, acc, cnt, l, c.K, c.d_mods, c.d_inv_last, c.d_tw, c.logN))
+    switch (mode) {
+    case 0: DC_FINAL(0); break;
+    case 1: DC_FINAL(1); break;
+    case 2: DC_FINAL(2); break;
+    default: DC_FINAL(3); break;
     }
-    if (mode == 0) {
-        DC_K_SWITCH(c.k2, hipLaunchKernelGGL((f_frows_final_kernel<KK, 0>), grid, dim3(kTileThreads), 0, s, tmp, items, single, plain, acc, cnt, l,
-                                             c.K, c.d_mods, c.d_inv_last, c.d_tw, c.logN));
-    } else if (mode == 1) {
-        DC_K_SWITCH(c.k2, hipLaunchKernelGGL((f_frows_final_kernel<KK, 1>), grid, dim3(kTileThreads), 0, s, tmp, items, single, plain, acc, cnt, l,
-                                             c.K, c.d_mods, c.d_inv_last, c.d_tw, c.logN));
-    } else {
-        DC_K_SWITCH(c.k2, hipLaunchKernelGGL((f_frows_final_kernel<KK, 2>), grid, dim3(kTileThreads), 0, s, tmp, items, single, plain, acc, cnt, l,
-                                             c.K, c.d_mods, c.d_inv_last, c.d_tw, c.logN));
-    }
+#undef DC_FINAL
 }
 
 } // namespace dacapo

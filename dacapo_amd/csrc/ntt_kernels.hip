@@ -6,27 +6,27 @@
 
 namespace dacapo {
 
-template <int K, bool COLS, bool INV, bool CANON>
+template <int K, int LOGE, bool COLS, bool INV, bool CANON>
 __global__ __launch_bounds__(kTileThreads) void ntt_phase_kernel(u64 *__restrict__ data, long limb_stride,
                                                                   const int *__restrict__ prime_idx, int prime_base,
                                                                   int prime_period, const DModulus *__restrict__ mods,
                                                                   const u64 *__restrict__ tw, int logN)
 {
-    __shared__ __attribute__((aligned(16))) u64 lds[kTileLdsElems];
+    __shared__ __attribute__((aligned(16))) u64 lds[TileGeo<LOGE>::LDS_ELEMS];
     const int limb = blockIdx.y;
     const int p = prime_idx ? prime_idx[limb % prime_period] : prime_base + (limb % prime_period);
     u64 *a = data + (long)limb * limb_stride;
     const DModulus M = mods[p];
-    ntt_tile<K, COLS, INV, CANON>(
+    ntt_tile<K, LOGE, COLS, INV, CANON>(
         M, tw + ((size_t)p << logN), logN, blockIdx.x, [=](int i) { return a[i]; }, [=](int i, u64 v) { a[i] = v; }, lds);
 }
 
-template <int K, bool COLS, bool INV, bool CANON>
+template <int K, int LOGE, bool COLS, bool INV, bool CANON>
 static void launch_phase(const Context &c, u64 *data, long limb_stride, int count, const int *d_prime_idx, int prime_base,
                          int prime_period, hipStream_t s)
 {
-    dim3 grid((unsigned)(c.N >> kTileLog), (unsigned)count);
-    hipLaunchKernelGGL((ntt_phase_kernel<K, COLS, INV, CANON>), grid, dim3(kTileThreads), 0, s, data, limb_stride,
+    dim3 grid((unsigned)(c.N >> TileGeo<LOGE>::LOG), (unsigned)count);
+    hipLaunchKernelGGL((ntt_phase_kernel<K, LOGE, COLS, INV, CANON>), grid, dim3(kTileThreads), 0, s, data, limb_stride,
                        d_prime_idx, prime_base, prime_period, c.d_mods, INV ? c.d_itw : c.d_tw, c.logN);
 }
 
@@ -34,13 +34,22 @@ template <bool COLS, bool INV, bool CANON>
 static void launch_phase_k(int K, const Context &c, u64 *data, long limb_stride, int count, const int *d_prime_idx,
                            int prime_base, int prime_period, hipStream_t s)
 {
+    const bool small = use_small_tiles(c.N, count);
+#define DC_PHASE(KK)                                                                                                           \
+    case KK:                                                                                                                   \
+        if (small)                                                                                                             \
+            launch_phase<KK, 2, COLS, INV, CANON>(c, data, limb_stride, count, d_prime_idx, prime_base, prime_period, s);       \
+        else                                                                                                                   \
+            launch_phase<KK, 3, COLS, INV, CANON>(c, data, limb_stride, count, d_prime_idx, prime_base, prime_period, s);       \
+        break;
     switch (K) {
-    case 6: launch_phase<6, COLS, INV, CANON>(c, data, limb_stride, count, d_prime_idx, prime_base, prime_period, s); break;
-    case 7: launch_phase<7, COLS, INV, CANON>(c, data, limb_stride, count, d_prime_idx, prime_base, prime_period, s); break;
-    case 8: launch_phase<8, COLS, INV, CANON>(c, data, limb_stride, count, d_prime_idx, prime_base, prime_period, s); break;
-    case 9: launch_phase<9, COLS, INV, CANON>(c, data, limb_stride, count, d_prime_idx, prime_base, prime_period, s); break;
+        DC_PHASE(6)
+        DC_PHASE(7)
+        DC_PHASE(8)
+        DC_PHASE(9)
     default: fprintf(stderr, "[dacapo_amd] unsupported NTT phase size 2^%d\n", K); abort();
     }
+#undef DC_PHASE
 }
 
 void launch_ntt_rows_fwd(const Context &c, u64 *data, long limb_stride, int count, const int *d_prime_idx, int prime_base,

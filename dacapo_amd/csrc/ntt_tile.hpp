@@ -1,6 +1,6 @@
-// One workgroup = one 2048-coefficient tile of one RNS limb; the negacyclic NTT of a limb of N = 2^logN
-// coefficients is two launches ("phases") of this tile routine, so that a single limb already spreads over
-// N/2048 workgroups (16 at the HEVM ring N = 2^15) and a key switch at small level still fills the chip:
+// One workgroup (256 threads) = one tile of one RNS limb; the negacyclic NTT of a limb of N = 2^logN coefficients is
+// two launches ("phases") of this tile routine, so that a single limb already spreads over many workgroups and a key
+// switch at small level still fills the chip:
 //
 //   forward  (SEAL ntt_negacyclic_harvey: natural in, bit-reversed out; stage with m groups uses psi^bitrev(m+i))
 //     phase COLS : first k1 stages.  View the limb as an [N1 = 2^k1][N2 = N/N1] matrix; these stages only
@@ -12,36 +12,48 @@
 //   inverse (Gentleman-Sande, bit-reversed in, natural out): ROWS phase first, then COLS, same tiles and the
 //     same table indices with inverse twiddles; N^{-1} is merged into the very last stage.
 //
-// Inside a tile each thread keeps 8 coefficients in registers and runs up to three butterfly stages
-// (radix-8) per pass; between passes the tile is transposed through LDS.  The LDS image is laid out for the
-// READER: element j of thread t lives at j*(T+pad)+t, so every ds_read_b64 is lane-contiguous; the pad is
-// chosen per exchange so the scattered ds_write_b64 of the writer is conflict-free as well
-// (tools/lds_conflicts.py enumerates them).
+// Two geometries (template parameter LOGE = log2 of the coefficients a thread keeps in registers):
+//   LOGE = 3 : 2048-coefficient tiles, radix-8 passes (3 stages per pass)  -- throughput: fewest LDS exchanges
+//   LOGE = 2 : 1024-coefficient tiles, radix-4 passes (2 stages per pass)  -- latency: twice the workgroups, half
+//              the butterflies per thread; used when a launch has too few tiles to occupy the chip (a lone wave per
+//              SIMD is bound by its own instruction latency, so halving its work nearly halves the phase).
+// Between passes the tile is transposed through LDS.  The LDS image is laid out for the READER: element j of thread
+// t lives at j*(T+pad)+t, so every ds_read_b64 is lane-contiguous.
 #pragma once
+#include <stdlib.h>
+
 #include "modarith.hpp"
 
 namespace dacapo {
 
-constexpr int kTileLog = 11;              // 2048 coefficients per workgroup
-constexpr int kTileElems = 1 << kTileLog; // 16 KiB of u64
-constexpr int kTileThreads = kTileElems / 8;
+constexpr int kTileThreads = 256;
+constexpr int kLdsPad = 4;
+template <int LOGE>
+struct TileGeo {
+    static constexpr int E = 1 << LOGE;            // coefficients per thread
+    static constexpr int LOG = 8 + LOGE;           // log2(coefficients per tile)
+    static constexpr int ELEMS = 1 << LOG;
+    static constexpr int LDS_ELEMS = E * (kTileThreads + kLdsPad);
+};
+// the throughput geometry's constants, used by host code to size grids
+constexpr int kTileLog = TileGeo<3>::LOG;
+constexpr int kTileElems = TileGeo<3>::ELEMS;
+constexpr int kTileLdsElems = TileGeo<3>::LDS_ELEMS;
 
-__host__ __device__ constexpr int pass_stages(int K, int p) { return (K - 3 * p) >= 3 ? 3 : (K - 3 * p); }
-__host__ __device__ constexpr int num_passes(int K) { return (K + 2) / 3; }
-
-// pad (in u64 elements) added to the register stride of the LDS image read by pass `p_reader`
-template <int K, bool COLS>
-__host__ __device__ constexpr int lds_pad(int p_reader, bool inverse);
+template <int LOGE>
+__host__ __device__ constexpr int pass_stages(int K, int p) { return (K - LOGE * p) >= LOGE ? LOGE : (K - LOGE * p); }
+template <int LOGE>
+__host__ __device__ constexpr int num_passes(int K) { return (K + LOGE - 1) / LOGE; }
 
 // ---- per-pass index algebra (all compile-time foldable once loops are unrolled) ----------------------
-template <int K>
+template <int K, int LOGE>
 struct PassMap {
-    // thread sub-index s in [0, n/8), register j in [0,8)  ->  local coefficient index in [0, n)
+    // thread sub-index s in [0, n/E), register j in [0,E)  ->  local coefficient index in [0, n)
     __device__ static __forceinline__ int idx_of(int p, int s, int j)
     {
-        const int s0 = 3 * p, r = pass_stages(K, p);
+        const int s0 = LOGE * p, r = pass_stages<LOGE>(K, p);
         const int u = j >> r, kk = j & ((1 << r) - 1);
-        const int vt = (s << (3 - r)) | u;
+        const int vt = (s << (LOGE - r)) | u;
         const int lob = K - s0 - r;
         const int hi = vt >> lob, lo = vt & ((1 << lob) - 1);
         return (hi << (K - s0)) | (kk << lob) | lo;
@@ -49,14 +61,14 @@ struct PassMap {
     // inverse of idx_of: local index -> (s, j) under pass p
     __device__ static __forceinline__ void sj_of(int p, int idx, int &s, int &j)
     {
-        const int s0 = 3 * p, r = pass_stages(K, p);
+        const int s0 = LOGE * p, r = pass_stages<LOGE>(K, p);
         const int lob = K - s0 - r;
         const int lo = idx & ((1 << lob) - 1);
         const int kk = (idx >> lob) & ((1 << r) - 1);
         const int hi = idx >> (K - s0);
         const int vt = (hi << lob) | lo;
-        s = vt >> (3 - r);
-        j = ((vt & ((1 << (3 - r)) - 1)) << r) | kk;
+        s = vt >> (LOGE - r);
+        j = ((vt & ((1 << (LOGE - r)) - 1)) << r) | kk;
     }
 };
 
@@ -64,7 +76,7 @@ struct PassMap {
 __device__ __forceinline__ void ct_bfly(u64 &x, u64 &y, u64 w, const DModulus &M)
 {
     u64 xf = fold60(x, M.delta);            // < 2^60 + 2^31
-    u64 t = mulmod_lazy(w, y, M.delta);     // < 2^62 (w < 2^60, y < 2^63: product < 2^123)
+    u64 t = mulmod_lazy(w, y, M.delta);     // < 4q (w < 2^60, y < 2^63)
     x = xf + t;                             // < 2^63
     y = xf + (M.q << 2) - t;                // 4q > t : < 2^60 + 2^31 + 2^62
 }
@@ -84,12 +96,14 @@ __device__ __forceinline__ void gs_bfly(u64 &x, u64 &y, u64 w, const DModulus &M
 // KEEP     : leave the result in x[] (canonical if CANON) instead of calling st.  The last pass of an inverse phase and
 //            the first pass of a forward phase of the same shape use the same thread<->coefficient map, so an inverse
 //            tile can hand its output to a forward tile in registers (the fused iNTT -> base change -> NTT kernels).
-template <int K, bool COLS, bool INV, bool CANON, bool PRELOADED, bool KEEP, class Ld, class St>
-__device__ __forceinline__ void ntt_tile_x(u64 (&x)[8], const DModulus M, const u64 *__restrict__ tw, int logN, int tile, Ld ld,
-                                           St st, u64 *__restrict__ lds)
+template <int K, int LOGE, bool COLS, bool INV, bool CANON, bool PRELOADED, bool KEEP, class Ld, class St>
+__device__ __forceinline__ void ntt_tile_x(u64 (&x)[1 << LOGE], const DModulus M, const u64 *__restrict__ tw, int logN, int tile,
+                                           Ld ld, St st, u64 *__restrict__ lds)
 {
-    constexpr int n = 1 << K, LOGB = kTileLog - K, B = 1 << LOGB, T = kTileThreads, SUBT = n / 8;
-    constexpr int NP = num_passes(K);
+    constexpr int E = 1 << LOGE, n = 1 << K, LOGB = TileGeo<LOGE>::LOG - K, B = 1 << LOGB, T = kTileThreads, SUBT = n / E;
+    constexpr int NP = num_passes<LOGE>(K);
+    constexpr int stride = T + kLdsPad;
+    static_assert(LOGB >= 0, "sub-transform larger than the tile");
     const int t = threadIdx.x;
     int b, s;
     if (COLS) {
@@ -107,23 +121,22 @@ __device__ __forceinline__ void ntt_tile_x(u64 (&x)[8], const DModulus M, const 
 #pragma unroll
     for (int pp = 0; pp < NP; pp++) {
         const int p = INV ? (NP - 1 - pp) : pp;
-        const int s0 = 3 * p, r = pass_stages(K, p);
+        const int s0 = LOGE * p, r = pass_stages<LOGE>(K, p);
         const bool first = (pp == 0), last = (pp == NP - 1);
         // ---- load
         if (first) {
             if (!PRELOADED) {
 #pragma unroll
-                for (int j = 0; j < 8; j++) x[j] = ld(gidx(PassMap<K>::idx_of(p, s, j)));
+                for (int j = 0; j < E; j++) x[j] = ld(gidx(PassMap<K, LOGE>::idx_of(p, s, j)));
             }
         } else {
-            const int stride = T + lds_pad<K, COLS>(p, INV);
 #pragma unroll
-            for (int j = 0; j < 8; j++) x[j] = lds[j * stride + t];
+            for (int j = 0; j < E; j++) x[j] = lds[j * stride + t];
         }
-        // ---- butterflies: 2^(3-r) independent radix-2^r networks per thread
+        // ---- butterflies: 2^(LOGE-r) independent radix-2^r networks per thread
 #pragma unroll
-        for (int u = 0; u < (1 << (3 - r)); u++) {
-            const int vt = (s << (3 - r)) | u;
+        for (int u = 0; u < (1 << (LOGE - r)); u++) {
+            const int vt = (s << (LOGE - r)) | u;
             const int hi = vt >> (K - s0 - r);
 #pragma unroll
             for (int tt = 0; tt < r; tt++) {
@@ -155,20 +168,19 @@ __device__ __forceinline__ void ntt_tile_x(u64 (&x)[8], const DModulus M, const 
             if (KEEP) {
                 if (CANON) {
 #pragma unroll
-                    for (int j = 0; j < 8; j++) x[j] = canon(x[j], M);
+                    for (int j = 0; j < E; j++) x[j] = canon(x[j], M);
                 }
             } else {
 #pragma unroll
-                for (int j = 0; j < 8; j++) st(gidx(PassMap<K>::idx_of(p, s, j)), CANON ? canon(x[j], M) : x[j]);
+                for (int j = 0; j < E; j++) st(gidx(PassMap<K, LOGE>::idx_of(p, s, j)), CANON ? canon(x[j], M) : x[j]);
             }
         } else {
             const int pn = INV ? p - 1 : p + 1;
-            const int stride = T + lds_pad<K, COLS>(pn, INV);
             if (!first) __syncthreads(); // everyone has finished reading the previous image
 #pragma unroll
-            for (int j = 0; j < 8; j++) {
+            for (int j = 0; j < E; j++) {
                 int s2, j2;
-                PassMap<K>::sj_of(pn, PassMap<K>::idx_of(p, s, j), s2, j2);
+                PassMap<K, LOGE>::sj_of(pn, PassMap<K, LOGE>::idx_of(p, s, j), s2, j2);
                 const int t2 = COLS ? ((s2 << LOGB) | b) : (b * SUBT + s2);
                 lds[j2 * stride + t2] = x[j];
             }
@@ -177,36 +189,21 @@ __device__ __forceinline__ void ntt_tile_x(u64 (&x)[8], const DModulus M, const 
     }
 }
 
-template <int K, bool COLS, bool INV, bool CANON, class Ld, class St>
+template <int K, int LOGE, bool COLS, bool INV, bool CANON, class Ld, class St>
 __device__ __forceinline__ void ntt_tile(const DModulus M, const u64 *__restrict__ tw, int logN, int tile, Ld ld, St st,
                                          u64 *__restrict__ lds)
 {
-    u64 x[8];
-    ntt_tile_x<K, COLS, INV, CANON, false, false>(x, M, tw, logN, tile, ld, st, lds);
+    u64 x[1 << LOGE];
+    ntt_tile_x<K, LOGE, COLS, INV, CANON, false, false>(x, M, tw, logN, tile, ld, st, lds);
 }
 
-// polynomial index of register j of this thread in the first pass of a forward tile (= last pass of an inverse tile)
-template <int K, bool COLS>
-__device__ __forceinline__ int tile_first_pass_gidx(int logN, int tile, int j)
+// geometry choice for a launch of `limbs` limb-phases: the latency geometry while the throughput one would leave most
+// of the 256 CUs without a workgroup
+inline long small_tile_threshold()
 {
-    constexpr int LOGB = kTileLog - K, B = 1 << LOGB, SUBT = (1 << K) / 8;
-    const int t = threadIdx.x;
-    const int b = COLS ? (t & (B - 1)) : (t / SUBT), s = COLS ? (t >> LOGB) : (t & (SUBT - 1));
-    const int idx = PassMap<K>::idx_of(0, s, j);
-    const int lane_id = tile * B + b;
-    return COLS ? ((idx << (logN - K)) + lane_id) : ((lane_id << K) + idx);
+    static const long v = getenv("DACAPO_SMALL_TILE_WGS") ? atol(getenv("DACAPO_SMALL_TILE_WGS")) : 20000;
+    return v;
 }
-
-// Pads found with tools/lds_conflicts.py (0 = already conflict-free).  Max pad bounds the LDS allocation.
-constexpr int kMaxLdsPad = 8;
-constexpr int kTileLdsElems = 8 * (kTileThreads + kMaxLdsPad);
-
-template <int K, bool COLS>
-__host__ __device__ constexpr int lds_pad(int p_reader, bool inverse)
-{
-    (void)p_reader;
-    (void)inverse;
-    return 4;
-}
+inline bool use_small_tiles(size_t N, long limbs) { return (long)(N >> kTileLog) * limbs < small_tile_threshold(); }
 
 } // namespace dacapo
