@@ -135,6 +135,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--layers", type=int, default=20, help="ResNet-shaped program depth (20 = the traced op mix)")
+    ap.add_argument("--streams", type=int, default=1, help="independent ciphertext streams per GPU (throughput mode; 1 = the reference's one image per run)")
     args = ap.parse_args()
 
     from dacapo_amd.dist import Group
@@ -156,12 +157,15 @@ def main():
     # ---- set-up (untimed, like hc-test: context/keys, load, preprocess, encrypt) ---------------------------------
     t_setup = time.time()
     hevm = runner.HEVM(seed=0x4845564D + rank, logN=15, num_primes=14)
+    if args.streams > 1:
+        hevm.set_streams(args.streams)
     prog = ha.resnet_shaped(seed=100, layers=args.layers)  # independent stream per rank: same program, own keys/inputs
     cst, hv, info = prog.assemble()
     hevm.load_mem(cst, hv)
     rng = np.random.default_rng(100 + rank)
-    image = rng.uniform(-0.5, 0.5, hevm.slots)
-    hevm.setInput(0, image)
+    for sidx in range(args.streams):
+        hevm.select_stream(sidx)
+        hevm.setInput(0, rng.uniform(-0.5, 0.5, hevm.slots))
     t_setup = time.time() - t_setup
 
     for _ in range(args.warmup):
@@ -198,6 +202,7 @@ def main():
         "config": {"workload": "ResNet-shaped HEVM program (SURVEY App. C op mix), nt=2^14 slots, N=2^15, 14 x 60-bit primes "
                                "(SEAL_HEVM.cpp:39-53); one independent ciphertext stream per GPU",
                    "ops": info["op_mix"], "key_switches_per_step": stats["keyswitches"], "ntt_equivalents_per_step": ntts_per_step,
+                   "streams_per_gpu": args.streams,
                    "parallelism": f"replicas x{world} (no collective in the op path)"},
         "hevm_wall_s": round(ms_per_step / 1e3, 4),
         "hevm_bootstrap_s_per_step": round(stats["bootstrap_s"], 4),

@@ -615,17 +615,46 @@ void HEVM::reset_res_dst()
 hevm_ctxt &HEVM::reg(size_t i)
 {
     while (i >= ciphers.size()) ciphers.push_back(hevm_ctxt{ nullptr, 0, 0, 0, 1.0 }); // deque: references stay valid
-    while (i >= home.size()) home.push_back(nullptr);
+    while (i >= home.size()) home.push_back(nullptr), reg_base.push_back(nullptr);
     hevm_ctxt &r = ciphers[i];
-    if (!home[i]) // a register's own buffer, full capacity [2][K][N] (K limbs: encryption stages one extra prime)
-        home[i] = dalloc((size_t)2 * ctx->K * ctx->N);
+    const size_t slice = (size_t)2 * ctx->K * ctx->N; // full capacity [2][K][N] (K limbs: encryption stages one extra prime)
+    if (!home[i]) home[i] = dalloc(slice * (size_t)streams);
     if (!r.data) {
         r.poly_stride = (int64_t)ctx->K * (int64_t)ctx->N;
-        r.data = home[i];
+        reg_base[i] = home[i];
+        r.data = reg_base[i] + (size_t)sel * slice;
         r.level = 0;
         r.scale = 1.0;
     }
     return r;
+}
+
+void HEVM::set_streams(int n)
+{
+    if (n < 1) n = 1;
+    if (n == streams) return;
+    DC_HIP_CHECK(hipDeviceSynchronize());
+    for (u64 *&p : home)
+        if (p) (void)hipFree(p), p = nullptr;
+    for (u64 *p : plan.pool) (void)hipFree(p);
+    plan.pool.clear();
+    plan.ready = false;
+    for (auto &r : ciphers) r.data = nullptr;
+    streams = n;
+    sel = 0;
+    for (size_t i = 0; i < ciphers.size(); i++) reg(i);
+}
+
+void HEVM::select_stream(int s)
+{
+    if (s < 0 || s >= streams) {
+        fprintf(stderr, "[dacapo_amd] stream %d outside 0..%d\n", s, streams - 1);
+        abort();
+    }
+    sel = s;
+    const size_t slice = (size_t)2 * ctx->K * ctx->N;
+    for (size_t i = 0; i < ciphers.size(); i++)
+        if (reg_base[i]) ciphers[i].data = reg_base[i] + (size_t)sel * slice;
 }
 
 void HEVM::bump_epoch(hipStream_t s) { hipLaunchKernelGGL(bump_epoch_kernel, dim3(1), dim3(1), 0, s, d_epoch); }
@@ -709,7 +738,8 @@ void HEVM::encrypt(int64_t i, const double *dat, int len)
     Plain pt;
     encode_internal(pt, dat, (size_t)len, (int)arg_level.at((size_t)i), (int)arg_scale.at((size_t)i));
     hevm_ctxt &r = reg((size_t)i);
-    r.data = home[(size_t)i]; // program inputs always live in the register's own buffer (a plan may have re-pointed it)
+    reg_base[(size_t)i] = home[(size_t)i]; // program inputs always live in the register's own block (a plan may have re-pointed it)
+    r.data = reg_base[(size_t)i] + (size_t)sel * (size_t)2 * ctx->K * ctx->N;
     r.poly_stride = (int64_t)ctx->K * (int64_t)ctx->N;
     encrypt_plain(r, pt);
     DC_HIP_CHECK(hipStreamSynchronize(S()));
@@ -1200,6 +1230,10 @@ void HEVM::run()
         run_plan();
         return;
     }
+    if (streams != 1) {
+        fprintf(stderr, "[dacapo_amd] several ciphertext streams need the batched plan (DACAPO_HEVM_PLAN=1, no debug)\n");
+        abort();
+    }
     const bool multi = n_lanes > 1 && !debug;
     if (!use_graph || debug) {
         execute(multi);
@@ -1365,6 +1399,8 @@ void hevm_load_mem(void *vm, const void *cst, uint64_t cst_len, const void *hevm
     h->load_constants(cst, cst_len);
     h->load_program(hevm, hevm_len, false);
 }
+void hevm_set_streams(void *vm, int n) { static_cast<HEVM *>(vm)->set_streams(n); }
+void hevm_select_stream(void *vm, int s) { static_cast<HEVM *>(vm)->select_stream(s); }
 double hevm_last_run_bootstrap_seconds(void *vm) { return static_cast<HEVM *>(vm)->t_bootstrap; }
 void hevm_last_run_stats(void *vm, int64_t *op_counts, int64_t *keyswitches, int64_t *ntts)
 {

@@ -186,7 +186,13 @@ class HEVM {
     void issue_plan(hipStream_t s);
     bool use_plan = true;
     int max_batch = 128;
-    std::vector<u64 *> home; // permanent buffer of every architectural register (program inputs live here)
+    std::vector<u64 *> home; // permanent buffer block of every architectural register (program inputs live here)
+    // Throughput mode: `streams` independent ciphertext streams share the program, keys and plaintexts; every buffer is a
+    // block of `streams` slices and encrypt/decrypt/getCtxt address the slice selected by hevm_select_stream().
+    int streams = 1, sel = 0;
+    std::vector<u64 *> reg_base; // base of the block currently holding each architectural register
+    void set_streams(int n);
+    void select_stream(int s);
     void build_plan();
     void run_plan();
     void boot_item(CtView src, int src_level, double src_scale, hevm_ctxt &dst, int target_level);

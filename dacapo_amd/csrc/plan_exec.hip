@@ -37,6 +37,7 @@ void HEVM::build_plan()
     P.vals.clear(), P.pops.clear(), P.steps.clear();
     P.n_keyswitch = P.n_ntt = 0;
     const size_t nreg = ciphers.size();
+    const int S = streams; // independent ciphertext streams executed side by side (items of every step are replicated)
     std::vector<int> cur(nreg, -1);
     auto new_val = [&](int level, double scale) {
         Val v;
@@ -235,7 +236,7 @@ void HEVM::build_plan()
         for (auto &kv : buckets) {
             const PopKind kind = (PopKind)kv.first.first;
             const bool heavy = kind == P_ROT || kind == P_MULCC || kind == P_RESCALE;
-            const size_t chunk = kind == P_BOOT ? 1 : (heavy ? (size_t)max_batch : (size_t)4096);
+            const size_t chunk = kind == P_BOOT ? 1 : std::max<size_t>(1, (heavy ? (size_t)max_batch : (size_t)4096) / (size_t)S);
             for (size_t off = 0; off < kv.second.size(); off += chunk) {
                 Step st;
                 st.kind = kind, st.level = kv.first.second;
@@ -278,7 +279,7 @@ void HEVM::build_plan()
                 b = free_list.back();
                 free_list.pop_back();
             } else {
-                DC_HIP_CHECK(hipMalloc(&b, buf_elems * sizeof(u64)));
+                DC_HIP_CHECK(hipMalloc(&b, buf_elems * (size_t)S * sizeof(u64))); // one block = the value in all S streams
                 P.pool.push_back(b);
             }
             V[(size_t)v].buf = b;
@@ -289,61 +290,72 @@ void HEVM::build_plan()
     }
     // ---- 6. device item tables ----------------------------------------------------------------------------------------
     const long ps = (long)c.K * (long)N;
-    auto view = [&](int v) {
+    auto view = [&](int v, int sidx) {
         u64 *b = V[(size_t)V[(size_t)v].root].buf;
         if (!b) {
             fprintf(stderr, "[dacapo_amd] plan: value %d has no buffer (internal error)\n", v);
             abort();
         }
-        return CtView{ b, ps };
+        return CtView{ b + (size_t)sidx * buf_elems, ps };
     };
     size_t need_t = 0, need_d = 0, need_e = 0, need_a = 0, need_m = 0, need_c = 0;
     P.launches = 0;
     for (size_t s = 0; s < P.steps.size(); s++) {
         Step &st = P.steps[s];
+        if (st.kind != P_BOOT) st.count *= S; // items = pseudo-ops x streams
         const size_t B = (size_t)st.count, l = (size_t)st.level;
         switch (st.kind) {
         case P_ROT:
             st.first = (int)h_ks.size();
-            for (int pi : step_pops[s]) h_ks.push_back(KsItem{ view(O[(size_t)pi].srcs[0]), view(O[(size_t)pi].dst), O[(size_t)pi].key, O[(size_t)pi].elt, 0 });
+            for (int pi : step_pops[s])
+                for (int q = 0; q < S; q++)
+                    h_ks.push_back(KsItem{ view(O[(size_t)pi].srcs[0], q), view(O[(size_t)pi].dst, q), O[(size_t)pi].key, O[(size_t)pi].elt, 0 });
             break;
         case P_MULCC:
             st.first = (int)h_mul.size();
-            for (int pi : step_pops[s]) h_mul.push_back(MulItem{ view(O[(size_t)pi].srcs[0]), view(O[(size_t)pi].srcs[1]), view(O[(size_t)pi].dst) });
+            for (int pi : step_pops[s])
+                for (int q = 0; q < S; q++)
+                    h_mul.push_back(MulItem{ view(O[(size_t)pi].srcs[0], q), view(O[(size_t)pi].srcs[1], q), view(O[(size_t)pi].dst, q) });
             break;
         case P_RESCALE:
             st.first = (int)h_rs.size();
-            for (int pi : step_pops[s]) h_rs.push_back(RsItem{ view(O[(size_t)pi].srcs[0]), view(O[(size_t)pi].dst) });
+            for (int pi : step_pops[s])
+                for (int q = 0; q < S; q++) h_rs.push_back(RsItem{ view(O[(size_t)pi].srcs[0], q), view(O[(size_t)pi].dst, q) });
             break;
         case P_SUM:
             st.first = (int)h_sum.size();
-            for (int pi : step_pops[s]) {
-                h_sum.push_back(SumItem{ view(O[(size_t)pi].dst), (int)h_srcs.size(), (int)O[(size_t)pi].srcs.size() });
-                for (int sv : O[(size_t)pi].srcs) h_srcs.push_back(view(sv));
-            }
+            for (int pi : step_pops[s])
+                for (int q = 0; q < S; q++) {
+                    h_sum.push_back(SumItem{ view(O[(size_t)pi].dst, q), (int)h_srcs.size(), (int)O[(size_t)pi].srcs.size() });
+                    for (int sv : O[(size_t)pi].srcs) h_srcs.push_back(view(sv, q));
+                }
             break;
         case P_NEG:
         case P_COPY:
             st.first = (int)h_ew.size();
-            for (int pi : step_pops[s]) h_ew.push_back(EwItem{ view(O[(size_t)pi].dst), view(O[(size_t)pi].srcs[0]), view(O[(size_t)pi].srcs[0]) });
+            for (int pi : step_pops[s])
+                for (int q = 0; q < S; q++)
+                    h_ew.push_back(EwItem{ view(O[(size_t)pi].dst, q), view(O[(size_t)pi].srcs[0], q), view(O[(size_t)pi].srcs[0], q) });
             break;
         case P_MULP:
         case P_ADDP:
             st.first = (int)h_ew.size();
             for (int pi : step_pops[s])
-                h_ew.push_back(EwItem{ view(O[(size_t)pi].dst), view(O[(size_t)pi].srcs[0]), CtView{ plains.at((size_t)O[(size_t)pi].plain).d, 0 } });
+                for (int q = 0; q < S; q++)
+                    h_ew.push_back(EwItem{ view(O[(size_t)pi].dst, q), view(O[(size_t)pi].srcs[0], q),
+                                           CtView{ plains.at((size_t)O[(size_t)pi].plain).d, 0 } });
             break;
         case P_BOOT: break;
         }
         if (st.kind == P_ROT || st.kind == P_MULCC) {
             need_t = std::max(need_t, B * l), need_d = std::max(need_d, B * std::max<size_t>(l, 2)), need_e = std::max(need_e, B * l * l);
             need_a = std::max(need_a, B * 2 * (l + 1)), need_m = std::max(need_m, B * 2 * l), need_c = std::max(need_c, B * l);
-            P.launches += 13;
+            P.launches += 8;
         } else if (st.kind == P_RESCALE) {
             need_d = std::max(need_d, B * 2), need_m = std::max(need_m, B * 2 * l);
-            P.launches += 7;
+            P.launches += 3;
         } else
-            P.launches += st.kind == P_BOOT ? 25 : 1;
+            P.launches += st.kind == P_BOOT ? 13 * (size_t)S : 1;
     }
     P.d_ks = upload(h_ks), P.d_mul = upload(h_mul), P.d_rs = upload(h_rs), P.d_ew = upload(h_ew), P.d_sum = upload(h_sum);
     P.d_sum_srcs = upload(h_srcs);
@@ -356,6 +368,7 @@ void HEVM::build_plan()
     };
     P.ws.target = alloc(need_t), P.ws.digits = alloc(need_d), P.ws.ext = alloc(need_e);
     P.ws.acc = alloc(need_a), P.ws.tmp = alloc(need_m), P.ws.c0perm = alloc(need_c);
+    P.n_keyswitch *= S, P.n_ntt *= S;
     P.ready = true;
     if (getenv("DACAPO_HEVM_TRACE"))
         fprintf(stderr, "[dacapo_amd] plan: %zu ops -> %zu pseudo-ops -> %zu steps in %d waves, ~%zu launches, %zu live buffers (%.1f GB pool)\n",
@@ -380,8 +393,11 @@ void HEVM::issue_plan(hipStream_t s)
         case P_BOOT: {
             const Pop &p = P.pops[(size_t)st.pop];
             const Val &sv = P.vals[(size_t)p.srcs[0]];
-            hevm_ctxt d{ P.vals[(size_t)P.vals[(size_t)p.dst].root].buf, ps, 0, 0, 1.0 };
-            boot_item(CtView{ P.vals[(size_t)sv.root].buf, ps }, sv.level, sv.scale, d, p.target_level);
+            const size_t be = (size_t)2 * c.K * c.N;
+            for (int q = 0; q < streams; q++) {
+                hevm_ctxt d{ P.vals[(size_t)P.vals[(size_t)p.dst].root].buf + (size_t)q * be, ps, 0, 0, 1.0 };
+                boot_item(CtView{ P.vals[(size_t)sv.root].buf + (size_t)q * be, ps }, sv.level, sv.scale, d, p.target_level);
+            }
             break;
         }
         }
@@ -416,7 +432,8 @@ void HEVM::run_plan()
     for (size_t r = 0; r < P.final_val.size() && r < ciphers.size(); r++) {
         const int v = P.final_val[r];
         if (v < 0) continue;
-        ciphers[r].data = P.vals[(size_t)P.vals[(size_t)v].root].buf;
+        reg_base[r] = P.vals[(size_t)P.vals[(size_t)v].root].buf;
+        ciphers[r].data = reg_base[r] + (size_t)sel * (size_t)2 * c.K * c.N;
         ciphers[r].poly_stride = ps;
         ciphers[r].level = P.vals[(size_t)v].level;
         ciphers[r].scale = P.vals[(size_t)v].scale;

@@ -67,6 +67,8 @@ def reinit_lw():  # runner.py:73-117
     lw.hevm_load_mem.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_char_p, ctypes.c_uint64]
     lw.hevm_last_run_stats.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64),
                                        ctypes.POINTER(ctypes.c_int64)]
+    lw.hevm_set_streams.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    lw.hevm_select_stream.argtypes = [ctypes.c_void_p, ctypes.c_int]
     lw.hevm_last_run_bootstrap_seconds.argtypes = [ctypes.c_void_p]
     lw.hevm_last_run_bootstrap_seconds.restype = ctypes.c_double
     return lw
@@ -138,6 +140,13 @@ class HEVM:
         self.arglen = lw.getArgLen(self.vm)
         self.reslen = lw.getResLen(self.vm)
         self.hevm_path = "<memory>"
+
+    def set_streams(self, n):
+        """extension: n independent ciphertext streams through the same program (call before load)"""
+        lw.hevm_set_streams(self.vm, n)
+
+    def select_stream(self, s):
+        lw.hevm_select_stream(self.vm, s)
 
     def run(self):
         lw.run(self.vm)

@@ -84,6 +84,11 @@ const uint64_t *hevm_plain(void *vm, int64_t i, int32_t *level, double *scale);
 void hevm_load_mem(void *vm, const void *cst, uint64_t cst_len, const void *hevm, uint64_t hevm_len);
 /* per-opcode launch statistics of the last run(): counts[11], NTT-equivalents executed */
 void hevm_last_run_stats(void *vm, int64_t *op_counts /*[11]*/, int64_t *keyswitches, int64_t *ntts);
+/* Throughput mode: run `n` independent ciphertext streams of the same program side by side (shared keys and
+ * plaintexts; every step of the batched plan processes all streams in one launch sequence).  Call before load();
+ * encrypt / decrypt / decrypt_result / getCtxt then address the stream chosen with hevm_select_stream. */
+void hevm_set_streams(void *vm, int n);
+void hevm_select_stream(void *vm, int s);
 /* wall seconds the last run() spent inside opcode 10 (decrypt / re-encode / encrypt) */
 double hevm_last_run_bootstrap_seconds(void *vm);
 

@@ -223,3 +223,41 @@ def test_file_based_runner_sequence(tmp_path, monkeypatch):
     client = runner.HEVM(path=str(keydir), option="client")
     client.load(str(tmp_path / "_hecate_t.cst"), str(tmp_path / "t.40._hecate_t.hevm"))
     assert client.arglen == 1 and client.reslen == 1
+
+
+def test_throughput_mode_three_streams_bit_exact(tmp_path):
+    """hevm_set_streams: 3 independent ciphertext streams through one batched plan; every stream's result limbs equal
+    the oracle VM's on that stream's input, and decrypt to that stream's expected plaintext."""
+    from dacapo_amd import hevm_asm as ha
+    from dacapo_amd import lowlevel as ll
+    from dacapo_amd import runner
+
+    hevm = runner.HEVM(seed=0x4845564D, logN=13, num_primes=7)
+    o = Oracle(13, 7)
+    _import_keys(o, hevm, ll)
+    hevm.set_streams(3)
+    rng = np.random.default_rng(11)
+    imgs = [rng.uniform(0, 1, 4096) for _ in range(3)]
+    builders = [ha.sobel_filter(im, slots=o.slots, init_level=6) for im in imgs]
+    cst, hv, info = builders[0].assemble()  # the program does not depend on the data
+    hevm.load_mem(cst, hv)
+    ovm = _mirror_vm(hevm, ll, o, cst, hv, tmp_path)
+    inputs = []
+    for s, im in enumerate(imgs):
+        hevm.select_stream(s)
+        hevm.setInput(0, im)
+        inputs.append(_get_ct(hevm, ll, 0))
+    assert not (inputs[0].data == inputs[1].data).all()
+    hevm.run()
+    assert hevm.stats()["keyswitches"] == 3 * (12 + 4)  # 9 rotations = 12 hops (offset 0 is free) + 4 ct*ct per stream
+    for s in (2, 0, 1):
+        hevm.select_stream(s)
+        ovm.ciphers = [None] * len(ovm.ciphers)
+        ovm.ciphers[0] = inputs[s]
+        ovm.run()
+        got = _get_ct(hevm, ll, ovm.prog.res_dst[0])
+        want = ovm.ciphers[ovm.prog.res_dst[0]]
+        assert got.ell == want.ell and (got.data == want.data).all()
+        res = hevm.getOutput()[0]
+        ref = builders[s].expected()[0]
+        assert np.sqrt(np.mean((res - ref) ** 2)) < 1e-4 * max(1.0, np.abs(ref).max())
