@@ -104,9 +104,9 @@ class Builder:
 
     def _emit(self, opcode, dst: Value, lhs: Value, rhs=0, rhs_is_value=False):
         idx = len(self.ops)
-        lhs.last_use = idx
+        lhs.last_use = max(lhs.last_use, idx)  # a value already declared an output stays live to the end
         if rhs_is_value:
-            self.values[rhs].last_use = idx
+            self.values[rhs].last_use = max(self.values[rhs].last_use, idx)
         self.ops.append(_Op(opcode, dst.id, lhs.id, rhs, True, rhs_is_value))
 
     def _tile(self, vec):

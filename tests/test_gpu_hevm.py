@@ -261,3 +261,39 @@ def test_throughput_mode_three_streams_bit_exact(tmp_path):
         res = hevm.getOutput()[0]
         ref = builders[s].expected()[0]
         assert np.sqrt(np.mean((res - ref) ** 2)) < 1e-4 * max(1.0, np.abs(ref).max())
+
+
+def test_reference_parameters_full_size_properties():
+    """N = 2^15, 14 x 60-bit primes (SEAL_HEVM.cpp:39-53), default key set: size-independent properties of a program that
+    touches every opcode -- rotate(k) then rotate(-k) is the identity, (x*y)*1 == x*y after rescale, x + (-x) == 0,
+    a 6-hop NAF rotation equals np.roll, opcode 10 preserves the plaintext."""
+    from dacapo_amd import hevm_asm as ha
+    from dacapo_amd import runner
+
+    hevm = runner.HEVM(seed=0x4845564D)  # reference defaults
+    assert hevm.logN == 15 and hevm.K == 14 and hevm.slots == 1 << 14
+    rng = np.random.default_rng(21)
+    x, y = rng.uniform(-1, 1, hevm.slots), rng.uniform(-1, 1, hevm.slots)
+    b = ha.Builder(slots=hevm.slots, init_level=13)
+    vx, vy = b.input(x), b.input(y)
+    r = b.rotate(b.rotate(vx, 1365), -1365)            # 1365 = 0b10101010101: 6 NAF hops each way
+    b.output(r)
+    b.output(b.rotate(vy, 8191))                        # largest left rotation, NAF 8192 - 1
+    p = b.mul(vx, vy)
+    p = b.mul_plain(p, [1.0])                           # scale 2^120 -> rescale
+    b.output(p)
+    b.output(b.add(vx, b.negate(vx)))
+    z = b.bootstrap(b.modswitch(p, 9), 4)
+    b.output(b.add_plain(z, [0.5]))
+    cst, hv, info = b.assemble()
+    hevm.load_mem(cst, hv)
+    hevm.setInput(0, x)
+    hevm.setInput(1, y)
+    hevm.run()
+    res = hevm.getOutput()
+    exp = b.expected()
+    for got, want in zip(res, exp):  # key-switch noise at 13 primes and scale 2^40 is ~3e-6 per hop
+        assert np.abs(got - want).max() < 2e-4
+    assert np.abs(res[1] - np.roll(y, -8191)).max() < 2e-4
+    st = hevm.stats()
+    assert st["op_counts"][10] == 1 and st["keyswitches"] == 12 + 2 + 1

@@ -67,3 +67,24 @@ def test_library_exports_every_declared_symbol():
     assert reference_18 <= names and len(names) >= 18 + 25
     for n in sorted(names):
         assert hasattr(lib, n), n
+
+
+def test_outputs_keep_their_registers_when_used_afterwards():
+    from dacapo_amd import hevm_asm as ha
+    from oracle.oracle import read_hevm
+    import tempfile
+
+    b = ha.Builder(slots=1 << 11, init_level=4)
+    x = b.input(np.arange(4.0))
+    p = b.mul_plain(x, [2.0])
+    b.output(p)                      # declared an output, then still used
+    q = b.add_plain(b.negate(p), [1.0])
+    b.output(q)
+    cst, hv, info = b.assemble()
+    with tempfile.NamedTemporaryFile(suffix=".hevm") as f:
+        f.write(hv)
+        f.flush()
+        prog = read_hevm(f.name)
+    assert len(set(prog.res_dst)) == 2
+    writes_after = [op for op in prog.ops[[i for i, o in enumerate(prog.ops) if o[0] == 9][0] + 1:] if op[0] != 0 and op[1] == prog.res_dst[0]]
+    assert not writes_after  # nothing overwrites the first result's register
