@@ -297,3 +297,49 @@ def test_reference_parameters_full_size_properties():
     assert np.abs(res[1] - np.roll(y, -8191)).max() < 2e-4
     st = hevm.stats()
     assert st["op_counts"][10] == 1 and st["keyswitches"] == 12 + 2 + 1
+
+
+def test_edge_cases_constants_markers_and_noops(tmp_path):
+    """ragged / scalar / over-long constants (src[i % len], SEAL_HEVM.cpp:259-261), the all-ones upscale constant (lhs 0xFFFF),
+    buffer-allocation markers (opcode 0xFFFF, EmitHEVM.cpp:54-58), rotate by 0, modswitch by 0, unknown opcodes."""
+    import ctypes
+
+    from dacapo_amd import hevm_asm as ha
+    from dacapo_amd import lowlevel as ll
+    from dacapo_amd import runner
+
+    hevm = runner.HEVM(seed=7, logN=12, num_primes=4)
+    o = Oracle(12, 4)
+    slots = o.slots
+    rng = np.random.default_rng(3)
+    consts = [np.array([0.75]), rng.uniform(-1, 1, 3), rng.uniform(-1, 1, slots), rng.uniform(-1, 1, 4 * slots)]
+    E, ROT, MSW, ADDCP, MULCP = ha.OP_ENCODE, ha.OP_ROTATE, ha.OP_MODSWITCH, ha.OP_ADDCP, ha.OP_MULCP
+    ops = [(0xFFFF, 0, 0, 0)]                                 # tensor.empty marker
+    for i in range(4):
+        ops.append((E, i, i, (3 << 10) + 30))                 # plain regs 0..3 at level 3, scale 2^30
+    ops += [(E, 4, 0xFFFF, (3 << 10) + 20),                   # all-ones constant at scale 2^20
+            (ROT, 1, 0, 0),                                   # rotate by 0 into another register: a copy
+            (MSW, 1, 1, 0),                                   # modswitch by 0: untouched
+            (77, 1, 0, 0),                                    # unknown opcode: no-op
+            (MULCP, 1, 1, 4),                                 # upscale by 2^20
+            (ADDCP, 1, 1, 1)]                                 # + ragged constant... at the wrong scale? addcp forces lhs.scale = plain.scale
+    hv = ha.pack_hevm([30], [3], [30], [3], [1], 2, 5, 3, np.array(ops, dtype=np.uint16))
+    hevm.load_mem(ha.pack_cst(consts), hv)
+    for i, cvec in enumerate(consts):                          # encoder tiling == oracle's, limb for limb (+-1 on a coefficient)
+        lvl, sc = ctypes.c_int32(), ctypes.c_double()
+        p = runner.lw.hevm_plain(hevm.vm, i, ctypes.byref(lvl), ctypes.byref(sc))
+        got = ll.read_device(p, (lvl.value, o.N))
+        want = o.encode(cvec, 2.0**30, 3)
+        assert lvl.value == 3 and sc.value == 2.0**30
+        d = o.ntt_inv(got, [0, 1, 2]).astype(np.int64) - o.ntt_inv(want.data, [0, 1, 2]).astype(np.int64)
+        assert np.abs(d).max() <= 1
+        assert np.abs(o.decode(Plaintext(got, 2.0**30)) - cvec[np.arange(slots) % len(cvec)]).max() < 1e-6
+    x = rng.uniform(-1, 1, 5)                                  # ragged input, tiled the same way
+    hevm.setInput(0, x)
+    hevm.run()
+    res = hevm.getOutput()[0]
+    # register 1 = x * 1 (scale 2^50) then "+ c1" with the reference's scale overwrite: (x*2^50 + c1*2^30) / 2^30
+    want = x[np.arange(slots) % 5] * 2.0**20 + consts[1][np.arange(slots) % 3]
+    assert np.abs(res - want).max() < 1e-4 * 2.0**20  # input noise at scale 2^30, amplified by the 2^20 overwrite
+    c = hevm.getCtxt(1)
+    assert c.level == 3 and c.scale == 2.0**30
