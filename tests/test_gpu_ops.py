@@ -169,3 +169,27 @@ def test_baseline_config3_mul_relin_n65536_l24():
     L.dc_ct_mul_relin(ctx.h, dd.ptr, st, dx.ptr, st, dy.ptr, st, drel.ptr, ell, None)
     got = o.decode(o.decrypt(Ciphertext(dd.to_host(), 2.0**80)))
     assert np.abs(got - x * y).max() < 1e-6
+
+
+def test_reference_size_keyswitch_ops_l13():
+    """The reference ring and chain (N = 2^15, 14 x 60-bit, SEAL_HEVM.cpp:39-53) at the top level l = 13:
+    rotate hop, mul+relin and rescale bit-exact vs the oracle (210 NTT-equivalents per key switch)."""
+    from dacapo_amd import lowlevel as ll
+
+    logN, K = 15, 14
+    o = Oracle(logN, K)
+    o.keygen(seed=0x4845564D, galois_elts=[3])
+    ctx = ll.Context(logN, K)
+    L, N, ell = ll.lib(), o.N, K - 1
+    a, b = _rand_ct(o, ell, 41), _rand_ct(o, ell, 42)
+    A, B = Ciphertext(a, 2.0**40), Ciphertext(b, 2.0**40)
+    st = ell * N
+    da, db, dd = ll.DeviceBuffer.from_host(a), ll.DeviceBuffer.from_host(b), ll.DeviceBuffer((2, ell, N))
+    dgal, drel = ll.DeviceBuffer.from_host(o.galois[3]), ll.DeviceBuffer.from_host(o.relin)
+    L.dc_ct_rotate_hop(ctx.h, dd.ptr, st, da.ptr, st, 3, dgal.ptr, ell, None)
+    assert (dd.to_host() == o.apply_galois(A, 3).data).all()
+    L.dc_ct_mul_relin(ctx.h, dd.ptr, st, da.ptr, st, db.ptr, st, drel.ptr, ell, None)
+    want = o.mul_relin(A, B)
+    assert (dd.to_host() == want.data).all()
+    L.dc_ct_rescale(ctx.h, dd.ptr, st, dd.ptr, st, ell, None)
+    assert (dd.to_host()[:, : ell - 1] == o.rescale(want).data).all()
