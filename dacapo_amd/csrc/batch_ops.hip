@@ -203,9 +203,11 @@ void b_add_plain(Context &c, const EwItem *d_items, int B, int ell, hipStream_t 
                        c.N, c.d_mods);
 }
 
-// dst = sum of the item's sources: exact modular additions, so the limbs equal those of any sequential order of the
-// reference's ct+ct chain.  grid = (N/512, l, 2B)
-__global__ __launch_bounds__(kBT) void b_sum_kernel(const SumItem *__restrict__ items, const CtView *__restrict__ srcs, size_t N,
+// dst = sum of the item's terms; a term is a ciphertext or a ciphertext times a plaintext (a single-use mulcp result
+// folded in).  Modular addition and multiplication are exact, so the limbs equal those of the reference's sequence
+// multiply_plain ... add ... add in any order.  Products accumulate in 128 bits (reduced every 16), plain terms lazily.
+// grid = (N/512, l, 2B)
+__global__ __launch_bounds__(kBT) void b_sum_kernel(const SumItem *__restrict__ items, const SumSrc *__restrict__ srcs, size_t N,
                                                      const DModulus *__restrict__ mods)
 {
     const int i = blockIdx.y, p = blockIdx.z & 1, b = blockIdx.z >> 1;
@@ -213,22 +215,37 @@ __global__ __launch_bounds__(kBT) void b_sum_kernel(const SumItem *__restrict__ 
     const DModulus M = mods[i];
     const size_t k = ((size_t)blockIdx.x * kBT + threadIdx.x) * 2;
     u64 s0 = 0, s1 = 0; // lazy: every term < 2^60, folded every 8 terms
+    Acc128 a0, a1;
+    a0.clear(), a1.clear();
+    int n_plain = 0, n_prod = 0;
     for (int t = 0; t < it.count; t++) {
-        const u64x2 v = *reinterpret_cast<const u64x2 *>(srcs[it.first + t].limb(p, i, N) + k);
-        s0 += v.x;
-        s1 += v.y;
-        if ((t & 7) == 7) {
-            s0 = fold60(s0, M.delta);
-            s1 = fold60(s1, M.delta);
+        const SumSrc src = srcs[it.first + t];
+        const u64x2 v = *reinterpret_cast<const u64x2 *>(src.v.limb(p, i, N) + k);
+        if (src.plain) {
+            const u64x2 w = *reinterpret_cast<const u64x2 *>(src.plain + (size_t)i * N + k);
+            a0.mac(v.x, w.x);
+            a1.mac(v.y, w.y);
+            if ((++n_prod & 15) == 0) {
+                s0 = fold60(s0, M.delta) + a0.reduce(M);
+                s1 = fold60(s1, M.delta) + a1.reduce(M);
+                a0.clear(), a1.clear();
+            }
+        } else {
+            s0 += v.x;
+            s1 += v.y;
+            if ((++n_plain & 7) == 0) {
+                s0 = fold60(s0, M.delta);
+                s1 = fold60(s1, M.delta);
+            }
         }
     }
     u64x2 r;
-    r.x = canon(s0, M);
-    r.y = canon(s1, M);
+    r.x = addmod(canon(s0, M), a0.reduce(M), M.q);
+    r.y = addmod(canon(s1, M), a1.reduce(M), M.q);
     *reinterpret_cast<u64x2 *>(it.dst.limb(p, i, N) + k) = r;
 }
 
-void b_sum(Context &c, const SumItem *d_items, const CtView *d_srcs, int B, int ell, hipStream_t s)
+void b_sum(Context &c, const SumItem *d_items, const SumSrc *d_srcs, int B, int ell, hipStream_t s)
 {
     hipLaunchKernelGGL(b_sum_kernel, dim3((unsigned)(c.N / (2 * kBT)), (unsigned)ell, (unsigned)(2 * B)), dim3(kBT), 0, s, d_items, d_srcs,
                        c.N, c.d_mods);

@@ -152,6 +152,7 @@ class HEVM {
         int level = 0;
         int dst = -1;
         std::vector<int> srcs;
+        std::vector<int> src_plain; // P_SUM: plain register multiplying srcs[k], or -1
         u32 elt = 0;
         const u64 *key = nullptr;
         int plain = -1, target_level = 0;
@@ -174,7 +175,7 @@ class HEVM {
         RsItem *d_rs = nullptr;
         EwItem *d_ew = nullptr;
         SumItem *d_sum = nullptr;
-        CtView *d_sum_srcs = nullptr;
+        SumSrc *d_sum_srcs = nullptr;
         BatchWs ws;
         std::vector<u64 *> pool; // every pool buffer ever allocated (reused across plans)
         int64_t n_keyswitch = 0, n_ntt = 0;

@@ -30,7 +30,11 @@ struct RsItem {   // dst = rescale_to_next(src)
 struct EwItem {   // dst = a (op) b ; plaintext operand: b.p = limbs, b.poly_stride = 0
     CtView dst, a, b;
 };
-struct SumItem {  // dst = sum of `count` ciphertexts srcs[first ...]
+struct SumSrc {   // one term of a sum: a ciphertext, optionally times a plaintext (a ct*pt product folded into the sum)
+    CtView v;
+    const u64 *plain; // [level][N] or null
+};
+struct SumItem {  // dst = sum of `count` terms srcs[first ...]
     CtView dst;
     int first, count;
 };
@@ -51,7 +55,7 @@ void b_rescale(Context &c, const BatchWs &w, const RsItem *d_items, int B, int e
 // op: Neg / Mul (ct * plain) / Copy ; b_polys as in launch_ew
 void b_ew(Context &c, EwOp op, const EwItem *d_items, int B, int polys, int b_polys, int ell, hipStream_t s);
 void b_add_plain(Context &c, const EwItem *d_items, int B, int ell, hipStream_t s);
-void b_sum(Context &c, const SumItem *d_items, const CtView *d_srcs, int B, int ell, hipStream_t s);
+void b_sum(Context &c, const SumItem *d_items, const SumSrc *d_srcs, int B, int ell, hipStream_t s);
 
 // fused phase launchers (fused_ks.hip)
 void f_irows_strided(const Context &c, const u64 *base, long stride, int prime_base, int period, u64 *out, long out_stride, int count,

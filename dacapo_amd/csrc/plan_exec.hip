@@ -205,6 +205,22 @@ void HEVM::build_plan()
         }
         p.srcs = flat;
     }
+    // ... and fold single-use ct*pt products into the sum that consumes them (one pass over a, pt instead of
+    // write product / read product)
+    for (Pop &p : O) {
+        if (p.kind != P_SUM || p.dead) continue;
+        p.src_plain.assign(p.srcs.size(), -1);
+        for (size_t k = 0; k < p.srcs.size(); k++) {
+            const int sidx = p.srcs[k];
+            const Val &sv = V[(size_t)sidx];
+            const int dp = sv.root == sidx ? sv.def_pop : -1;
+            if (dp >= 0 && O[(size_t)dp].kind == P_MULP && !O[(size_t)dp].dead && sv.uses == 1 && O[(size_t)dp].dst == sidx) {
+                p.srcs[k] = O[(size_t)dp].srcs[0];
+                p.src_plain[k] = O[(size_t)dp].plain;
+                O[(size_t)dp].dead = true;
+            }
+        }
+    }
 
     // ---- 3. dataflow depth ------------------------------------------------------------------------------------------
     int max_wave = 0;
@@ -228,7 +244,7 @@ void HEVM::build_plan()
     std::vector<RsItem> h_rs;
     std::vector<EwItem> h_ew;
     std::vector<SumItem> h_sum;
-    std::vector<CtView> h_srcs;
+    std::vector<SumSrc> h_srcs;
     std::vector<std::vector<int>> step_pops;
     for (int w = 1; w <= max_wave; w++) {
         std::map<std::pair<int, int>, std::vector<int>> buckets; // (kind, level) -> pops
@@ -327,7 +343,10 @@ void HEVM::build_plan()
             for (int pi : step_pops[s])
                 for (int q = 0; q < S; q++) {
                     h_sum.push_back(SumItem{ view(O[(size_t)pi].dst, q), (int)h_srcs.size(), (int)O[(size_t)pi].srcs.size() });
-                    for (int sv : O[(size_t)pi].srcs) h_srcs.push_back(view(sv, q));
+                    for (size_t k = 0; k < O[(size_t)pi].srcs.size(); k++) {
+                        const int pl = O[(size_t)pi].src_plain.empty() ? -1 : O[(size_t)pi].src_plain[k];
+                        h_srcs.push_back(SumSrc{ view(O[(size_t)pi].srcs[k], q), pl >= 0 ? plains.at((size_t)pl).d : nullptr });
+                    }
                 }
             break;
         case P_NEG:
