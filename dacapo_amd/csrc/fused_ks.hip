@@ -145,6 +145,57 @@ __global__ __launch_bounds__(kTileThreads) void f_dr_icols_lift_fcols_kernel(con
         x, Mi, tw + ((size_t)i << logN), logN, blockIdx.x, nold, [=](int g, u64 v) { out[g] = v; }, lds);
 }
 
+// Throughput variants of L2 / L6 for large batches: the inverse COLS phase has already been run once per source limb
+// (launch_ntt_cols_inv, canonical output), so each workgroup only does the base change and ONE forward phase instead of
+// recomputing the inverse phase per target modulus.
+template <int K, int LOGE>
+__global__ __launch_bounds__(kTileThreads) void f_ks_lift_fcols_kernel(const u64 *__restrict__ digits, u64 *__restrict__ ext, int ell,
+                                                                        int sp, const DModulus *__restrict__ mods,
+                                                                        const u64 *__restrict__ tw, int logN)
+{
+    __shared__ __attribute__((aligned(16))) u64 lds[TileGeo<LOGE>::LDS_ELEMS];
+    const int z = blockIdx.y, e = z % ell, dj = z / ell, j = dj % ell;
+    const size_t N = (size_t)1 << logN;
+    const u64 *in = digits + (size_t)dj * N;
+    u64 *out = ext + (size_t)z * N;
+    const int pm = ks_other_prime(j, e, ell, sp);
+    const DModulus Mm = mods[pm];
+    ntt_tile<K, LOGE, true, false, false>(
+        Mm, tw + ((size_t)pm << logN), logN, blockIdx.x,
+        [=](int g) {
+            const u64 v = in[g];
+            return v >= Mm.q ? v - Mm.q : v;
+        },
+        [=](int g, u64 v) { out[g] = v; }, lds);
+}
+
+template <int K, int LOGE>
+__global__ __launch_bounds__(kTileThreads) void f_dr_lift_fcols_kernel(const u64 *__restrict__ last, long last_stride,
+                                                                        u64 *__restrict__ tmp, int cnt, int l, int Kp,
+                                                                        const DModulus *__restrict__ mods,
+                                                                        const u64 *__restrict__ half_mod, const u64 *__restrict__ tw,
+                                                                        int logN)
+{
+    __shared__ __attribute__((aligned(16))) u64 lds[TileGeo<LOGE>::LDS_ELEMS];
+    const int z = blockIdx.y, i = z % cnt, bp = z / cnt;
+    const size_t N = (size_t)1 << logN;
+    const u64 *in = last + (long)bp * last_stride;
+    u64 *out = tmp + (size_t)z * N;
+    const DModulus Mi = mods[i];
+    const u64 ql = mods[l].q, qi = Mi.q, half = ql >> 1;
+    const u64 neg_half = qi - half_mod[(size_t)l * Kp + i];
+    ntt_tile<K, LOGE, true, false, false>(
+        Mi, tw + ((size_t)i << logN), logN, blockIdx.x,
+        [=](int g) {
+            u64 y = in[g] + half;
+            y = y >= ql ? y - ql : y;
+            y = y >= qi ? y - qi : y;
+            y += neg_half;
+            return y >= qi ? y - qi : y;
+        },
+        [=](int g, u64 v) { out[g] = v; }, lds);
+}
+
 // L7 / R3: z = bp*cnt + i.  MODE 0 rotation, 1 relinearisation, 2 rescale
 template <int K, int LOGE, int MODE>
 __global__ __launch_bounds__(kTileThreads) void f_frows_final_kernel(const u64 *__restrict__ tmp, const void *__restrict__ items_,
@@ -260,6 +311,18 @@ void f_dr_icols_lift_fcols(const Context &c, const u64 *last, long last_stride, 
 {
     DC_GEO_SWITCH(c.k1, polys * cnt, hipLaunchKernelGGL((f_dr_icols_lift_fcols_kernel<KK, LE>), grid, dim3(kTileThreads), 0, s, last,
                                                         last_stride, tmp, cnt, l, c.K, c.d_mods, c.d_half_mod, c.d_tw, c.d_itw, c.logN));
+}
+
+void f_ks_lift_fcols(const Context &c, const u64 *digits, u64 *ext, int B, int ell, hipStream_t s)
+{
+    DC_GEO_SWITCH(c.k1, B * ell * ell, hipLaunchKernelGGL((f_ks_lift_fcols_kernel<KK, LE>), grid, dim3(kTileThreads), 0, s, digits, ext, ell,
+                                                          c.K - 1, c.d_mods, c.d_tw, c.logN));
+}
+
+void f_dr_lift_fcols(const Context &c, const u64 *last, long last_stride, u64 *tmp, int polys, int cnt, int l, hipStream_t s)
+{
+    DC_GEO_SWITCH(c.k1, polys * cnt, hipLaunchKernelGGL((f_dr_lift_fcols_kernel<KK, LE>), grid, dim3(kTileThreads), 0, s, last, last_stride,
+                                                        tmp, cnt, l, c.K, c.d_mods, c.d_half_mod, c.d_tw, c.logN));
 }
 
 void f_frows_final(const Context &c, int mode, const u64 *tmp, const void *items, const u64 *acc, int polys, int cnt, int l,

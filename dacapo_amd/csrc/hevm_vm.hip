@@ -701,6 +701,7 @@ void HEVM::encode_internal(Plain &dst, const double *src, size_t len, int level,
 
 void HEVM::preprocess()
 {
+    plan.ready = false; // plaintext registers may move: item tables of an existing plan would dangle
     const std::vector<double> identity(1, 1.0); // tiled to all ones, like the reference's identity vector
     for (const WireOp &op : ops)
         if (op.opcode == 0) {

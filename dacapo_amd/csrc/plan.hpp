@@ -66,6 +66,9 @@ void f_irows_rs_single(const Context &c, CtView src, int l, u64 *out, hipStream_
 void f_irows_decrypt(const Context &c, CtView ct, const u64 *sk, int ell, u64 *out, hipStream_t s);
 void f_ks_icols_lift_fcols(const Context &c, const u64 *digits, u64 *ext, int B, int ell, hipStream_t s);
 void f_dr_icols_lift_fcols(const Context &c, const u64 *last, long last_stride, u64 *tmp, int polys, int cnt, int l, hipStream_t s);
+// large-batch variants: inverse COLS phase run separately (once per source limb), then base change + forward COLS
+void f_ks_lift_fcols(const Context &c, const u64 *digits, u64 *ext, int B, int ell, hipStream_t s);
+void f_dr_lift_fcols(const Context &c, const u64 *last, long last_stride, u64 *tmp, int polys, int cnt, int l, hipStream_t s);
 // mode 0 rotation / 1 relinearisation / 2 rescale items / 3 one rescale by value (+ optional plaintext added to c0)
 void f_frows_final(const Context &c, int mode, const u64 *tmp, const void *items, const u64 *acc, int polys, int cnt, int l,
                    hipStream_t s, RsItem single = RsItem{}, const u64 *plain = nullptr);

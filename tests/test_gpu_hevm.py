@@ -343,3 +343,38 @@ def test_edge_cases_constants_markers_and_noops(tmp_path):
     assert np.abs(res - want).max() < 1e-4 * 2.0**20  # input noise at scale 2^30, amplified by the 2^20 overwrite
     c = hevm.getCtxt(1)
     assert c.level == 3 and c.scale == 2.0**30
+
+
+def test_large_batch_path_bit_exact(tmp_path):
+    """64 independent rotations + ct*pt products of one ciphertext summed into one: one batched key-switch step large
+    enough to take the throughput variants (separate inverse phase, base change + forward launch); limbs == oracle's."""
+    from dacapo_amd import hevm_asm as ha
+    from dacapo_amd import lowlevel as ll
+    from dacapo_amd import runner
+
+    hevm = runner.HEVM(seed=0x4845564D, logN=13, num_primes=5)
+    o = Oracle(13, 5)
+    _import_keys(o, hevm, ll)
+    rng = np.random.default_rng(17)
+    x = rng.uniform(-1, 1, o.slots)
+    b = ha.Builder(slots=o.slots, init_level=4)
+    v = b.modswitch(b.input(x), 1)  # level 3
+    acc = None
+    for k in range(64):
+        r = b.rotate(v, [1, -1, 2, -2, 4, -4, 8, -8][k % 8] * (1 + k // 8 % 2 * 15))  # single- and two-hop offsets
+        t = b.mul_plain(r, rng.uniform(-0.1, 0.1, 8), normalise=False)
+        acc = t if acc is None else b.add(acc, t)
+    sq = b.mul(acc, acc)
+    b.output(sq)
+    cst, hv, info = b.assemble()
+    hevm.load_mem(cst, hv)
+    ovm = _mirror_vm(hevm, ll, o, cst, hv, tmp_path)
+    hevm.setInput(0, x)
+    ovm.ciphers[0] = _get_ct(hevm, ll, 0)
+    hevm.run()
+    ovm.run()
+    got = _get_ct(hevm, ll, ovm.prog.res_dst[0])
+    want = ovm.ciphers[ovm.prog.res_dst[0]]
+    assert got.ell == want.ell and got.scale == want.scale and (got.data == want.data).all()
+    res = hevm.getOutput()[0]
+    assert np.sqrt(np.mean((res - b.expected()[0]) ** 2)) < 1e-4
