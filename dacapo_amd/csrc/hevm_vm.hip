@@ -328,8 +328,13 @@ void HEVM::init_context(int logN, int K, const u64 *primes)
     ctx.reset(new Context(logN, K, kQBits, primes));
     ctx->ensure_scratch();
     encoder.reset(new HostEncoder(logN));
-    if (const char *e = getenv("DACAPO_HEVM_STREAMS")) n_lanes = std::max(1, atoi(e));
+    if (const char *e = getenv("DACAPO_HEVM_LANES")) n_lanes = std::max(1, atoi(e));
     if (const char *e = getenv("DACAPO_HEVM_GRAPH")) use_graph = atoi(e) != 0;
+    if (use_graph && n_lanes > 2) {
+        fprintf(stderr, "[dacapo_amd] DACAPO_HEVM_GRAPH with %d lanes: hipStreamEndCapture on ROCm 7.2 overflows its stack on captures "
+                        "of >= 3 mutually waiting streams (tools/graph_repro.hip); using 2 lanes\n", n_lanes);
+        n_lanes = 2;
+    }
     if (const char *e = getenv("DACAPO_HEVM_PLAN")) use_plan = atoi(e) != 0;
     if (const char *e = getenv("DACAPO_HEVM_PLAN_GRAPH")) plan_graph = atoi(e) != 0;
     if (const char *e = getenv("DACAPO_HEVM_MAX_BATCH")) max_batch = std::max(1, atoi(e));
@@ -678,12 +683,7 @@ void HEVM::encode_internal(Plain &dst, const double *src, size_t len, int level,
         lohi[j] = (u64)(unsigned __int128)coeffs[j];
         lohi[N + j] = (u64)((unsigned __int128)coeffs[j] >> 64);
     }
-    u64 *stage = W().ks_digits; // >= 2N elements whenever K >= 3
-    static u64 *stage_small = nullptr;
-    if (c.max_level() < 2) {
-        if (!stage_small) stage_small = dalloc(2 * N);
-        stage = stage_small;
-    }
+    u64 *stage = W().ks_digits; // always >= 2N elements (Context::new_workspace)
     DC_HIP_CHECK(hipMemcpyAsync(stage, lohi.data(), 2 * N * 8, hipMemcpyHostToDevice, S()));
     if (dst.d && dst.level != level) {
         DC_HIP_CHECK(hipStreamSynchronize(S()));
@@ -1375,8 +1375,10 @@ void *hevm_init_seeded(int logN, int num_primes, uint64_t seed)
     return vm;
 }
 void *hevm_context(void *vm)
-{ // borrowed kernel-level handle (never freed, like the VM itself)
-    return new dc_context{ static_cast<HEVM *>(vm)->ctx.get(), false };
+{ // borrowed kernel-level handle, one per VM (never freed, like the VM itself)
+    auto h = static_cast<HEVM *>(vm);
+    if (!h->ckks_handle) h->ckks_handle = new dc_context{ h->ctx.get(), false };
+    return h->ckks_handle;
 }
 const uint64_t *hevm_relin_key(void *vm) { return static_cast<HEVM *>(vm)->keys.relin; }
 const uint64_t *hevm_galois_key(void *vm, uint32_t elt)

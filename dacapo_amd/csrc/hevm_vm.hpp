@@ -70,6 +70,7 @@ class HEVM {
     std::unique_ptr<HostEncoder> encoder;
     KeySet keys;
     bool debug = false;
+    void *ckks_handle = nullptr; // dc_context* handed out by hevm_context()
     u64 seed = 0, enc_counter = 0;
     u64 *d_epoch = nullptr; // run() counter in HBM, mixed into the encryption randomness (graph replays stay fresh)
 
@@ -88,7 +89,7 @@ class HEVM {
     int cur = 0; // lane the handlers currently issue to
     hipStream_t S() const { return lanes[cur].stream; }
     const Workspace &W() const { return lanes[cur].ws; }
-    // defaults: one lane, eager.  More lanes / graph capture are opt-in (DACAPO_HEVM_STREAMS / DACAPO_HEVM_GRAPH): on
+    // defaults: one lane, eager.  More lanes / graph capture are opt-in (DACAPO_HEVM_LANES / DACAPO_HEVM_GRAPH): on
     // ROCm 7.2 hipStreamEndCapture overflows its stack on captures with >= 3 mutually waiting streams
     // (tools/graph_repro.hip), and eager multi-stream issue is host-bound (DESIGN.md "Scheduling").
     int n_lanes = 1;

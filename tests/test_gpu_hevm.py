@@ -59,8 +59,8 @@ def vm13(request):
     from dacapo_amd import lowlevel as ll
     from dacapo_amd import runner
 
-    env = {"plan": {}, "eager1": {"DACAPO_HEVM_PLAN": "0"}, "eager4": {"DACAPO_HEVM_PLAN": "0", "DACAPO_HEVM_STREAMS": "4"},
-           "graph2": {"DACAPO_HEVM_PLAN": "0", "DACAPO_HEVM_STREAMS": "2", "DACAPO_HEVM_GRAPH": "1"}}[request.param]
+    env = {"plan": {}, "eager1": {"DACAPO_HEVM_PLAN": "0"}, "eager4": {"DACAPO_HEVM_PLAN": "0", "DACAPO_HEVM_LANES": "4"},
+           "graph2": {"DACAPO_HEVM_PLAN": "0", "DACAPO_HEVM_LANES": "2", "DACAPO_HEVM_GRAPH": "1"}}[request.param]
     os.environ.update(env)
     try:
         hevm = runner.HEVM(seed=0x4845564D, logN=13, num_primes=7)
