@@ -1,9 +1,13 @@
 #!/usr/bin/env python3
 """bench.py -- HEVM hot-path benchmark on MI355X (contract: see the task statement / DESIGN.md "Measurement").
 
-step      = one run() of the ResNet-shaped HEVM program (nt = 2^14 slots, N = 2^15, 14 x 60-bit primes: the
-            parameters SEAL_HEVM.cpp:39-53 hard-codes) on ciphertexts already resident in HBM; the timed region is
-            run() only, exactly what examples/tests/ResNet.py:109-111 times.
+step      = one run() of the ResNet-20 HEVM program (nt = 2^14 slots, N = 2^15, 14 x 60-bit primes: the parameters
+            SEAL_HEVM.cpp:39-53 hard-codes) on ciphertexts already resident in HBM; the timed region is run() only,
+            exactly what examples/tests/ResNet.py:109-111 times.  The program is the op stream of the reference's own
+            examples/benchmarks/ResNet.py (traced through python/poly, lowered by hevm_asm's lazy-rescale policy) with
+            the real BN-folded weights, committed as data under tests/golden/resnet20.* ; the decrypted logits are
+            compared with the torch model's (rms_vs_torch, what examples/tests/ResNet.py prints).
+            --program shaped selects the older synthetic program with the same op mix.
 value     = NTT-equivalents per second over the whole job (all ranks): (l+1)(l+2) per key switch, 2l per rescale
             (SURVEY.md 3.4 / BASELINE.md 1) divided by the max-over-ranks wall time of K steps.
 roofline  = the dominant kernel pair (forward negacyclic NTT = COLS phase + ROWS phase launch) on a 4096-limb batch,
@@ -80,7 +84,7 @@ def ntt_micro_leg(ll, iters=200):
     return {"workload": "single forward NTT, N=2^14, 1 limb", "us_per_ntt_back_to_back": round(us, 2)}
 
 
-def cpu_baseline_leg(cst: bytes, hv: bytes, budget_s=15.0):
+def cpu_baseline_leg(cst: bytes, hv: bytes, image, budget_s=15.0):
     """oracle VM (1 thread) on a prefix of the same program; returns NTT-equivalents/s"""
     import tempfile
 
@@ -94,8 +98,7 @@ def cpu_baseline_leg(cst: bytes, hv: bytes, budget_s=15.0):
         (Path(d) / "p.hevm").write_bytes(hv)
         vm = OracleVM(o)
         vm.load(Path(d) / "p.cst", Path(d) / "p.hevm")
-    rng = np.random.default_rng(100)
-    vm.encrypt(0, rng.uniform(-0.5, 0.5, o.slots))
+    vm.encrypt(0, image)
     setup_s = time.time() - t0
     ntts, n_ops, spent, ks = 0, 0, 0.0, 0
     for op in vm.prog.ops:
@@ -122,7 +125,7 @@ def cpu_baseline_leg(cst: bytes, hv: bytes, budget_s=15.0):
         if spent > budget_s:
             break
     return {"value": round(ntts / spent, 1), "unit": "NTT/s", "cores": 1, "kind": "port",
-            "sample": f"first {n_ops} run-time ops ({ks} key switches) of the same ResNet-shaped program, "
+            "sample": f"first {n_ops} run-time ops ({ks} key switches) of the same HEVM program, "
                       f"{spent:.1f} s of single-thread work (+{setup_s:.0f} s untimed keygen/encrypt)",
             "seconds": round(spent, 2), "ntt_equivalents": ntts,
             "reference_published": "README.md:176-188: 53.73 s for the DaCapo-compiled ResNet-20 on SEAL CPU (hardware unstated)"}
@@ -134,7 +137,9 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--layers", type=int, default=20, help="ResNet-shaped program depth (20 = the traced op mix)")
+    ap.add_argument("--program", default="resnet20", choices=["resnet20", "shaped"],
+                    help="resnet20 = the reference model's traced op stream + real weights (tests/golden); shaped = synthetic op mix")
+    ap.add_argument("--layers", type=int, default=20, help="--program shaped: depth (20 = the traced op mix)")
     ap.add_argument("--streams", type=int, default=1, help="independent ciphertext streams per GPU (throughput mode; 1 = the reference's one image per run)")
     args = ap.parse_args()
 
@@ -159,13 +164,23 @@ def main():
     hevm = runner.HEVM(seed=0x4845564D + rank, logN=15, num_primes=14)
     if args.streams > 1:
         hevm.set_streams(args.streams)
-    prog = ha.resnet_shaped(seed=100, layers=args.layers)  # independent stream per rank: same program, own keys/inputs
-    cst, hv, info = prog.assemble()
+    # independent stream per rank: same program, own keys (and own encryption randomness)
+    fx = None
+    if args.program == "resnet20":
+        fx = ha.read_fixture(ROOT / "tests" / "golden" / "resnet20")
+        cst, hv, info = fx["cst"], fx["hevm"], fx["meta"]["info"]
+        image = fx["packed"]
+        workload = ("ResNet-20 (SiLU) HEVM program traced from the reference's examples/benchmarks/ResNet.py with its "
+                    "resnet20.silu.model weights")
+    else:
+        prog = ha.resnet_shaped(seed=100, layers=args.layers)
+        cst, hv, info = prog.assemble()
+        image = np.random.default_rng(100 + rank).uniform(-0.5, 0.5, hevm.slots)
+        workload = "ResNet-shaped HEVM program (SURVEY App. C op mix)"
     hevm.load_mem(cst, hv)
-    rng = np.random.default_rng(100 + rank)
     for sidx in range(args.streams):
         hevm.select_stream(sidx)
-        hevm.setInput(0, rng.uniform(-0.5, 0.5, hevm.slots))
+        hevm.setInput(0, image)
     t_setup = time.time() - t_setup
 
     for _ in range(args.warmup):
@@ -177,6 +192,13 @@ def main():
     barrier_sync()
     elapsed = time.perf_counter() - t0
     stats = hevm.stats()
+    rms = None
+    if fx is not None:  # decrypted logits vs the torch model (examples/tests/ResNet.py:76-81: first 10 slots * 32)
+        hevm.select_stream(0)
+        out = hevm.getOutput()[0]
+        rms = {"rms_vs_torch": float(np.sqrt(np.mean((out[:10] * 32 - fx["torch_result"]) ** 2))),
+               "rms_vs_plaintext_evaluation": float(np.sqrt(np.mean((out - fx["expected"]) ** 2))),
+               "reference_published_rms": 9.5e-4}
 
     ntts_per_step = ntt_equivalents(stats)
     elapsed, total_ntts = grp.job_totals(elapsed, float(ntts_per_step) * args.steps)  # max time, summed work over ranks
@@ -192,21 +214,23 @@ def main():
     micro = ntt_micro_leg(ll)
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline_leg(cst, hv)
+        cpu = cpu_baseline_leg(cst, hv, image)
 
     line = {
-        "metric": "NTT/s (NTT-equivalents over one run() of the ResNet-shaped HEVM program, nt=2^14)",
+        "metric": "NTT/s (NTT-equivalents over one run() of the ResNet HEVM program, nt=2^14)",
         "value": round(value, 1), "unit": "NTT/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "u64", "data": "synthetic",
-        "config": {"workload": "ResNet-shaped HEVM program (SURVEY App. C op mix), nt=2^14 slots, N=2^15, 14 x 60-bit primes "
-                               "(SEAL_HEVM.cpp:39-53); one independent ciphertext stream per GPU",
+        "dtype": "u64",
+        "data": "synthetic" if fx is None else "synthetic image; weights = the reference's resnet20.silu.model",
+        "config": {"workload": workload + ", nt=2^14 slots, N=2^15, 14 x 60-bit primes (SEAL_HEVM.cpp:39-53); one "
+                               "independent ciphertext stream per GPU",
                    "ops": info["op_mix"], "key_switches_per_step": stats["keyswitches"], "ntt_equivalents_per_step": ntts_per_step,
                    "streams_per_gpu": args.streams,
                    "parallelism": f"replicas x{world} (no collective in the op path)"},
         "hevm_wall_s": round(ms_per_step / 1e3, 4),
         "hevm_bootstrap_s_per_step": round(stats["bootstrap_s"], 4),
         "setup_s_untimed": round(t_setup, 1),
+        "decrypted_error": rms,
         "roofline": roof,
         "ntt_micro": micro,
         "cpu_baseline": cpu,

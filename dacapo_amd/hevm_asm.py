@@ -59,6 +59,70 @@ def pack_hevm(arg_scale, arg_level, res_scale, res_level, res_dst, num_ctxt, num
     return b"".join(out)
 
 
+def unpack_hevm(raw: bytes) -> dict:
+    """inverse of pack_hevm (HEVMHeader.h:10-35)"""
+    magic, hsize, na, nr = struct.unpack_from("<IIQQ", raw, 0)
+    assert magic == MAGIC and hsize == 24
+    body_len, nops, nct, npt, init_level = struct.unpack_from("<5Q", raw, 24)
+    off, arrs = 64, []
+    for n in (na, na, nr, nr, nr):
+        arrs.append(list(struct.unpack_from(f"<{n}Q", raw, off)))
+        off += 8 * n
+    ops = np.frombuffer(raw, dtype="<u2", count=4 * nops, offset=off).reshape(nops, 4).copy()
+    return {"arg_scale": arrs[0], "arg_level": arrs[1], "res_scale": arrs[2], "res_level": arrs[3], "res_dst": arrs[4],
+            "num_ctxt": nct, "num_ptxt": npt, "init_level": init_level, "ops": ops}
+
+
+def truncate_hevm(raw: bytes, num_ops: int):
+    """The first `num_ops` instructions of a program as a program of its own whose single result is the register
+    the last kept ciphertext instruction wrote.  Returns (hevm_bytes, level, scale_bits) of that result, tracked
+    through the instruction stream the way SEAL_HEVM.cpp:268-334 updates them."""
+    h = unpack_hevm(raw)
+    ops = h["ops"][:num_ops]
+    lvl = {i: int(v) for i, v in enumerate(h["arg_level"])}
+    scl = {i: int(v) for i, v in enumerate(h["arg_scale"])}
+    plvl, pscl, last = {}, {}, None
+    for opc, dst, lhs, rhs in ops.tolist():
+        if opc == OP_ENCODE:
+            plvl[dst], pscl[dst] = rhs >> 10, rhs & 0x3FF
+            continue
+        if opc > OP_BOOTSTRAP:
+            continue
+        l, sc = lvl[lhs], scl[lhs]
+        if opc == OP_RESCALE:
+            l, sc = l - 1, sc - 60
+        elif opc == OP_MODSWITCH:
+            l -= rhs
+        elif opc == OP_ADDCC:
+            sc = scl[rhs]
+        elif opc == OP_ADDCP:
+            sc = pscl[rhs]
+        elif opc == OP_MULCC:
+            sc += scl[rhs]
+        elif opc == OP_MULCP:
+            sc += pscl[rhs]
+        elif opc == OP_BOOTSTRAP:
+            l = rhs
+        lvl[dst], scl[dst], last = l, sc, dst
+    assert last is not None
+    out = pack_hevm(h["arg_scale"], h["arg_level"], [scl[last]], [lvl[last]], [last], h["num_ctxt"], h["num_ptxt"],
+                    h["init_level"], ops)
+    return out, lvl[last], scl[last]
+
+
+def read_fixture(prefix) -> dict:
+    """A traced program committed as data (tests/golden/<name>.{hevm.gz,cst.xz,input.npz,json}; written by
+    tools/trace_reference_model.py): returns the decompressed `.hevm` / `.cst` bytes, the packed input and metadata."""
+    import gzip
+    import json
+    import lzma
+    prefix = str(prefix)
+    z = np.load(prefix + ".input.npz")
+    return {"hevm": gzip.open(prefix + ".hevm.gz").read(), "cst": lzma.open(prefix + ".cst.xz").read(),
+            "meta": json.loads(Path(prefix + ".json").read_text()), "packed": z["packed"], "torch_result": z["torch_result"],
+            "expected": z["expected"]}
+
+
 @dataclass
 class Value:
     """An SSA ciphertext value of the traced program."""
@@ -80,9 +144,20 @@ class _Op:
 
 
 class Builder:
-    def __init__(self, slots=1 << 14, waterline=40, init_level=13, rescale_bits=60, min_level=1, shadow=True):
+    def __init__(self, slots=1 << 14, waterline=40, init_level=13, rescale_bits=60, min_level=1, shadow=True,
+                 policy="eager", boot_level=None, headroom=16, rotate_reserve=0):
+        """policy "eager": rescale a product as soon as its scale allows (EVA's waterline rule; the caller places
+        bootstraps).  policy "lazy": products keep their scale, sums of products are rescaled ONCE when the sum is next
+        multiplied or rotated (what the reference's scale-management passes achieve by moving rescales below
+        additions, EarthOps.td:350-564), and a value that runs out of primes is bootstrapped to `boot_level` primes.
+        `headroom` = bits kept free above the scale for the magnitude of the slot values."""
         self.slots, self.waterline, self.init_level, self.rescale_bits = slots, waterline, init_level, rescale_bits
         self.min_level, self.shadow = min_level, shadow
+        assert policy in ("eager", "lazy")
+        self.lazy, self.headroom = policy == "lazy", headroom
+        self.rotate_reserve = rotate_reserve  # lazy: scale bits a rotation's result must still be able to absorb
+        self.boot_level = init_level if boot_level is None else boot_level
+        self._memo: dict = {}  # lazy policy: (kind, value id, arg) -> value, so a shared operand is rescaled/bootstrapped once
         self.values: list[Value] = []
         self.ops: list[_Op] = []
         self.constants: list[np.ndarray] = []
@@ -144,6 +219,8 @@ class Builder:
     # ---- ciphertext ops ------------------------------------------------------------------------------------------
     def rotate(self, x: Value, offset: int) -> Value:
         assert -(1 << 15) <= offset < (1 << 15)
+        if self.lazy:
+            x = self._prepare(x, self.rotate_reserve)  # a key switch is cheapest at the lowest level the value can have
         out = self._new(x.level, x.scale_bits, np.roll(x.plain, -offset) if self.shadow else None)
         self._emit(OP_ROTATE, out, x, offset & 0xFFFF)
         return out
@@ -163,8 +240,12 @@ class Builder:
         if down <= 0:
             return x
         assert x.level - down >= 1
+        if self.lazy and ("modswitch", x.id, down) in self._memo:
+            return self._memo[("modswitch", x.id, down)]
         out = self._new(x.level - down, x.scale_bits, x.plain)
         self._emit(OP_MODSWITCH, out, x, down)
+        if self.lazy:
+            self._memo[("modswitch", x.id, down)] = out
         return out
 
     def upscale(self, x: Value, bits: int) -> Value:
@@ -187,8 +268,63 @@ class Builder:
             x = self.rescale(x)
         return x
 
+    # ---- lazy policy ---------------------------------------------------------------------------------------------
+    def _fits(self, level: int, scale_bits: int) -> bool:
+        return scale_bits + self.headroom <= self.rescale_bits * level
+
+    def _memoised(self, kind, x: Value, arg, make) -> Value:
+        key = (kind, x.id, arg)
+        if key not in self._memo:
+            self._memo[key] = make()
+        return self._memo[key]
+
+    def _boot(self, x: Value) -> Value:
+        return self._memoised("boot", x, self.boot_level, lambda: self.bootstrap(x, self.boot_level))
+
+    def _rescale_or_boot(self, x: Value) -> Value:
+        if x.level <= self.min_level:
+            x = self._boot(x)
+        return self._memoised("rescale", x, 0, lambda: self.rescale(x))
+
+    def _prepare(self, x: Value, extra_bits: int) -> Value:
+        """bring x to the waterline exactly (whole primes by rescaling; a remainder by the EVA trick of upscaling to
+        waterline + one prime first) and make sure an op that adds `extra_bits` of scale still fits its primes"""
+        while x.scale_bits - self.rescale_bits >= self.waterline:
+            x = self._rescale_or_boot(x)
+        if x.scale_bits > self.waterline:
+            up = self.waterline + self.rescale_bits - x.scale_bits
+            if x.level <= self.min_level or not self._fits(x.level, x.scale_bits + up):
+                x = self._boot(x)
+            y = x
+            x = self._memoised("uprescale", y, up, lambda: self.rescale(self.upscale(y, up)))
+        if not self._fits(x.level, x.scale_bits + extra_bits):
+            x = self._boot(x)
+            assert self._fits(x.level, x.scale_bits + extra_bits), "boot_level too small for this product"
+        return x
+
+    def finish(self, x: Value) -> Value:
+        """a program result: rescaled to the waterline like any other consumer would see it"""
+        if not self.lazy:
+            return x
+        while x.scale_bits - self.rescale_bits >= self.waterline and x.level > 1:
+            x = self.rescale(x)
+        return x
+
     def _match(self, x: Value, y: Value, scales: bool):
+        if self.lazy and scales and x.scale_bits != y.scale_bits:
+            # bring the larger scale down by whole primes first; only the remainder is paid for with an upscale
+            if x.scale_bits < y.scale_bits:
+                y, x = self._match(y, x, True)
+                return x, y
+            while x.scale_bits - self.rescale_bits >= y.scale_bits:
+                x = self._rescale_or_boot(x)
         lv = min(x.level, y.level)
+        if scales and x.scale_bits != y.scale_bits:
+            s = max(x.scale_bits, y.scale_bits)
+            if self.lazy and not self._fits(lv, s):
+                x = x if self._fits(x.level, s) else self._boot(x)
+                y = y if self._fits(y.level, s) else self._boot(y)
+                lv = min(x.level, y.level)
         x, y = self.modswitch(x, x.level - lv), self.modswitch(y, y.level - lv)
         if scales and x.scale_bits != y.scale_bits:
             s = max(x.scale_bits, y.scale_bits)
@@ -211,21 +347,32 @@ class Builder:
         return out
 
     def mul_plain(self, x: Value, vec, scale_bits=None, normalise=True) -> Value:
-        sb = self.waterline if scale_bits is None else scale_bits
+        # lazy policy: ct at the waterline times a plaintext at one prime's worth of scale -> one rescale restores it
+        sb = (self.rescale_bits if self.lazy else self.waterline) if scale_bits is None else scale_bits
+        if self.lazy:
+            x = self._prepare(x, sb)
         reg = self._encode(self._const(vec), x.level, sb)
         out = self._new(x.level, x.scale_bits + sb, x.plain * self._tile(vec) if self.shadow else None)
         self._emit(OP_MULCP, out, x, reg)
-        return self._normalise(out) if normalise else out
+        return self._normalise(out) if (normalise and not self.lazy) else out
 
     def normalise(self, x: Value) -> Value:
         """rescale while the scale stays at or above the waterline (what WaterlineRescaling does after a sum)"""
         return self._normalise(x)
 
     def mul(self, x: Value, y: Value) -> Value:
+        if self.lazy:
+            same = x is y
+            x = self._prepare(x, 0)
+            y = x if same else self._prepare(y, 0)
+            need = x.scale_bits + y.scale_bits  # only an operand that is itself too low is bootstrapped
+            if not self._fits(x.level, need):
+                x = self._boot(x)
+            y = x if same else (y if self._fits(y.level, need) else self._boot(y))
         x, y = self._match(x, y, False)
         out = self._new(x.level, x.scale_bits + y.scale_bits, x.plain * y.plain if self.shadow else None)
         self._emit(OP_MULCC, out, x, y.id, True)
-        return self._normalise(out)
+        return out if self.lazy else self._normalise(out)
 
     # ---- register allocation + serialisation -----------------------------------------------------------------------
     def assemble(self, preserve_args=True):

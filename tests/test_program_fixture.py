@@ -1,0 +1,106 @@
+"""CPU: the traced ResNet-20 fixture (tests/golden/resnet20.*) and the lazy scale-management policy that lowered it."""
+import hashlib
+from pathlib import Path
+
+import numpy as np
+
+from dacapo_amd import hevm_asm as ha
+from oracle.oracle import OracleVM, read_cst, read_hevm
+
+import pytest
+
+GOLDEN = Path(__file__).resolve().parent / "golden" / "resnet20"
+
+
+@pytest.fixture(scope="module")
+def fx():
+    return ha.read_fixture(GOLDEN)
+
+
+def test_resnet20_fixture_is_consistent(fx, tmp_path):
+    meta = fx["meta"]
+    assert hashlib.sha256(fx["hevm"]).hexdigest() == meta["hevm_sha256"]
+    assert hashlib.sha256(fx["cst"]).hexdigest() == meta["cst_sha256"]
+    (tmp_path / "p.hevm").write_bytes(fx["hevm"])
+    prog = read_hevm(tmp_path / "p.hevm")  # the oracle's reader accepts what the assembler wrote
+    h = ha.unpack_hevm(fx["hevm"])
+    assert (prog.ops == h["ops"]).all() and prog.num_ctxt == h["num_ctxt"] and prog.num_ptxt == h["num_ptxt"]
+    mix = {ha.OP_NAMES[k]: int((h["ops"][:, 0] == k).sum()) for k in range(11)}
+    assert mix == meta["info"]["op_mix"]
+    # the reference's traced op mix at nt = 2^14: 2 510 rotates of which 42 by a multiple of the slot
+    # count (dropped by the tracer), 361 ct*ct
+    assert mix["rotate"] == 2510 - 42 and mix["mulcc"] == 361
+    assert h["arg_level"] == [meta["init_level"]] and h["arg_scale"] == [40] and h["res_scale"] == [40]
+    # every cipher operand is written before it is read, registers stay inside the declared file
+    written = {0}
+    for opc, dst, lhs, rhs in h["ops"].tolist():
+        if opc == ha.OP_ENCODE:
+            assert dst < h["num_ptxt"] and (lhs == 0xFFFF or lhs < meta["num_constants"]) and 0 < (rhs >> 10) <= meta["boot_level"]
+            continue
+        assert lhs in written and dst < h["num_ctxt"]
+        if opc in (ha.OP_ADDCC, ha.OP_MULCC):
+            assert rhs in written
+        written.add(dst)
+    assert h["res_dst"][0] in written
+    assert len(fx["packed"]) == meta["slots"] and len(fx["torch_result"]) == 10
+    # plaintext evaluation of the traced program reproduces the torch model up to the polynomial activation's error
+    rms = np.sqrt(np.mean((fx["expected"][:10] * 32 - fx["torch_result"]) ** 2))
+    assert abs(rms - meta["plain_vs_torch_rms"]) < 1e-12 and rms < 1e-3
+
+
+def test_constant_file_of_fixture_parses(fx, tmp_path):
+    (tmp_path / "p.cst").write_bytes(fx["cst"])
+    consts = read_cst(tmp_path / "p.cst")
+    assert len(consts) == fx["meta"]["num_constants"]
+    # Func.py:56 hard-codes 2^16-long vectors for the classifier; the VM uses src[i % len] for i < 16384 (SEAL_HEVM.cpp:256-267)
+    assert {len(c) for c in consts} <= {1, 16384, 65536}
+
+
+def test_truncate_tracks_level_and_scale():
+    b = ha.Builder(slots=64, init_level=3, policy="lazy", boot_level=3)
+    x = b.input(np.linspace(-1, 1, 64))
+    y = b.mul_plain(b.rotate(x, 3), [0.5])
+    z = b.mul(b.add(y, y), x)
+    b.output(b.finish(z))
+    _, hv, _ = b.assemble()
+    ops = ha.unpack_hevm(hv)["ops"]
+    k = int(np.nonzero(ops[:, 0] == ha.OP_MULCP)[0][0]) + 1
+    cut, lvl, sc = ha.truncate_hevm(hv, k)
+    h = ha.unpack_hevm(cut)
+    assert len(h["ops"]) == k and (lvl, sc) == (3, 100) and h["res_level"] == [3] and h["res_scale"] == [100]
+    assert h["res_dst"] == [int(ops[k - 1, 1])]
+
+
+def test_lazy_policy_program_runs_on_oracle(oracle_mid, tmp_path):
+    """depth-6 polynomial with rotations on 5 primes: the policy has to rescale sums once, upscale ct*ct products and
+    re-encrypt when the chain runs out of primes; the oracle VM's decryption must match the plaintext shadow."""
+    o = oracle_mid
+    rng = np.random.default_rng(5)
+    v = rng.uniform(-1, 1, o.slots)
+    b = ha.Builder(slots=o.slots, init_level=3, policy="lazy", boot_level=3)
+    x = b.input(v)
+    acc = None
+    for k in (1, 5, -7):
+        t = b.mul_plain(b.rotate(x, k), rng.uniform(-0.5, 0.5, o.slots))
+        acc = t if acc is None else b.add(acc, t)
+    t2 = b.add_plain(b.mul(acc, acc), [0.25])          # scale 80 product, plaintext added at that scale
+    t4 = b.mul(t2, t2)
+    t5 = b.add(b.mul(t4, acc), b.mul_plain(x, [0.125]))  # scales 80 vs 100: the smaller is upscaled
+    t6 = b.sub(b.mul(t5, t2), acc)
+    b.output(b.finish(t6))
+    cst, hv, info = b.assemble()
+    assert info["op_mix"]["bootstrap"] >= 1 and info["op_mix"]["rescale"] >= 4
+    # sums are rescaled once: three products, one rescale before the first ct*ct
+    ops = ha.unpack_hevm(hv)["ops"]
+    first_mul = int(np.nonzero(ops[:, 0] == ha.OP_MULCC)[0][0])
+    assert (ops[:first_mul, 0] == ha.OP_RESCALE).sum() == 1
+    (tmp_path / "p.cst").write_bytes(cst)
+    (tmp_path / "p.hevm").write_bytes(hv)
+    vm = OracleVM(o)
+    vm.load(tmp_path / "p.cst", tmp_path / "p.hevm")
+    vm.preprocess()
+    vm.encrypt(0, v)
+    vm.run()
+    got = vm.decrypt_result(0)
+    want = b.expected()[0]
+    assert np.abs(got - want).max() < 1e-4
