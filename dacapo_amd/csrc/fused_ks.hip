@@ -70,6 +70,22 @@ struct SrcDecrypt { // limb z of c0 + c1*s  (Decryptor::decrypt fused into the f
     }
 };
 
+struct SrcDecryptItems { // limb z = b*ell + i of item b's c0 + c1*s
+    const BootItem *items;
+    const u64 *sk;
+    const DModulus *mods;
+    int ell;
+    __device__ int prime(int z) const { return z % ell; }
+    __device__ u64 load(int z, int g, int logN) const
+    {
+        const size_t N = (size_t)1 << logN;
+        const int i = z % ell;
+        const CtView ct = items[z / ell].src;
+        const DModulus M = mods[i];
+        return addmod(ct.limb(0, i, N)[g], mulmod(ct.limb(1, i, N)[g], sk[(size_t)i * N + g], M), M.q);
+    }
+};
+
 // L1 / L5 / R1: inverse ROWS phase, out[z] (lazy values) = phase(src limb z)
 template <int K, int LOGE, class Src>
 __global__ __launch_bounds__(kTileThreads) void f_irows_kernel(Src src, u64 *__restrict__ out, long out_stride,
@@ -251,6 +267,29 @@ __global__ __launch_bounds__(kTileThreads) void f_frows_final_kernel(const u64 *
     }
 }
 
+// opcode 10, last launch: z = b*t + i.  dst.c0 = zenc.c0 + NTT(re-encoded plaintext), dst.c1 = zenc.c1
+template <int K, int LOGE>
+__global__ __launch_bounds__(kTileThreads) void f_frows_boot_final_kernel(const u64 *__restrict__ ptx, const BootItem *__restrict__ items,
+                                                                           int t, const DModulus *__restrict__ mods,
+                                                                           const u64 *__restrict__ tw, int logN)
+{
+    __shared__ __attribute__((aligned(16))) u64 lds[TileGeo<LOGE>::LDS_ELEMS];
+    const int z = blockIdx.y, i = z % t;
+    const size_t N = (size_t)1 << logN;
+    const BootItem it = items[z / t];
+    const DModulus M = mods[i];
+    const u64 *in = ptx + (size_t)z * N;
+    const u64 *z0 = it.zenc + (size_t)i * N, *z1 = it.zenc + ((size_t)t + i) * N;
+    u64 *o0 = it.dst.limb(0, i, N), *o1 = it.dst.limb(1, i, N);
+    ntt_tile<K, LOGE, false, false, true>(
+        M, tw + ((size_t)i << logN), logN, blockIdx.x, [=](int g) { return in[g]; },
+        [=](int g, u64 v) {
+            o0[g] = addmod(v, z0[g], M.q);
+            o1[g] = z1[g];
+        },
+        lds);
+}
+
 // ---- launchers (K and geometry dispatch) ---------------------------------------------------------------------------------
 #define DC_K_SWITCH(Kval, ...)                                                                            \
     switch (Kval) {                                                                                       \
@@ -299,6 +338,16 @@ void f_irows_rs_single(const Context &c, CtView src, int l, u64 *out, hipStream_
 void f_irows_decrypt(const Context &c, CtView ct, const u64 *sk, int ell, u64 *out, hipStream_t s)
 {
     launch_irows(c, SrcDecrypt{ ct, sk, c.d_mods }, out, (long)c.N, ell, s);
+}
+
+void f_irows_decrypt_items(const Context &c, const BootItem *items, const u64 *sk, int ell, u64 *out, int B, hipStream_t s)
+{
+    launch_irows(c, SrcDecryptItems{ items, sk, c.d_mods, ell }, out, (long)c.N, B * ell, s);
+}
+void f_frows_boot_final(const Context &c, const u64 *ptx, const BootItem *items, int B, int t, hipStream_t s)
+{
+    DC_GEO_SWITCH(c.k2, B * t, hipLaunchKernelGGL((f_frows_boot_final_kernel<KK, LE>), grid, dim3(kTileThreads), 0, s, ptx, items, t,
+                                                  c.d_mods, c.d_tw, c.logN));
 }
 
 void f_ks_icols_lift_fcols(const Context &c, const u64 *digits, u64 *ext, int B, int ell, hipStream_t s)

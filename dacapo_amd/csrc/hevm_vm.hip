@@ -232,6 +232,89 @@ __global__ __launch_bounds__(kVmThreads) void reencode_kernel(u64 *__restrict__ 
     }
 }
 
+// ---- batched opcode 10 (plan mode) -------------------------------------------------------------------------------
+// Enc(pt) = Enc(0) + (pt, 0): the randomness-dependent half of every opcode 10 of the program does not depend on any
+// ciphertext, so the plan makes all the zero-encryptions in a few large launches at the start of run() and the
+// data-dependent half (decrypt -> re-encode -> NTT -> add) is 5 launches per batch of same-wave items.
+
+// randomness of items first..first+B-1: out[b][z][i] (z = 0: ternary u; 1, 2: centred-binomial e0, e1).  grid = (N/256, cnt, 3B)
+__global__ __launch_bounds__(kVmThreads) void sample_enc_batch_kernel(u64 *__restrict__ out, size_t N, int cnt, u64 seed, u64 stream0,
+                                                                       const DModulus *__restrict__ mods,
+                                                                       const u64 *__restrict__ epoch)
+{
+    const int i = blockIdx.y, b = blockIdx.z / 3, z = blockIdx.z % 3;
+    const u64 q = mods[i].q;
+    const size_t k = (size_t)blockIdx.x * kVmThreads + threadIdx.x;
+    const u64 r = prng(seed, stream0 + 4 * (u64)b + (u64)z + (*epoch << 32), k, 0);
+    const int v = z ? (__popcll(r & 0x1FFFFF) - __popcll((r >> 21) & 0x1FFFFF)) : ((int)(r % 3) - 1);
+    out[(((size_t)b * 3 + z) * cnt + i) * N + k] = v < 0 ? q - (u64)(-v) : (u64)v;
+}
+
+// tmp[b][p][i] = pk[p][i]*u[b][i] + e[b][p][i]  (ue as written by sample_enc_batch_kernel, NTT form).  grid = (N/512, cnt, 2B)
+__global__ __launch_bounds__(kVmThreads) void pk_encrypt_batch_kernel(u64 *__restrict__ tmp, const u64 *__restrict__ pk, long pk_ps,
+                                                                       const u64 *__restrict__ ue, int cnt, size_t N,
+                                                                       const DModulus *__restrict__ mods)
+{
+    const int i = blockIdx.y, b = blockIdx.z >> 1, p = blockIdx.z & 1;
+    const DModulus M = mods[i];
+    const size_t k = ((size_t)blockIdx.x * kVmThreads + threadIdx.x) * 2;
+    const u64 *u = ue + (((size_t)b * 3) * cnt + i) * N + k, *e = ue + (((size_t)b * 3 + 1 + p) * cnt + i) * N + k;
+    const u64x2 ev = *reinterpret_cast<const u64x2 *>(e), a = *reinterpret_cast<const u64x2 *>(pk + p * pk_ps + (size_t)i * N + k),
+                uu = *reinterpret_cast<const u64x2 *>(u);
+    u64x2 r;
+#pragma unroll
+    for (int t = 0; t < 2; t++) r[t] = addmod(mulmod(a[t], uu[t], M), ev[t], M.q);
+    *reinterpret_cast<u64x2 *>(tmp + (((size_t)b * 2 + p) * cnt + i) * N + k) = r;
+}
+
+__device__ inline void store_residues(u64 *__restrict__ out, size_t idx, size_t N, int t, double x, bool flip,
+                                      const DModulus *__restrict__ mods)
+{ // x integral, |x| < 2^120: writes (flip ? -x : x) mod q_k for k < t
+    const bool neg = (x < 0.0) != flip;
+    const double a = fabs(x);
+    u64 l, h;
+    if (a < 0x1p63) {
+        l = (u64)a;
+        h = 0;
+    } else {
+        int e;
+        const double fr = frexp(a, &e);
+        const u64 mant = (u64)ldexp(fr, 53);
+        const int sh = e - 53;
+        l = sh < 64 ? mant << sh : 0;
+        h = sh < 64 ? mant >> (64 - sh) : mant << (sh - 64);
+    }
+    for (int k = 0; k < t; k++) {
+        const DModulus M = mods[k];
+        const u64 r = canon(reduce128_lazy(h, l, M.delta), M);
+        out[(size_t)k * N + idx] = (neg && r) ? M.q - r : r;
+    }
+}
+
+// reencode_kernel + lift_i128_kernel for a batch: coef [B][ell][N] (coefficient domain, canonical) -> ptx [B][t][N]
+// (coefficient domain residues of the re-encoded plaintext).  grid = (ceil((N/2+1)/256), B)
+__global__ __launch_bounds__(kVmThreads) void reencode_lift_batch_kernel(u64 *__restrict__ ptx, const u64 *__restrict__ coef,
+                                                                          const BootItem *__restrict__ items, int ell, int t, size_t N,
+                                                                          const DModulus *__restrict__ mods, const CrtDev c)
+{
+    const size_t i = (size_t)blockIdx.x * kVmThreads + threadIdx.x;
+    if (i > N / 2) return;
+    const int b = blockIdx.y;
+    const double ratio = items[b].ratio;
+    const u64 *cf = coef + (size_t)b * ell * N;
+    u64 *out = ptx + (size_t)b * t * N;
+    if (i == 0) {
+        store_residues(out, 0, N, t, round(crt_centered(cf, 0, ell, N, mods, c) * ratio), false, mods);
+    } else if (i == N / 2) {
+        store_residues(out, i, N, t, 0.0, false, mods);
+    } else {
+        const double a = crt_centered(cf, i, ell, N, mods, c), bb = crt_centered(cf, N - i, ell, N, mods, c);
+        const double r = round((a - bb) * 0.5 * ratio);
+        store_residues(out, i, N, t, r, false, mods);
+        store_residues(out, N - i, N, t, r, true, mods);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // CKKSEncoder on the host  [SEAL-upstream ckks.cpp, dwthandler.h]
 // ---------------------------------------------------------------------------------------------------------
@@ -1088,6 +1171,47 @@ void HEVM::boot_item(CtView src, int ell, double src_scale, hevm_ctxt &dst, int 
                        ptx.d, lohi, lohi + N, N, c.d_mods);
     launch_ntt(c, false, ptx.d, (long)N, target_level, nullptr, 0, 0, S());
     encrypt_plain(dst, ptx);
+}
+
+// batched opcode 10, randomness half: zero-encryptions of items [first, first+B) of the plan's boot table (all with target
+// level t) into their zenc slots.  7 launches whatever B is.
+void HEVM::plan_zero_encrypt(int first, int B, int t, hipStream_t s)
+{
+    Context &c = *ctx;
+    const size_t N = c.N;
+    const int cnt = t + 1;
+    if (!keys.pk) {
+        fprintf(stderr, "[dacapo_amd] bootstrap: this VM has no public key\n");
+        abort();
+    }
+    Plan &P = plan;
+    hipLaunchKernelGGL(sample_enc_batch_kernel, dim3((unsigned)(N / kVmThreads), (unsigned)cnt, (unsigned)(3 * B)), dim3(kVmThreads), 0, s,
+                       P.boot_ue, N, cnt, seed, (u64)0x40000000 + 4 * (u64)first, c.d_mods, d_epoch);
+    launch_ntt(c, false, P.boot_ue, (long)N, 3 * cnt * B, nullptr, 0, cnt, s);
+    hipLaunchKernelGGL(pk_encrypt_batch_kernel, dim3((unsigned)(N / (2 * kVmThreads)), (unsigned)cnt, (unsigned)(2 * B)), dim3(kVmThreads),
+                       0, s, P.boot_tmp, keys.pk, (long)c.K * (long)N, P.boot_ue, cnt, N, c.d_mods);
+    b_rescale(c, P.ws, P.d_boot_rs + first, B, cnt, s); // divide-and-round by the extra prime, straight into the zenc slots
+}
+
+// batched opcode 10, data half: B items at `ell` primes -> `t` primes.  5 launches.
+void HEVM::plan_boot_step(int first, int B, int ell, int t, hipStream_t s)
+{
+    Context &c = *ctx;
+    const size_t N = c.N;
+    if (!keys.sk) {
+        fprintf(stderr, "[dacapo_amd] bootstrap: needs a full VM (secret + public key)\n");
+        abort();
+    }
+    Plan &P = plan;
+    const BootItem *items = P.d_boot + first;
+    const CrtTables &tb = crt_tables(ell);
+    const CrtDev cd{ tb.inv, tb.mmod, tb.hmod, tb.hdig, tb.mdbl };
+    f_irows_decrypt_items(c, items, keys.sk, ell, P.boot_pt, B, s);
+    launch_ntt_cols_inv(c, P.boot_pt, (long)N, B * ell, nullptr, 0, ell, s);
+    hipLaunchKernelGGL(reencode_lift_batch_kernel, dim3((unsigned)((N / 2 + kVmThreads) / kVmThreads), (unsigned)B), dim3(kVmThreads), 0, s,
+                       P.boot_ptx, P.boot_pt, items, ell, t, N, c.d_mods, cd);
+    launch_ntt_cols_fwd(c, P.boot_ptx, (long)N, B * t, nullptr, 0, t, s);
+    f_frows_boot_final(c, P.boot_ptx, items, B, t, s);
 }
 
 hipEvent_t HEVM::new_event()

@@ -163,7 +163,7 @@ class HEVM {
     struct Step {
         PopKind kind;
         int level = 0, first = 0, count = 0; // range in the kind's device item table
-        int pop = -1;                       // P_BOOT: the single pop
+        int target = 0;                     // P_BOOT: primes of the result
     };
     struct Plan {
         bool ready = false;
@@ -177,6 +177,12 @@ class HEVM {
         EwItem *d_ew = nullptr;
         SumItem *d_sum = nullptr;
         SumSrc *d_sum_srcs = nullptr;
+        // opcode 10: item table, the divide-and-round items of the zero-encryptions, the zero-encryption arena and scratch
+        BootItem *d_boot = nullptr;
+        RsItem *d_boot_rs = nullptr;
+        u64 *zenc = nullptr, *boot_ue = nullptr, *boot_tmp = nullptr, *boot_pt = nullptr, *boot_ptx = nullptr;
+        struct BootChunk { int first, count, target; };
+        std::vector<BootChunk> boot_chunks; // zero-encryption launches at the start of every run
         BatchWs ws;
         std::vector<u64 *> pool; // every pool buffer ever allocated (reused across plans)
         int64_t n_keyswitch = 0, n_ntt = 0;
@@ -198,6 +204,8 @@ class HEVM {
     void build_plan();
     void run_plan();
     void boot_item(CtView src, int src_level, double src_scale, hevm_ctxt &dst, int target_level);
+    void plan_zero_encrypt(int first, int B, int t, hipStream_t s);
+    void plan_boot_step(int first, int B, int ell, int t, hipStream_t s);
     void bump_epoch(hipStream_t s);
 
     // statistics of the last run()

@@ -25,6 +25,10 @@ void launch_ntt(const Context &c, bool inverse, u64 *data, long limb_stride, int
 void launch_ntt_rows_fwd(const Context &c, u64 *data, long limb_stride, int count, const int *d_prime_idx, int prime_base,
                          int prime_period, hipStream_t s);
 
+// first (COLS) phase of a forward NTT only (lazy output; a fused ROWS-phase kernel finishes the transform)
+void launch_ntt_cols_fwd(const Context &c, u64 *data, long limb_stride, int count, const int *d_prime_idx, int prime_base,
+                         int prime_period, hipStream_t s);
+
 // second (COLS) phase of an inverse NTT only: the input holds the output of an inverse ROWS phase
 void launch_ntt_cols_inv(const Context &c, u64 *data, long limb_stride, int count, const int *d_prime_idx, int prime_base,
                          int prime_period, hipStream_t s);

@@ -60,6 +60,14 @@ void launch_ntt_rows_fwd(const Context &c, u64 *data, long limb_stride, int coun
     launch_phase_k<false, false, true>(c.k2, c, data, limb_stride, count, d_prime_idx, prime_base, prime_period, s);
 }
 
+void launch_ntt_cols_fwd(const Context &c, u64 *data, long limb_stride, int count, const int *d_prime_idx, int prime_base,
+                         int prime_period, hipStream_t s)
+{
+    if (count <= 0) return;
+    if (prime_period <= 0) prime_period = 1 << 30;
+    launch_phase_k<true, false, false>(c.k1, c, data, limb_stride, count, d_prime_idx, prime_base, prime_period, s);
+}
+
 void launch_ntt_cols_inv(const Context &c, u64 *data, long limb_stride, int count, const int *d_prime_idx, int prime_base,
                          int prime_period, hipStream_t s)
 {

@@ -39,6 +39,12 @@ struct SumItem {  // dst = sum of `count` terms srcs[first ...]
     int first, count;
 };
 
+struct BootItem { // opcode 10: dst = Enc(re-encode(Dec(src))) = zenc + (plaintext, 0)
+    CtView src, dst;
+    const u64 *zenc; // fresh public-key encryption of zero at the target level, [2][t][N], made at the start of the run
+    double ratio;    // new_scale / old_scale
+};
+
 // scratch of one batched step, sized for the largest batch of the plan
 struct BatchWs {
     u64 *target = nullptr; // [B][l][N]     key-switch target, NTT form
@@ -64,6 +70,10 @@ void f_irows_rot_c1(const Context &c, const KsItem *items, int ell, u64 *out, in
 void f_irows_rs_last(const Context &c, const RsItem *items, int l, u64 *out, int B, hipStream_t s);
 void f_irows_rs_single(const Context &c, CtView src, int l, u64 *out, hipStream_t s);
 void f_irows_decrypt(const Context &c, CtView ct, const u64 *sk, int ell, u64 *out, hipStream_t s);
+// batched opcode 10: inverse ROWS phase of c0 + c1*s of every item -> out[B][ell][N] ...
+void f_irows_decrypt_items(const Context &c, const BootItem *items, const u64 *sk, int ell, u64 *out, int B, hipStream_t s);
+// ... and the last forward phase of the re-encoded plaintexts ptx[B][t][N], added to the items' zero-encryptions
+void f_frows_boot_final(const Context &c, const u64 *ptx, const BootItem *items, int B, int t, hipStream_t s);
 void f_ks_icols_lift_fcols(const Context &c, const u64 *digits, u64 *ext, int B, int ell, hipStream_t s);
 void f_dr_icols_lift_fcols(const Context &c, const u64 *last, long last_stride, u64 *tmp, int polys, int cnt, int l, hipStream_t s);
 // large-batch variants: inverse COLS phase run separately (once per source limb), then base change + forward COLS

@@ -29,8 +29,11 @@ void HEVM::build_plan()
     Context &c = *ctx;
     const size_t N = c.N;
     Plan &P = plan;
-    for (void *p : { (void *)P.d_ks, (void *)P.d_mul, (void *)P.d_rs, (void *)P.d_ew, (void *)P.d_sum, (void *)P.d_sum_srcs })
+    for (void *p : { (void *)P.d_ks, (void *)P.d_mul, (void *)P.d_rs, (void *)P.d_ew, (void *)P.d_sum, (void *)P.d_sum_srcs, (void *)P.d_boot,
+                     (void *)P.d_boot_rs, (void *)P.zenc, (void *)P.boot_ue, (void *)P.boot_tmp, (void *)P.boot_pt, (void *)P.boot_ptx })
         if (p) (void)hipFree(p);
+    P.d_boot = nullptr, P.d_boot_rs = nullptr, P.zenc = P.boot_ue = P.boot_tmp = P.boot_pt = P.boot_ptx = nullptr;
+    P.boot_chunks.clear();
     if (P.graph_exec) (void)hipGraphExecDestroy(P.graph_exec);
     if (P.graph) (void)hipGraphDestroy(P.graph);
     P.graph_exec = nullptr, P.graph = nullptr;
@@ -247,19 +250,19 @@ void HEVM::build_plan()
     std::vector<SumSrc> h_srcs;
     std::vector<std::vector<int>> step_pops;
     for (int w = 1; w <= max_wave; w++) {
-        std::map<std::pair<int, int>, std::vector<int>> buckets; // (kind, level) -> pops
-        for (int pi : by_wave[(size_t)w]) buckets[{ (int)O[(size_t)pi].kind, O[(size_t)pi].level }].push_back(pi);
+        std::map<std::tuple<int, int, int>, std::vector<int>> buckets; // (kind, level, target level of opcode 10) -> pops
+        for (int pi : by_wave[(size_t)w])
+            buckets[std::make_tuple((int)O[(size_t)pi].kind, O[(size_t)pi].level, O[(size_t)pi].target_level)].push_back(pi);
         for (auto &kv : buckets) {
-            const PopKind kind = (PopKind)kv.first.first;
-            const bool heavy = kind == P_ROT || kind == P_MULCC || kind == P_RESCALE;
-            const size_t chunk = kind == P_BOOT ? 1 : std::max<size_t>(1, (heavy ? (size_t)max_batch : (size_t)4096) / (size_t)S);
+            const PopKind kind = (PopKind)std::get<0>(kv.first);
+            const bool heavy = kind == P_ROT || kind == P_MULCC || kind == P_RESCALE || kind == P_BOOT;
+            const size_t chunk = std::max<size_t>(1, (heavy ? (size_t)max_batch : (size_t)4096) / (size_t)S);
             for (size_t off = 0; off < kv.second.size(); off += chunk) {
                 Step st;
-                st.kind = kind, st.level = kv.first.second;
+                st.kind = kind, st.level = std::get<1>(kv.first), st.target = std::get<2>(kv.first);
                 st.count = (int)std::min(chunk, kv.second.size() - off);
                 std::vector<int> members(kv.second.begin() + (long)off, kv.second.begin() + (long)off + st.count);
                 for (int pi : members) O[(size_t)pi].step = (int)P.steps.size();
-                if (kind == P_BOOT) st.pop = members[0];
                 P.steps.push_back(st);
                 step_pops.push_back(members);
             }
@@ -315,10 +318,14 @@ void HEVM::build_plan()
         return CtView{ b + (size_t)sidx * buf_elems, ps };
     };
     size_t need_t = 0, need_d = 0, need_e = 0, need_a = 0, need_m = 0, need_c = 0;
+    size_t need_bpt = 0, need_bptx = 0;
+    int boot_tmax = 0;
+    std::vector<std::pair<int, int>> h_boot_pops; // (pop, stream) per boot item; device tables are filled once the arena exists
+    std::vector<double> h_boot_ratio;
     P.launches = 0;
     for (size_t s = 0; s < P.steps.size(); s++) {
         Step &st = P.steps[s];
-        if (st.kind != P_BOOT) st.count *= S; // items = pseudo-ops x streams
+        st.count *= S; // items = pseudo-ops x streams
         const size_t B = (size_t)st.count, l = (size_t)st.level;
         switch (st.kind) {
         case P_ROT:
@@ -364,7 +371,13 @@ void HEVM::build_plan()
                     h_ew.push_back(EwItem{ view(O[(size_t)pi].dst, q), view(O[(size_t)pi].srcs[0], q),
                                            CtView{ plains.at((size_t)O[(size_t)pi].plain).d, 0 } });
             break;
-        case P_BOOT: break;
+        case P_BOOT:
+            st.first = (int)h_boot_pops.size();
+            for (int pi : step_pops[s])
+                for (int q = 0; q < S; q++) h_boot_pops.push_back({ pi, q });
+            need_bpt = std::max(need_bpt, B * l), need_bptx = std::max(need_bptx, B * (size_t)st.target);
+            boot_tmax = std::max(boot_tmax, st.target);
+            break;
         }
         if (st.kind == P_ROT || st.kind == P_MULCC) {
             need_t = std::max(need_t, B * l), need_d = std::max(need_d, B * std::max<size_t>(l, 2)), need_e = std::max(need_e, B * l * l);
@@ -374,7 +387,48 @@ void HEVM::build_plan()
             need_d = std::max(need_d, B * 2), need_m = std::max(need_m, B * 2 * l);
             P.launches += 3;
         } else
-            P.launches += st.kind == P_BOOT ? 13 * (size_t)S : 1;
+            P.launches += st.kind == P_BOOT ? 5 : 1;
+    }
+    // opcode 10: every item owns a slot of the zero-encryption arena; the zero-encryptions are made in chunks of items with
+    // the same target level at the start of each run (plan_zero_encrypt)
+    if (!h_boot_pops.empty()) {
+        const size_t nb = h_boot_pops.size(), slot = (size_t)2 * boot_tmax * N;
+        DC_HIP_CHECK(hipMalloc(&P.zenc, nb * slot * sizeof(u64)));
+        std::vector<int> order(nb); // boot items sorted by target level (stable): chunks are ranges of the sorted tables
+        for (size_t i = 0; i < nb; i++) order[i] = (int)i;
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+            return O[(size_t)h_boot_pops[(size_t)a].first].target_level < O[(size_t)h_boot_pops[(size_t)b].first].target_level;
+        });
+        const size_t bc = std::min<size_t>(nb, (size_t)std::max(max_batch, 1));
+        const size_t cmax = (size_t)boot_tmax + 1;
+        DC_HIP_CHECK(hipMalloc(&P.boot_ue, bc * 3 * cmax * N * sizeof(u64)));
+        DC_HIP_CHECK(hipMalloc(&P.boot_tmp, bc * 2 * cmax * N * sizeof(u64)));
+        DC_HIP_CHECK(hipMalloc(&P.boot_pt, std::max<size_t>(need_bpt, 1) * N * sizeof(u64)));
+        DC_HIP_CHECK(hipMalloc(&P.boot_ptx, std::max<size_t>(need_bptx, 1) * N * sizeof(u64)));
+        std::vector<BootItem> h_boot(nb);
+        std::vector<RsItem> h_brs(nb);
+        for (size_t k = 0; k < nb;) { // chunks over the sorted order
+            const int t = O[(size_t)h_boot_pops[(size_t)order[k]].first].target_level;
+            size_t e = k;
+            while (e < nb && e - k < bc && O[(size_t)h_boot_pops[(size_t)order[e]].first].target_level == t) e++;
+            P.boot_chunks.push_back({ (int)k, (int)(e - k), t });
+            for (size_t j = k; j < e; j++) { // sorted position j <-> item order[j]; zenc slot = item index
+                const size_t item = (size_t)order[j];
+                u64 *z = P.zenc + item * slot;
+                h_brs[j] = RsItem{ CtView{ P.boot_tmp + (j - k) * 2 * (size_t)(t + 1) * N, (long)(t + 1) * (long)N }, CtView{ z, (long)t * (long)N } };
+            }
+            need_d = std::max(need_d, (e - k) * 2), need_m = std::max(need_m, (e - k) * 2 * (size_t)(t + 1));
+            P.launches += 7;
+            k = e;
+        }
+        for (size_t item = 0; item < nb; item++) {
+            const Pop &p = O[(size_t)h_boot_pops[item].first];
+            const int q = h_boot_pops[item].second;
+            const Val &sv = V[(size_t)p.srcs[0]];
+            const double new_scale = V[(size_t)p.dst].scale;
+            h_boot[item] = BootItem{ view(p.srcs[0], q), view(p.dst, q), P.zenc + item * slot, new_scale / sv.scale };
+        }
+        P.d_boot = upload(h_boot), P.d_boot_rs = upload(h_brs);
     }
     P.d_ks = upload(h_ks), P.d_mul = upload(h_mul), P.d_rs = upload(h_rs), P.d_ew = upload(h_ew), P.d_sum = upload(h_sum);
     P.d_sum_srcs = upload(h_srcs);
@@ -398,7 +452,7 @@ void HEVM::issue_plan(hipStream_t s)
 {
     Context &c = *ctx;
     Plan &P = plan;
-    const long ps = (long)c.K * (long)c.N;
+    for (const Plan::BootChunk &bc : P.boot_chunks) plan_zero_encrypt(bc.first, bc.count, bc.target, s);
     for (const Step &st : P.steps) {
         switch (st.kind) {
         case P_ROT: b_rotate_hops(c, P.ws, P.d_ks + st.first, st.count, st.level, s); break;
@@ -409,16 +463,7 @@ void HEVM::issue_plan(hipStream_t s)
         case P_COPY: b_ew(c, EwOp::Copy, P.d_ew + st.first, st.count, 2, 2, st.level, s); break;
         case P_MULP: b_ew(c, EwOp::Mul, P.d_ew + st.first, st.count, 2, 1, st.level, s); break;
         case P_ADDP: b_add_plain(c, P.d_ew + st.first, st.count, st.level, s); break;
-        case P_BOOT: {
-            const Pop &p = P.pops[(size_t)st.pop];
-            const Val &sv = P.vals[(size_t)p.srcs[0]];
-            const size_t be = (size_t)2 * c.K * c.N;
-            for (int q = 0; q < streams; q++) {
-                hevm_ctxt d{ P.vals[(size_t)P.vals[(size_t)p.dst].root].buf + (size_t)q * be, ps, 0, 0, 1.0 };
-                boot_item(CtView{ P.vals[(size_t)sv.root].buf + (size_t)q * be, ps }, sv.level, sv.scale, d, p.target_level);
-            }
-            break;
-        }
+        case P_BOOT: plan_boot_step(st.first, st.count, st.level, st.target, s); break;
         }
     }
     bump_epoch(s);
