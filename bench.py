@@ -139,6 +139,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--program", default="resnet20", choices=["resnet20", "shaped"],
                     help="resnet20 = the reference model's traced op stream + real weights (tests/golden); shaped = synthetic op mix")
+    ap.add_argument("--hevm-gz", default=None, help="--program resnet20: another lowering of the same trace (same constants)")
     ap.add_argument("--layers", type=int, default=20, help="--program shaped: depth (20 = the traced op mix)")
     ap.add_argument("--streams", type=int, default=1, help="independent ciphertext streams per GPU (throughput mode; 1 = the reference's one image per run)")
     args = ap.parse_args()
@@ -169,6 +170,10 @@ def main():
     if args.program == "resnet20":
         fx = ha.read_fixture(ROOT / "tests" / "golden" / "resnet20")
         cst, hv, info = fx["cst"], fx["hevm"], fx["meta"]["info"]
+        if args.hevm_gz:
+            import gzip
+            hv = gzip.open(args.hevm_gz).read()
+            info = {"op_mix": "see " + args.hevm_gz}
         image = fx["packed"]
         workload = ("ResNet-20 (SiLU) HEVM program traced from the reference's examples/benchmarks/ResNet.py with its "
                     "resnet20.silu.model weights")

@@ -143,13 +143,13 @@ void b_mul_relin(Context &c, const BatchWs &w, const MulItem *d_items, const u64
     b_ks_tail<1>(c, w, nullptr, d_items, relin_key, B, ell, s);
 }
 
-void b_rescale(Context &c, const BatchWs &w, const RsItem *d_items, int B, int ell, hipStream_t s)
+void b_rescale(Context &c, const BatchWs &w, const RsItem *d_items, int B, int ell, hipStream_t s, const SumSrc *d_srcs)
 {
     const int l = ell - 1;
     u64 *last = w.digits; // [B][2][N]
-    f_irows_rs_last(c, d_items, l, last, B, s);
+    f_irows_rs_last(c, d_items, d_srcs, l, last, B, s);
     f_dr_icols_lift_fcols(c, last, (long)c.N, w.tmp, 2 * B, l, l, s);
-    f_frows_final(c, 2, w.tmp, d_items, nullptr, 2 * B, l, l, s);
+    f_frows_final(c, 2, w.tmp, d_items, nullptr, 2 * B, l, l, s, RsItem{}, nullptr, d_srcs);
 }
 
 void rescale_fused(Context &c, const Workspace &w, CtView dst, CtView src, int ell, const u64 *plain, hipStream_t s)
@@ -158,7 +158,7 @@ void rescale_fused(Context &c, const Workspace &w, CtView dst, CtView src, int e
     u64 *last = w.ks_digits; // [2][N]
     f_irows_rs_single(c, src, l, last, s);
     f_dr_icols_lift_fcols(c, last, (long)c.N, w.ks_tmp, 2, l, l, s);
-    f_frows_final(c, 3, w.ks_tmp, nullptr, nullptr, 2, l, l, s, RsItem{ src, dst }, plain);
+    f_frows_final(c, 3, w.ks_tmp, nullptr, nullptr, 2, l, l, s, RsItem{ src, dst, 0, 0, nullptr, nullptr }, plain);
 }
 
 // ---- limb-wise batched kernels ---------------------------------------------------------------------------------

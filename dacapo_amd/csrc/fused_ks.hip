@@ -44,12 +44,80 @@ struct SrcRotC1 { // limb z = b*l + j : c1 of item b, limb j, read through the i
         return it.src.limb(1, z % ell, (size_t)1 << logN)[galois_idx((u32)g, it.elt, logN)];
     }
 };
-struct SrcRsLast { // limb z = b*2 + p : the limb being dropped by a rescale
-    const RsItem *items;
-    int l;
-    __device__ int prime(int) const { return l; }
-    __device__ u64 load(int z, int g, int logN) const { return items[z >> 1].src.limb(z & 1, l, (size_t)1 << logN)[g]; }
-};
+// Operand of a rescale item (plan.hpp RsItem) for the E coefficients a thread owns: elementwise producers (n-ary sum,
+// + plaintext, * plaintext) that nothing else reads are evaluated here instead of being materialised.  Modular
+// arithmetic is exact, so the values equal what the separate ops would have stored.  Every stage issues its E loads
+// together (term loop outermost) -- a per-coefficient evaluation would serialise one memory latency per term.
+template <int E>
+__device__ __forceinline__ void rs_operand(u64 (&v)[E], const int (&g)[E], const RsItem &it, const SumSrc *__restrict__ srcs, int p, int i,
+                                           size_t N, const DModulus &M)
+{
+    if (it.count == 0) {
+        const u64 *x = it.src.limb(p, i, N);
+#pragma unroll
+        for (int j = 0; j < E; j++) v[j] = x[g[j]];
+    } else {
+        u64 s[E];
+        Acc128 a[E];
+#pragma unroll
+        for (int j = 0; j < E; j++) s[j] = 0, a[j].clear();
+        int n_plain = 0, n_prod = 0;
+        for (int t = 0; t < it.count; t++) {
+            const SumSrc src = srcs[it.first + t];
+            const u64 *x = src.v.limb(p, i, N);
+            if (src.plain) {
+                const u64 *w = src.plain + (size_t)i * N;
+#pragma unroll
+                for (int j = 0; j < E; j++) a[j].mac(x[g[j]], w[g[j]]);
+                if ((++n_prod & 15) == 0) {
+#pragma unroll
+                    for (int j = 0; j < E; j++) s[j] = fold60(s[j], M.delta) + a[j].reduce(M), a[j].clear();
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < E; j++) s[j] += x[g[j]];
+                if ((++n_plain & 7) == 0) {
+#pragma unroll
+                    for (int j = 0; j < E; j++) s[j] = fold60(s[j], M.delta);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < E; j++) v[j] = addmod(canon(s[j], M), a[j].reduce(M), M.q);
+    }
+    if (it.add && p == 0) {
+        const u64 *w = it.add + (size_t)i * N;
+#pragma unroll
+        for (int j = 0; j < E; j++) v[j] = addmod(v[j], w[g[j]], M.q);
+    }
+    if (it.mul) {
+        const u64 *w = it.mul + (size_t)i * N;
+#pragma unroll
+        for (int j = 0; j < E; j++) v[j] = mulmod(v[j], w[g[j]], M);
+    }
+}
+
+// R1: inverse ROWS phase of the limb a rescale drops.  z = b*2 + p
+template <int K, int LOGE>
+__global__ __launch_bounds__(kTileThreads) void f_irows_rs_kernel(const RsItem *__restrict__ items, const SumSrc *__restrict__ srcs, int l,
+                                                                   u64 *__restrict__ out, const DModulus *__restrict__ mods,
+                                                                   const u64 *__restrict__ itw, int logN)
+{
+    __shared__ __attribute__((aligned(16))) u64 lds[TileGeo<LOGE>::LDS_ELEMS];
+    constexpr int E = 1 << LOGE;
+    const int z = blockIdx.y;
+    const size_t N = (size_t)1 << logN;
+    const DModulus M = mods[l];
+    u64 *o = out + (size_t)z * N;
+    int g[E];
+#pragma unroll
+    for (int j = 0; j < E; j++) g[j] = tile_gidx<K, LOGE, false>(num_passes<LOGE>(K) - 1, logN, blockIdx.x, j);
+    u64 x[E];
+    rs_operand<E>(x, g, items[z >> 1], srcs, z & 1, l, N, M);
+    auto nold = [](int) -> u64 { return 0; };
+    ntt_tile_x<K, LOGE, false, true, false, true, false>(x, M, itw + ((size_t)l << logN), logN, blockIdx.x, nold,
+                                                         [=](int gi, u64 v) { o[gi] = v; }, lds);
+}
 
 struct SrcRsLast1 { // single rescale without a device item table (encryption's divide-and-round)
     CtView src;
@@ -216,6 +284,7 @@ __global__ __launch_bounds__(kTileThreads) void f_dr_lift_fcols_kernel(const u64
 template <int K, int LOGE, int MODE>
 __global__ __launch_bounds__(kTileThreads) void f_frows_final_kernel(const u64 *__restrict__ tmp, const void *__restrict__ items_,
                                                                       RsItem single, const u64 *__restrict__ plain,
+                                                                      const SumSrc *__restrict__ srcs,
                                                                       const u64 *__restrict__ acc, int cnt, int l, int Kp,
                                                                       const DModulus *__restrict__ mods,
                                                                       const u64 *__restrict__ inv_last, const u64 *__restrict__ tw,
@@ -259,11 +328,18 @@ __global__ __launch_bounds__(kTileThreads) void f_frows_final_kernel(const u64 *
             lds);
     } else {
         const RsItem it = reinterpret_cast<const RsItem *>(items_)[b];
-        const u64 *x = it.src.limb(p, i, N);
         u64 *o = it.dst.limb(p, i, N);
-        ntt_tile<K, LOGE, false, false, true>(
-            M, tw + ((size_t)i << logN), logN, blockIdx.x, [=](int g) { return in[g]; },
-            [=](int g, u64 v) { o[g] = mulmod(submod(x[g], v, M.q), inv, M); }, lds);
+        constexpr int E = 1 << LOGE;
+        u64 x[E], op[E];
+        int g[E];
+        auto nost = [](int, u64) {};
+        ntt_tile_x<K, LOGE, false, false, true, false, true>(x, M, tw + ((size_t)i << logN), logN, blockIdx.x,
+                                                             [=](int gi) { return in[gi]; }, nost, lds);
+#pragma unroll
+        for (int j = 0; j < E; j++) g[j] = tile_gidx<K, LOGE, false>(num_passes<LOGE>(K) - 1, logN, blockIdx.x, j);
+        rs_operand<E>(op, g, it, srcs, p, i, N, M);
+#pragma unroll
+        for (int j = 0; j < E; j++) o[g[j]] = mulmod(submod(op[j], x[j], M.q), inv, M);
     }
 }
 
@@ -327,9 +403,10 @@ void f_irows_rot_c1(const Context &c, const KsItem *items, int ell, u64 *out, in
 {
     launch_irows(c, SrcRotC1{ items, ell }, out, (long)c.N, B * ell, s);
 }
-void f_irows_rs_last(const Context &c, const RsItem *items, int l, u64 *out, int B, hipStream_t s)
+void f_irows_rs_last(const Context &c, const RsItem *items, const SumSrc *srcs, int l, u64 *out, int B, hipStream_t s)
 {
-    launch_irows(c, SrcRsLast{ items, l }, out, (long)c.N, 2 * B, s);
+    DC_GEO_SWITCH(c.k2, 2 * B, hipLaunchKernelGGL((f_irows_rs_kernel<KK, LE>), grid, dim3(kTileThreads), 0, s, items, srcs, l, out, c.d_mods,
+                                                  c.d_itw, c.logN));
 }
 void f_irows_rs_single(const Context &c, CtView src, int l, u64 *out, hipStream_t s)
 {
@@ -375,11 +452,11 @@ void f_dr_lift_fcols(const Context &c, const u64 *last, long last_stride, u64 *t
 }
 
 void f_frows_final(const Context &c, int mode, const u64 *tmp, const void *items, const u64 *acc, int polys, int cnt, int l,
-                   hipStream_t s, RsItem single, const u64 *plain)
+                   hipStream_t s, RsItem single, const u64 *plain, const SumSrc *srcs)
 {
 #define DC_FINAL(MD)                                                                                                                   \
     DC_GEO_SWITCH(c.k2, polys * cnt, hipLaunchKernelGGL((f_frows_final_kernel<KK, LE, MD>), grid, dim3(kTileThreads), 0, s, tmp, items, single, \
-                                                        plain, acc, cnt, l, c.K, c.d_mods, c.d_inv_last, c.d_tw, c.logN))
+                                                        plain, srcs, acc, cnt, l, c.K, c.d_mods, c.d_inv_last, c.d_tw, c.logN))
     switch (mode) {
     case 0: DC_FINAL(0); break;
     case 1: DC_FINAL(1); break;

@@ -157,6 +157,8 @@ class HEVM {
         u32 elt = 0;
         const u64 *key = nullptr;
         int plain = -1, target_level = 0;
+        int rs_add = -1, rs_mul = -1; // P_RESCALE: plain registers of a folded addcp / mulcp (operand = (srcs + add) * mul)
+        bool rs_sum = false;          // P_RESCALE: srcs/src_plain are the terms of a folded n-ary sum
         bool dead = false;
         int wave = 0, step = -1;
     };

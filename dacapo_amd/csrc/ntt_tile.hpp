@@ -117,6 +117,28 @@ __device__ __forceinline__ void ntt_tile_x(u64 (&x)[1 << LOGE], const DModulus M
     const int lane_id = tile * B + b;
     const u32 twroot = COLS ? 1u : ((1u << sh) + (u32)lane_id);
     auto gidx = [&](int idx) -> int { return COLS ? ((idx << sh) + lane_id) : ((lane_id << K) + idx); };
+    // Latency geometry: fetch every pass's twiddles (<= E - 1 per pass) before the first butterfly.  The barriers between
+    // passes pin memory operations in place, so otherwise each pass starts by waiting for its own twiddle loads.
+    constexpr bool PF = (LOGE == 2);
+    u64 wpre[PF ? NP : 1][E];
+    if (PF) {
+#pragma unroll
+        for (int pp = 0; pp < NP; pp++) {
+            const int p = INV ? (NP - 1 - pp) : pp;
+            const int s0 = LOGE * p, r = pass_stages<LOGE>(K, p);
+#pragma unroll
+            for (int u = 0; u < (1 << (LOGE - r)); u++) {
+                const int vt = (s << (LOGE - r)) | u;
+                const int hi = vt >> (K - s0 - r);
+#pragma unroll
+                for (int st_ = 0; st_ < r; st_++) {
+#pragma unroll
+                    for (int g = 0; g < (1 << st_); g++)
+                        wpre[pp][(u << r) | ((1 << st_) + g)] = tw[(twroot << (s0 + st_)) + (u32)((hi << st_) | g)];
+                }
+            }
+        }
+    }
 
 #pragma unroll
     for (int pp = 0; pp < NP; pp++) {
@@ -146,7 +168,7 @@ __device__ __forceinline__ void ntt_tile_x(u64 (&x)[1 << LOGE], const DModulus M
 #pragma unroll
                 for (int g = 0; g < (1 << st_); g++) {
                     const u32 twi = (twroot << gs) + (u32)((hi << st_) | g);
-                    u64 w = tw[twi];
+                    const u64 w = PF ? wpre[PF ? pp : 0][(u << r) | ((1 << st_) + g)] : tw[twi];
 #pragma unroll
                     for (int e = 0; e < half; e++) {
                         const int j0 = (u << r) | (g << (r - st_)) | e, j1 = j0 | half;
@@ -187,6 +209,19 @@ __device__ __forceinline__ void ntt_tile_x(u64 (&x)[1 << LOGE], const DModulus M
             __syncthreads();
         }
     }
+}
+
+// global coefficient index of register j of this thread under pass p (what ld/st are called with): lets a kernel fill
+// x[] itself (PRELOADED) or consume it (KEEP) with all its loads in flight at once.  An inverse tile starts and a forward
+// tile ends with pass num_passes - 1.
+template <int K, int LOGE, bool COLS>
+__device__ __forceinline__ int tile_gidx(int p, int logN, int tile, int j)
+{
+    constexpr int LOGB = TileGeo<LOGE>::LOG - K, B = 1 << LOGB, SUBT = (1 << K) >> LOGE;
+    const int t = threadIdx.x;
+    const int b = COLS ? (t & (B - 1)) : (t / SUBT), s = COLS ? (t >> LOGB) : (t & (SUBT - 1));
+    const int lane_id = tile * B + b, idx = PassMap<K, LOGE>::idx_of(p, s, j);
+    return COLS ? ((idx << (logN - K)) + lane_id) : ((lane_id << K) + idx);
 }
 
 template <int K, int LOGE, bool COLS, bool INV, bool CANON, class Ld, class St>

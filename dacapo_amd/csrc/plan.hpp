@@ -24,8 +24,11 @@ struct KsItem {   // one key-switch hop of a rotation: dst = apply_galois(src)
 struct MulItem {  // dst = relinearize(a * b)
     CtView a, b, dst;
 };
-struct RsItem {   // dst = rescale_to_next(src)
+struct RsItem {   // dst = rescale_to_next(expr), expr = ((src | sum of `count` terms srcs[first ...]) + add on c0) * mul
     CtView src, dst;
+    int first = 0, count = 0;          // count == 0: expr starts from src
+    const u64 *add = nullptr;          // plaintext [level][N] added to c0 (a single-use addcp folded in), or null
+    const u64 *mul = nullptr;          // plaintext multiplying both polys (a single-use mulcp folded in), or null
 };
 struct EwItem {   // dst = a (op) b ; plaintext operand: b.p = limbs, b.poly_stride = 0
     CtView dst, a, b;
@@ -57,7 +60,7 @@ struct BatchWs {
 
 void b_rotate_hops(Context &c, const BatchWs &w, const KsItem *d_items, int B, int ell, hipStream_t s);
 void b_mul_relin(Context &c, const BatchWs &w, const MulItem *d_items, const u64 *relin_key, int B, int ell, hipStream_t s);
-void b_rescale(Context &c, const BatchWs &w, const RsItem *d_items, int B, int ell, hipStream_t s);
+void b_rescale(Context &c, const BatchWs &w, const RsItem *d_items, int B, int ell, hipStream_t s, const SumSrc *d_srcs = nullptr);
 // op: Neg / Mul (ct * plain) / Copy ; b_polys as in launch_ew
 void b_ew(Context &c, EwOp op, const EwItem *d_items, int B, int polys, int b_polys, int ell, hipStream_t s);
 void b_add_plain(Context &c, const EwItem *d_items, int B, int ell, hipStream_t s);
@@ -67,7 +70,7 @@ void b_sum(Context &c, const SumItem *d_items, const SumSrc *d_srcs, int B, int 
 void f_irows_strided(const Context &c, const u64 *base, long stride, int prime_base, int period, u64 *out, long out_stride, int count,
                      hipStream_t s);
 void f_irows_rot_c1(const Context &c, const KsItem *items, int ell, u64 *out, int B, hipStream_t s);
-void f_irows_rs_last(const Context &c, const RsItem *items, int l, u64 *out, int B, hipStream_t s);
+void f_irows_rs_last(const Context &c, const RsItem *items, const SumSrc *srcs, int l, u64 *out, int B, hipStream_t s);
 void f_irows_rs_single(const Context &c, CtView src, int l, u64 *out, hipStream_t s);
 void f_irows_decrypt(const Context &c, CtView ct, const u64 *sk, int ell, u64 *out, hipStream_t s);
 // batched opcode 10: inverse ROWS phase of c0 + c1*s of every item -> out[B][ell][N] ...
@@ -81,7 +84,7 @@ void f_ks_lift_fcols(const Context &c, const u64 *digits, u64 *ext, int B, int e
 void f_dr_lift_fcols(const Context &c, const u64 *last, long last_stride, u64 *tmp, int polys, int cnt, int l, hipStream_t s);
 // mode 0 rotation / 1 relinearisation / 2 rescale items / 3 one rescale by value (+ optional plaintext added to c0)
 void f_frows_final(const Context &c, int mode, const u64 *tmp, const void *items, const u64 *acc, int polys, int cnt, int l,
-                   hipStream_t s, RsItem single = RsItem{}, const u64 *plain = nullptr);
+                   hipStream_t s, RsItem single = RsItem{}, const u64 *plain = nullptr, const SumSrc *srcs = nullptr);
 // a single rescale_to_next of `src` (level ell) into dst, optionally adding a level-(ell-1) plaintext to c0: 3 launches
 void rescale_fused(Context &c, const Workspace &w, CtView dst, CtView src, int ell, const u64 *plain, hipStream_t s);
 

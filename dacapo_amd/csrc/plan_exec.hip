@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <map>
 #include <queue>
+#include <string>
 #include <tuple>
 
 #include "hevm_vm.hpp"
@@ -225,6 +226,28 @@ void HEVM::build_plan()
         }
     }
 
+    // ... and fold the elementwise producers of a rescale's operand into the rescale itself: the operand is read exactly
+    // twice (dropped limb by the first inverse phase, the other limbs by the last kernel), so a single-use
+    // mulcp / addcp / n-ary sum in front of it need not be materialised:  rescale(((sum) + a) * m)
+    for (Pop &p : O) {
+        if (p.kind != P_RESCALE || p.dead) continue;
+        auto single_def = [&](int v, PopKind k) -> int { // pop defining v if v is a plain (non-view) single-use value made by kind k
+            const Val &sv = V[(size_t)v];
+            const int dp = sv.root == v ? sv.def_pop : -1;
+            if (dp >= 0 && O[(size_t)dp].kind == k && !O[(size_t)dp].dead && sv.uses == 1 && O[(size_t)dp].dst == v && !sv.pinned) return dp;
+            return -1;
+        };
+        int x = p.srcs[0], dp;
+        if ((dp = single_def(x, P_MULP)) >= 0) p.rs_mul = O[(size_t)dp].plain, x = O[(size_t)dp].srcs[0], O[(size_t)dp].dead = true;
+        if ((dp = single_def(x, P_ADDP)) >= 0) p.rs_add = O[(size_t)dp].plain, x = O[(size_t)dp].srcs[0], O[(size_t)dp].dead = true;
+        p.srcs[0] = x;
+        if ((dp = single_def(x, P_SUM)) >= 0) {
+            p.rs_sum = true;
+            p.srcs = O[(size_t)dp].srcs, p.src_plain = O[(size_t)dp].src_plain;
+            O[(size_t)dp].dead = true;
+        }
+    }
+
     // ---- 3. dataflow depth ------------------------------------------------------------------------------------------
     int max_wave = 0;
     for (Pop &p : O) {
@@ -343,7 +366,20 @@ void HEVM::build_plan()
         case P_RESCALE:
             st.first = (int)h_rs.size();
             for (int pi : step_pops[s])
-                for (int q = 0; q < S; q++) h_rs.push_back(RsItem{ view(O[(size_t)pi].srcs[0], q), view(O[(size_t)pi].dst, q) });
+                for (int q = 0; q < S; q++) {
+                    const Pop &rp = O[(size_t)pi];
+                    RsItem it{ view(rp.srcs[0], q), view(rp.dst, q), 0, 0, nullptr, nullptr };
+                    if (rp.rs_sum) {
+                        it.first = (int)h_srcs.size(), it.count = (int)rp.srcs.size();
+                        for (size_t k = 0; k < rp.srcs.size(); k++) {
+                            const int pl = rp.src_plain.empty() ? -1 : rp.src_plain[k];
+                            h_srcs.push_back(SumSrc{ view(rp.srcs[k], q), pl >= 0 ? plains.at((size_t)pl).d : nullptr });
+                        }
+                    }
+                    if (rp.rs_add >= 0) it.add = plains.at((size_t)rp.rs_add).d;
+                    if (rp.rs_mul >= 0) it.mul = plains.at((size_t)rp.rs_mul).d;
+                    h_rs.push_back(it);
+                }
             break;
         case P_SUM:
             st.first = (int)h_sum.size();
@@ -443,6 +479,34 @@ void HEVM::build_plan()
     P.ws.acc = alloc(need_a), P.ws.tmp = alloc(need_m), P.ws.c0perm = alloc(need_c);
     P.n_keyswitch *= S, P.n_ntt *= S;
     P.ready = true;
+    if (getenv("DACAPO_HEVM_TRACE")) {
+        static const char *kn[] = { "rot", "mulcc", "rescale", "sum", "neg", "mulp", "addp", "copy", "boot" };
+        size_t nsteps[9] = { 0 }, nitems[9] = { 0 };
+        std::map<std::pair<int, int>, std::pair<size_t, size_t>> ks; // (kind, level) -> steps, items
+        for (const Step &st : P.steps) {
+            nsteps[st.kind]++, nitems[st.kind] += (size_t)st.count;
+            if (st.kind == P_ROT || st.kind == P_MULCC || st.kind == P_RESCALE || st.kind == P_BOOT) {
+                auto &e = ks[{ (int)st.kind, st.level }];
+                e.first++, e.second += (size_t)st.count;
+            }
+        }
+        if (atoi(getenv("DACAPO_HEVM_TRACE")) >= 2) {
+            int lastw = -1;
+            for (size_t i = 0; i < P.steps.size() && i < 400; i++) {
+                const Step &st = P.steps[i];
+                const int w = O[(size_t)step_pops[i][0]].wave;
+                fprintf(stderr, "%s%s%d/%d", w != lastw ? "\n  w" : " ", w != lastw ? (std::to_string(w) + ": ").c_str() : "", 0, 0);
+                fprintf(stderr, "[%s l%d x%d]", kn[st.kind], st.level, st.count);
+                lastw = w;
+            }
+            fprintf(stderr, "\n");
+        }
+        for (int k = 0; k < 9; k++)
+            if (nsteps[k]) fprintf(stderr, "[dacapo_amd] plan:   %-8s %5zu steps %6zu items\n", kn[k], nsteps[k], nitems[k]);
+        for (auto &kv : ks)
+            fprintf(stderr, "[dacapo_amd] plan:   %-8s level %2d: %5zu steps %6zu items\n", kn[kv.first.first], kv.first.second,
+                    kv.second.first, kv.second.second);
+    }
     if (getenv("DACAPO_HEVM_TRACE"))
         fprintf(stderr, "[dacapo_amd] plan: %zu ops -> %zu pseudo-ops -> %zu steps in %d waves, ~%zu launches, %zu live buffers (%.1f GB pool)\n",
                 ops.size(), O.size(), P.steps.size(), max_wave, P.launches, P.max_live, (double)P.pool.size() * buf_elems * 8 / 1e9);
@@ -457,7 +521,7 @@ void HEVM::issue_plan(hipStream_t s)
         switch (st.kind) {
         case P_ROT: b_rotate_hops(c, P.ws, P.d_ks + st.first, st.count, st.level, s); break;
         case P_MULCC: b_mul_relin(c, P.ws, P.d_mul + st.first, keys.relin, st.count, st.level, s); break;
-        case P_RESCALE: b_rescale(c, P.ws, P.d_rs + st.first, st.count, st.level, s); break;
+        case P_RESCALE: b_rescale(c, P.ws, P.d_rs + st.first, st.count, st.level, s, P.d_sum_srcs); break;
         case P_SUM: b_sum(c, P.d_sum + st.first, P.d_sum_srcs, st.count, st.level, s); break;
         case P_NEG: b_ew(c, EwOp::Neg, P.d_ew + st.first, st.count, 2, 2, st.level, s); break;
         case P_COPY: b_ew(c, EwOp::Copy, P.d_ew + st.first, st.count, 2, 2, st.level, s); break;
