@@ -166,6 +166,7 @@ class HEVM {
         PopKind kind;
         int level = 0, first = 0, count = 0; // range in the kind's device item table
         int target = 0;                     // P_BOOT: primes of the result
+        int wave = 0, lane = 0;             // steps of one wave are independent: lane 1 runs on the auxiliary stream
     };
     struct Plan {
         bool ready = false;
@@ -182,10 +183,11 @@ class HEVM {
         // opcode 10: item table, the divide-and-round items of the zero-encryptions, the zero-encryption arena and scratch
         BootItem *d_boot = nullptr;
         RsItem *d_boot_rs = nullptr;
-        u64 *zenc = nullptr, *boot_ue = nullptr, *boot_tmp = nullptr, *boot_pt = nullptr, *boot_ptx = nullptr;
+        u64 *zenc = nullptr, *boot_ue = nullptr, *boot_tmp = nullptr, *boot_pt[2] = { nullptr, nullptr }, *boot_ptx[2] = { nullptr, nullptr };
         struct BootChunk { int first, count, target; };
         std::vector<BootChunk> boot_chunks; // zero-encryption launches at the start of every run
-        BatchWs ws;
+        BatchWs ws[2]; // per lane
+        std::vector<hipEvent_t> events; // fork/join pairs of the waves that use the auxiliary stream
         std::vector<u64 *> pool; // every pool buffer ever allocated (reused across plans)
         int64_t n_keyswitch = 0, n_ntt = 0;
         size_t launches = 0, max_live = 0;
@@ -207,7 +209,9 @@ class HEVM {
     void run_plan();
     void boot_item(CtView src, int src_level, double src_scale, hevm_ctxt &dst, int target_level);
     void plan_zero_encrypt(int first, int B, int t, hipStream_t s);
-    void plan_boot_step(int first, int B, int ell, int t, hipStream_t s);
+    void plan_boot_step(int first, int B, int ell, int t, int lane, hipStream_t s);
+    hipStream_t aux_stream = nullptr;
+    int plan_lanes = 1; // DACAPO_HEVM_PLAN_LANES=2: independent steps of a wave also use an auxiliary stream (pays off only with PLAN_GRAPH)
     void bump_epoch(hipStream_t s);
 
     // statistics of the last run()

@@ -31,9 +31,11 @@ void HEVM::build_plan()
     const size_t N = c.N;
     Plan &P = plan;
     for (void *p : { (void *)P.d_ks, (void *)P.d_mul, (void *)P.d_rs, (void *)P.d_ew, (void *)P.d_sum, (void *)P.d_sum_srcs, (void *)P.d_boot,
-                     (void *)P.d_boot_rs, (void *)P.zenc, (void *)P.boot_ue, (void *)P.boot_tmp, (void *)P.boot_pt, (void *)P.boot_ptx })
+                     (void *)P.d_boot_rs, (void *)P.zenc, (void *)P.boot_ue, (void *)P.boot_tmp, (void *)P.boot_pt[0], (void *)P.boot_ptx[0],
+                     (void *)P.boot_pt[1], (void *)P.boot_ptx[1] })
         if (p) (void)hipFree(p);
-    P.d_boot = nullptr, P.d_boot_rs = nullptr, P.zenc = P.boot_ue = P.boot_tmp = P.boot_pt = P.boot_ptx = nullptr;
+    P.d_boot = nullptr, P.d_boot_rs = nullptr, P.zenc = P.boot_ue = P.boot_tmp = nullptr;
+    P.boot_pt[0] = P.boot_pt[1] = P.boot_ptx[0] = P.boot_ptx[1] = nullptr;
     P.boot_chunks.clear();
     if (P.graph_exec) (void)hipGraphExecDestroy(P.graph_exec);
     if (P.graph) (void)hipGraphDestroy(P.graph);
@@ -282,13 +284,33 @@ void HEVM::build_plan()
             const size_t chunk = std::max<size_t>(1, (heavy ? (size_t)max_batch : (size_t)4096) / (size_t)S);
             for (size_t off = 0; off < kv.second.size(); off += chunk) {
                 Step st;
-                st.kind = kind, st.level = std::get<1>(kv.first), st.target = std::get<2>(kv.first);
+                st.kind = kind, st.level = std::get<1>(kv.first), st.target = std::get<2>(kv.first), st.wave = w;
                 st.count = (int)std::min(chunk, kv.second.size() - off);
                 std::vector<int> members(kv.second.begin() + (long)off, kv.second.begin() + (long)off + st.count);
                 for (int pi : members) O[(size_t)pi].step = (int)P.steps.size();
                 P.steps.push_back(st);
                 step_pops.push_back(members);
             }
+        }
+    }
+    // steps of one wave are mutually independent: the costliest stays on the main stream, the rest is balanced over
+    // (main, auxiliary) when the auxiliary share is worth a fork/join (>= 3 launches)
+    if (plan_lanes >= 2) {
+        auto cost = [](const Step &st) { return st.kind == P_ROT || st.kind == P_MULCC ? 8 : st.kind == P_BOOT ? 5 : st.kind == P_RESCALE ? 3 : 1; };
+        for (size_t a = 0; a < P.steps.size();) {
+            size_t b = a;
+            while (b < P.steps.size() && P.steps[b].wave == P.steps[a].wave) b++;
+            std::vector<size_t> idx;
+            for (size_t i = a; i < b; i++) idx.push_back(i);
+            std::stable_sort(idx.begin(), idx.end(), [&](size_t x, size_t y) { return cost(P.steps[x]) > cost(P.steps[y]); });
+            int load[2] = { 0, 0 };
+            for (size_t i : idx) {
+                const int lane = load[1] < load[0] ? 1 : 0;
+                P.steps[i].lane = lane, load[lane] += cost(P.steps[i]);
+            }
+            if (load[1] < 3)
+                for (size_t i = a; i < b; i++) P.steps[i].lane = 0;
+            a = b;
         }
     }
     // ---- 5. lifetimes and pool buffers ---------------------------------------------------------------------------------
@@ -310,7 +332,8 @@ void HEVM::build_plan()
     for (size_t v = 0; v < V.size(); v++)
         if (V[v].root == (int)v && V[v].def_step >= 0 && !V[v].external) defs[(size_t)V[v].def_step].push_back((int)v);
     for (size_t s = 0; s < P.steps.size(); s++) {
-        while (!busy.empty() && busy.top().first < (int)s) {
+        // a buffer is recycled only for values defined in a LATER wave than its last reader (steps of a wave may overlap)
+        while (!busy.empty() && P.steps[(size_t)busy.top().first].wave < P.steps[s].wave) {
             free_list.push_back(busy.top().second);
             busy.pop();
             live--;
@@ -439,8 +462,10 @@ void HEVM::build_plan()
         const size_t cmax = (size_t)boot_tmax + 1;
         DC_HIP_CHECK(hipMalloc(&P.boot_ue, bc * 3 * cmax * N * sizeof(u64)));
         DC_HIP_CHECK(hipMalloc(&P.boot_tmp, bc * 2 * cmax * N * sizeof(u64)));
-        DC_HIP_CHECK(hipMalloc(&P.boot_pt, std::max<size_t>(need_bpt, 1) * N * sizeof(u64)));
-        DC_HIP_CHECK(hipMalloc(&P.boot_ptx, std::max<size_t>(need_bptx, 1) * N * sizeof(u64)));
+        for (int ln = 0; ln < plan_lanes; ln++) {
+            DC_HIP_CHECK(hipMalloc(&P.boot_pt[ln], std::max<size_t>(need_bpt, 1) * N * sizeof(u64)));
+            DC_HIP_CHECK(hipMalloc(&P.boot_ptx[ln], std::max<size_t>(need_bptx, 1) * N * sizeof(u64)));
+        }
         std::vector<BootItem> h_boot(nb);
         std::vector<RsItem> h_brs(nb);
         for (size_t k = 0; k < nb;) { // chunks over the sorted order
@@ -468,15 +493,31 @@ void HEVM::build_plan()
     }
     P.d_ks = upload(h_ks), P.d_mul = upload(h_mul), P.d_rs = upload(h_rs), P.d_ew = upload(h_ew), P.d_sum = upload(h_sum);
     P.d_sum_srcs = upload(h_srcs);
-    for (void *p : { (void *)P.ws.target, (void *)P.ws.digits, (void *)P.ws.ext, (void *)P.ws.acc, (void *)P.ws.tmp, (void *)P.ws.c0perm })
-        if (p) (void)hipFree(p);
     auto alloc = [&](size_t limbs) {
         u64 *d = nullptr;
         DC_HIP_CHECK(hipMalloc(&d, std::max<size_t>(limbs, 1) * N * sizeof(u64)));
         return d;
     };
-    P.ws.target = alloc(need_t), P.ws.digits = alloc(need_d), P.ws.ext = alloc(need_e);
-    P.ws.acc = alloc(need_a), P.ws.tmp = alloc(need_m), P.ws.c0perm = alloc(need_c);
+    for (int ln = 0; ln < 2; ln++) {
+        BatchWs &w = P.ws[ln];
+        for (void *p : { (void *)w.target, (void *)w.digits, (void *)w.ext, (void *)w.acc, (void *)w.tmp, (void *)w.c0perm })
+            if (p) (void)hipFree(p);
+        w = BatchWs{};
+        if (ln >= plan_lanes) continue;
+        w.target = alloc(need_t), w.digits = alloc(need_d), w.ext = alloc(need_e);
+        w.acc = alloc(need_a), w.tmp = alloc(need_m), w.c0perm = alloc(need_c);
+    }
+    {
+        size_t aux_waves = 0;
+        for (size_t i = 0; i < P.steps.size(); i++)
+            if (P.steps[i].lane == 1 && (i == 0 || P.steps[i - 1].wave != P.steps[i].wave || P.steps[i - 1].lane != 1)) aux_waves++;
+        while (P.events.size() < 2 * aux_waves + 2) {
+            hipEvent_t e;
+            DC_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            P.events.push_back(e);
+        }
+        if (aux_waves && !aux_stream) DC_HIP_CHECK(hipStreamCreateWithFlags(&aux_stream, hipStreamNonBlocking));
+    }
     P.n_keyswitch *= S, P.n_ntt *= S;
     P.ready = true;
     if (getenv("DACAPO_HEVM_TRACE")) {
@@ -508,8 +549,9 @@ void HEVM::build_plan()
                     kv.second.first, kv.second.second);
     }
     if (getenv("DACAPO_HEVM_TRACE"))
-        fprintf(stderr, "[dacapo_amd] plan: %zu ops -> %zu pseudo-ops -> %zu steps in %d waves, ~%zu launches, %zu live buffers (%.1f GB pool)\n",
-                ops.size(), O.size(), P.steps.size(), max_wave, P.launches, P.max_live, (double)P.pool.size() * buf_elems * 8 / 1e9);
+        fprintf(stderr, "[dacapo_amd] plan: %zu ops -> %zu pseudo-ops -> %zu steps (%zu on the auxiliary stream) in %d waves, ~%zu launches, %zu live buffers (%.1f GB pool)\n",
+                ops.size(), O.size(), P.steps.size(), (size_t)std::count_if(P.steps.begin(), P.steps.end(), [](const Step &st) { return st.lane == 1; }),
+                max_wave, P.launches, P.max_live, (double)P.pool.size() * buf_elems * 8 / 1e9);
 }
 
 void HEVM::issue_plan(hipStream_t s)
@@ -517,18 +559,38 @@ void HEVM::issue_plan(hipStream_t s)
     Context &c = *ctx;
     Plan &P = plan;
     for (const Plan::BootChunk &bc : P.boot_chunks) plan_zero_encrypt(bc.first, bc.count, bc.target, s);
-    for (const Step &st : P.steps) {
-        switch (st.kind) {
-        case P_ROT: b_rotate_hops(c, P.ws, P.d_ks + st.first, st.count, st.level, s); break;
-        case P_MULCC: b_mul_relin(c, P.ws, P.d_mul + st.first, keys.relin, st.count, st.level, s); break;
-        case P_RESCALE: b_rescale(c, P.ws, P.d_rs + st.first, st.count, st.level, s, P.d_sum_srcs); break;
-        case P_SUM: b_sum(c, P.d_sum + st.first, P.d_sum_srcs, st.count, st.level, s); break;
-        case P_NEG: b_ew(c, EwOp::Neg, P.d_ew + st.first, st.count, 2, 2, st.level, s); break;
-        case P_COPY: b_ew(c, EwOp::Copy, P.d_ew + st.first, st.count, 2, 2, st.level, s); break;
-        case P_MULP: b_ew(c, EwOp::Mul, P.d_ew + st.first, st.count, 2, 1, st.level, s); break;
-        case P_ADDP: b_add_plain(c, P.d_ew + st.first, st.count, st.level, s); break;
-        case P_BOOT: plan_boot_step(st.first, st.count, st.level, st.target, s); break;
+    size_t ev = 0;
+    for (size_t a = 0; a < P.steps.size();) {
+        size_t b = a;
+        bool has_aux = false;
+        while (b < P.steps.size() && P.steps[b].wave == P.steps[a].wave) has_aux |= P.steps[b].lane == 1, b++;
+        if (has_aux) { // fork: the auxiliary stream sees everything the main stream has been given so far
+            DC_HIP_CHECK(hipEventRecord(P.events[ev], s));
+            DC_HIP_CHECK(hipStreamWaitEvent(aux_stream, P.events[ev], 0));
+            ev++;
         }
+        for (size_t i = a; i < b; i++) {
+            const Step &st = P.steps[i];
+            hipStream_t q = st.lane ? aux_stream : s;
+            const BatchWs &w = P.ws[st.lane];
+            switch (st.kind) {
+            case P_ROT: b_rotate_hops(c, w, P.d_ks + st.first, st.count, st.level, q); break;
+            case P_MULCC: b_mul_relin(c, w, P.d_mul + st.first, keys.relin, st.count, st.level, q); break;
+            case P_RESCALE: b_rescale(c, w, P.d_rs + st.first, st.count, st.level, q, P.d_sum_srcs); break;
+            case P_SUM: b_sum(c, P.d_sum + st.first, P.d_sum_srcs, st.count, st.level, q); break;
+            case P_NEG: b_ew(c, EwOp::Neg, P.d_ew + st.first, st.count, 2, 2, st.level, q); break;
+            case P_COPY: b_ew(c, EwOp::Copy, P.d_ew + st.first, st.count, 2, 2, st.level, q); break;
+            case P_MULP: b_ew(c, EwOp::Mul, P.d_ew + st.first, st.count, 2, 1, st.level, q); break;
+            case P_ADDP: b_add_plain(c, P.d_ew + st.first, st.count, st.level, q); break;
+            case P_BOOT: plan_boot_step(st.first, st.count, st.level, st.target, st.lane, q); break;
+            }
+        }
+        if (has_aux) { // join
+            DC_HIP_CHECK(hipEventRecord(P.events[ev], aux_stream));
+            DC_HIP_CHECK(hipStreamWaitEvent(s, P.events[ev], 0));
+            ev++;
+        }
+        a = b;
     }
     bump_epoch(s);
 }
