@@ -2,6 +2,8 @@
 // launch sequence.  Same arithmetic, same order of modular operations per limb as ckks_ops.hip -- only the grid grows
 // by the batch dimension and operands come from a device table of views.  Algorithms: SEAL 4.0
 // Evaluator::switch_key_inplace / rescale_to_next / multiply [SEAL-upstream], reached from SEAL_HEVM.cpp:273,283,315-316.
+#include <stdlib.h>
+
 #include "plan.hpp"
 
 namespace dacapo {
@@ -100,6 +102,12 @@ __global__ __launch_bounds__(kBT) void b_ks_mac_kernel(u64 *__restrict__ acc, co
     *reinterpret_cast<u64x2 *>(ac + ((size_t)1 * (ell + 1) + m) * N + k) = o1;
 }
 
+static bool fuse_mac()
+{
+    static const bool v = !(getenv("DACAPO_KS_FUSE_MAC") && atoi(getenv("DACAPO_KS_FUSE_MAC")) == 0);
+    return v;
+}
+
 // L2..L7 of the key-switch pipeline (fused_ks.hip) once the digits' inverse ROWS phase (L1) has been issued
 template <int MODE>
 static void b_ks_tail(Context &c, const BatchWs &w, const KsItem *items, const void *final_items, const u64 *shared_key, int B, int ell,
@@ -115,18 +123,22 @@ static void b_ks_tail(Context &c, const BatchWs &w, const KsItem *items, const v
         f_ks_lift_fcols(c, w.digits, w.ext, B, ell, s);
     } else
         f_ks_icols_lift_fcols(c, w.digits, w.ext, B, ell, s);
-    launch_ntt_rows_fwd(c, w.ext, (long)N, B * ell * ell, c.ks_prime_idx(ell), 0, ell * ell, s);
-    hipLaunchKernelGGL(b_ks_mac_kernel<MODE>, dim3((unsigned)(N / (2 * kBT)), ell + 1, B), dim3(kBT), 0, s, w.acc, w.ext, w.target, items,
-                       shared_key, ell, K, N, c.logN, c.d_mods);
     u64 *acc_last = w.acc + (size_t)ell * N;
     const long acc_ps = (long)(ell + 1) * (long)N;
-    f_irows_strided(c, acc_last, acc_ps, sp, 1, acc_last, acc_ps, 2 * B, s);
+    if (big || !fuse_mac()) {
+        launch_ntt_rows_fwd(c, w.ext, (long)N, B * ell * ell, c.ks_prime_idx(ell), 0, ell * ell, s);
+        hipLaunchKernelGGL(b_ks_mac_kernel<MODE>, dim3((unsigned)(N / (2 * kBT)), ell + 1, B), dim3(kBT), 0, s, w.acc, w.ext, w.target, items,
+                           shared_key, ell, K, N, c.logN, c.d_mods);
+        f_irows_strided(c, acc_last, acc_ps, sp, 1, acc_last, acc_ps, 2 * B, s);
+    } else // MODE 1: the operand a1*b1 is recomputed from the MulItem table (no tensor launch, see b_mul_relin)
+        f_ks_frows_mac(c, MODE, w.ext, MODE == 1 ? nullptr : w.target, MODE == 1 ? reinterpret_cast<const KsItem *>(final_items) : items,
+                       shared_key, w.acc, B, ell, s);
     if (big) {
         launch_ntt_cols_inv(c, acc_last, acc_ps, 2 * B, nullptr, sp, 1, s);
         f_dr_lift_fcols(c, acc_last, acc_ps, w.tmp, 2 * B, ell, sp, s);
     } else
         f_dr_icols_lift_fcols(c, acc_last, acc_ps, w.tmp, 2 * B, ell, sp, s);
-    f_frows_final(c, MODE, w.tmp, final_items, w.acc, 2 * B, ell, sp, s);
+    f_frows_final(c, (MODE == 1 && !big && fuse_mac()) ? 4 : MODE, w.tmp, final_items, w.acc, 2 * B, ell, sp, s);
 }
 
 void b_rotate_hops(Context &c, const BatchWs &w, const KsItem *d_items, int B, int ell, hipStream_t s)
@@ -138,8 +150,12 @@ void b_rotate_hops(Context &c, const BatchWs &w, const KsItem *d_items, int B, i
 void b_mul_relin(Context &c, const BatchWs &w, const MulItem *d_items, const u64 *relin_key, int B, int ell, hipStream_t s)
 {
     const size_t N = c.N;
-    hipLaunchKernelGGL(b_tensor_kernel, dim3((unsigned)(N / (2 * kBT)), ell, B), dim3(kBT), 0, s, d_items, w.target, ell, N, c.d_mods);
-    f_irows_strided(c, w.target, (long)N, 0, ell, w.digits, (long)N, B * ell, s);
+    const bool big = (long)(N >> 10) * B * ell * ell >= 4096; // same split as b_ks_tail
+    if (big || !fuse_mac()) {
+        hipLaunchKernelGGL(b_tensor_kernel, dim3((unsigned)(N / (2 * kBT)), ell, B), dim3(kBT), 0, s, d_items, w.target, ell, N, c.d_mods);
+        f_irows_strided(c, w.target, (long)N, 0, ell, w.digits, (long)N, B * ell, s);
+    } else // small batches: a1*b1 is formed in the loaders and a0*b0, a0*b1 + a1*b0 in the last kernel's epilogue
+        f_irows_tensor_c2(c, d_items, ell, w.digits, B, s);
     b_ks_tail<1>(c, w, nullptr, d_items, relin_key, B, ell, s);
 }
 

@@ -138,6 +138,19 @@ struct SrcDecrypt { // limb z of c0 + c1*s  (Decryptor::decrypt fused into the f
     }
 };
 
+struct SrcTensorC2 { // limb z = b*ell + i of a1*b1, the c2 of item b's tensor product (ckks_multiply) -- never materialised
+    const MulItem *items;
+    const DModulus *mods;
+    int ell;
+    __device__ int prime(int z) const { return z % ell; }
+    __device__ u64 load(int z, int g, int logN) const
+    {
+        const size_t N = (size_t)1 << logN;
+        const int i = z % ell;
+        const MulItem &it = items[z / ell];
+        return mulmod(it.a.limb(1, i, N)[g], it.b.limb(1, i, N)[g], mods[i]);
+    }
+};
 struct SrcDecryptItems { // limb z = b*ell + i of item b's c0 + c1*s
     const BootItem *items;
     const u64 *sk;
@@ -315,6 +328,34 @@ __global__ __launch_bounds__(kTileThreads) void f_frows_final_kernel(const u64 *
         ntt_tile<K, LOGE, false, false, true>(
             M, tw + ((size_t)i << logN), logN, blockIdx.x, [=](int g) { return in[g]; },
             [=](int g, u64 v) { o[g] = addmod(o[g], mulmod(submod(x[g], v, M.q), inv, M), M.q); }, lds);
+    } else if (MODE == 4) { // relinearisation whose c0, c1 tensor terms are computed here (dst holds nothing yet)
+        const MulItem it = reinterpret_cast<const MulItem *>(items_)[b];
+        const u64 *x = acc + (((size_t)bp) * (cnt + 1) + i) * N;
+        const u64 *a0 = it.a.limb(0, i, N), *a1 = it.a.limb(1, i, N), *b0 = it.b.limb(0, i, N), *b1 = it.b.limb(1, i, N);
+        u64 *o = it.dst.limb(p, i, N);
+        constexpr int E = 1 << LOGE;
+        u64 v[E], base[E];
+        int g[E];
+        auto nost = [](int, u64) {};
+        ntt_tile_x<K, LOGE, false, false, true, false, true>(v, M, tw + ((size_t)i << logN), logN, blockIdx.x,
+                                                             [=](int gi) { return in[gi]; }, nost, lds);
+#pragma unroll
+        for (int j = 0; j < E; j++) g[j] = tile_gidx<K, LOGE, false>(num_passes<LOGE>(K) - 1, logN, blockIdx.x, j);
+        if (p == 0) {
+#pragma unroll
+            for (int j = 0; j < E; j++) base[j] = mulmod(a0[g[j]], b0[g[j]], M);
+        } else {
+#pragma unroll
+            for (int j = 0; j < E; j++) {
+                Acc128 t;
+                t.clear();
+                t.mac(a0[g[j]], b1[g[j]]);
+                t.mac(a1[g[j]], b0[g[j]]);
+                base[j] = t.reduce(M);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < E; j++) o[g[j]] = addmod(base[j], mulmod(submod(x[g[j]], v[j], M.q), inv, M), M.q);
     } else if (MODE == 3) { // one rescale given by value, optionally followed by "+ plaintext" on c0 (Encryptor::encrypt)
         const u64 *x = single.src.limb(p, i, N);
         u64 *o = single.dst.limb(p, i, N);
@@ -340,6 +381,87 @@ __global__ __launch_bounds__(kTileThreads) void f_frows_final_kernel(const u64 *
         rs_operand<E>(op, g, it, srcs, p, i, N, M);
 #pragma unroll
         for (int j = 0; j < E; j++) o[g[j]] = mulmod(submod(op[j], x[j], M.q), inv, M);
+    }
+}
+
+// L3 + L4 + L5 in one launch (latency path): grid = (tiles, l + 2, B).  Workgroup (tile, y, b) owns one ROWS-phase tile of
+// output modulus slot m (y < l: prime y, both accumulators; y = l, l + 1: the special prime, accumulator y - l).  For every
+// digit j it finishes the NTT of the lifted digit (forward ROWS phase, result kept in registers) -- or, for j == m, reads the
+// operand itself, which is already in NTT form -- and multiplies by the key limb at the same coefficients.  The special-prime
+// accumulators continue in registers into the inverse ROWS phase that the mod-down starts with.
+// MODE 0: rotation (operand = c1 of the item through its Galois permutation, key per item); MODE 1: relinearisation.
+template <int K, int LOGE, int MODE>
+__global__ __launch_bounds__(kTileThreads) void f_ks_frows_mac_kernel(const u64 *__restrict__ ext, const u64 *__restrict__ target,
+                                                                       const KsItem *__restrict__ items,
+                                                                       const u64 *__restrict__ shared_key, u64 *__restrict__ acc, int ell,
+                                                                       int Kp, const DModulus *__restrict__ mods,
+                                                                       const u64 *__restrict__ tw, const u64 *__restrict__ itw, int logN)
+{
+    __shared__ __attribute__((aligned(16))) u64 lds[TileGeo<LOGE>::LDS_ELEMS];
+    constexpr int E = 1 << LOGE, NP = num_passes<LOGE>(K);
+    const int y = blockIdx.y, b = blockIdx.z, sp = Kp - 1;
+    const int m = y < ell ? y : ell, psel = y - ell; // psel < 0: both accumulators
+    const int pm = m == ell ? sp : m;
+    const size_t N = (size_t)1 << logN;
+    const DModulus M = mods[pm];
+    const u64 *key = MODE == 0 ? items[b].key : shared_key;
+    int g[E];
+#pragma unroll
+    for (int e = 0; e < E; e++) g[e] = tile_gidx<K, LOGE, false>(NP - 1, logN, blockIdx.x, e);
+    Acc128 a0[E], a1[E];
+#pragma unroll
+    for (int e = 0; e < E; e++) a0[e].clear(), a1[e].clear();
+    auto nost = [](int, u64) {};
+    bool lds_used = false;
+    for (int j = 0; j < ell; j++) {
+        u64 x[E];
+        if (j == m) {
+            if (MODE == 0) {
+                const KsItem &it = items[b];
+                const u64 *c1 = it.src.limb(1, j, N);
+#pragma unroll
+                for (int e = 0; e < E; e++) x[e] = c1[galois_idx((u32)g[e], it.elt, logN)];
+            } else if (target) {
+                const u64 *tg = target + ((size_t)b * ell + j) * N;
+#pragma unroll
+                for (int e = 0; e < E; e++) x[e] = tg[g[e]];
+            } else { // c2 = a1*b1 on the fly (items points at the MulItem table)
+                const MulItem &it = reinterpret_cast<const MulItem *>(items)[b];
+                const u64 *a1 = it.a.limb(1, j, N), *b1 = it.b.limb(1, j, N);
+#pragma unroll
+                for (int e = 0; e < E; e++) x[e] = mulmod(a1[g[e]], b1[g[e]], M);
+            }
+        } else {
+            const u64 *in = ext + (((size_t)b * ell + j) * ell + (m < j ? m : m - 1)) * N;
+            if (lds_used) __syncthreads(); // the previous tile's last LDS image has been read by everyone
+            ntt_tile_x<K, LOGE, false, false, true, false, true>(x, M, tw + ((size_t)pm << logN), logN, blockIdx.x,
+                                                                 [=](int gi) { return in[gi]; }, nost, lds);
+            lds_used = true;
+        }
+        const u64 *k0 = key + (((size_t)j * 2 + 0) * Kp + pm) * N, *k1 = key + (((size_t)j * 2 + 1) * Kp + pm) * N;
+        if (psel != 1) {
+#pragma unroll
+            for (int e = 0; e < E; e++) a0[e].mac(x[e], k0[g[e]]);
+        }
+        if (psel != 0) {
+#pragma unroll
+            for (int e = 0; e < E; e++) a1[e].mac(x[e], k1[g[e]]);
+        }
+    }
+    if (m < ell) {
+        u64 *ac = acc + (size_t)b * 2 * (ell + 1) * N;
+        u64 *o0 = ac + ((size_t)0 * (ell + 1) + m) * N, *o1 = ac + ((size_t)1 * (ell + 1) + m) * N;
+#pragma unroll
+        for (int e = 0; e < E; e++) o0[g[e]] = a0[e].reduce(M), o1[g[e]] = a1[e].reduce(M);
+    } else {
+        u64 r[E];
+#pragma unroll
+        for (int e = 0; e < E; e++) r[e] = psel == 0 ? a0[e].reduce(M) : a1[e].reduce(M);
+        u64 *o = acc + (((size_t)b * 2 + psel) * (ell + 1) + ell) * N;
+        if (lds_used) __syncthreads();
+        auto nold = [](int) -> u64 { return 0; };
+        ntt_tile_x<K, LOGE, false, true, false, true, false>(r, M, itw + ((size_t)sp << logN), logN, blockIdx.x, nold,
+                                                             [=](int gi, u64 v) { o[gi] = v; }, lds);
     }
 }
 
@@ -417,6 +539,10 @@ void f_irows_decrypt(const Context &c, CtView ct, const u64 *sk, int ell, u64 *o
     launch_irows(c, SrcDecrypt{ ct, sk, c.d_mods }, out, (long)c.N, ell, s);
 }
 
+void f_irows_tensor_c2(const Context &c, const MulItem *items, int ell, u64 *out, int B, hipStream_t s)
+{
+    launch_irows(c, SrcTensorC2{ items, c.d_mods, ell }, out, (long)c.N, B * ell, s);
+}
 void f_irows_decrypt_items(const Context &c, const BootItem *items, const u64 *sk, int ell, u64 *out, int B, hipStream_t s)
 {
     launch_irows(c, SrcDecryptItems{ items, sk, c.d_mods, ell }, out, (long)c.N, B * ell, s);
@@ -425,6 +551,20 @@ void f_frows_boot_final(const Context &c, const u64 *ptx, const BootItem *items,
 {
     DC_GEO_SWITCH(c.k2, B * t, hipLaunchKernelGGL((f_frows_boot_final_kernel<KK, LE>), grid, dim3(kTileThreads), 0, s, ptx, items, t,
                                                   c.d_mods, c.d_tw, c.logN));
+}
+
+void f_ks_frows_mac(const Context &c, int mode, const u64 *ext, const u64 *target, const KsItem *items, const u64 *shared_key, u64 *acc,
+                    int B, int ell, hipStream_t s)
+{
+    constexpr int LE = 2; // latency geometry only: large batches keep the three separate launches
+    const dim3 grid((unsigned)(c.N >> TileGeo<LE>::LOG), (unsigned)(ell + 2), (unsigned)B);
+    if (mode == 0) {
+        DC_K_SWITCH(c.k2, hipLaunchKernelGGL((f_ks_frows_mac_kernel<KK, LE, 0>), grid, dim3(kTileThreads), 0, s, ext, target, items, shared_key,
+                                             acc, ell, c.K, c.d_mods, c.d_tw, c.d_itw, c.logN));
+    } else {
+        DC_K_SWITCH(c.k2, hipLaunchKernelGGL((f_ks_frows_mac_kernel<KK, LE, 1>), grid, dim3(kTileThreads), 0, s, ext, target, items, shared_key,
+                                             acc, ell, c.K, c.d_mods, c.d_tw, c.d_itw, c.logN));
+    }
 }
 
 void f_ks_icols_lift_fcols(const Context &c, const u64 *digits, u64 *ext, int B, int ell, hipStream_t s)
@@ -461,6 +601,7 @@ void f_frows_final(const Context &c, int mode, const u64 *tmp, const void *items
     case 0: DC_FINAL(0); break;
     case 1: DC_FINAL(1); break;
     case 2: DC_FINAL(2); break;
+    case 4: DC_FINAL(4); break;
     default: DC_FINAL(3); break;
     }
 #undef DC_FINAL

@@ -73,16 +73,23 @@ void f_irows_rot_c1(const Context &c, const KsItem *items, int ell, u64 *out, in
 void f_irows_rs_last(const Context &c, const RsItem *items, const SumSrc *srcs, int l, u64 *out, int B, hipStream_t s);
 void f_irows_rs_single(const Context &c, CtView src, int l, u64 *out, hipStream_t s);
 void f_irows_decrypt(const Context &c, CtView ct, const u64 *sk, int ell, u64 *out, hipStream_t s);
+// first inverse phase of a1*b1 of every item (the tensor product's c2, computed in the loader)
+void f_irows_tensor_c2(const Context &c, const MulItem *items, int ell, u64 *out, int B, hipStream_t s);
 // batched opcode 10: inverse ROWS phase of c0 + c1*s of every item -> out[B][ell][N] ...
 void f_irows_decrypt_items(const Context &c, const BootItem *items, const u64 *sk, int ell, u64 *out, int B, hipStream_t s);
 // ... and the last forward phase of the re-encoded plaintexts ptx[B][t][N], added to the items' zero-encryptions
 void f_frows_boot_final(const Context &c, const u64 *ptx, const BootItem *items, int B, int t, hipStream_t s);
 void f_ks_icols_lift_fcols(const Context &c, const u64 *digits, u64 *ext, int B, int ell, hipStream_t s);
 void f_dr_icols_lift_fcols(const Context &c, const u64 *last, long last_stride, u64 *tmp, int polys, int cnt, int l, hipStream_t s);
+// L3 + L4 + L5 fused (small batches): second NTT phase of the lifted digits, inner products with the key, first inverse phase of
+// the special-prime accumulators.  mode 0 rotation (items[b].key, operand through the Galois permutation) / 1 relinearisation
+void f_ks_frows_mac(const Context &c, int mode, const u64 *ext, const u64 *target, const KsItem *items, const u64 *shared_key, u64 *acc,
+                    int B, int ell, hipStream_t s);
 // large-batch variants: inverse COLS phase run separately (once per source limb), then base change + forward COLS
 void f_ks_lift_fcols(const Context &c, const u64 *digits, u64 *ext, int B, int ell, hipStream_t s);
 void f_dr_lift_fcols(const Context &c, const u64 *last, long last_stride, u64 *tmp, int polys, int cnt, int l, hipStream_t s);
-// mode 0 rotation / 1 relinearisation / 2 rescale items / 3 one rescale by value (+ optional plaintext added to c0)
+// mode 0 rotation / 1 relinearisation / 2 rescale items / 3 one rescale by value (+ optional plaintext added to c0) /
+// 4 relinearisation with the c0, c1 tensor terms computed in the epilogue (small batches: no tensor launch)
 void f_frows_final(const Context &c, int mode, const u64 *tmp, const void *items, const u64 *acc, int polys, int cnt, int l,
                    hipStream_t s, RsItem single = RsItem{}, const u64 *plain = nullptr, const SumSrc *srcs = nullptr);
 // a single rescale_to_next of `src` (level ell) into dst, optionally adding a level-(ell-1) plaintext to c0: 3 launches

@@ -55,6 +55,27 @@ def test_resnet20_first_layer_bit_exact(vm15, fixture20, tmp_path):
     assert (got.data == want.data).all()
 
 
+def test_resnet20_two_lane_graph_replay(fixture20):
+    """opt-in execution mode: independent steps of a wave on an auxiliary stream, whole plan replayed as one HIP graph"""
+    import os
+
+    from dacapo_amd import runner
+
+    env = {"DACAPO_HEVM_PLAN_LANES": "2", "DACAPO_HEVM_PLAN_GRAPH": "1"}
+    os.environ.update(env)
+    try:
+        hevm = runner.HEVM(seed=0x4845564D + 1, logN=15, num_primes=14)
+    finally:
+        for k in env:
+            os.environ.pop(k)
+    hevm.load_mem(fixture20["cst"], fixture20["hevm"])
+    hevm.setInput(0, fixture20["packed"])
+    for _ in range(2):  # capture + replay
+        hevm.run()
+        out = hevm.getOutput()[0]
+        assert float(np.sqrt(np.mean((out - fixture20["expected"]) ** 2))) < 1e-3
+
+
 def test_resnet20_encrypted_inference_matches_torch(vm15, fixture20):
     hevm, ll = vm15
     hevm.load_mem(fixture20["cst"], fixture20["hevm"])

@@ -277,6 +277,7 @@ def main():
     ap.add_argument("--init-level", type=int, default=3)
     ap.add_argument("--waterline", type=int, default=40)
     ap.add_argument("--rotate-reserve", type=int, default=0)
+    ap.add_argument("--carry-scale", action="store_true")
     ap.add_argument("--no-shadow", action="store_true")
     ap.add_argument("--full", action="store_true", help="also write the real constants (<out>.cst, not committed)")
     ap.add_argument("--seed", type=int, default=1)
@@ -289,7 +290,7 @@ def main():
     src = src.replace('"nt" : 2**16', f'"nt" : 2**{a.slots_log}')
 
     slots = 1 << a.slots_log
-    b = hevm_asm.Builder(slots=slots, waterline=a.waterline, init_level=a.init_level, policy="lazy", boot_level=a.boot_level, rotate_reserve=a.rotate_reserve,
+    b = hevm_asm.Builder(slots=slots, waterline=a.waterline, init_level=a.init_level, policy="lazy", boot_level=a.boot_level, rotate_reserve=a.rotate_reserve, carry_scale=a.carry_scale,
                          shadow=not a.no_shadow)
     stub_torchvision()
     sys.path.insert(0, str(REF / "python/poly"))
