@@ -110,6 +110,49 @@ def truncate_hevm(raw: bytes, num_ops: int):
     return out, lvl[last], scl[last]
 
 
+def unpack_cst(raw: bytes):
+    (n,) = struct.unpack_from("<q", raw, 0)
+    off, out = 8, []
+    for _ in range(n):
+        (ln,) = struct.unpack_from("<q", raw, off)
+        off += 8
+        out.append(np.frombuffer(raw, dtype="<f8", count=ln, offset=off))
+        off += 8 * ln
+    return out
+
+
+def plain_eval(hevm: bytes, cst: bytes, inputs, slots=1 << 14):
+    """What the program computes on cleartext slot vectors (no encryption, no noise): the expected value of a run,
+    opcode semantics of SEAL_HEVM.cpp:268-334 with rescale / modswitch / opcode 10 as identities.  Returns the results."""
+    h = unpack_hevm(hevm)
+    consts = unpack_cst(cst)
+    idx = np.arange(slots)
+    tile = lambda v: np.asarray(v, dtype=np.float64).ravel()[idx % len(np.asarray(v).ravel())]  # noqa: E731
+    reg = {i: tile(v) for i, v in enumerate(inputs)}
+    plain = {}
+    for opc, dst, lhs, rhs in h["ops"].tolist():
+        if opc == OP_ENCODE:
+            plain[dst] = np.ones(slots) if lhs == 0xFFFF else tile(consts[lhs])
+        elif opc == OP_ROTATE:
+            reg[dst] = np.roll(reg[lhs], -(rhs - 65536 if rhs >= 32768 else rhs))
+        elif opc == OP_NEGATE:
+            reg[dst] = -reg[lhs]
+        elif opc in (OP_RESCALE, OP_BOOTSTRAP):
+            reg[dst] = reg[lhs]
+        elif opc == OP_MODSWITCH:
+            if (rhs - 65536 if rhs >= 32768 else rhs) > 0:
+                reg[dst] = reg[lhs]
+        elif opc == OP_ADDCC:
+            reg[dst] = reg[lhs] + reg[rhs]
+        elif opc == OP_ADDCP:
+            reg[dst] = reg[lhs] + plain[rhs]
+        elif opc == OP_MULCC:
+            reg[dst] = reg[lhs] * reg[rhs]
+        elif opc == OP_MULCP:
+            reg[dst] = reg[lhs] * plain[rhs]
+    return [reg[d] for d in h["res_dst"]]
+
+
 def read_fixture(prefix) -> dict:
     """A traced program committed as data (tests/golden/<name>.{hevm.gz,cst.xz,input.npz,json}; written by
     tools/trace_reference_model.py): returns the decompressed `.hevm` / `.cst` bytes, the packed input and metadata."""
@@ -117,10 +160,15 @@ def read_fixture(prefix) -> dict:
     import json
     import lzma
     prefix = str(prefix)
-    z = np.load(prefix + ".input.npz")
-    return {"hevm": gzip.open(prefix + ".hevm.gz").read(), "cst": lzma.open(prefix + ".cst.xz").read(),
-            "meta": json.loads(Path(prefix + ".json").read_text()), "packed": z["packed"], "torch_result": z["torch_result"],
-            "expected": z["expected"]}
+    fx = {"hevm": gzip.open(prefix + ".hevm.gz").read(), "cst": lzma.open(prefix + ".cst.xz").read(),
+          "meta": json.loads(Path(prefix + ".json").read_text())}
+    if Path(prefix + ".input.npz").exists():  # the ResNet fixture
+        z = np.load(prefix + ".input.npz")
+        fx.update(packed=z["packed"], torch_result=z["torch_result"], expected=z["expected"])
+    else:  # benchmark-suite fixtures: inputs as the reference's test script fed them, expected = cleartext evaluation
+        z = np.load(prefix + ".io.npz")
+        fx.update(inputs=[z[f"input{i}"] for i in range(fx["meta"]["num_inputs"])], expected=z["expected"])
+    return fx
 
 
 @dataclass

@@ -104,3 +104,41 @@ def test_lazy_policy_program_runs_on_oracle(oracle_mid, tmp_path):
     got = vm.decrypt_result(0)
     want = b.expected()[0]
     assert np.abs(got - want).max() < 1e-4
+
+
+SUITE = ["SobelFilter", "HarrisCornerDetection", "LinearRegression", "PolynomialRegression", "Multivariate", "MLP"]
+
+
+@pytest.mark.parametrize("name", SUITE)
+def test_suite_fixture_cleartext_evaluation(name):
+    """tests/golden/suite/<name>.*: the reference's examples/benchmarks/<name>.py traced (tools/trace_reference_model.py
+    --suite), with the inputs its examples/tests/<name>.py script fed and the script's own error figure on cleartext"""
+    fx = ha.read_fixture(GOLDEN.parent / "suite" / name)
+    meta = fx["meta"]
+    assert hashlib.sha256(fx["hevm"]).hexdigest() == meta["hevm_sha256"]
+    assert hashlib.sha256(fx["cst"]).hexdigest() == meta["cst_sha256"]
+    h = ha.unpack_hevm(fx["hevm"])
+    assert len(h["arg_level"]) == meta["num_inputs"] == len(fx["inputs"]) and len(h["res_dst"]) == meta["num_results"]
+    assert {ha.OP_NAMES[k]: int((h["ops"][:, 0] == k).sum()) for k in range(11)} == meta["info"]["op_mix"]
+    out = np.stack(ha.plain_eval(fx["hevm"], fx["cst"], fx["inputs"], meta["slots"]))
+    assert out.shape == fx["expected"].shape and np.array_equal(out, fx["expected"])
+    # the reference script compared these outputs with its own numpy/torch computation of the benchmark
+    assert meta["script_rms_on_cleartext"] < 1e-2
+
+
+def test_sobel_suite_program_on_oracle_at_reference_parameters(tmp_path):
+    """the traced SobelFilter under real CKKS arithmetic at N = 2^15, 14 primes (oracle VM) decrypts to the cleartext result"""
+    from oracle.oracle import Oracle
+
+    fx = ha.read_fixture(GOLDEN.parent / "suite" / "SobelFilter")
+    (tmp_path / "p.cst").write_bytes(fx["cst"])
+    (tmp_path / "p.hevm").write_bytes(fx["hevm"])
+    o = Oracle(15, 14)
+    o.keygen(seed=7)
+    vm = OracleVM(o)
+    vm.load(tmp_path / "p.cst", tmp_path / "p.hevm")
+    vm.preprocess()
+    vm.encrypt(0, fx["inputs"][0])
+    vm.run()
+    got = vm.decrypt_result(0)
+    assert np.abs(got - fx["expected"][0]).max() < 1e-5 * max(1.0, np.abs(fx["expected"][0]).max())

@@ -165,9 +165,9 @@ def make_shim(builder: hevm_asm.Builder, inputs):
 
         def eval(self):
             args = []
-            for kind, data in zip(self.params, inputs):
-                assert kind == "c"
-                args.append(Expr(ct=builder.input(data)))
+            for k, kind in enumerate(self.params):
+                assert kind.strip() == "c"
+                args.append(Expr(ct=builder.input(inputs[k] if k < len(inputs) else None)))
             ret = self.fun(*args)
             if isinstance(ret, Expr) or not isinstance(ret, Iterable):
                 ret = [ret]
@@ -186,6 +186,35 @@ def make_shim(builder: hevm_asm.Builder, inputs):
             f.eval()
         return "traced"
 
+    class HEVM:
+        """stand-in for python/hecate/hecate/runner.py:174-271 used when the reference's examples/tests/<name>.py is run
+        against a traced program: inputs are recorded, run() evaluates the program on cleartext (hevm_asm.plain_eval)"""
+
+        def __init__(self, *a, **k):
+            self.inputs, self.out, self.rms, self.hevm_path = {}, None, None, ""
+
+        def load(self, cst_path, hevm_path):
+            self.hevm_path = hevm_path
+
+        def setInput(self, i, data):
+            self.inputs[i] = np.asarray(data, dtype=np.float64).ravel().copy()
+
+        def run(self):
+            prog = state["program"]
+            self.out = np.stack(hevm_asm.plain_eval(prog[1], prog[0], [self.inputs[i] for i in sorted(self.inputs)], builder.slots))
+
+        def getOutput(self):
+            return self.out
+
+        def printer(self, latency, rms, mem_usage=0.0):
+            self.rms = float(np.max(rms)) if np.ndim(rms) else float(rms)
+            state["runner"] = self
+
+        def setDebug(self, enable):
+            pass
+
+    hc.HEVM = HEVM
+    hc.setLibnHW = lambda argv: None
     hc.Expr, hc.Plain, hc.Empty, hc.func, hc.save, hc.bootstrap = Expr, Plain, Empty, func, save, bootstrap
     hc.hecate_dir = str(REF)
     hc._state, hc._inputs = state, inputs
@@ -267,6 +296,62 @@ def ntt_equivalents(b: hevm_asm.Builder):
     return total
 
 
+SUITE = ["SobelFilter", "HarrisCornerDetection", "LinearRegression", "PolynomialRegression", "Multivariate", "MLP"]
+
+
+def trace_suite_program(name, slots_log, waterline, boot_level, out_dir):
+    """One of the non-ResNet benchmarks: trace examples/benchmarks/<name>.py (inputs unknown at trace time), give the
+    program the fewest primes it needs (what the reference's level assignment does), then run the reference's own
+    examples/tests/<name>.py against the traced program evaluated on cleartext to record its inputs, the expected
+    outputs and the error figure the script prints."""
+    slots = 1 << slots_log
+    script = REF / "examples/benchmarks" / f"{name}.py"
+    test = REF / "examples/tests" / f"{name}.py"
+
+    def trace(init_level):
+        b = hevm_asm.Builder(slots=slots, waterline=waterline, init_level=init_level, policy="lazy", boot_level=boot_level,
+                             shadow=False)
+        for m in [k for k in sys.modules if k == "hecate" or k.startswith("poly")]:
+            del sys.modules[m]
+        sys.modules["hecate"] = make_shim(b, [])
+        exec(compile(script.read_text(), str(script), "exec"), {"__name__": "__main__", "__file__": str(script)})
+        return b
+
+    b = trace(13)
+    if not any(op.opcode == hevm_asm.OP_BOOTSTRAP for op in b.ops):
+        slack = min(r.level for r in b.results) - 1
+        if slack > 0:
+            b = trace(13 - slack)
+    cst, hevm, info = b.assemble()
+    hc = sys.modules["hecate"]
+    hc._state["program"] = (cst, hevm)
+    argv, cwd = sys.argv, os.getcwd()
+    sys.argv = [str(test), "dacapo", str(waterline), "SEAL", "CPU"]
+    try:
+        exec(compile(test.read_text(), str(test), "exec"), {"__name__": "__main__", "__file__": str(test)})
+    finally:
+        sys.argv = argv
+        os.chdir(cwd)
+    run = hc._state["runner"]
+    hops, muls, boots = level_histogram(b)
+    meta = {"source": f"examples/benchmarks/{name}.py traced; inputs and error figure from examples/tests/{name}.py run against the "
+                      "cleartext evaluation of the traced program (tools/trace_reference_model.py --suite)",
+            "slots": slots, "waterline": waterline, "init_level": b.init_level, "boot_level": boot_level, "info": info,
+            "num_inputs": len(run.inputs), "num_results": len(b.results), "hops_per_level": {str(k): v for k, v in sorted(hops.items())},
+            "mulcc_per_level": {str(k): v for k, v in sorted(muls.items())}, "bootstraps": boots,
+            "ntt_equivalents": ntt_equivalents(b), "script_rms_on_cleartext": run.rms,
+            "hevm_sha256": hashlib.sha256(hevm).hexdigest(), "cst_sha256": hashlib.sha256(cst).hexdigest()}
+    out = Path(out_dir) / name
+    out.parent.mkdir(parents=True, exist_ok=True)
+    with gzip.GzipFile(str(out) + ".hevm.gz", "wb", mtime=0) as f:
+        f.write(hevm)
+    Path(str(out) + ".cst.xz").write_bytes(lzma.compress(cst, format=lzma.FORMAT_XZ, preset=6))
+    np.savez_compressed(str(out) + ".io.npz", expected=run.out, **{f"input{i}": run.inputs[i] for i in sorted(run.inputs)})
+    Path(str(out) + ".json").write_text(json.dumps(meta, indent=1))
+    print(f"{name:24s} init level {b.init_level:2d}  ops {info['num_ops']:6d}  key switches {sum(hops.values()) + sum(muls.values()):5d}  "
+          f"bootstraps {boots:3d}  script rms on cleartext {run.rms:.3e}")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("model", nargs="?", default="ResNet")
@@ -281,7 +366,18 @@ def main():
     ap.add_argument("--no-shadow", action="store_true")
     ap.add_argument("--full", action="store_true", help="also write the real constants (<out>.cst, not committed)")
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--suite", action="store_true", help="trace the small benchmarks (%s) into <out>/<name>.*" % ", ".join(SUITE))
     a = ap.parse_args()
+    if a.suite:
+        stub_torchvision()
+        sim = types.ModuleType("simfhe")
+        sim.simulate = lambda path: "n/a"
+        sys.modules["simfhe"] = sim
+        os.environ.setdefault("HECATE", str(REF))
+        names = SUITE if a.model == "ResNet" else [a.model]
+        for name in names:
+            trace_suite_program(name, a.slots_log, a.waterline, a.boot_level, a.out)
+        return
 
     script = REF / "examples/benchmarks" / f"{a.model}.py"
     src = script.read_text()
