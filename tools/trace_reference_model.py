@@ -230,12 +230,21 @@ def stub_torchvision():
     sys.modules["torchvision"] = tv
 
 
+MODELS = {  # script name -> (module under poly.models, constructor, weights file, key of the state dict, first convolution)
+    "ResNet": ("ResNet", "resnet20", "resnet20.silu.model", "state_dict", lambda m: m.conv1),
+    # SqueezeNet ("SqueezeNet", "squeezenet", "squeezeNet_silu_avgpool_model", None, m.conv_1.Conv2d) traces, but on a synthetic
+    # image its activations leave the interval of the SiLU polynomial (values ~1e8): it needs real CIFAR-10 inputs
+}
+
+
 def model_input(a, slots):
     """A CIFAR-shaped synthetic image (no dataset in this image): smooth random field in [0,1], normalised and packed
-    exactly as examples/tests/ResNet.py:31,50-69 does, plus the torch model's own answer for it."""
+    exactly as examples/tests/<model>.py does (ResNet.py:31,50-69), plus the torch model's own answer for it."""
+    import importlib
+
     import torch
-    from poly.models.ResNet import resnet20
     from poly.MPCB import CascadeConv, shapeClosure
+    mod, ctor, weights, key, first_conv = MODELS[a.model]
     rng = np.random.default_rng(a.seed)
     coarse = rng.uniform(0.0, 1.0, (3, 6, 6))
     img = torch.nn.functional.interpolate(torch.tensor(coarse)[None], size=(32, 32), mode="bicubic", align_corners=False)[0]
@@ -243,13 +252,16 @@ def model_input(a, slots):
     mean = torch.tensor([0.485, 0.456, 0.406])[:, None, None]
     std = torch.tensor([0.229, 0.224, 0.225])[:, None, None]
     x = ((img - mean) / std)[None].double()
-    model = torch.nn.DataParallel(resnet20())
-    sd = torch.load(str(REF / "examples/data/resnet20.silu.model"), map_location="cpu")
-    model.load_state_dict(sd["state_dict"])
+    model = torch.nn.DataParallel(getattr(importlib.import_module(f"poly.models.{mod}"), ctor)())
+    sd = torch.load(str(REF / "examples/data" / weights), map_location="cpu")
+    if key:
+        model.load_state_dict(sd[key])
+    else:
+        model.module.load_state_dict(sd)
     model = model.eval().double().cpu()
     with torch.no_grad():
         torch_res = model.module(x).numpy()[0]
-    shapes = CascadeConv({"nt": slots, "bb": 32, "ko": 1, "ho": 32, "wo": 32}, model.module.conv1)
+    shapes = CascadeConv({"nt": slots, "bb": 32, "ko": 1, "ho": 32, "wo": 32}, first_conv(model.module))
     packed = np.asarray(shapeClosure(**shapes)["MPP"](x)[0], dtype=np.float64).ravel()
     return x.numpy(), packed, torch_res
 
@@ -420,7 +432,7 @@ def main():
         exp = b.expected()
         meta["expected"] = [[float(x) for x in e[:16]] for e in exp]
         # examples/tests/ResNet.py:76-81 postprocess: first 10 slots * 32 (HE_Linear is traced with scale = 32)
-        got = exp[0][:len(torch_res)] * 32
+        got = exp[0][:torch_res.size].reshape(torch_res.shape) * 32
         meta["plain_vs_torch_rms"] = float(np.sqrt(np.mean((got - torch_res) ** 2)))
         print("plaintext evaluation of the traced program vs torch model: rms", meta["plain_vs_torch_rms"])
         print(" traced:", np.round(got, 4), "\n torch :", np.round(torch_res, 4))
