@@ -76,6 +76,31 @@ def test_resnet20_two_lane_graph_replay(fixture20):
         assert float(np.sqrt(np.mean((out - fixture20["expected"]) ** 2))) < 1e-3
 
 
+def test_resnet20_two_ciphertext_streams(fixture20):
+    """throughput mode: two independent images through one plan (every batched step carries both streams' items, every
+    opcode 10 its own zero-encryption)"""
+    from dacapo_amd import runner
+
+    hevm = runner.HEVM(seed=0x4845564D + 3, logN=15, num_primes=14)
+    hevm.set_streams(2)
+    hevm.load_mem(fixture20["cst"], fixture20["hevm"])
+    flipped = fixture20["packed"][::-1].copy()  # a different (meaningless) image for stream 1: same program, other data
+    from dacapo_amd import hevm_asm as ha
+
+    want1 = ha.plain_eval(fixture20["hevm"], fixture20["cst"], [flipped * 0.5])[0]
+    hevm.select_stream(0)
+    hevm.setInput(0, fixture20["packed"])
+    hevm.select_stream(1)
+    hevm.setInput(0, flipped * 0.5)
+    hevm.run()
+    hevm.select_stream(0)
+    out0 = hevm.getOutput()[0]
+    hevm.select_stream(1)
+    out1 = hevm.getOutput()[0]
+    assert float(np.sqrt(np.mean((out0 - fixture20["expected"]) ** 2))) < 1e-3
+    assert float(np.sqrt(np.mean((out1 - want1) ** 2))) < 1e-3 * max(1.0, float(np.abs(want1).max()))
+
+
 def test_resnet20_encrypted_inference_matches_torch(vm15, fixture20):
     hevm, ll = vm15
     hevm.load_mem(fixture20["cst"], fixture20["hevm"])
