@@ -29,3 +29,13 @@ def oracle_mid():
     o = Oracle(12, 5)
     o.keygen(seed=0x4845564D)
     return o
+
+
+@pytest.fixture(scope="session")
+def oracle_ref():
+    """The reference's parameters (N=2^15, 14 x 60-bit primes, SEAL_HEVM.cpp:39-53) with keys: ~25 s of keygen, shared."""
+    from oracle.oracle import Oracle
+
+    o = Oracle(15, 14)
+    o.keygen(seed=7)
+    return o

@@ -195,3 +195,28 @@ def test_homomorphic_opcodes(oracle_mid, enc):
     # chained: ((x*y rescaled) rotated + itself) at a lower level
     z = o.add(o.rotate(r, 4), r)
     assert np.abs(_dec(o, z) - (np.roll(x * y, -4) + x * y)).max() < tol
+
+
+def test_noise_statistics_against_the_reference_profile(oracle_ref):
+    """The only numbers the reference ships about SEAL's behaviour on this path are the noise figures of
+    /root/reference/profiled_SEAL_CPU.json ("noiseTable": variance the op ADDS to the slot error, times scale^2 = 2^80,
+    per level; consumed by ErrorEstimator.cpp:54-59).  A statistic, not a limb-level vector -- the oracle stays "parity
+    unpinned" -- but an implementation with the wrong rounding rule, secret-key distribution, error width or key-switch
+    structure does not reproduce it:
+      earth.rescale_single  [29041012, 28989829, 30513059, 29249886, ...]  (flat in the level)
+      earth.rotate_single   [1.24e9, 3.05e9, 4.20e9, 5.84e9, ...]          (grows with the level)"""
+    o = oracle_ref
+    rng = np.random.default_rng(0)
+    ref_rescale = [29041012.461168, 28989829.196367, 30513059.012577, 29249886.451856]
+    ref_rotate = [1243767652.125024, 3053517076.303607, 4202768329.642825, 5839542263.660615]
+    s2 = 2.0 ** 80
+    for lvl in (2, 3, 4):
+        x = rng.uniform(-1, 1, o.slots)
+        ct = o.encrypt(o.encode(x, 2.0 ** 40, lvl))
+        fresh = (o.decode(o.decrypt(ct)) - x).var() * s2
+        y = o.rescale(o.mul_plain(ct, o.encode(np.ones(1), 2.0 ** 60, lvl)))
+        added = (o.decode(o.decrypt(y)) - x).var() * s2 - fresh
+        assert abs(added / np.mean(ref_rescale) - 1.0) < 0.15, (lvl, added)
+        r = o.rotate(ct, 1)
+        rot = (o.decode(o.decrypt(r)) - np.roll(x, -1)).var() * s2 - fresh
+        assert 0.3 < rot / ref_rotate[lvl - 1] < 3.0, (lvl, rot)

@@ -126,15 +126,12 @@ def test_suite_fixture_cleartext_evaluation(name):
     assert meta["script_rms_on_cleartext"] < 1e-2
 
 
-def test_sobel_suite_program_on_oracle_at_reference_parameters(tmp_path):
+def test_sobel_suite_program_on_oracle_at_reference_parameters(oracle_ref, tmp_path):
     """the traced SobelFilter under real CKKS arithmetic at N = 2^15, 14 primes (oracle VM) decrypts to the cleartext result"""
-    from oracle.oracle import Oracle
-
     fx = ha.read_fixture(GOLDEN.parent / "suite" / "SobelFilter")
     (tmp_path / "p.cst").write_bytes(fx["cst"])
     (tmp_path / "p.hevm").write_bytes(fx["hevm"])
-    o = Oracle(15, 14)
-    o.keygen(seed=7)
+    o = oracle_ref
     vm = OracleVM(o)
     vm.load(tmp_path / "p.cst", tmp_path / "p.hevm")
     vm.preprocess()
