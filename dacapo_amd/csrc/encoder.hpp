@@ -1,0 +1,23 @@
+// Batched CKKS encoder on the device (encoder.hip).
+#pragma once
+#include "kernels.hpp"
+
+namespace dacapo {
+
+struct EncItem {
+    size_t src_off; // offset (in doubles) of the source vector in the device constant arena
+    u32 len;        // its length; 0 = the all-ones constant of an upscale (EmitHEVM.cpp: lhs 0xFFFF)
+    u32 pad;
+    double fix;     // scale / N
+};
+struct EncTables {
+    double2 *roots = nullptr; // [N] exp(2 pi i bitrev(k) / 2N), as HostEncoder builds it (long double sin/cos)
+    u32 *slot_map = nullptr;  // [N] CKKSEncoder::matrix_reps_index_map_
+};
+
+// P plaintexts of `level` primes: scratch [P][N] complex, out [P][level][N] (NTT form on return).  *d_overflow is set if a
+// coefficient does not fit 120 bits.
+void enc_batch(const Context &c, const EncTables &tb, const double *d_consts, const EncItem *d_items, int P, int level, double2 *scratch,
+               u64 *out, int *d_overflow, hipStream_t s);
+
+} // namespace dacapo

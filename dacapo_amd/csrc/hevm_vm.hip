@@ -421,6 +421,7 @@ void HEVM::init_context(int logN, int K, const u64 *primes)
     if (const char *e = getenv("DACAPO_HEVM_PLAN")) use_plan = atoi(e) != 0;
     if (const char *e = getenv("DACAPO_HEVM_PLAN_GRAPH")) plan_graph = atoi(e) != 0;
     if (const char *e = getenv("DACAPO_HEVM_PLAN_LANES")) plan_lanes = atoi(e) >= 2 ? 2 : 1;
+    if (const char *e = getenv("DACAPO_HEVM_HOST_ENCODER")) host_encoder = atoi(e) != 0;
     if (const char *e = getenv("DACAPO_HEVM_MAX_BATCH")) max_batch = std::max(1, atoi(e));
     lanes.resize((size_t)n_lanes);
     for (int i = 0; i < n_lanes; i++) {
@@ -686,8 +687,7 @@ void HEVM::load_program(const void *data, size_t len, bool header_only)
         ops.resize(config.num_operations);
         take(ops.data(), ops.size() * sizeof(WireOp));
         nct = std::max<size_t>(nct, config.num_ctxt_buffer);
-        for (auto &pl : plains)
-            if (pl.d) (void)hipFree(pl.d);
+        free_plains();
         plains.assign(config.num_ptxt_buffer, Plain{});
     }
     while (ciphers.size() < nct) ciphers.push_back(hevm_ctxt{ nullptr, 0, 0, 0, 1.0 });
@@ -769,10 +769,10 @@ void HEVM::encode_internal(Plain &dst, const double *src, size_t len, int level,
     }
     u64 *stage = W().ks_digits; // always >= 2N elements (Context::new_workspace)
     DC_HIP_CHECK(hipMemcpyAsync(stage, lohi.data(), 2 * N * 8, hipMemcpyHostToDevice, S()));
-    if (dst.d && dst.level != level) {
+    if (dst.d && (dst.level != level || dst.arena)) {
         DC_HIP_CHECK(hipStreamSynchronize(S()));
-        (void)hipFree(dst.d);
-        dst.d = nullptr;
+        if (!dst.arena) (void)hipFree(dst.d);
+        dst.d = nullptr, dst.arena = false;
     }
     if (!dst.d) dst.d = dalloc((size_t)level * N);
     dst.level = level;
@@ -783,15 +783,113 @@ void HEVM::encode_internal(Plain &dst, const double *src, size_t len, int level,
     DC_HIP_CHECK(hipStreamSynchronize(S())); // `lohi` and the staging buffer are reused by the next call
 }
 
+void HEVM::free_plains()
+{
+    for (auto &pl : plains)
+        if (pl.d && !pl.arena) (void)hipFree(pl.d);
+    for (u64 *a : plain_arenas) (void)hipFree(a);
+    plain_arenas.clear();
+    for (auto &pl : plains) pl = Plain{};
+}
+
+// All opcode-0 instructions of the program at once: constants uploaded once, plaintexts grouped by level, each group
+// encoded in chunks by encoder.hip (scatter, logN butterfly launches, round + reduce, NTT) straight into its arena.
+void HEVM::preprocess_device()
+{
+    Context &c = *ctx;
+    const size_t N = c.N;
+    if (!enc_tables.roots) {
+        std::vector<double2> r(N);
+        for (size_t k = 0; k < N; k++) r[k] = make_double2(encoder->roots()[k].real(), encoder->roots()[k].imag());
+        DC_HIP_CHECK(hipMalloc(&enc_tables.roots, N * sizeof(double2)));
+        DC_HIP_CHECK(hipMemcpy(enc_tables.roots, r.data(), N * sizeof(double2), hipMemcpyHostToDevice));
+        DC_HIP_CHECK(hipMalloc(&enc_tables.slot_map, N * sizeof(u32)));
+        DC_HIP_CHECK(hipMemcpy(enc_tables.slot_map, encoder->slot_map().data(), N * sizeof(u32), hipMemcpyHostToDevice));
+    }
+    free_plains();
+    // constants referenced by the program -> one device arena
+    std::vector<size_t> off(buffer.size(), (size_t)-1);
+    std::vector<double> host;
+    std::map<int, std::vector<std::pair<int, EncItem>>> by_level; // level -> (plain register, item)
+    std::vector<long> last_write(plains.size(), -1); // a register encoded more than once keeps its last value
+    for (size_t k = 0; k < ops.size(); k++)
+        if (ops[k].opcode == 0) last_write.at(ops[k].dst) = (long)k;
+    for (size_t k = 0; k < ops.size(); k++) {
+        const WireOp &op = ops[k];
+        if (op.opcode != 0 || last_write[op.dst] != (long)k) continue;
+        const int level = op.rhs >> 10, scale_bits = op.rhs & 0x3FF;
+        if (level < 1 || level > c.max_level()) {
+            fprintf(stderr, "[dacapo_amd] encode: level %d outside 1..%d\n", level, c.max_level());
+            abort();
+        }
+        EncItem it{ 0, 0, 0, pow(2.0, (double)scale_bits) / (double)N };
+        if (op.lhs != 0xFFFF) {
+            const std::vector<double> &src = buffer.at(op.lhs);
+            if (src.empty()) {
+                fprintf(stderr, "[dacapo_amd] encode: constant %u is empty\n", (unsigned)op.lhs);
+                abort();
+            }
+            if (off[op.lhs] == (size_t)-1) {
+                off[op.lhs] = host.size();
+                host.insert(host.end(), src.begin(), src.end());
+            }
+            it.src_off = off[op.lhs], it.len = (u32)src.size();
+        }
+        Plain &pl = plains.at(op.dst);
+        pl.level = level, pl.scale = pow(2.0, (double)scale_bits), pl.arena = true;
+        by_level[level].push_back({ (int)op.dst, it });
+    }
+    if (by_level.empty()) return;
+    double *d_consts = nullptr;
+    DC_HIP_CHECK(hipMalloc(&d_consts, std::max<size_t>(host.size(), 1) * sizeof(double)));
+    if (!host.empty()) DC_HIP_CHECK(hipMemcpy(d_consts, host.data(), host.size() * sizeof(double), hipMemcpyHostToDevice));
+    const int chunk = 1024;
+    double2 *scratch = nullptr;
+    EncItem *d_items = nullptr;
+    int *d_overflow = nullptr;
+    DC_HIP_CHECK(hipMalloc(&scratch, (size_t)chunk * N * sizeof(double2)));
+    DC_HIP_CHECK(hipMalloc(&d_items, (size_t)chunk * sizeof(EncItem)));
+    DC_HIP_CHECK(hipMalloc(&d_overflow, sizeof(int)));
+    DC_HIP_CHECK(hipMemset(d_overflow, 0, sizeof(int)));
+    for (auto &kv : by_level) {
+        const int level = kv.first;
+        const size_t P = kv.second.size();
+        u64 *arena = dalloc(P * (size_t)level * N);
+        plain_arenas.push_back(arena);
+        std::vector<EncItem> items(P);
+        for (size_t k = 0; k < P; k++) {
+            items[k] = kv.second[k].second;
+            plains.at((size_t)kv.second[k].first).d = arena + k * (size_t)level * N;
+        }
+        for (size_t k = 0; k < P; k += (size_t)chunk) {
+            const int cnt = (int)std::min<size_t>((size_t)chunk, P - k);
+            DC_HIP_CHECK(hipMemcpyAsync(d_items, items.data() + k, (size_t)cnt * sizeof(EncItem), hipMemcpyHostToDevice, S()));
+            enc_batch(c, enc_tables, d_consts, d_items, cnt, level, scratch, arena + k * (size_t)level * N, d_overflow, S());
+            DC_HIP_CHECK(hipStreamSynchronize(S())); // d_items is reused by the next chunk
+        }
+    }
+    int overflow = 0;
+    DC_HIP_CHECK(hipMemcpy(&overflow, d_overflow, sizeof(int), hipMemcpyDeviceToHost));
+    (void)hipFree(d_consts), (void)hipFree(scratch), (void)hipFree(d_items), (void)hipFree(d_overflow);
+    if (overflow) {
+        fprintf(stderr, "[dacapo_amd] encode: coefficient does not fit 120 bits (scale too large)\n");
+        abort();
+    }
+}
+
 void HEVM::preprocess()
 {
     plan.ready = false; // plaintext registers may move: item tables of an existing plan would dangle
-    const std::vector<double> identity(1, 1.0); // tiled to all ones, like the reference's identity vector
-    for (const WireOp &op : ops)
-        if (op.opcode == 0) {
-            const std::vector<double> &src = (op.lhs == 0xFFFF) ? identity : buffer.at(op.lhs);
-            encode_internal(plains.at(op.dst), src.data(), src.size(), op.rhs >> 10, op.rhs & 0x3FF);
-        }
+    if (!host_encoder)
+        preprocess_device();
+    else {
+        const std::vector<double> identity(1, 1.0); // tiled to all ones, like the reference's identity vector
+        for (const WireOp &op : ops)
+            if (op.opcode == 0) {
+                const std::vector<double> &src = (op.lhs == 0xFFFF) ? identity : buffer.at(op.lhs);
+                encode_internal(plains.at(op.dst), src.data(), src.size(), op.rhs >> 10, op.rhs & 0x3FF);
+            }
+    }
     // The reference times run() alone (examples/tests/ResNet.py:109-111) after an untimed preprocess(): the execution plan
     // of the loaded program is part of the preparation, not of the run.  (A VM without evaluation keys cannot run anyway.)
     if (use_plan && !debug && n_lanes == 1 && !use_graph && keys.relin && !keys.galois.empty()) build_plan();

@@ -11,6 +11,7 @@
 
 #include "../../include/hevm_abi.h"
 #include "kernels.hpp"
+#include "encoder.hpp"
 #include "plan.hpp"
 
 namespace dacapo {
@@ -45,6 +46,8 @@ class HostEncoder {
     void decode(std::vector<std::complex<double>> &coeffs, double *out) const;
     size_t N, slots;
     int logN;
+    const std::vector<std::complex<double>> &roots() const { return root_; }
+    const std::vector<uint32_t> &slot_map() const { return slot_map_; }
 
   private:
     std::vector<std::complex<double>> root_; // exp(2 pi i bitrev(k) / 2N)
@@ -55,6 +58,7 @@ struct Plain {
     u64 *d = nullptr;
     int level = 0;
     double scale = 1.0;
+    bool arena = false; // d points into HEVM::plain_arenas (batched device encoder): not freed individually
 };
 
 struct KeySet {
@@ -120,6 +124,12 @@ class HEVM {
 
     // program
     std::vector<std::vector<double>> buffer; // constants of the .cst file
+    // batched device encoder (encoder.hip): tables, and the arenas the plaintext registers of the loaded program live in
+    EncTables enc_tables;
+    std::vector<u64 *> plain_arenas;
+    bool host_encoder = false; // DACAPO_HEVM_HOST_ENCODER=1: encode on the host (HostEncoder), one plaintext at a time
+    void preprocess_device();
+    void free_plains();
     WireHeader header{};
     WireConfigBody config{};
     std::vector<WireOp> ops;

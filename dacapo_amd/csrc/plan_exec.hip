@@ -7,7 +7,6 @@
 #include <algorithm>
 #include <map>
 #include <queue>
-#include <string>
 #include <tuple>
 
 #include "hevm_vm.hpp"
@@ -531,14 +530,13 @@ void HEVM::build_plan()
                 e.first++, e.second += (size_t)st.count;
             }
         }
-        if (atoi(getenv("DACAPO_HEVM_TRACE")) >= 2) {
+        if (atoi(getenv("DACAPO_HEVM_TRACE")) >= 2) { // the first 400 steps, one line per wave
             int lastw = -1;
             for (size_t i = 0; i < P.steps.size() && i < 400; i++) {
                 const Step &st = P.steps[i];
-                const int w = O[(size_t)step_pops[i][0]].wave;
-                fprintf(stderr, "%s%s%d/%d", w != lastw ? "\n  w" : " ", w != lastw ? (std::to_string(w) + ": ").c_str() : "", 0, 0);
-                fprintf(stderr, "[%s l%d x%d]", kn[st.kind], st.level, st.count);
-                lastw = w;
+                if (st.wave != lastw) fprintf(stderr, "\n  wave %d:", st.wave);
+                fprintf(stderr, " [%s l%d x%d%s]", kn[st.kind], st.level, st.count, st.lane ? " aux" : "");
+                lastw = st.wave;
             }
             fprintf(stderr, "\n");
         }

@@ -378,3 +378,45 @@ def test_large_batch_path_bit_exact(tmp_path):
     assert got.ell == want.ell and got.scale == want.scale and (got.data == want.data).all()
     res = hevm.getOutput()[0]
     assert np.sqrt(np.mean((res - b.expected()[0]) ** 2)) < 1e-4
+
+
+def test_device_encoder_is_bit_identical_to_host_encoder():
+    """preprocess() encodes every plaintext register in batched device kernels (encoder.hip); DACAPO_HEVM_HOST_ENCODER=1
+    keeps the one-at-a-time host FFT.  Same algorithm, same operation order, no FMA contraction: identical limbs."""
+    import ctypes
+    import os
+
+    from dacapo_amd import hevm_asm as ha
+    from dacapo_amd import lowlevel as ll
+    from dacapo_amd import runner
+
+    rng = np.random.default_rng(9)
+    b = ha.Builder(slots=1 << 12, init_level=5, shadow=False)
+    x = b.input(None)
+    acc = None
+    for n, (ln, sb, amp) in enumerate([(1, 40, 1.0), (7, 40, 3.0), (4096, 60, 1.0), (4096, 30, 1e-3), (5000, 40, 100.0), (16384, 50, 1.0),
+                                       (3, 20, 7.5), (4096, 59, 0.5)]):
+        t = b.mul_plain(x, rng.uniform(-amp, amp, ln), scale_bits=sb, normalise=False)
+        t = b.add_plain(t, rng.uniform(-amp, amp, max(1, ln // 2)))
+        acc = t if acc is None else acc
+    b.output(b.upscale(acc, 20))  # the all-ones constant (lhs 0xFFFF)
+    cst, hv, info = b.assemble()
+    assert info["num_ptxt"] == 17
+    plains = []
+    for host in (False, True):
+        if host:
+            os.environ["DACAPO_HEVM_HOST_ENCODER"] = "1"
+        try:
+            hevm = runner.HEVM(seed=5, logN=13, num_primes=7)
+        finally:
+            os.environ.pop("DACAPO_HEVM_HOST_ENCODER", None)
+        hevm.load_mem(cst, hv)
+        got = []
+        for i in range(info["num_ptxt"]):
+            lvl, sc = ctypes.c_int32(), ctypes.c_double()
+            p = runner.lw.hevm_plain(hevm.vm, i, ctypes.byref(lvl), ctypes.byref(sc))
+            assert p and lvl.value == 5
+            got.append((ll.read_device(p, (lvl.value, hevm.N)), sc.value))
+        plains.append(got)
+    for (a, sa), (h, sh) in zip(*plains):
+        assert sa == sh and (a == h).all()
