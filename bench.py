@@ -54,7 +54,15 @@ def roofline_leg(ll, ctx, limbs=4096, iters=10):
     ms = L.dc_event_elapsed_ms(e0, e1) / iters
     alg_bytes = 2.0 * limbs * N * 8
     gbs = alg_bytes / (ms * 1e-3) / 1e9
-    del buf
+    # what a plain device-to-device copy of the same buffer reaches on this GPU (read + write), for scale
+    dst = ll.DeviceBuffer((limbs, N))
+    L.dc_memcpy_d2d(dst.ptr, buf.ptr, buf.nbytes, None)
+    L.dc_event_record(e0, None)
+    for _ in range(iters):
+        L.dc_memcpy_d2d(dst.ptr, buf.ptr, buf.nbytes, None)
+    L.dc_event_record(e1, None)
+    copy_gbs = 2.0 * buf.nbytes / (L.dc_event_elapsed_ms(e0, e1) / iters * 1e-3) / 1e9
+    del buf, dst
     # HBM bytes per forward NTT of this batch from the PMC passes committed under profiles/ (FETCH_SIZE doubled per the
     # gfx950 correction + WRITE_SIZE, separate rocprofv3 --pmc runs of tools/ntt_only.py); bench.py cannot read counters itself
     traffic = None
@@ -64,7 +72,8 @@ def roofline_leg(ll, ctx, limbs=4096, iters=10):
     return {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
             "traffic": traffic, "kernel": "ntt_phase_kernel<7,COLS,fwd> + ntt_phase_kernel<8,ROWS,fwd> (one forward NTT = both launches)",
             "launch": {"limbs": limbs, "N": N, "algorithmic_bytes": alg_bytes, "avg_us": round(ms * 1e3, 2),
-                       "ntt_per_s": round(limbs / (ms * 1e-3))}}
+                       "ntt_per_s": round(limbs / (ms * 1e-3))},
+            "copy_kernel_gbs": round(copy_gbs, 1), "frac_of_copy": round(gbs / copy_gbs, 4)}
 
 
 def ntt_micro_leg(ll, iters=200):

@@ -53,6 +53,10 @@ void dc_free(void *dptr) { DC_HIP_CHECK(hipFree(dptr)); }
 void dc_memcpy_h2d(void *dst, const void *src, size_t bytes) { DC_HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice)); }
 void dc_memcpy_d2h(void *dst, const void *src, size_t bytes) { DC_HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost)); }
 void dc_memset(void *dst, int value, size_t bytes) { DC_HIP_CHECK(hipMemset(dst, value, bytes)); }
+void dc_memcpy_d2d(void *dst, const void *src, size_t bytes, void *stream)
+{
+    DC_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+}
 void dc_stream_sync(void *stream) { DC_HIP_CHECK(hipStreamSynchronize(S(stream))); }
 
 void dc_set_device(int device) { DC_HIP_CHECK(hipSetDevice(device)); }

@@ -32,6 +32,7 @@ def lib():
         L.dc_memcpy_h2d.argtypes = [vp, vp, C.c_size_t]
         L.dc_memcpy_d2h.argtypes = [vp, vp, C.c_size_t]
         L.dc_memset.argtypes = [vp, i32, C.c_size_t]
+        L.dc_memcpy_d2d.argtypes = [vp, vp, C.c_size_t, vp]
         L.dc_stream_sync.argtypes = [vp]
         L.dc_set_device.argtypes = [i32]
         L.dc_event_create.restype = vp

@@ -42,6 +42,7 @@ void dc_free(void *dptr);
 void dc_memcpy_h2d(void *dst, const void *src, size_t bytes);
 void dc_memcpy_d2h(void *dst, const void *src, size_t bytes);
 void dc_memset(void *dst, int value, size_t bytes);
+void dc_memcpy_d2d(void *dst, const void *src, size_t bytes, void *stream); /* asynchronous on `stream` */
 void dc_stream_sync(void *stream);
 void dc_set_device(int device);  /* hipSetDevice: one process per GPU, call before creating contexts/VMs */
 void dc_device_sync(void);       /* hipDeviceSynchronize */
