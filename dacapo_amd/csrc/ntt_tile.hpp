@@ -104,6 +104,16 @@ __device__ __forceinline__ void ntt_tile_x(u64 (&x)[1 << LOGE], const DModulus M
     constexpr int NP = num_passes<LOGE>(K);
     constexpr int stride = T + kLdsPad;
     static_assert(LOGB >= 0, "sub-transform larger than the tile");
+    // ROWS tiles give each sub-transform SUBT consecutive threads: when that is at most one wavefront, an exchange only moves
+    // data between lanes of the same wave, LDS serves a wave's requests in order, and the workgroup barrier can be replaced by
+    // "my own LDS traffic has drained" (no s_barrier, no waiting for the other three waves).
+    constexpr bool WAVE_LOCAL = !COLS && SUBT <= 64;
+    auto exchange_sync = [&]() {
+        if (WAVE_LOCAL)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        else
+            __syncthreads();
+    };
     const int t = threadIdx.x;
     int b, s;
     if (COLS) {
@@ -198,7 +208,7 @@ __device__ __forceinline__ void ntt_tile_x(u64 (&x)[1 << LOGE], const DModulus M
             }
         } else {
             const int pn = INV ? p - 1 : p + 1;
-            if (!first) __syncthreads(); // everyone has finished reading the previous image
+            if (!first) exchange_sync(); // everyone has finished reading the previous image
 #pragma unroll
             for (int j = 0; j < E; j++) {
                 int s2, j2;
@@ -206,7 +216,7 @@ __device__ __forceinline__ void ntt_tile_x(u64 (&x)[1 << LOGE], const DModulus M
                 const int t2 = COLS ? ((s2 << LOGB) | b) : (b * SUBT + s2);
                 lds[j2 * stride + t2] = x[j];
             }
-            __syncthreads();
+            exchange_sync();
         }
     }
 }
