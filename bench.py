@@ -93,6 +93,33 @@ def ntt_micro_leg(ll, iters=200):
     return {"workload": "single forward NTT, N=2^14, 1 limb", "us_per_ntt_back_to_back": round(us, 2)}
 
 
+def cfg3_leg(ll, iters=5):
+    """BASELINE config 3: one ct x ct multiply + relinearise at N = 2^16, 24 data primes + 1 special (bit-exactness of this
+    size is tests/test_gpu_ops.py::test_baseline_config3_...).  Operands are constant-filled canonical residues: timing only.
+    Algorithmic bytes per SURVEY.md 8(d): (4l [in] + l [target] + 2l(l+1) [key] + 4l [ct RMW]) * P_limb = 708 MiB."""
+    L = ll.lib()
+    logN, K = 16, 25
+    ctx = ll.Context(logN, K)
+    N, ell = 1 << logN, K - 1
+    a, b, d = ll.DeviceBuffer((2, ell, N)), ll.DeviceBuffer((2, ell, N)), ll.DeviceBuffer((2, ell, N))
+    key = ll.DeviceBuffer((K - 1, 2, K, N))
+    for buf, v in ((a, 1), (b, 2), (key, 3)):
+        L.dc_memset(buf.ptr, v, buf.nbytes)
+    st = ell * N
+    L.dc_ct_mul_relin(ctx.h, d.ptr, st, a.ptr, st, b.ptr, st, key.ptr, ell, None)
+    e0, e1 = L.dc_event_create(), L.dc_event_create()
+    L.dc_event_record(e0, None)
+    for _ in range(iters):
+        L.dc_ct_mul_relin(ctx.h, d.ptr, st, a.ptr, st, b.ptr, st, key.ptr, ell, None)
+    L.dc_event_record(e1, None)
+    us = L.dc_event_elapsed_ms(e0, e1) / iters * 1e3
+    alg = (4 * ell + ell + 2 * ell * (ell + 1) + 4 * ell) * N * 8
+    ntts = (ell + 1) * (ell + 2)
+    return {"workload": "ct x ct multiply + relinearise, N=2^16, 24+1 primes, 1 ciphertext pair", "us": round(us, 1),
+            "ntt_equivalents": ntts, "ntt_per_s": round(ntts / (us * 1e-6)), "algorithmic_bytes": alg,
+            "achieved_gbs": round(alg / (us * 1e-6) / 1e9, 1), "frac_of_hbm_peak": round(alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
+
+
 def cpu_baseline_leg(cst: bytes, hv: bytes, image, budget_s=15.0):
     """oracle VM (1 thread) on a prefix of the same program; returns NTT-equivalents/s"""
     import tempfile
@@ -226,6 +253,7 @@ def main():
     ctx = ll.Context(15, 14)
     roof = roofline_leg(ll, ctx)
     micro = ntt_micro_leg(ll)
+    cfg3 = cfg3_leg(ll)
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline_leg(cst, hv, image)
@@ -247,6 +275,7 @@ def main():
         "decrypted_error": rms,
         "roofline": roof,
         "ntt_micro": micro,
+        "cfg3_mul_relin": cfg3,
         "cpu_baseline": cpu,
     }
     if cpu:

@@ -2,6 +2,7 @@
 #include "../../include/dacapo_ckks.h"
 
 #include "kernels.hpp"
+#include "plan.hpp"
 
 using namespace dacapo;
 
@@ -9,6 +10,24 @@ using namespace dacapo;
 
 static inline hipStream_t S(void *s) { return (hipStream_t)s; }
 static inline CtView V(const uint64_t *p, long stride) { return CtView{ const_cast<u64 *>(p), stride }; }
+
+// The composite ops run the same fused launch sequences as the HEVM execution plan (batch_ops.hip, fused_ks.hip) with a batch
+// of one item; the item descriptor goes through a small ring of device slots, written in stream order.  Operands that alias
+// the destination in a way the fused epilogues cannot tolerate fall back to the alias-safe unfused composites (ckks_ops.hip).
+namespace {
+constexpr int kItemSlots = 64;
+constexpr size_t kItemBytes = 128;
+static_assert(sizeof(KsItem) <= kItemBytes && sizeof(MulItem) <= kItemBytes && sizeof(RsItem) <= kItemBytes, "item slot too small");
+void *item_slot(dc_context *ctx, const void *host_item, size_t bytes, hipStream_t s)
+{
+    if (!ctx->item_ring) DC_HIP_CHECK(hipMalloc(&ctx->item_ring, kItemSlots * kItemBytes));
+    char *slot = static_cast<char *>(ctx->item_ring) + (size_t)(ctx->item_next++ % kItemSlots) * kItemBytes;
+    DC_HIP_CHECK(hipMemcpyAsync(slot, host_item, bytes, hipMemcpyHostToDevice, s));
+    return slot;
+}
+BatchWs batch_ws(const Workspace &w) { return BatchWs{ w.ct_tmp, w.ks_digits, w.ks_ext, w.ks_acc, w.ks_tmp, nullptr }; }
+bool overlaps(const uint64_t *a, const uint64_t *b) { return a == b; }
+} // namespace
 
 extern "C" {
 
@@ -29,6 +48,7 @@ dc_context *dc_context_create(int logN, int num_primes, int bit_size, const uint
 }
 void dc_context_destroy(dc_context *ctx)
 {
+    if (ctx && ctx->item_ring) (void)hipFree(ctx->item_ring);
     if (ctx && ctx->owned) delete ctx->c;
     delete ctx;
 }
@@ -116,16 +136,30 @@ void dc_ct_mul_plain(dc_context *ctx, uint64_t *dst, long dst_stride, const uint
 void dc_ct_mul_relin(dc_context *ctx, uint64_t *dst, long dst_stride, const uint64_t *a, long a_stride, const uint64_t *b,
                      long b_stride, const uint64_t *relin_key, int ell, void *stream)
 {
-    mul_relin(*ctx->c, ctx->c->ws0, V(dst, dst_stride), V(a, a_stride), V(b, b_stride), relin_key, ell, S(stream));
+    if (overlaps(dst, a) || overlaps(dst, b)) {
+        mul_relin(*ctx->c, ctx->c->ws0, V(dst, dst_stride), V(a, a_stride), V(b, b_stride), relin_key, ell, S(stream));
+        return;
+    }
+    const MulItem it{ V(a, a_stride), V(b, b_stride), V(dst, dst_stride) };
+    const MulItem *d = static_cast<const MulItem *>(item_slot(ctx, &it, sizeof(it), S(stream)));
+    b_mul_relin(*ctx->c, batch_ws(ctx->c->ws0), d, relin_key, 1, ell, S(stream));
 }
 void dc_ct_rotate_hop(dc_context *ctx, uint64_t *dst, long dst_stride, const uint64_t *src, long src_stride,
                       uint32_t galois_elt, const uint64_t *galois_key, int ell, void *stream)
 {
-    rotate_hop(*ctx->c, ctx->c->ws0, V(dst, dst_stride), V(src, src_stride), galois_elt, galois_key, ell, S(stream));
+    if (overlaps(dst, src)) {
+        rotate_hop(*ctx->c, ctx->c->ws0, V(dst, dst_stride), V(src, src_stride), galois_elt, galois_key, ell, S(stream));
+        return;
+    }
+    const KsItem it{ V(src, src_stride), V(dst, dst_stride), galois_key, galois_elt, 0 };
+    const KsItem *d = static_cast<const KsItem *>(item_slot(ctx, &it, sizeof(it), S(stream)));
+    b_rotate_hops(*ctx->c, batch_ws(ctx->c->ws0), d, 1, ell, S(stream));
 }
 void dc_ct_rescale(dc_context *ctx, uint64_t *dst, long dst_stride, const uint64_t *src, long src_stride, int ell, void *stream)
 {
-    rescale(*ctx->c, ctx->c->ws0, V(dst, dst_stride), V(src, src_stride), ell, S(stream));
+    const RsItem it{ V(src, src_stride), V(dst, dst_stride), 0, 0, nullptr, nullptr }; // element-wise epilogue: in place is fine
+    const RsItem *d = static_cast<const RsItem *>(item_slot(ctx, &it, sizeof(it), S(stream)));
+    b_rescale(*ctx->c, batch_ws(ctx->c->ws0), d, 1, ell, S(stream));
 }
 void dc_ct_modswitch(dc_context *ctx, uint64_t *dst, long dst_stride, const uint64_t *src, long src_stride, int ell, int down,
                      void *stream)
