@@ -420,3 +420,51 @@ def test_device_encoder_is_bit_identical_to_host_encoder():
         plains.append(got)
     for (a, sa), (h, sh) in zip(*plains):
         assert sa == sh and (a == h).all()
+
+
+def test_rescale_operand_expressions_bit_exact(vm13, tmp_path):
+    """Elementwise producers folded into the rescale that consumes them (plan mode; the other modes execute the same
+    program op by op): a 40-term sum of ct*pt products and plain terms (more than one 16-product accumulation round),
+    + plaintext, * plaintext, each combination feeding a rescale; ct*ct -> upscale -> rescale; everything bit-exact."""
+    from dacapo_amd import hevm_asm as ha
+
+    hevm, o, ll = vm13
+    if getattr(hevm, "mode", "plan") == "graph2":
+        pytest.skip("covered by the other three modes")
+    rng = np.random.default_rng(23)
+    xv, yv = rng.uniform(-1, 1, o.slots), rng.uniform(-1, 1, o.slots)
+    b = ha.Builder(slots=o.slots, init_level=6, shadow=True)
+    x, y = b.input(xv), b.input(yv)
+    w = lambda: rng.uniform(-0.2, 0.2, o.slots)  # noqa: E731
+
+    def big_sum():  # single-use, so the whole sum is evaluated inside the rescale's loaders
+        acc = None
+        for k in range(40):
+            src = x if k % 3 else y
+            t = b.mul_plain(src, w(), scale_bits=60, normalise=False) if k % 5 else b.upscale(src, 60)
+            acc = t if acc is None else b.add(acc, t)
+        return acc
+
+    r1 = b.rescale(big_sum())                                              # rescale(sum)
+    r2 = b.rescale(b.add_plain(big_sum(), w()))                            # rescale(sum + pt)
+    r3 = b.rescale(b.mul_plain(b.add_plain(r1, w()), w(), scale_bits=60, normalise=False))  # rescale((ct + pt) * pt)
+    m = b.mul(r1, r2)                                                      # scale 80, level 5
+    r4 = b.rescale(b.upscale(m, 20))                                       # the EVA upscale-then-rescale of a ct*ct product
+    r5 = b.rescale(b.mul_plain(b.negate(r2), w(), scale_bits=60, normalise=False))
+    out = b.add(b.add(b.modswitch(r3, 1), r4), b.modswitch(r5, 1))
+    b.output(out)
+    b.output(r1)  # r1 stays observable although it also feeds folded expressions
+    cst, hv, info = b.assemble()
+    hevm.load_mem(cst, hv)
+    ovm = _mirror_vm(hevm, ll, o, cst, hv, tmp_path)
+    hevm.setInput(0, xv)
+    hevm.setInput(1, yv)
+    ovm.ciphers[0], ovm.ciphers[1] = _get_ct(hevm, ll, 0), _get_ct(hevm, ll, 1)
+    hevm.run()
+    ovm.run()
+    for r in ovm.prog.res_dst:
+        got, want = _get_ct(hevm, ll, r), ovm.ciphers[r]
+        assert got.ell == want.ell and got.scale == want.scale and (got.data == want.data).all()
+    res = hevm.getOutput()
+    for k, ref in enumerate(b.expected()):
+        assert np.sqrt(np.mean((res[k] - ref) ** 2)) < 1e-5 * max(1.0, np.abs(ref).max())
