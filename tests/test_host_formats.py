@@ -88,3 +88,32 @@ def test_outputs_keep_their_registers_when_used_afterwards():
     assert len(set(prog.res_dst)) == 2
     writes_after = [op for op in prog.ops[[i for i, o in enumerate(prog.ops) if o[0] == 9][0] + 1:] if op[0] != 0 and op[1] == prog.res_dst[0]]
     assert not writes_after  # nothing overwrites the first result's register
+
+
+def test_headers_are_plain_c_and_link_against_the_library(tmp_path):
+    """the drop-in boundary is a C ABI: include/*.h compile as C99 (no C++ or torch types in any signature) and a C caller
+    that references every declared function links against dacapo_amd/lib/libSEAL_HEVM.so (no GPU needed to link)"""
+    import re
+    import shutil
+    import subprocess
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    lib = root / "dacapo_amd" / "lib" / "libSEAL_HEVM.so"
+    if not lib.exists() or not shutil.which("gcc"):
+        import pytest
+
+        pytest.skip("library not built or no gcc")
+    names = []
+    for h in ("hevm_abi.h", "dacapo_ckks.h"):
+        text = (root / "include" / h).read_text()
+        names += re.findall(r"^[A-Za-z_][\w \*]*?\b(\w+)\s*\(", re.sub(r"/\*.*?\*/", "", text, flags=re.S), flags=re.M)
+    names = sorted({n for n in names if n not in ("defined", "if", "sizeof")})
+    assert len(names) >= 50 and "initFullVM" in names and "dc_ntt_forward" in names
+    src = '#include "hevm_abi.h"\n#include "dacapo_ckks.h"\nvoid *table[] = {\n' + "".join(f"    (void *){n},\n" for n in names) + "};\n"
+    src += "int main(void) { return sizeof(table) == 0; }\n"
+    (tmp_path / "c.c").write_text(src)
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-Wno-pedantic", f"-I{root / 'include'}", "-c", str(tmp_path / "c.c"), "-o",
+                           str(tmp_path / "c.o")])
+    subprocess.check_call(["gcc", str(tmp_path / "c.o"), f"-L{lib.parent}", "-lSEAL_HEVM", "-Wl,--unresolved-symbols=ignore-in-shared-libs",
+                           "-o", str(tmp_path / "c")])
