@@ -81,6 +81,36 @@ __global__ __launch_bounds__(kEncThreads) void enc_round_lift_kernel(u64 *__rest
     }
 }
 
+// ---- decoder: CKKSEncoder::decode's forward special FFT (transform_to_rev: Cooley-Tukey butterflies, root[m + i]) -------------
+// v[N] holds the plaintext coefficients already composed and divided by the scale (real parts; see dec_crt_kernel in
+// hevm_vm.hip).  One launch per stage: group i of m, butterfly j of gap.  grid = (N/2/256)
+__global__ __launch_bounds__(kEncThreads) void dec_stage_kernel(double2 *__restrict__ v, const double2 *__restrict__ roots, size_t N,
+                                                                 unsigned log_gap)
+{
+    const size_t t = (size_t)blockIdx.x * kEncThreads + threadIdx.x;
+    const size_t gap = (size_t)1 << log_gap, i = t >> log_gap, j = t & (gap - 1), m = (N >> 1) >> log_gap;
+    double2 *x = v + 2 * i * gap + j, *y = x + gap;
+    const double2 a = *x, b = cmul(*y, roots[m + i]);
+    *x = make_double2(a.x + b.x, a.y + b.y);
+    *y = make_double2(a.x - b.x, a.y - b.y);
+}
+
+// out[i] = Re v[slot_map[i]] for the N/2 slots.  grid = (N/2/256)
+__global__ __launch_bounds__(kEncThreads) void dec_gather_kernel(double *__restrict__ out, const double2 *__restrict__ v,
+                                                                  const u32 *__restrict__ slot_map)
+{
+    const size_t i = (size_t)blockIdx.x * kEncThreads + threadIdx.x;
+    out[i] = v[slot_map[i]].x;
+}
+
+void dec_fft(const Context &c, const EncTables &tb, double2 *v, double *out, hipStream_t s)
+{
+    const size_t N = c.N;
+    for (int lg = c.logN - 1; lg >= 0; lg--) // m = 1, 2, ..., N/2  <=>  gap = N/2, ..., 1
+        hipLaunchKernelGGL(dec_stage_kernel, dim3((unsigned)(N / 2 / kEncThreads)), dim3(kEncThreads), 0, s, v, tb.roots, N, (unsigned)lg);
+    hipLaunchKernelGGL(dec_gather_kernel, dim3((unsigned)(N / 2 / kEncThreads)), dim3(kEncThreads), 0, s, out, v, tb.slot_map);
+}
+
 void enc_batch(const Context &c, const EncTables &tb, const double *d_consts, const EncItem *d_items, int P, int level, double2 *scratch,
                u64 *out, int *d_overflow, hipStream_t s)
 {

@@ -20,4 +20,7 @@ struct EncTables {
 void enc_batch(const Context &c, const EncTables &tb, const double *d_consts, const EncItem *d_items, int P, int level, double2 *scratch,
                u64 *out, int *d_overflow, hipStream_t s);
 
+// decode: v [N] complex (real parts = plaintext coefficients / scale) -> out [N/2] slot values (real parts), on the device
+void dec_fft(const Context &c, const EncTables &tb, double2 *v, double *out, hipStream_t s);
+
 } // namespace dacapo

@@ -315,6 +315,15 @@ __global__ __launch_bounds__(kVmThreads) void reencode_lift_batch_kernel(u64 *__
     }
 }
 
+// decode, first half (CKKSEncoder::decode_internal): compose every coefficient from its residues, centre it, divide by the scale.
+// grid = (N/256)
+__global__ __launch_bounds__(kVmThreads) void dec_crt_kernel(double2 *__restrict__ v, const u64 *__restrict__ coef, int ell, size_t N,
+                                                              const DModulus *__restrict__ mods, const CrtDev c, double inv_scale)
+{
+    const size_t n = (size_t)blockIdx.x * kVmThreads + threadIdx.x;
+    v[n] = make_double2(crt_centered(coef, n, ell, N, mods, c) * inv_scale, 0.0);
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // CKKSEncoder on the host  [SEAL-upstream ckks.cpp, dwthandler.h]
 // ---------------------------------------------------------------------------------------------------------
@@ -794,10 +803,9 @@ void HEVM::free_plains()
 
 // All opcode-0 instructions of the program at once: constants uploaded once, plaintexts grouped by level, each group
 // encoded in chunks by encoder.hip (scatter, logN butterfly launches, round + reduce, NTT) straight into its arena.
-void HEVM::preprocess_device()
+void HEVM::ensure_enc_tables()
 {
-    Context &c = *ctx;
-    const size_t N = c.N;
+    const size_t N = ctx->N;
     if (!enc_tables.roots) {
         std::vector<double2> r(N);
         for (size_t k = 0; k < N; k++) r[k] = make_double2(encoder->roots()[k].real(), encoder->roots()[k].imag());
@@ -806,6 +814,13 @@ void HEVM::preprocess_device()
         DC_HIP_CHECK(hipMalloc(&enc_tables.slot_map, N * sizeof(u32)));
         DC_HIP_CHECK(hipMemcpy(enc_tables.slot_map, encoder->slot_map().data(), N * sizeof(u32), hipMemcpyHostToDevice));
     }
+}
+
+void HEVM::preprocess_device()
+{
+    Context &c = *ctx;
+    const size_t N = c.N;
+    ensure_enc_tables();
     free_plains();
     // constants referenced by the program -> one device arena
     std::vector<size_t> off(buffer.size(), (size_t)-1);
@@ -946,6 +961,18 @@ void HEVM::decrypt(int64_t i, double *out)
     hipLaunchKernelGGL(decrypt_kernel, dim3((unsigned)(N / (2 * kVmThreads)), (unsigned)ell), dim3(kVmThreads), 0, S(), pt,
                        view(ct), keys.sk, N, c.d_mods);
     launch_ntt(c, true, pt, (long)N, ell, nullptr, 0, 0, S());
+    if (!host_encoder) { // compose + forward special FFT + slot gather on the device; only the N/2 slot values cross PCIe
+        ensure_enc_tables();
+        const CrtTables &tb = crt_tables(ell);
+        const CrtDev cd{ tb.inv, tb.mmod, tb.hmod, tb.hdig, tb.mdbl };
+        double2 *v = reinterpret_cast<double2 *>(W().ks_ext); // >= 3K limbs = 3K*N u64 >= 2N doubles
+        double *slots = reinterpret_cast<double *>(W().ks_acc);
+        hipLaunchKernelGGL(dec_crt_kernel, dim3((unsigned)(N / kVmThreads)), dim3(kVmThreads), 0, S(), v, pt, ell, N, c.d_mods, cd, 1.0 / ct.scale);
+        dec_fft(c, enc_tables, v, slots, S());
+        DC_HIP_CHECK(hipMemcpyAsync(out, slots, (N / 2) * sizeof(double), hipMemcpyDeviceToHost, S()));
+        DC_HIP_CHECK(hipStreamSynchronize(S()));
+        return;
+    }
     std::vector<u64> coef((size_t)ell * N);
     DC_HIP_CHECK(hipMemcpyAsync(coef.data(), pt, coef.size() * 8, hipMemcpyDeviceToHost, S()));
     DC_HIP_CHECK(hipStreamSynchronize(S()));

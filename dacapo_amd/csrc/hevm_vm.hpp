@@ -128,6 +128,7 @@ class HEVM {
     EncTables enc_tables;
     std::vector<u64 *> plain_arenas;
     bool host_encoder = false; // DACAPO_HEVM_HOST_ENCODER=1: encode on the host (HostEncoder), one plaintext at a time
+    void ensure_enc_tables();
     void preprocess_device();
     void free_plains();
     WireHeader header{};

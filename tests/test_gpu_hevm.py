@@ -381,8 +381,9 @@ def test_large_batch_path_bit_exact(tmp_path):
 
 
 def test_device_encoder_is_bit_identical_to_host_encoder():
-    """preprocess() encodes every plaintext register in batched device kernels (encoder.hip); DACAPO_HEVM_HOST_ENCODER=1
-    keeps the one-at-a-time host FFT.  Same algorithm, same operation order, no FMA contraction: identical limbs."""
+    """preprocess() encodes every plaintext register in batched device kernels (encoder.hip) and decrypt() decodes on the
+    device; DACAPO_HEVM_HOST_ENCODER=1 keeps the one-at-a-time host FFTs.  Encoder: same algorithm, same operation order,
+    no FMA contraction: identical limbs.  Decoder: same values to 1e-10."""
     import ctypes
     import os
 
@@ -402,7 +403,7 @@ def test_device_encoder_is_bit_identical_to_host_encoder():
     b.output(b.upscale(acc, 20))  # the all-ones constant (lhs 0xFFFF)
     cst, hv, info = b.assemble()
     assert info["num_ptxt"] == 17
-    plains = []
+    plains, decoded = [], []
     for host in (False, True):
         if host:
             os.environ["DACAPO_HEVM_HOST_ENCODER"] = "1"
@@ -418,8 +419,14 @@ def test_device_encoder_is_bit_identical_to_host_encoder():
             assert p and lvl.value == 5
             got.append((ll.read_device(p, (lvl.value, hevm.N)), sc.value))
         plains.append(got)
+        # same seed, same keys, same encryption randomness: the two VMs hold the same ciphertexts, so the outputs differ
+        # only by the decoder (device: Garner digits -> double -> FFT kernels; host: SEAL's multi-precision compose + FFT)
+        hevm.setInput(0, np.linspace(-1, 1, 4096))
+        hevm.run()
+        decoded.append(hevm.getOutput()[0])
     for (a, sa), (h, sh) in zip(*plains):
         assert sa == sh and (a == h).all()
+    assert np.abs(decoded[0]).max() > 1e-3 and np.abs(decoded[0] - decoded[1]).max() < 1e-10 * max(1.0, np.abs(decoded[1]).max())
 
 
 def test_rescale_operand_expressions_bit_exact(vm13, tmp_path):
