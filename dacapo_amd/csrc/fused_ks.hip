@@ -465,6 +465,28 @@ __global__ __launch_bounds__(kTileThreads) void f_ks_frows_mac_kernel(const u64 
     }
 }
 
+// opcode 10, third launch (source at 1 prime, the usual case: a value is re-encrypted when it has run out of primes): z = b*t + k.  The loader re-encodes coefficient g of item b from its decrypted
+// coefficient-domain limbs (CRT compose, conjugate projection, scale, round), reduces it into target prime k, and the tile
+// runs the first forward phase -- reencode_lift_batch_kernel + launch_ntt_cols_fwd without the round trip through ptx.
+template <int K, int LOGE, int ELL>
+__global__ __launch_bounds__(kTileThreads) void f_boot_reencode_fcols_kernel(const u64 *__restrict__ pt, u64 *__restrict__ ptx,
+                                                                              const BootItem *__restrict__ items, int t,
+                                                                              const DModulus *__restrict__ mods, const CrtDev crt,
+                                                                              const u64 *__restrict__ tw, int logN)
+{
+    __shared__ __attribute__((aligned(16))) u64 lds[TileGeo<LOGE>::LDS_ELEMS];
+    const int z = blockIdx.y, k = z % t, b = z / t;
+    const size_t N = (size_t)1 << logN;
+    const double ratio = items[b].ratio;
+    const u64 *cf = pt + (size_t)b * ELL * N;
+    u64 *out = ptx + (size_t)z * N;
+    const DModulus M = mods[k];
+    ntt_tile<K, LOGE, true, false, false>(
+        M, tw + ((size_t)k << logN), logN, blockIdx.x,
+        [=](int g) { return residue_of_double(reencoded_coeff(cf, (size_t)g, ELL, N, mods, crt, ratio), M); },
+        [=](int g, u64 v) { out[g] = v; }, lds);
+}
+
 // opcode 10, last launch: z = b*t + i.  dst.c0 = zenc.c0 + NTT(re-encoded plaintext), dst.c1 = zenc.c1
 template <int K, int LOGE>
 __global__ __launch_bounds__(kTileThreads) void f_frows_boot_final_kernel(const u64 *__restrict__ ptx, const BootItem *__restrict__ items,
@@ -546,6 +568,17 @@ void f_irows_tensor_c2(const Context &c, const MulItem *items, int ell, u64 *out
 void f_irows_decrypt_items(const Context &c, const BootItem *items, const u64 *sk, int ell, u64 *out, int B, hipStream_t s)
 {
     launch_irows(c, SrcDecryptItems{ items, sk, c.d_mods, ell }, out, (long)c.N, B * ell, s);
+}
+void f_boot_reencode_fcols(const Context &c, const u64 *pt, u64 *ptx, const BootItem *items, int B, int ell, int t, CrtDev crt,
+                           hipStream_t s)
+{
+    if (ell == 1) {
+        DC_GEO_SWITCH(c.k1, B * t, hipLaunchKernelGGL((f_boot_reencode_fcols_kernel<KK, LE, 1>), grid, dim3(kTileThreads), 0, s, pt, ptx, items,
+                                                      t, c.d_mods, crt, c.d_tw, c.logN));
+    } else {
+        fprintf(stderr, "[dacapo_amd] f_boot_reencode_fcols: source level %d not instantiated\n", ell);
+        abort();
+    }
 }
 void f_frows_boot_final(const Context &c, const u64 *ptx, const BootItem *items, int B, int t, hipStream_t s)
 {

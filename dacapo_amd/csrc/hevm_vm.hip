@@ -164,31 +164,6 @@ __global__ __launch_bounds__(kVmThreads) void decrypt_kernel(u64 *__restrict__ o
 // mixed-radix digits taken relative to the digits of floor(Q/2) (so small values cancel digit-wise instead of
 // catastrophically), project, scale, round (half away from zero, like std::round in CKKSEncoder::encode) and emit
 // the 128-bit two's-complement integer that lift_i128_kernel reduces into the target primes.
-struct CrtDev {
-    const u64 *inv;  // [ell]       (q_0...q_{k-1})^{-1} mod q_k
-    const u64 *mmod; // [ell][ell]  (q_0...q_{i-1}) mod q_k at [i*ell+k]
-    const u64 *hmod; // [ell]       floor(Q/2) mod q_k
-    const u64 *hdig; // [ell]       mixed-radix digits of floor(Q/2)
-    const double *mdbl; // [ell]    (double)(q_0...q_{k-1})
-};
-constexpr int kMaxCrt = 32;
-
-__device__ inline double crt_centered(const u64 *__restrict__ coef, size_t n, int ell, size_t N,
-                                      const DModulus *__restrict__ mods, const CrtDev c)
-{
-    u64 v[kMaxCrt];
-    double acc = 0.0;
-    for (int k = 0; k < ell; k++) {
-        const DModulus M = mods[k];
-        u64 s = 0;
-        for (int i = 0; i < k; i++) s = addmod(s, mulmod(v[i], c.mmod[i * ell + k], M), M.q);
-        const u64 y = addmod(coef[(size_t)k * N + n], c.hmod[k], M.q);
-        v[k] = mulmod(submod(y, s, M.q), c.inv[k], M);
-    }
-    for (int k = ell - 1; k >= 0; k--) acc += (double)((long long)v[k] - (long long)c.hdig[k]) * c.mdbl[k];
-    return acc;
-}
-
 __device__ inline void store_i128(u64 *lo, u64 *hi, size_t idx, double x)
 { // x is integral, |x| < 2^120
     const bool neg = x < 0.0;
@@ -1338,9 +1313,13 @@ void HEVM::plan_boot_step(int first, int B, int ell, int t, int lane, hipStream_
     u64 *pt = P.boot_pt[lane], *ptx = P.boot_ptx[lane];
     f_irows_decrypt_items(c, items, keys.sk, ell, pt, B, s);
     launch_ntt_cols_inv(c, pt, (long)N, B * ell, nullptr, 0, ell, s);
-    hipLaunchKernelGGL(reencode_lift_batch_kernel, dim3((unsigned)((N / 2 + kVmThreads) / kVmThreads), (unsigned)B), dim3(kVmThreads), 0, s,
-                       ptx, pt, items, ell, t, N, c.d_mods, cd);
-    launch_ntt_cols_fwd(c, ptx, (long)N, B * t, nullptr, 0, t, s);
+    if (ell == 1) // trivial composition: re-encode inside the first forward phase's loader (4 launches per batch)
+        f_boot_reencode_fcols(c, pt, ptx, items, B, ell, t, cd, s);
+    else {
+        hipLaunchKernelGGL(reencode_lift_batch_kernel, dim3((unsigned)((N / 2 + kVmThreads) / kVmThreads), (unsigned)B), dim3(kVmThreads), 0,
+                           s, ptx, pt, items, ell, t, N, c.d_mods, cd);
+        launch_ntt_cols_fwd(c, ptx, (long)N, B * t, nullptr, 0, t, s);
+    }
     f_frows_boot_final(c, ptx, items, B, t, s);
 }
 

@@ -12,6 +12,7 @@
 //      are bit-identical to the sequential chain.
 // Every kernel takes a device-resident table of per-item views; level/scale bookkeeping is resolved at plan time.
 #pragma once
+#include "crt_device.hpp"
 #include "kernels.hpp"
 
 namespace dacapo {
@@ -77,6 +78,10 @@ void f_irows_decrypt(const Context &c, CtView ct, const u64 *sk, int ell, u64 *o
 void f_irows_tensor_c2(const Context &c, const MulItem *items, int ell, u64 *out, int B, hipStream_t s);
 // batched opcode 10: inverse ROWS phase of c0 + c1*s of every item -> out[B][ell][N] ...
 void f_irows_decrypt_items(const Context &c, const BootItem *items, const u64 *sk, int ell, u64 *out, int B, hipStream_t s);
+// re-encode + reduce + first forward phase in one launch (ell == 1: every target limb recomputes the trivial composition):
+// pt [B][ell][N] coefficient domain -> ptx [B][t][N] after the COLS phase
+void f_boot_reencode_fcols(const Context &c, const u64 *pt, u64 *ptx, const BootItem *items, int B, int ell, int t, CrtDev crt,
+                           hipStream_t s);
 // ... and the last forward phase of the re-encoded plaintexts ptx[B][t][N], added to the items' zero-encryptions
 void f_frows_boot_final(const Context &c, const u64 *ptx, const BootItem *items, int B, int t, hipStream_t s);
 void f_ks_icols_lift_fcols(const Context &c, const u64 *digits, u64 *ext, int B, int ell, hipStream_t s);
