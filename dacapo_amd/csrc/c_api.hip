@@ -25,7 +25,7 @@ void *item_slot(dc_context *ctx, const void *host_item, size_t bytes, hipStream_
     DC_HIP_CHECK(hipMemcpyAsync(slot, host_item, bytes, hipMemcpyHostToDevice, s));
     return slot;
 }
-BatchWs batch_ws(const Workspace &w) { return BatchWs{ w.ct_tmp, w.ks_digits, w.ks_ext, w.ks_acc, w.ks_tmp, nullptr }; }
+BatchWs batch_ws(const Workspace &w) { return BatchWs{ w.ct_tmp, w.ks_digits, w.ks_ext, w.ks_acc, w.ks_tmp }; }
 bool overlaps(const uint64_t *a, const uint64_t *b) { return a == b; }
 } // namespace
 

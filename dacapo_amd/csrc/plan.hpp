@@ -56,7 +56,6 @@ struct BatchWs {
     u64 *ext = nullptr;    // [B][l*l][N]   digits lifted to the other moduli
     u64 *acc = nullptr;    // [B][2][l+1][N]
     u64 *tmp = nullptr;    // [B][2][l][N]
-    u64 *c0perm = nullptr; // [B][l][N]     permuted c0 of a rotation
 };
 
 void b_rotate_hops(Context &c, const BatchWs &w, const KsItem *d_items, int B, int ell, hipStream_t s);

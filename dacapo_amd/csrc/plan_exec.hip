@@ -362,7 +362,7 @@ void HEVM::build_plan()
         }
         return CtView{ b + (size_t)sidx * buf_elems, ps };
     };
-    size_t need_t = 0, need_d = 0, need_e = 0, need_a = 0, need_m = 0, need_c = 0;
+    size_t need_t = 0, need_d = 0, need_e = 0, need_a = 0, need_m = 0;
     size_t need_bpt = 0, need_bptx = 0;
     int boot_tmax = 0;
     std::vector<std::pair<int, int>> h_boot_pops; // (pop, stream) per boot item; device tables are filled once the arena exists
@@ -439,7 +439,7 @@ void HEVM::build_plan()
         }
         if (st.kind == P_ROT || st.kind == P_MULCC) {
             need_t = std::max(need_t, B * l), need_d = std::max(need_d, B * std::max<size_t>(l, 2)), need_e = std::max(need_e, B * l * l);
-            need_a = std::max(need_a, B * 2 * (l + 1)), need_m = std::max(need_m, B * 2 * l), need_c = std::max(need_c, B * l);
+            need_a = std::max(need_a, B * 2 * (l + 1)), need_m = std::max(need_m, B * 2 * l);
             P.launches += 8;
         } else if (st.kind == P_RESCALE) {
             need_d = std::max(need_d, B * 2), need_m = std::max(need_m, B * 2 * l);
@@ -499,12 +499,12 @@ void HEVM::build_plan()
     };
     for (int ln = 0; ln < 2; ln++) {
         BatchWs &w = P.ws[ln];
-        for (void *p : { (void *)w.target, (void *)w.digits, (void *)w.ext, (void *)w.acc, (void *)w.tmp, (void *)w.c0perm })
+        for (void *p : { (void *)w.target, (void *)w.digits, (void *)w.ext, (void *)w.acc, (void *)w.tmp })
             if (p) (void)hipFree(p);
         w = BatchWs{};
         if (ln >= plan_lanes) continue;
         w.target = alloc(need_t), w.digits = alloc(need_d), w.ext = alloc(need_e);
-        w.acc = alloc(need_a), w.tmp = alloc(need_m), w.c0perm = alloc(need_c);
+        w.acc = alloc(need_a), w.tmp = alloc(need_m);
     }
     {
         size_t aux_waves = 0;
