@@ -29,6 +29,36 @@ __device__ __forceinline__ double crt_centered(const u64 *__restrict__ coef, siz
     return acc;
 }
 
+// the same composition with the limb count known at compile time (no local array indexing left after unrolling)
+template <int ELL>
+__device__ __forceinline__ double crt_centered_fixed(const u64 *__restrict__ coef, size_t n, size_t N, const DModulus *__restrict__ mods,
+                                                     const CrtDev c)
+{
+    u64 v[ELL];
+#pragma unroll
+    for (int k = 0; k < ELL; k++) {
+        const DModulus M = mods[k];
+        u64 s = 0;
+#pragma unroll
+        for (int i = 0; i < k; i++) s = addmod(s, mulmod(v[i], c.mmod[i * ELL + k], M), M.q);
+        const u64 y = addmod(coef[(size_t)k * N + n], c.hmod[k], M.q);
+        v[k] = mulmod(submod(y, s, M.q), c.inv[k], M);
+    }
+    double acc = 0.0;
+#pragma unroll
+    for (int k = ELL - 1; k >= 0; k--) acc += (double)((long long)v[k] - (long long)c.hdig[k]) * c.mdbl[k];
+    return acc;
+}
+
+template <int ELL>
+__device__ __forceinline__ double reencoded_coeff_fixed(const u64 *__restrict__ coef, size_t g, size_t N, const DModulus *__restrict__ mods,
+                                                        const CrtDev c, double ratio)
+{
+    if (g == 0) return round(crt_centered_fixed<ELL>(coef, 0, N, mods, c) * ratio);
+    if (g == N / 2) return 0.0;
+    return round((crt_centered_fixed<ELL>(coef, g, N, mods, c) - crt_centered_fixed<ELL>(coef, N - g, N, mods, c)) * 0.5 * ratio);
+}
+
 // residue mod q of an integral double |x| < 2^120 (exact: at most 53 significant bits, shifted)
 __device__ __forceinline__ u64 residue_of_double(double x, const DModulus &M)
 {

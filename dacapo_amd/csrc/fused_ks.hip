@@ -97,6 +97,36 @@ __device__ __forceinline__ void rs_operand(u64 (&v)[E], const int (&g)[E], const
     }
 }
 
+// opcode 10, first launch: Decryptor::decrypt (c0 + c1*s) of every item's operand fused into the first inverse phase.
+// z = b*ell + i.  The operand may be an expression (a rescale folded into the opcode, with what had been folded into it).
+template <int K, int LOGE>
+__global__ __launch_bounds__(kTileThreads) void f_irows_boot_kernel(const BootItem *__restrict__ items, const SumSrc *__restrict__ srcs,
+                                                                     const u64 *__restrict__ sk, int ell, u64 *__restrict__ out,
+                                                                     const DModulus *__restrict__ mods, const u64 *__restrict__ itw,
+                                                                     int logN)
+{
+    __shared__ __attribute__((aligned(16))) u64 lds[TileGeo<LOGE>::LDS_ELEMS];
+    constexpr int E = 1 << LOGE;
+    const int z = blockIdx.y, i = z % ell;
+    const size_t N = (size_t)1 << logN;
+    const BootItem bi = items[z / ell];
+    const RsItem it{ bi.src, bi.dst, bi.first, bi.count, bi.add, bi.mul };
+    const DModulus M = mods[i];
+    const u64 *s = sk + (size_t)i * N;
+    u64 *o = out + (size_t)z * N;
+    int g[E];
+#pragma unroll
+    for (int j = 0; j < E; j++) g[j] = tile_gidx<K, LOGE, false>(num_passes<LOGE>(K) - 1, logN, blockIdx.x, j);
+    u64 x[E], x1[E];
+    rs_operand<E>(x, g, it, srcs, 0, i, N, M);
+    rs_operand<E>(x1, g, it, srcs, 1, i, N, M);
+#pragma unroll
+    for (int j = 0; j < E; j++) x[j] = addmod(x[j], mulmod(x1[j], s[g[j]], M), M.q);
+    auto nold = [](int) -> u64 { return 0; };
+    ntt_tile_x<K, LOGE, false, true, false, true, false>(x, M, itw + ((size_t)i << logN), logN, blockIdx.x, nold,
+                                                         [=](int gi, u64 v) { o[gi] = v; }, lds);
+}
+
 // R1: inverse ROWS phase of the limb a rescale drops.  z = b*2 + p
 template <int K, int LOGE>
 __global__ __launch_bounds__(kTileThreads) void f_irows_rs_kernel(const RsItem *__restrict__ items, const SumSrc *__restrict__ srcs, int l,
@@ -151,22 +181,6 @@ struct SrcTensorC2 { // limb z = b*ell + i of a1*b1, the c2 of item b's tensor p
         return mulmod(it.a.limb(1, i, N)[g], it.b.limb(1, i, N)[g], mods[i]);
     }
 };
-struct SrcDecryptItems { // limb z = b*ell + i of item b's c0 + c1*s
-    const BootItem *items;
-    const u64 *sk;
-    const DModulus *mods;
-    int ell;
-    __device__ int prime(int z) const { return z % ell; }
-    __device__ u64 load(int z, int g, int logN) const
-    {
-        const size_t N = (size_t)1 << logN;
-        const int i = z % ell;
-        const CtView ct = items[z / ell].src;
-        const DModulus M = mods[i];
-        return addmod(ct.limb(0, i, N)[g], mulmod(ct.limb(1, i, N)[g], sk[(size_t)i * N + g], M), M.q);
-    }
-};
-
 // L1 / L5 / R1: inverse ROWS phase, out[z] (lazy values) = phase(src limb z)
 template <int K, int LOGE, class Src>
 __global__ __launch_bounds__(kTileThreads) void f_irows_kernel(Src src, u64 *__restrict__ out, long out_stride,
@@ -465,7 +479,8 @@ __global__ __launch_bounds__(kTileThreads) void f_ks_frows_mac_kernel(const u64 
     }
 }
 
-// opcode 10, third launch (source at 1 prime, the usual case: a value is re-encrypted when it has run out of primes): z = b*t + k.  The loader re-encodes coefficient g of item b from its decrypted
+// opcode 10, third launch (source at 1 prime; with 2 the composition in the loader spills and the separate launches are
+// faster): z = b*t + k.  The loader re-encodes coefficient g of item b from its decrypted
 // coefficient-domain limbs (CRT compose, conjugate projection, scale, round), reduces it into target prime k, and the tile
 // runs the first forward phase -- reencode_lift_batch_kernel + launch_ntt_cols_fwd without the round trip through ptx.
 template <int K, int LOGE, int ELL>
@@ -483,7 +498,7 @@ __global__ __launch_bounds__(kTileThreads) void f_boot_reencode_fcols_kernel(con
     const DModulus M = mods[k];
     ntt_tile<K, LOGE, true, false, false>(
         M, tw + ((size_t)k << logN), logN, blockIdx.x,
-        [=](int g) { return residue_of_double(reencoded_coeff(cf, (size_t)g, ELL, N, mods, crt, ratio), M); },
+        [=](int g) { return residue_of_double(reencoded_coeff_fixed<ELL>(cf, (size_t)g, N, mods, crt, ratio), M); },
         [=](int g, u64 v) { out[g] = v; }, lds);
 }
 
@@ -565,9 +580,11 @@ void f_irows_tensor_c2(const Context &c, const MulItem *items, int ell, u64 *out
 {
     launch_irows(c, SrcTensorC2{ items, c.d_mods, ell }, out, (long)c.N, B * ell, s);
 }
-void f_irows_decrypt_items(const Context &c, const BootItem *items, const u64 *sk, int ell, u64 *out, int B, hipStream_t s)
+void f_irows_decrypt_items(const Context &c, const BootItem *items, const SumSrc *srcs, const u64 *sk, int ell, u64 *out, int B,
+                           hipStream_t s)
 {
-    launch_irows(c, SrcDecryptItems{ items, sk, c.d_mods, ell }, out, (long)c.N, B * ell, s);
+    DC_GEO_SWITCH(c.k2, B * ell, hipLaunchKernelGGL((f_irows_boot_kernel<KK, LE>), grid, dim3(kTileThreads), 0, s, items, srcs, sk, ell, out,
+                                                    c.d_mods, c.d_itw, c.logN));
 }
 void f_boot_reencode_fcols(const Context &c, const u64 *pt, u64 *ptx, const BootItem *items, int B, int ell, int t, CrtDev crt,
                            hipStream_t s)

@@ -406,6 +406,7 @@ void HEVM::init_context(int logN, int K, const u64 *primes)
     if (const char *e = getenv("DACAPO_HEVM_PLAN_GRAPH")) plan_graph = atoi(e) != 0;
     if (const char *e = getenv("DACAPO_HEVM_PLAN_LANES")) plan_lanes = atoi(e) >= 2 ? 2 : 1;
     if (const char *e = getenv("DACAPO_HEVM_HOST_ENCODER")) host_encoder = atoi(e) != 0;
+    if (const char *e = getenv("DACAPO_HEVM_FOLD_RESCALE_BOOT")) fold_rescale_into_boot = atoi(e) != 0;
     if (const char *e = getenv("DACAPO_HEVM_MAX_BATCH")) max_batch = std::max(1, atoi(e));
     lanes.resize((size_t)n_lanes);
     for (int i = 0; i < n_lanes; i++) {
@@ -1311,7 +1312,7 @@ void HEVM::plan_boot_step(int first, int B, int ell, int t, int lane, hipStream_
     const CrtTables &tb = crt_tables(ell);
     const CrtDev cd{ tb.inv, tb.mmod, tb.hmod, tb.hdig, tb.mdbl };
     u64 *pt = P.boot_pt[lane], *ptx = P.boot_ptx[lane];
-    f_irows_decrypt_items(c, items, keys.sk, ell, pt, B, s);
+    f_irows_decrypt_items(c, items, P.d_sum_srcs, keys.sk, ell, pt, B, s);
     launch_ntt_cols_inv(c, pt, (long)N, B * ell, nullptr, 0, ell, s);
     if (ell == 1) // trivial composition: re-encode inside the first forward phase's loader (4 launches per batch)
         f_boot_reencode_fcols(c, pt, ptx, items, B, ell, t, cd, s);

@@ -170,6 +170,8 @@ class HEVM {
         int plain = -1, target_level = 0;
         int rs_add = -1, rs_mul = -1; // P_RESCALE: plain registers of a folded addcp / mulcp (operand = (srcs + add) * mul)
         bool rs_sum = false;          // P_RESCALE: srcs/src_plain are the terms of a folded n-ary sum
+        int boot_drop = -1;           // P_BOOT: prime index of a folded rescale (operand read before the division), or -1
+        double boot_src_scale = 0.0;  // P_BOOT with boot_drop: scale of the folded rescale's result
         bool dead = false;
         int wave = 0, step = -1;
     };
@@ -222,6 +224,7 @@ class HEVM {
     void plan_zero_encrypt(int first, int B, int t, hipStream_t s);
     void plan_boot_step(int first, int B, int ell, int t, int lane, hipStream_t s);
     hipStream_t aux_stream = nullptr;
+    bool fold_rescale_into_boot = true; // DACAPO_HEVM_FOLD_RESCALE_BOOT=0: execute a rescale feeding only an opcode 10
     int plan_lanes = 1; // DACAPO_HEVM_PLAN_LANES=2: independent steps of a wave also use an auxiliary stream (pays off only with PLAN_GRAPH)
     void bump_epoch(hipStream_t s);
 

@@ -46,7 +46,10 @@ struct SumItem {  // dst = sum of `count` terms srcs[first ...]
 struct BootItem { // opcode 10: dst = Enc(re-encode(Dec(src))) = zenc + (plaintext, 0)
     CtView src, dst;
     const u64 *zenc; // fresh public-key encryption of zero at the target level, [2][t][N], made at the start of the run
-    double ratio;    // new_scale / old_scale
+    double ratio;    // new_scale / old_scale (divided by the dropped prime when a rescale has been folded in, see plan_exec.hip)
+    // operand expression like RsItem's: ((src | sum of `count` terms) + add on c0) * mul, decrypted in the first loader
+    int first = 0, count = 0;
+    const u64 *add = nullptr, *mul = nullptr;
 };
 
 // scratch of one batched step, sized for the largest batch of the plan
@@ -76,7 +79,8 @@ void f_irows_decrypt(const Context &c, CtView ct, const u64 *sk, int ell, u64 *o
 // first inverse phase of a1*b1 of every item (the tensor product's c2, computed in the loader)
 void f_irows_tensor_c2(const Context &c, const MulItem *items, int ell, u64 *out, int B, hipStream_t s);
 // batched opcode 10: inverse ROWS phase of c0 + c1*s of every item -> out[B][ell][N] ...
-void f_irows_decrypt_items(const Context &c, const BootItem *items, const u64 *sk, int ell, u64 *out, int B, hipStream_t s);
+void f_irows_decrypt_items(const Context &c, const BootItem *items, const SumSrc *srcs, const u64 *sk, int ell, u64 *out, int B,
+                           hipStream_t s);
 // re-encode + reduce + first forward phase in one launch (ell == 1: every target limb recomputes the trivial composition):
 // pt [B][ell][N] coefficient domain -> ptx [B][t][N] after the COLS phase
 void f_boot_reencode_fcols(const Context &c, const u64 *pt, u64 *ptx, const BootItem *items, int B, int ell, int t, CrtDev crt,

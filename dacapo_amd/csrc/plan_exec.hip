@@ -249,6 +249,25 @@ void HEVM::build_plan()
         }
     }
 
+    // ... and a rescale whose only consumer is an opcode 10 is not executed at all.  Opcode 10 decrypts, re-encodes and
+    // re-encrypts with fresh randomness; decrypt(rescale(x)) = (decrypt(x) - (d0 + d1*s)) / q with |d| <= q/2 the rounding
+    // remainders, i.e. decrypt(x) / q up to a term of a few dozen units in a 2^40-scaled coefficient (1e-11 relative, far
+    // under the ciphertext's own noise), so the re-encoder reads x itself at one prime more and divides by q in its
+    // double-precision step.  (Limb-level equality with the reference never extends past an opcode 10 anyway.)
+    for (Pop &p : O) {
+        if (p.kind != P_BOOT || p.dead || !fold_rescale_into_boot) continue;
+        const int x = p.srcs[0];
+        const Val &sv = V[(size_t)x];
+        const int dp = sv.root == x ? sv.def_pop : -1;
+        if (dp < 0 || O[(size_t)dp].kind != P_RESCALE || O[(size_t)dp].dead || sv.uses != 1 || O[(size_t)dp].dst != x || sv.pinned) continue;
+        Pop &r = O[(size_t)dp];
+        p.srcs = r.srcs, p.src_plain = r.src_plain, p.rs_sum = r.rs_sum, p.rs_add = r.rs_add, p.rs_mul = r.rs_mul;
+        p.level = r.level, p.boot_drop = r.level - 1, p.boot_src_scale = sv.scale;
+        (void)crt_tables(p.level);
+        P.n_ntt -= 2 * r.level;
+        r.dead = true;
+    }
+
     // ---- 3. dataflow depth ------------------------------------------------------------------------------------------
     int max_wave = 0;
     for (Pop &p : O) {
@@ -484,9 +503,25 @@ void HEVM::build_plan()
         for (size_t item = 0; item < nb; item++) {
             const Pop &p = O[(size_t)h_boot_pops[item].first];
             const int q = h_boot_pops[item].second;
-            const Val &sv = V[(size_t)p.srcs[0]];
+            // scale of what is decrypted: the (possibly folded) rescale's result when there is one, else the source value
             const double new_scale = V[(size_t)p.dst].scale;
-            h_boot[item] = BootItem{ view(p.srcs[0], q), view(p.dst, q), P.zenc + item * slot, new_scale / sv.scale };
+            BootItem bi{ view(p.srcs[0], q), view(p.dst, q), P.zenc + item * slot, 1.0 };
+            double src_scale;
+            if (p.boot_drop >= 0) { // new_scale = 2^floor(log2(scale after the rescale)) was fixed by the SSA walk
+                src_scale = p.boot_src_scale * (double)c.primes[(size_t)p.boot_drop];
+            } else
+                src_scale = V[(size_t)p.srcs[0]].scale;
+            bi.ratio = new_scale / src_scale;
+            if (p.rs_sum) {
+                bi.first = (int)h_srcs.size(), bi.count = (int)p.srcs.size();
+                for (size_t k = 0; k < p.srcs.size(); k++) {
+                    const int pl = p.src_plain.empty() ? -1 : p.src_plain[k];
+                    h_srcs.push_back(SumSrc{ view(p.srcs[k], q), pl >= 0 ? plains.at((size_t)pl).d : nullptr });
+                }
+            }
+            if (p.rs_add >= 0) bi.add = plains.at((size_t)p.rs_add).d;
+            if (p.rs_mul >= 0) bi.mul = plains.at((size_t)p.rs_mul).d;
+            h_boot[item] = bi;
         }
         P.d_boot = upload(h_boot), P.d_boot_rs = upload(h_brs);
     }
