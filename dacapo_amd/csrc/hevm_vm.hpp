@@ -224,7 +224,7 @@ class HEVM {
     void plan_zero_encrypt(int first, int B, int t, hipStream_t s);
     void plan_boot_step(int first, int B, int ell, int t, int lane, hipStream_t s);
     hipStream_t aux_stream = nullptr;
-    bool fold_rescale_into_boot = true; // DACAPO_HEVM_FOLD_RESCALE_BOOT=0: execute a rescale feeding only an opcode 10
+    bool fold_rescale_into_boot = false; // DACAPO_HEVM_FOLD_RESCALE_BOOT=1: do a rescale that only feeds an opcode 10 inside its re-encoder
     int plan_lanes = 1; // DACAPO_HEVM_PLAN_LANES=2: independent steps of a wave also use an auxiliary stream (pays off only with PLAN_GRAPH)
     void bump_epoch(hipStream_t s);
 

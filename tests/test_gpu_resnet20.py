@@ -76,6 +76,25 @@ def test_resnet20_two_lane_graph_replay(fixture20):
         assert float(np.sqrt(np.mean((out - fixture20["expected"]) ** 2))) < 1e-3
 
 
+def test_resnet20_rescale_folded_into_opcode10(fixture20):
+    """opt-in: a rescale that only feeds an opcode 10 is done inside its re-encoder; same logits"""
+    import os
+
+    from dacapo_amd import runner
+
+    os.environ["DACAPO_HEVM_FOLD_RESCALE_BOOT"] = "1"
+    try:
+        hevm = runner.HEVM(seed=0x4845564D + 4, logN=15, num_primes=14)
+    finally:
+        os.environ.pop("DACAPO_HEVM_FOLD_RESCALE_BOOT")
+    hevm.load_mem(fixture20["cst"], fixture20["hevm"])
+    hevm.setInput(0, fixture20["packed"])
+    hevm.run()
+    out = hevm.getOutput()[0]
+    assert float(np.sqrt(np.mean((out - fixture20["expected"]) ** 2))) < 1e-3
+    assert hevm.stats()["ntts"] < 55280  # the folded rescales' NTTs are neither executed nor counted
+
+
 def test_resnet20_two_ciphertext_streams(fixture20):
     """throughput mode: two independent images through one plan (every batched step carries both streams' items, every
     opcode 10 its own zero-encryption)"""
