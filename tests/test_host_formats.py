@@ -117,3 +117,53 @@ def test_headers_are_plain_c_and_link_against_the_library(tmp_path):
                            str(tmp_path / "c.o")])
     subprocess.check_call(["gcc", str(tmp_path / "c.o"), f"-L{lib.parent}", "-lSEAL_HEVM", "-Wl,--unresolved-symbols=ignore-in-shared-libs",
                            "-o", str(tmp_path / "c")])
+
+
+def _ref_wire():
+    from pathlib import Path
+
+    p = Path(__file__).resolve().parent.parent / "oracle" / "_ref" / "hevm_wire_ref"
+    return p if p.exists() else None
+
+
+def test_wire_format_against_the_reference_header(tmp_path):
+    """oracle/_ref/hevm_wire_ref is built from the reference's own include/hecate/Support/HEVMHeader.h (the one source of
+    its HEVM path that compiles here) and reads a .hevm file in the order SEAL_HEVM::loadHEVM does (SEAL_HEVM.cpp:202-234).
+    What it sees must be what our assembler wrote and what our reader returns -- for hand-assembled programs and for the
+    traced fixtures."""
+    import gzip
+    import json
+    import subprocess
+    from pathlib import Path
+
+    import pytest
+
+    from dacapo_amd import hevm_asm as ha
+
+    exe = _ref_wire()
+    if exe is None:
+        pytest.skip("oracle/_ref/hevm_wire_ref not built (needs /root/reference at build time)")
+    layout = json.loads(subprocess.check_output([str(exe)]))
+    assert (layout["sizeof_HEVMHeader"], layout["sizeof_ConfigBody"], layout["sizeof_HEVMOperation"]) == (24, 40, 8)
+    assert layout["default_magic"] == ha.MAGIC and layout["offsetof_arg_length"] == 8 and layout["offsetof_init_level"] == 32
+    golden = Path(__file__).resolve().parent / "golden"
+    images = {p.name: gzip.open(p).read() for p in sorted(golden.glob("*.hevm.gz")) + sorted((golden / "suite").glob("*.hevm.gz"))}
+    rng = np.random.default_rng(3)
+    images["sobel"] = ha.sobel_filter(rng.uniform(0, 1, 4096), slots=4096, init_level=6).assemble()[1]
+    images["linreg"] = ha.linear_regression(rng.uniform(-1, 1, 4096), rng.uniform(-1, 1, 4096), slots=4096, init_level=12).assemble()[1]
+    assert len(images) >= 9
+    for name, raw in images.items():
+        (tmp_path / "p.hevm").write_bytes(raw)
+        ref = json.loads(subprocess.check_output([str(exe), str(tmp_path / "p.hevm")]))
+        ours = ha.unpack_hevm(raw)
+        assert ref["complete"] and ref["at_end"], name  # the reference reader consumes the file exactly
+        assert ref["magic_number"] == ha.MAGIC and ref["hevm_header_size"] == 24
+        assert ref["config_body_length"] == 40 + 8 * (2 * len(ours["arg_scale"]) + 3 * len(ours["res_scale"]))
+        for k in ("arg_scale", "arg_level", "res_scale", "res_level", "res_dst", "num_ctxt", "num_ptxt", "init_level"):
+            assert ref[{"num_ctxt": "num_ctxt_buffer", "num_ptxt": "num_ptxt_buffer"}.get(k, k)] == ours[k], (name, k)
+        assert ref["num_operations"] == len(ours["ops"])
+        h = 1469598103934665603
+        for w in ours["ops"].ravel().tolist():
+            h = ((h ^ w) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+        assert ref["ops_fnv1a"] == h, name
+        assert ref["op_counts"][:11] == [int((ours["ops"][:, 0] == k).sum()) for k in range(11)]
