@@ -167,3 +167,27 @@ def test_wire_format_against_the_reference_header(tmp_path):
             h = ((h ^ w) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
         assert ref["ops_fnv1a"] == h, name
         assert ref["op_counts"][:11] == [int((ours["ops"][:, 0] == k).sum()) for k in range(11)]
+
+
+def test_boundary_matches_the_reference_callers_bindings():
+    """tests/golden/runner_bindings.json = what the reference's Python driver binds with ctypes (runner.py:34-71, extracted
+    by tools/extract_runner_bindings.py).  Every one of those 18 symbols is exported by the library and declared in
+    include/hevm_abi.h with a parameter list of the same length and compatible C types, result included."""
+    import json
+
+    spec = json.loads((ROOT / "tests" / "golden" / "runner_bindings.json").read_text())["bindings"]
+    assert len(spec) == 18
+    header = re.sub(r"/\*.*?\*/", "", (ROOT / "include" / "hevm_abi.h").read_text(), flags=re.S)
+    lib = ctypes.CDLL(str(ROOT / "dacapo_amd" / "lib" / "libSEAL_HEVM.so"))
+    ctype_of = {"c_char_p": {"char *", "const char *"}, "c_bool": {"bool"}, "c_void_p": {"void *", "struct hevm_ctxt *", "const void *"},
+                "c_int64": {"int64_t"}, "c_int": {"int", "void"}, "POINTER(c_double)": {"double *", "const double *"}}
+    for name, b in spec.items():
+        assert hasattr(lib, name), name
+        m = re.search(r"^([\w \*]+?)\b" + name + r"\s*\(([^)]*)\)\s*;", header, flags=re.M)
+        assert m, f"{name} not declared in include/hevm_abi.h"
+        ret = m.group(1).strip()
+        params = [re.sub(r"\s*\b\w+$", "", p.strip()).strip() for p in m.group(2).split(",") if p.strip() and p.strip() != "void"]
+        assert len(params) == len(b["argtypes"]), (name, params, b["argtypes"])
+        for have, want in zip(params, b["argtypes"]):
+            assert have.replace(" *", " *") in ctype_of[want], (name, have, want)
+        assert ret in ctype_of[b["restype"]], (name, ret, b["restype"])
