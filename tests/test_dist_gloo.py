@@ -24,13 +24,18 @@ def test_two_rank_gloo_sharding_and_aggregation(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(WORKER % str(ROOT))
     import socket
+    import time
 
-    with socket.socket() as sk:  # a free rendezvous port
-        sk.bind(("127.0.0.1", 0))
-        port = str(sk.getsockname()[1])
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
-    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
-                          "127.0.0.1", "--master-port", port, str(script)], env=env, capture_output=True, text=True, timeout=600)
+    for attempt in range(3):  # the rendezvous port is picked free but can be taken in between: retry with another one
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = str(sk.getsockname()[1])
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+        out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+                              "127.0.0.1", "--master-port", port, str(script)], env=env, capture_output=True, text=True, timeout=600)
+        if out.returncode == 0:
+            break
+        time.sleep(2.0)
     assert out.returncode == 0, out.stderr[-2000:]
     import json
 
