@@ -167,7 +167,7 @@ def cpu_baseline_leg(cst: bytes, hv: bytes, image, budget_s=15.0):
             "reference_published": "README.md:176-188: 53.73 s for the DaCapo-compiled ResNet-20 on SEAL CPU (hardware unstated)"}
 
 
-def main():
+def build_parser():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -178,12 +178,69 @@ def main():
     ap.add_argument("--hevm-gz", default=None, help="--program resnet20: another lowering of the same trace (same constants)")
     ap.add_argument("--layers", type=int, default=20, help="--program shaped: depth (20 = the traced op mix)")
     ap.add_argument("--streams", type=int, default=1, help="independent ciphertext streams per GPU (throughput mode; 1 = the reference's one image per run)")
-    args = ap.parse_args()
+    ap.add_argument("--no-lowerings", action="store_true", help="skip the other lowerings of the trace (config.lowerings)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="exercise the launch / rank / aggregation path without a GPU: no kernel runs, the step is a sleep, the process "
+                         "group uses gloo (tests/test_dist_gloo.py)")
+    return ap
+
+
+def spawn_ranks(args, argv) -> int:
+    """`python bench.py --gpus N` outside a launcher: start N ranks as a CHILD torch.distributed.run (this parent has not touched the
+    GPU and never does -- a process that has initialised HIP must not exec another program on this pool) and hand its exit code back."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = str(sk.getsockname()[1])
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", port, str(Path(__file__).resolve())] + list(argv)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this pool (RCCL needs it)
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run(args, grp):
+    """The rank / barrier / aggregation / JSON path of a real run with the device work replaced by a sleep."""
+    from dacapo_amd import hevm_asm as ha
+    from dacapo_amd import progstats
+
+    fx = ha.read_fixture(ROOT / "tests" / "golden" / "resnet20")
+    st = progstats.walk(fx["hevm"])
+    for _ in range(args.warmup):
+        time.sleep(0.001)
+    grp.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.002)
+    grp.barrier()
+    elapsed = time.perf_counter() - t0
+    elapsed, total = grp.job_totals(elapsed, float(st["ntt_equivalents"]) * args.steps)
+    if grp.rank == 0:
+        print(json.dumps({"metric": "NTT/s (dry run: no kernel executed)", "value": round(total / elapsed, 1), "unit": "NTT/s",
+                          "n_gpus": grp.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "none (dry run)",
+                          "dry_run": True,
+                          "config": {"workload": "dry run", "ntt_equivalents_per_step": st["ntt_equivalents"],
+                                     "parallelism": f"replicas x{grp.world} (no collective in the op path)"}}), flush=True)
+    grp.close()
+
+
+def main():
+    argv = sys.argv[1:]
+    args = build_parser().parse_args(argv)
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(spawn_ranks(args, argv))
 
     from dacapo_amd.dist import Group
 
-    grp = Group(backend="nccl")
+    grp = Group(backend="gloo" if args.dry_run else "nccl")
     rank, local_rank, world = grp.rank, grp.local_rank, grp.world
+    if world != args.gpus and rank == 0:
+        print(f"[bench] --gpus {args.gpus} but the launcher started {world} rank(s): reporting n_gpus = {world}", file=sys.stderr)
+    if args.dry_run:
+        return dry_run(args, grp)
 
     from dacapo_amd import hevm_asm as ha
     from dacapo_amd import lowlevel as ll

@@ -57,3 +57,47 @@ def test_single_process_group_is_a_noop():
     assert g.world == 1 and g.job_totals(0.5, 7.0) == (0.5, 7.0)
     g.barrier()
     g.close()
+
+
+def _bench_lines(args, env=None):
+    import json
+
+    out = subprocess.run([sys.executable, str(ROOT / "bench.py")] + args, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    return [json.loads(ln) for ln in out.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_bench_gpus_flag_starts_the_ranks_itself():
+    """`python bench.py --gpus 2` with no launcher around it: bench.py starts two ranks as a child torch.distributed.run and
+    exactly one JSON line (rank 0's) reports the whole job.  --dry-run replaces the device work by a sleep and RCCL by gloo;
+    argument parsing, rank discovery, barrier, max-over-ranks time and summed work are the real run's code."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    rows = _bench_lines(["--gpus", "2", "--steps", "2", "--warmup", "1", "--dry-run"], env)
+    assert len(rows) == 1
+    r = rows[0]
+    assert r["n_gpus"] == 2 and r["steps"] == 2 and r["scaling"] == "weak" and r["dry_run"] is True
+    # whole-job value: the work of both ranks over the max-over-ranks time
+    per_step = r["config"]["ntt_equivalents_per_step"]
+    assert abs(r["value"] - 2 * per_step * r["steps"] / (r["ms_per_step"] * r["steps"] * 1e-3)) / r["value"] < 1e-3
+
+
+def test_bench_under_an_external_launcher_uses_its_world_size():
+    """the driver's own form: torch.distributed.run ... bench.py --gpus N (RANK set => no second spawn)"""
+    import json
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = str(sk.getsockname()[1])
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                          "--master-port", port, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--dry-run"],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rows = [json.loads(ln) for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(rows) == 1 and rows[0]["n_gpus"] == 2
+
+
+def test_bench_single_rank_dry_run():
+    rows = _bench_lines(["--dry-run"])
+    assert len(rows) == 1 and rows[0]["n_gpus"] == 1
