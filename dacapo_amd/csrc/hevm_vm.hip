@@ -5,9 +5,12 @@
 #include "hevm_vm.hpp"
 
 #include "c_api_types.hpp"
+#include "chacha.hpp"
+#include "seal_serial.hpp"
 
 #include <math.h>
 #include <string.h>
+#include <sys/random.h>
 
 #include <algorithm>
 #include <chrono>
@@ -22,62 +25,91 @@ constexpr int kVmThreads = 256;
 // ---------------------------------------------------------------------------------------------------------
 // device kernels private to the VM: samplers, RNS lift, RLWE glue
 // ---------------------------------------------------------------------------------------------------------
-__host__ __device__ inline u64 sm64(u64 z)
-{
-    z += 0x9E3779B97F4A7C15ull;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    return z ^ (z >> 31);
+// Samplers: every thread owns 8 consecutive coefficients = one ChaCha20 block (chacha.hpp).
+constexpr int kRngCoefs = 8;
+
+__device__ __forceinline__ int rng_cbd(u64 w)
+{ // sample_poly_cbd: 21 - 21 coin flips, sigma = 3.24 [SEAL-upstream clipnormal.h / rlwe.cpp]
+    return __popcll(w & 0x1FFFFF) - __popcll((w >> 21) & 0x1FFFFF);
 }
-// counter-based generator: (seed, S(), index, attempt) -> 64 random bits
-__host__ __device__ inline u64 prng(u64 seed, u64 stream, u64 idx, u64 attempt)
+__device__ __forceinline__ void store_small8(u64 *__restrict__ out, const int (&v)[kRngCoefs], u64 q)
 {
-    return sm64(sm64(sm64(seed ^ (stream * 0xD1342543DE82EF95ull)) + idx) + attempt * 0xA0761D6478BD642Full);
+    u64x2 *o = reinterpret_cast<u64x2 *>(out);
+#pragma unroll
+    for (int e = 0; e < kRngCoefs; e += 2) {
+        u64x2 t;
+        t.x = v[e] < 0 ? q - (u64)(-v[e]) : (u64)v[e];
+        t.y = v[e + 1] < 0 ? q - (u64)(-v[e + 1]) : (u64)v[e + 1];
+        o[e >> 1] = t;
+    }
 }
 
-// uniform residues mod q_i by rejection on 60-bit draws (sample_poly_uniform).  grid = (N/256, limbs)
-__global__ __launch_bounds__(kVmThreads) void sample_uniform_kernel(u64 *__restrict__ out, size_t N, u64 seed, u64 stream,
+// uniform residues mod q_i by rejection on 60-bit draws (sample_poly_uniform); limb i draws from object*64 + i.
+// grid = (N/2048, limbs)
+__global__ __launch_bounds__(kVmThreads) void sample_uniform_kernel(u64 *__restrict__ out, size_t N, ChaChaKey key, u64 object, u32 domain,
                                                                      const DModulus *__restrict__ mods)
 {
     const int i = blockIdx.y;
     const u64 q = mods[i].q;
-    const size_t k = (size_t)blockIdx.x * kVmThreads + threadIdx.x;
-    u64 r, attempt = 0;
-    do r = prng(seed, stream, (u64)i * N + k, attempt++) >> 4;
-    while (r >= q);
-    out[(size_t)i * N + k] = r;
+    const size_t blk = (size_t)blockIdx.x * kVmThreads + threadIdx.x;
+    u64 w[kRngCoefs], r[kRngCoefs];
+    rng_words8(key, object * 64 + (u64)i, blk, 0, 0, domain, w);
+#pragma unroll
+    for (int e = 0; e < kRngCoefs; e++) r[e] = w[e] >> 4;
+    for (u32 attempt = 1; attempt < 256; attempt++) { // a 60-bit draw is >= q with probability ~2^-35: retry that word from a fresh block
+        bool again = false;
+#pragma unroll
+        for (int e = 0; e < kRngCoefs; e++) again |= r[e] >= q;
+        if (!again) break;
+        rng_words8(key, object * 64 + (u64)i, blk, 0, attempt, domain, w);
+#pragma unroll
+        for (int e = 0; e < kRngCoefs; e++)
+            if (r[e] >= q) r[e] = w[e] >> 4;
+    }
+    u64x2 *o = reinterpret_cast<u64x2 *>(out + (size_t)i * N + blk * kRngCoefs);
+#pragma unroll
+    for (int e = 0; e < kRngCoefs; e += 2) o[e >> 1] = u64x2{ r[e], r[e + 1] };
 }
 
-// one small signed polynomial (ternary: sample_poly_ternary; cbd: sample_poly_cbd, 21-21 coin pairs) lifted to the
-// first `limbs` primes.  grid = (N/256, limbs)
-__global__ __launch_bounds__(kVmThreads) void sample_small_kernel(u64 *__restrict__ out, size_t N, int cbd, u64 seed,
-                                                                   u64 stream, const DModulus *__restrict__ mods,
-                                                                   const u64 *__restrict__ epoch)
+// one small signed polynomial (ternary: sample_poly_ternary; cbd: sample_poly_cbd) lifted to the first `limbs` primes.
+// grid = (N/2048)
+__global__ __launch_bounds__(kVmThreads) void sample_small_kernel(u64 *__restrict__ out, size_t N, int limbs, int cbd, ChaChaKey key,
+                                                                   u64 object, u32 domain, const DModulus *__restrict__ mods)
 {
-    const int i = blockIdx.y;
-    const u64 q = mods[i].q;
-    const size_t k = (size_t)blockIdx.x * kVmThreads + threadIdx.x;
-    // `epoch` lives in HBM and is bumped once per run(): a replayed HIP graph still draws fresh encryption randomness
-    const u64 r = prng(seed, stream + (epoch ? (*epoch << 32) : 0), k, 0);
-    int v;
-    if (cbd)
-        v = __popcll(r & 0x1FFFFF) - __popcll((r >> 21) & 0x1FFFFF);
-    else
-        v = (int)(r % 3) - 1;
-    out[(size_t)i * N + k] = v < 0 ? q - (u64)(-v) : (u64)v;
+    const size_t blk = (size_t)blockIdx.x * kVmThreads + threadIdx.x;
+    u64 w[kRngCoefs];
+    rng_words8(key, object, blk, 0, 0, domain, w);
+    int v[kRngCoefs];
+#pragma unroll
+    for (int e = 0; e < kRngCoefs; e++) v[e] = cbd ? rng_cbd(w[e]) : rng_ternary(w[e]);
+    for (int i = 0; i < limbs; i++) store_small8(out + (size_t)i * N + blk * kRngCoefs, v, mods[i].q);
 }
 
-// Encryptor::encrypt randomness in one launch: out[0] = ternary u, out[1], out[2] = centred-binomial e0, e1, each lifted
-// to `cnt` primes.  grid = (N/256, cnt, 3)
-__global__ __launch_bounds__(kVmThreads) void sample_enc_kernel(u64 *__restrict__ out, size_t N, int cnt, u64 seed, u64 stream,
-                                                                 const DModulus *__restrict__ mods, const u64 *__restrict__ epoch)
+// Encryptor::encrypt randomness of B encryptions in one launch: out[b][0] = ternary u, out[b][1], out[b][2] =
+// centred-binomial e0, e1, each lifted to `cnt` primes.  Encryption b draws from object0 + b at the run() epoch kept in HBM
+// (a replayed HIP graph still encrypts with fresh randomness).  grid = (N/2048, 3B)
+__global__ __launch_bounds__(kVmThreads) void sample_enc_batch_kernel(u64 *__restrict__ out, size_t N, int cnt, ChaChaKey key, u64 object0,
+                                                                       const DModulus *__restrict__ mods,
+                                                                       const u64 *__restrict__ epoch)
 {
-    const int i = blockIdx.y, z = blockIdx.z;
-    const u64 q = mods[i].q;
-    const size_t k = (size_t)blockIdx.x * kVmThreads + threadIdx.x;
-    const u64 r = prng(seed, stream + (u64)z + (epoch ? (*epoch << 32) : 0), k, 0);
-    const int v = z ? (__popcll(r & 0x1FFFFF) - __popcll((r >> 21) & 0x1FFFFF)) : ((int)(r % 3) - 1);
-    out[((size_t)z * cnt + i) * N + k] = v < 0 ? q - (u64)(-v) : (u64)v;
+    const int b = blockIdx.y / 3, z = blockIdx.y % 3;
+    const size_t blk = (size_t)blockIdx.x * kVmThreads + threadIdx.x;
+    u64 w[kRngCoefs];
+    rng_words8(key, object0 + (u64)b, blk, *epoch, 0, RNG_ENC_U + (u32)z, w);
+    int v[kRngCoefs];
+#pragma unroll
+    for (int e = 0; e < kRngCoefs; e++) v[e] = z ? rng_cbd(w[e]) : rng_ternary(w[e]);
+    for (int i = 0; i < cnt; i++) store_small8(out + (((size_t)b * 3 + z) * cnt + i) * N + blk * kRngCoefs, v, mods[i].q);
+}
+
+// test hook: `blocks` consecutive ChaCha20 blocks starting at `counter` (16 words each)
+__global__ void chacha_blocks_kernel(u32 *__restrict__ out, ChaChaKey key, u64 counter, u64 nonce, int blocks)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= blocks) return;
+    u32 o[16];
+    chacha20_block(key, counter + (u64)b, nonce, o);
+    for (int i = 0; i < 16; i++) out[b * 16 + i] = o[i];
 }
 
 // signed 128-bit integer coefficients (two's complement, |x| < 2^120) -> residues.  grid = (N/256, ell)
@@ -211,19 +243,6 @@ __global__ __launch_bounds__(kVmThreads) void reencode_kernel(u64 *__restrict__ 
 // Enc(pt) = Enc(0) + (pt, 0): the randomness-dependent half of every opcode 10 of the program does not depend on any
 // ciphertext, so the plan makes all the zero-encryptions in a few large launches at the start of run() and the
 // data-dependent half (decrypt -> re-encode -> NTT -> add) is 5 launches per batch of same-wave items.
-
-// randomness of items first..first+B-1: out[b][z][i] (z = 0: ternary u; 1, 2: centred-binomial e0, e1).  grid = (N/256, cnt, 3B)
-__global__ __launch_bounds__(kVmThreads) void sample_enc_batch_kernel(u64 *__restrict__ out, size_t N, int cnt, u64 seed, u64 stream0,
-                                                                       const DModulus *__restrict__ mods,
-                                                                       const u64 *__restrict__ epoch)
-{
-    const int i = blockIdx.y, b = blockIdx.z / 3, z = blockIdx.z % 3;
-    const u64 q = mods[i].q;
-    const size_t k = (size_t)blockIdx.x * kVmThreads + threadIdx.x;
-    const u64 r = prng(seed, stream0 + 4 * (u64)b + (u64)z + (*epoch << 32), k, 0);
-    const int v = z ? (__popcll(r & 0x1FFFFF) - __popcll((r >> 21) & 0x1FFFFF)) : ((int)(r % 3) - 1);
-    out[(((size_t)b * 3 + z) * cnt + i) * N + k] = v < 0 ? q - (u64)(-v) : (u64)v;
-}
 
 // tmp[b][p][i] = pk[p][i]*u[b][i] + e[b][p][i]  (ue as written by sample_enc_batch_kernel, NTT form).  grid = (N/512, cnt, 2B)
 __global__ __launch_bounds__(kVmThreads) void pk_encrypt_batch_kernel(u64 *__restrict__ tmp, const u64 *__restrict__ pk, long pk_ps,
@@ -378,6 +397,39 @@ void HostEncoder::decode(std::vector<std::complex<double>> &v, double *out) cons
 // ---------------------------------------------------------------------------------------------------------
 // context + keys
 // ---------------------------------------------------------------------------------------------------------
+RngKeys rng_keys_from_os()
+{
+    RngKeys k;
+    unsigned char buf[sizeof(RngKeys)];
+    size_t got = 0;
+    while (got < sizeof(buf)) {
+        const ssize_t r = getrandom(buf + got, sizeof(buf) - got, 0);
+        if (r <= 0) {
+            fprintf(stderr, "[dacapo_amd] getrandom() failed: no cryptographic randomness available, refusing to generate keys or encrypt\n");
+            abort();
+        }
+        got += (size_t)r;
+    }
+    memcpy(&k, buf, sizeof(k));
+    return k;
+}
+
+RngKeys rng_keys_from_test_seed(uint64_t seed)
+{ // splitmix64 expansion: reproducible, NOT secret (64 bits of entropy at most)
+    RngKeys k;
+    uint32_t *w = reinterpret_cast<uint32_t *>(&k);
+    u64 z = seed;
+    for (size_t i = 0; i < sizeof(RngKeys) / 4; i += 2) {
+        z += 0x9E3779B97F4A7C15ull;
+        u64 x = z;
+        x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+        x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+        x ^= x >> 31;
+        w[i] = (uint32_t)x, w[i + 1] = (uint32_t)(x >> 32);
+    }
+    return k;
+}
+
 static u64 *dalloc(size_t elems)
 {
     u64 *p = nullptr;
@@ -395,43 +447,35 @@ void HEVM::init_context(int logN, int K, const u64 *primes)
     ctx.reset(new Context(logN, K, kQBits, primes));
     ctx->ensure_scratch();
     encoder.reset(new HostEncoder(logN));
-    if (const char *e = getenv("DACAPO_HEVM_LANES")) n_lanes = std::max(1, atoi(e));
-    if (const char *e = getenv("DACAPO_HEVM_GRAPH")) use_graph = atoi(e) != 0;
-    if (use_graph && n_lanes > 2) {
-        fprintf(stderr, "[dacapo_amd] DACAPO_HEVM_GRAPH with %d lanes: hipStreamEndCapture on ROCm 7.2 overflows its stack on captures "
-                        "of >= 3 mutually waiting streams (tools/graph_repro.hip); using 2 lanes\n", n_lanes);
-        n_lanes = 2;
-    }
     if (const char *e = getenv("DACAPO_HEVM_PLAN")) use_plan = atoi(e) != 0;
     if (const char *e = getenv("DACAPO_HEVM_PLAN_GRAPH")) plan_graph = atoi(e) != 0;
     if (const char *e = getenv("DACAPO_HEVM_PLAN_LANES")) plan_lanes = atoi(e) >= 2 ? 2 : 1;
     if (const char *e = getenv("DACAPO_HEVM_HOST_ENCODER")) host_encoder = atoi(e) != 0;
     if (const char *e = getenv("DACAPO_HEVM_FOLD_RESCALE_BOOT")) fold_rescale_into_boot = atoi(e) != 0;
     if (const char *e = getenv("DACAPO_HEVM_MAX_BATCH")) max_batch = std::max(1, atoi(e));
-    lanes.resize((size_t)n_lanes);
-    for (int i = 0; i < n_lanes; i++) {
-        DC_HIP_CHECK(hipStreamCreateWithFlags(&lanes[i].stream, hipStreamNonBlocking));
-        lanes[i].ws = i == 0 ? ctx->ws0 : ctx->new_workspace();
-        lanes[i].boot_plain.d = dalloc((size_t)ctx->max_level() * ctx->N);
-        lanes[i].boot_plain.level = ctx->max_level();
-    }
+    lanes.resize(1);
+    DC_HIP_CHECK(hipStreamCreateWithFlags(&lanes[0].stream, hipStreamNonBlocking));
+    lanes[0].ws = ctx->ws0;
+    lanes[0].boot_plain.d = dalloc((size_t)ctx->max_level() * ctx->N);
+    lanes[0].boot_plain.level = ctx->max_level();
     DC_HIP_CHECK(hipMalloc(&d_epoch, 8));
     DC_HIP_CHECK(hipMemset(d_epoch, 0, 8));
     cur = 0;
 }
 
 // KeyGenerator::generate_one_kswitch_key for every digit: key[j] = (-(a_j s + e_j) + [limb j](P mod q_j) s', a_j)
-void HEVM::gen_kswitch_key(u64 *key, const u64 *new_key, u64 stream_id)
+void HEVM::gen_kswitch_key(u64 *key, const u64 *new_key, u64 key_id)
 {
     Context &c = *ctx;
     const size_t N = c.N;
     const int K = c.K;
-    const dim3 g1((unsigned)(N / kVmThreads), (unsigned)K), g2((unsigned)(N / (2 * kVmThreads)), (unsigned)K);
+    const dim3 gu((unsigned)(N / (kRngCoefs * kVmThreads)), (unsigned)K), gs((unsigned)(N / (kRngCoefs * kVmThreads))),
+        g2((unsigned)(N / (2 * kVmThreads)), (unsigned)K);
     for (int j = 0; j < K - 1; j++) {
         u64 *c0 = key + (size_t)j * 2 * K * N, *c1 = c0 + (size_t)K * N;
-        hipLaunchKernelGGL(sample_uniform_kernel, g1, dim3(kVmThreads), 0, S(), c1, N, seed, stream_id * 4096 + 2 * j, c.d_mods);
-        hipLaunchKernelGGL(sample_small_kernel, g1, dim3(kVmThreads), 0, S(), c0, N, 1, seed, stream_id * 4096 + 2 * j + 1,
-                           c.d_mods, (const u64 *)nullptr);
+        const u64 object = key_id * 64 + (u64)j; // one object per (key, digit)
+        hipLaunchKernelGGL(sample_uniform_kernel, gu, dim3(kVmThreads), 0, S(), c1, N, rng.pub, object, (u32)RNG_KSK_A, c.d_mods);
+        hipLaunchKernelGGL(sample_small_kernel, gs, dim3(kVmThreads), 0, S(), c0, N, K, 1, rng.secret, object, (u32)RNG_KSK_E, c.d_mods);
         launch_ntt(c, false, c0, (long)N, K, nullptr, 0, 0, S());
         const u64 factor = c.primes[K - 1] % c.primes[j];
         hipLaunchKernelGGL(ezs_final_kernel, g2, dim3(kVmThreads), 0, S(), c0, c1, keys.sk, new_key, j, factor, N, c.d_mods);
@@ -445,27 +489,28 @@ void HEVM::add_galois_key(u32 elt)
     u64 *rot = W().ct_tmp; // [K][N] fits: scratch is 3*(K-1)*N
     launch_galois(c, CtView{ rot, 0 }, CtView{ keys.sk, 0 }, elt, 1, c.K, S());
     u64 *key = dalloc(key_elems());
-    gen_kswitch_key(key, rot, 16 + (u64)elt);
+    gen_kswitch_key(key, rot, 16 + (u64)elt); // key ids: 8 = relinearisation, 16 + elt = Galois element
     keys.galois[elt] = key;
 }
 
 // SEAL_HEVM::create_context's key set (SEAL_HEVM.cpp:60-83): secret, public, relin, default Galois keys
-void HEVM::generate_keys(u64 seed_, bool secret, bool pub, bool eval)
+void HEVM::generate_keys(const RngKeys &rng_, bool secret, bool pub, bool eval)
 {
     (void)secret;
     Context &c = *ctx;
-    seed = seed_;
+    rng = rng_;
     const size_t N = c.N;
     const int K = c.K;
-    const dim3 g1((unsigned)(N / kVmThreads), (unsigned)K), g2((unsigned)(N / (2 * kVmThreads)), (unsigned)K);
+    const dim3 gu((unsigned)(N / (kRngCoefs * kVmThreads)), (unsigned)K), gs((unsigned)(N / (kRngCoefs * kVmThreads))),
+        g2((unsigned)(N / (2 * kVmThreads)), (unsigned)K);
     keys.sk = dalloc((size_t)K * N);
-    hipLaunchKernelGGL(sample_small_kernel, g1, dim3(kVmThreads), 0, S(), keys.sk, N, 0, seed, 1, c.d_mods, (const u64 *)nullptr);
+    hipLaunchKernelGGL(sample_small_kernel, gs, dim3(kVmThreads), 0, S(), keys.sk, N, K, 0, rng.secret, (u64)0, (u32)RNG_SK, c.d_mods);
     launch_ntt(c, false, keys.sk, (long)N, K, nullptr, 0, 0, S());
     if (pub) {
         keys.pk = dalloc((size_t)2 * K * N);
         u64 *c0 = keys.pk, *c1 = keys.pk + (size_t)K * N;
-        hipLaunchKernelGGL(sample_uniform_kernel, g1, dim3(kVmThreads), 0, S(), c1, N, seed, 2, c.d_mods);
-        hipLaunchKernelGGL(sample_small_kernel, g1, dim3(kVmThreads), 0, S(), c0, N, 1, seed, 3, c.d_mods, (const u64 *)nullptr);
+        hipLaunchKernelGGL(sample_uniform_kernel, gu, dim3(kVmThreads), 0, S(), c1, N, rng.pub, (u64)0, (u32)RNG_PK_A, c.d_mods);
+        hipLaunchKernelGGL(sample_small_kernel, gs, dim3(kVmThreads), 0, S(), c0, N, K, 1, rng.secret, (u64)0, (u32)RNG_PK_E, c.d_mods);
         launch_ntt(c, false, c0, (long)N, K, nullptr, 0, 0, S());
         hipLaunchKernelGGL(ezs_final_kernel, g2, dim3(kVmThreads), 0, S(), c0, c1, keys.sk, (const u64 *)nullptr, -1, (u64)0, N,
                            c.d_mods);
@@ -494,131 +539,222 @@ void HEVM::generate_keys(u64 seed_, bool secret, bool pub, bool eval)
     DC_HIP_CHECK(hipStreamSynchronize(S()));
 }
 
-// ---- key files: raw-limb container (NOT SEAL's serialization) -------------------------
-struct FileHeader {
-    char magic[8]; // "DCHEVM01"
-    uint32_t kind, logN, K, count;
-    uint64_t seed;
-};
-enum : uint32_t { F_PARM = 1, F_PUB = 2, F_SEC = 3, F_RELIN = 4, F_GAL = 5 };
-
+// ---- key files: SEAL 4.0 serialization (seal_serial.hpp), the five files of SEAL_HEVM.cpp:55-88 / :91-180 -------------
 static std::string join(const std::string &dir, const char *name)
 {
     return (!dir.empty() && dir.back() == '/') ? dir + name : dir + "/" + name;
 }
 
-static void write_dev(std::ofstream &f, const u64 *d, size_t elems)
+static std::vector<u64> from_dev(const u64 *d, size_t elems)
 {
     std::vector<u64> h(elems);
     DC_HIP_CHECK(hipMemcpy(h.data(), d, elems * 8, hipMemcpyDeviceToHost));
-    f.write((const char *)h.data(), (std::streamsize)(elems * 8));
+    return h;
 }
-static u64 *read_dev(std::ifstream &f, size_t elems)
-{
-    std::vector<u64> h(elems);
-    f.read((char *)h.data(), (std::streamsize)(elems * 8));
-    if (!f) {
-        fprintf(stderr, "[dacapo_amd] truncated key file\n");
-        abort();
-    }
+static u64 *to_dev(const u64 *h, size_t elems)
+{ // `h` may be unaligned (it points into a file image): hipMemcpy takes any byte pointer
     u64 *d = dalloc(elems);
-    DC_HIP_CHECK(hipMemcpy(d, h.data(), elems * 8, hipMemcpyHostToDevice));
+    DC_HIP_CHECK(hipMemcpy(d, h, elems * 8, hipMemcpyHostToDevice));
     return d;
+}
+
+sealio::ParmsId HEVM::parms_id_at(int limbs) const { return sealio::parms_id(ctx->N, ctx->primes.data(), (size_t)limbs); }
+
+// KSwitchKeys::save_members: keys_[index][digit] = PublicKey; present[index] = device key [K-1][2][K][N] or absent
+static void put_kswitch_keys(sealio::Writer &w, const Context &c, const sealio::ParmsId &key_id, size_t dim1,
+                             const std::map<size_t, const u64 *> &present)
+{
+    const size_t per_digit = (size_t)2 * c.K * c.N;
+    w.buf.reserve(w.buf.size() + 64 + dim1 * 8 + present.size() * (size_t)(c.K - 1) * (per_digit * 8 + 128));
+    w.put(key_id);
+    w.put<uint64_t>(dim1);
+    sealio::CtHeader h;
+    h.id = key_id, h.is_ntt = true, h.size = 2, h.N = c.N, h.limbs = (uint64_t)c.K, h.correction_factor = 1, h.scale = 1.0;
+    for (size_t index = 0; index < dim1; index++) {
+        auto it = present.find(index);
+        if (it == present.end()) {
+            w.put<uint64_t>(0);
+            continue;
+        }
+        w.put<uint64_t>((uint64_t)(c.K - 1));
+        const std::vector<u64> key = from_dev(it->second, (size_t)(c.K - 1) * per_digit);
+        for (int j = 0; j < c.K - 1; j++) { // PublicKey::save = Ciphertext::save (own header, compr none)
+            sealio::Writer one;
+            one.buf.reserve(per_digit * 8 + 128);
+            put_ciphertext(one, h, key.data() + (size_t)j * per_digit);
+            w.put_header(one.buf.size());
+            w.put_bytes(one.buf.data(), one.buf.size());
+        }
+    }
 }
 
 void HEVM::save_keys(const std::string &dir)
 {
     const Context &c = *ctx;
-    auto open = [&](const char *name, uint32_t kind, uint32_t count) {
-        std::ofstream f(join(dir, name), std::ios::out | std::ios::binary);
-        if (!f) {
-            fprintf(stderr, "[dacapo_amd] cannot write %s\n", join(dir, name).c_str());
-            abort();
-        }
-        FileHeader h{};
-        memcpy(h.magic, "DCHEVM01", 8);
-        h.kind = kind, h.logN = (uint32_t)c.logN, h.K = (uint32_t)c.K, h.count = count, h.seed = 0;
-        f.write((const char *)&h, sizeof(h));
-        return f;
-    };
+    const sealio::Compr mode = sealio::compr_from_env();
+    const sealio::ParmsId key_id = parms_id_at(c.K);
     {
-        auto f = open("parm.seal", F_PARM, (uint32_t)c.K);
-        f.write((const char *)c.primes.data(), (std::streamsize)(c.K * 8));
+        sealio::Writer w;
+        sealio::Params p;
+        p.N = c.N, p.primes = c.primes;
+        put_params(w, p);
+        write_object_file(join(dir, "parm.seal"), w.buf, mode);
     }
-    {
-        auto f = open("pub.seal", F_PUB, 1);
-        write_dev(f, keys.pk, (size_t)2 * c.K * c.N);
+    if (keys.pk) {
+        sealio::Writer w;
+        sealio::CtHeader h;
+        h.id = key_id, h.N = c.N, h.limbs = (uint64_t)c.K;
+        put_ciphertext(w, h, from_dev(keys.pk, (size_t)2 * c.K * c.N).data());
+        write_object_file(join(dir, "pub.seal"), w.buf, mode);
     }
-    {
-        auto f = open("sec.seal", F_SEC, 1);
-        write_dev(f, keys.sk, (size_t)c.K * c.N);
+    if (keys.sk) { // SecretKey::save = its Plaintext (NTT form over the whole chain, scale 1)
+        sealio::Writer w;
+        sealio::PtHeader h;
+        h.id = key_id, h.coeff_count = (uint64_t)c.K * c.N, h.scale = 1.0;
+        put_plaintext(w, h, from_dev(keys.sk, (size_t)c.K * c.N).data());
+        write_object_file(join(dir, "sec.seal"), w.buf, mode);
     }
-    {
-        auto f = open("relin.seal", F_RELIN, 1);
-        write_dev(f, keys.relin, key_elems());
+    if (keys.relin) { // RelinKeys: keys_[0] = the key for s^2
+        sealio::Writer w;
+        put_kswitch_keys(w, c, key_id, 1, { { 0, keys.relin } });
+        write_object_file(join(dir, "relin.seal"), w.buf, mode);
     }
-    {
-        auto f = open("gal.seal", F_GAL, (uint32_t)keys.galois.size());
-        for (auto &kv : keys.galois) {
-            uint64_t elt = kv.first;
-            f.write((const char *)&elt, 8);
-            write_dev(f, kv.second, key_elems());
-        }
+    if (!keys.galois.empty()) { // GaloisKeys: N entries, Galois element e at index (e - 1) / 2
+        sealio::Writer w;
+        std::map<size_t, const u64 *> present;
+        for (auto &kv : keys.galois) present[(size_t)((kv.first - 1) >> 1)] = kv.second;
+        put_kswitch_keys(w, c, key_id, c.N, present);
+        write_object_file(join(dir, "gal.seal"), w.buf, mode);
     }
 }
 
-static FileHeader read_header(std::ifstream &f, const std::string &path, uint32_t kind)
+// one PublicKey of a key-switch key, or pub.seal: checks it against the context and returns its [2][K][N] limbs
+static const u64 *get_key_ciphertext(sealio::Reader &members, const Context &c, const sealio::ParmsId &key_id)
 {
-    FileHeader h{};
-    f.read((char *)&h, sizeof(h));
-    if (!f || memcmp(h.magic, "DCHEVM01", 8) != 0 || h.kind != kind) {
-        fprintf(stderr, "[dacapo_amd] %s is not a key file of this runtime (SEAL-serialized files are not supported yet)\n",
-                path.c_str());
-        abort();
+    const u64 *data = nullptr;
+    const sealio::CtHeader h = get_ciphertext(members, data);
+    if (h.size != 2 || h.N != c.N || h.limbs != (uint64_t)c.K || !h.is_ntt) members.fail("key polynomial dimensions do not match parm.seal");
+    if (h.id != key_id) members.fail("parms_id is not the key-level id of parm.seal (key generated under other parameters?)");
+    return data;
+}
+
+// KSwitchKeys::load_members: calls sink(index, digits [K-1][2][K][N] on the device) for every non-empty entry
+template <class Sink>
+static void get_kswitch_keys(sealio::Reader &r, const Context &c, const sealio::ParmsId &key_id, Sink sink)
+{
+    if (r.get<sealio::ParmsId>() != key_id) r.fail("parms_id is not the key-level id of parm.seal");
+    const uint64_t dim1 = r.get<uint64_t>();
+    if (dim1 > (1ull << 20)) r.fail("implausible key count");
+    const size_t per_digit = (size_t)2 * c.K * c.N;
+    for (uint64_t index = 0; index < dim1; index++) {
+        const uint64_t dim2 = r.get<uint64_t>();
+        if (dim2 == 0) continue;
+        if (dim2 != (uint64_t)(c.K - 1)) r.fail("decomposition digit count differs from coeff_modulus_size - 1");
+        u64 *key = dalloc((size_t)(c.K - 1) * per_digit);
+        for (uint64_t j = 0; j < dim2; j++) {
+            std::vector<uint8_t> owned;
+            sealio::Reader m = open_object(r, owned);
+            const u64 *data = get_key_ciphertext(m, c, key_id);
+            DC_HIP_CHECK(hipMemcpy(key + j * per_digit, data, per_digit * 8, hipMemcpyHostToDevice));
+        }
+        sink((size_t)index, key);
     }
-    return h;
 }
 
 void HEVM::load_keys(const std::string &dir, bool need_secret, bool need_public, bool need_eval)
 {
+    auto open_file = [&](const char *name, std::vector<uint8_t> &file, std::vector<uint8_t> &owned) {
+        const std::string p = join(dir, name);
+        file = sealio::read_file(p);
+        sealio::Reader outer(file.data(), file.size(), p);
+        return open_object(outer, owned);
+    };
     {
-        const std::string p = join(dir, "parm.seal");
-        std::ifstream f(p, std::ios::in | std::ios::binary);
-        FileHeader h = read_header(f, p, F_PARM);
-        std::vector<u64> primes(h.K);
-        f.read((char *)primes.data(), (std::streamsize)(h.K * 8));
-        init_context((int)h.logN, (int)h.K, primes.data());
+        std::vector<uint8_t> file, owned;
+        sealio::Reader m = open_file("parm.seal", file, owned);
+        const sealio::Params p = get_params(m);
+        if (p.scheme != sealio::kSchemeCkks) m.fail("scheme is not CKKS");
+        int logN = 0;
+        while (((uint64_t)1 << logN) < p.N) logN++;
+        for (u64 q : p.primes)
+            if ((q >> 59) != 1 || ((1ull << kQBits) - q) >= kMaxDelta)
+                m.fail("coefficient modulus outside this backend's range: every prime must be 2^60 - delta with delta < 2^28 "
+                       "(what CoeffModulus::Create(N, {60, ...}) of SEAL_HEVM.cpp:48-53 yields)");
+        init_context(logN, (int)p.primes.size(), p.primes.data());
     }
     const Context &c = *ctx;
+    const sealio::ParmsId key_id = parms_id_at(c.K);
     if (need_public) {
-        const std::string p = join(dir, "pub.seal");
-        std::ifstream f(p, std::ios::in | std::ios::binary);
-        read_header(f, p, F_PUB);
-        keys.pk = read_dev(f, (size_t)2 * c.K * c.N);
+        std::vector<uint8_t> file, owned;
+        sealio::Reader m = open_file("pub.seal", file, owned);
+        keys.pk = to_dev(get_key_ciphertext(m, c, key_id), (size_t)2 * c.K * c.N);
     }
     if (need_secret) {
-        const std::string p = join(dir, "sec.seal");
-        std::ifstream f(p, std::ios::in | std::ios::binary);
-        read_header(f, p, F_SEC);
-        keys.sk = read_dev(f, (size_t)c.K * c.N);
+        std::vector<uint8_t> file, owned;
+        sealio::Reader m = open_file("sec.seal", file, owned);
+        const u64 *data = nullptr;
+        const sealio::PtHeader h = get_plaintext(m, data);
+        if (h.coeff_count != (uint64_t)c.K * c.N || h.id != key_id) m.fail("secret key does not match parm.seal");
+        keys.sk = to_dev(data, (size_t)c.K * c.N);
     }
     if (need_eval) {
         {
-            const std::string p = join(dir, "relin.seal");
-            std::ifstream f(p, std::ios::in | std::ios::binary);
-            read_header(f, p, F_RELIN);
-            keys.relin = read_dev(f, key_elems());
+            std::vector<uint8_t> file, owned;
+            sealio::Reader m = open_file("relin.seal", file, owned);
+            get_kswitch_keys(m, c, key_id, [&](size_t index, u64 *key) {
+                if (index == 0)
+                    keys.relin = key;
+                else
+                    (void)hipFree(key); // keys for higher powers of s: the HEVM path never multiplies without relinearising
+            });
+            if (!keys.relin) m.fail("no relinearisation key for s^2");
         }
-        const std::string p = join(dir, "gal.seal");
-        std::ifstream f(p, std::ios::in | std::ios::binary);
-        FileHeader h = read_header(f, p, F_GAL);
-        for (uint32_t i = 0; i < h.count; i++) {
-            uint64_t elt = 0;
-            f.read((char *)&elt, 8);
-            keys.galois[(u32)elt] = read_dev(f, key_elems());
-        }
+        std::vector<uint8_t> file, owned;
+        sealio::Reader m = open_file("gal.seal", file, owned);
+        get_kswitch_keys(m, c, key_id, [&](size_t index, u64 *key) { keys.galois[(u32)(2 * index + 1)] = key; });
     }
-    seed = 0x4845564Dull ^ (u64)(uintptr_t)this;
+    rng = rng_keys_from_os(); // encryption randomness of this VM: fresh from the OS, unrelated to whatever generated the loaded keys
+}
+
+// seal::Ciphertext::save / load of a cipher register (what getCtxt's seal::Ciphertext* is for in the reference,
+// SEAL_HEVM.cpp:463-473 "use this to implement communication"): [2][level][N] limbs, the parms_id of that level, the scale
+void HEVM::save_ctxt(size_t r, const std::string &path)
+{
+    const Context &c = *ctx;
+    hevm_ctxt &ct = reg(r);
+    if (ct.level < 1) {
+        fprintf(stderr, "[dacapo_amd] save: cipher register %zu is empty\n", r);
+        abort();
+    }
+    DC_HIP_CHECK(hipStreamSynchronize(S()));
+    const size_t ln = (size_t)ct.level * c.N;
+    std::vector<u64> h(2 * ln);
+    for (int p = 0; p < 2; p++) DC_HIP_CHECK(hipMemcpy(h.data() + (size_t)p * ln, ct.data + (size_t)p * ct.poly_stride, ln * 8, hipMemcpyDeviceToHost));
+    sealio::Writer w;
+    sealio::CtHeader hd;
+    hd.id = parms_id_at(ct.level), hd.N = c.N, hd.limbs = (uint64_t)ct.level, hd.scale = ct.scale;
+    put_ciphertext(w, hd, h.data());
+    write_object_file(path, w.buf, sealio::compr_from_env());
+}
+
+void HEVM::load_ctxt(size_t r, const std::string &path)
+{
+    const Context &c = *ctx;
+    const std::vector<uint8_t> file = sealio::read_file(path);
+    std::vector<uint8_t> owned;
+    sealio::Reader outer(file.data(), file.size(), path);
+    sealio::Reader m = open_object(outer, owned);
+    const u64 *data = nullptr;
+    const sealio::CtHeader h = get_ciphertext(m, data);
+    if (h.size != 2 || h.N != c.N || h.limbs < 1 || h.limbs > (uint64_t)c.max_level() || !h.is_ntt) m.fail("not a size-2 NTT-form ciphertext of this context");
+    if (h.id != parms_id_at((int)h.limbs)) m.fail("parms_id does not name a level of this context's modulus chain");
+    hevm_ctxt &ct = reg(r);
+    reg_base[r] = home[r];
+    ct.data = reg_base[r] + (size_t)sel * (size_t)2 * c.K * c.N;
+    ct.poly_stride = (int64_t)c.K * (int64_t)c.N;
+    const size_t ln = (size_t)h.limbs * c.N;
+    for (int p = 0; p < 2; p++) DC_HIP_CHECK(hipMemcpy(ct.data + (size_t)p * ct.poly_stride, data + (size_t)p * ln, ln * 8, hipMemcpyHostToDevice));
+    ct.level = (int32_t)h.limbs, ct.scale = h.scale;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -677,7 +813,6 @@ void HEVM::load_program(const void *data, size_t len, bool header_only)
     }
     while (ciphers.size() < nct) ciphers.push_back(hevm_ctxt{ nullptr, 0, 0, 0, 1.0 });
     for (size_t i = 0; i < nct; i++) reg(i); // allocate now: nothing may call hipMalloc while run() is being captured
-    invalidate_graph();
     plan.ready = false;
 }
 
@@ -883,7 +1018,7 @@ void HEVM::preprocess()
     }
     // The reference times run() alone (examples/tests/ResNet.py:109-111) after an untimed preprocess(): the execution plan
     // of the loaded program is part of the preparation, not of the run.  (A VM without evaluation keys cannot run anyway.)
-    if (use_plan && !debug && n_lanes == 1 && !use_graph && keys.relin && !keys.galois.empty()) build_plan();
+    if (use_plan && !debug && keys.relin && !keys.galois.empty()) build_plan();
 }
 
 // Encryptor::encrypt at the plaintext's level: zero-encryption under pk with one extra prime, divide-and-round by it,
@@ -899,9 +1034,9 @@ void HEVM::encrypt_plain(hevm_ctxt &dst, const Plain &pt)
     }
     u64 *ue = W().ks_ext; // [3][cnt][N]: u, e0, e1
     const CtView tmp{ dst.data, (long)dst.poly_stride };
-    const u64 s0 = 1000 + 4 * (enc_counter++);
-    hipLaunchKernelGGL(sample_enc_kernel, dim3((unsigned)(N / kVmThreads), (unsigned)cnt, 3), dim3(kVmThreads), 0, S(), ue, N, cnt, seed,
-                       s0, c.d_mods, d_epoch);
+    // one object per encryption of this VM's lifetime (opcode-10 items of a plan use the range above 2^32)
+    hipLaunchKernelGGL(sample_enc_batch_kernel, dim3((unsigned)(N / (kRngCoefs * kVmThreads)), 3), dim3(kVmThreads), 0, S(), ue, N, cnt,
+                       rng.secret, enc_counter++, c.d_mods, d_epoch);
     launch_ntt(c, false, ue, (long)N, 3 * cnt, nullptr, 0, cnt, S());
     hipLaunchKernelGGL(pk_encrypt_kernel, dim3((unsigned)(N / (2 * kVmThreads)), (unsigned)cnt, 2), dim3(kVmThreads), 0, S(),
                        tmp.p, tmp.poly_stride, keys.pk, (long)c.K * (long)N, ue, ue + (size_t)cnt * N, (long)cnt * (long)N, N, c.d_mods);
@@ -1290,8 +1425,8 @@ void HEVM::plan_zero_encrypt(int first, int B, int t, hipStream_t s)
         abort();
     }
     Plan &P = plan;
-    hipLaunchKernelGGL(sample_enc_batch_kernel, dim3((unsigned)(N / kVmThreads), (unsigned)cnt, (unsigned)(3 * B)), dim3(kVmThreads), 0, s,
-                       P.boot_ue, N, cnt, seed, (u64)0x40000000 + 4 * (u64)first, c.d_mods, d_epoch);
+    hipLaunchKernelGGL(sample_enc_batch_kernel, dim3((unsigned)(N / (kRngCoefs * kVmThreads)), (unsigned)(3 * B)), dim3(kVmThreads), 0, s,
+                       P.boot_ue, N, cnt, rng.secret, ((u64)1 << 32) + (u64)first, c.d_mods, d_epoch);
     launch_ntt(c, false, P.boot_ue, (long)N, 3 * cnt * B, nullptr, 0, cnt, s);
     hipLaunchKernelGGL(pk_encrypt_batch_kernel, dim3((unsigned)(N / (2 * kVmThreads)), (unsigned)cnt, (unsigned)(2 * B)), dim3(kVmThreads),
                        0, s, P.boot_tmp, keys.pk, (long)c.K * (long)N, P.boot_ue, cnt, N, c.d_mods);
@@ -1324,24 +1459,6 @@ void HEVM::plan_boot_step(int first, int B, int ell, int t, int lane, hipStream_
     f_frows_boot_final(c, ptx, items, B, t, s);
 }
 
-hipEvent_t HEVM::new_event()
-{
-    if (ev_next == ev_pool.size()) {
-        hipEvent_t e;
-        DC_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        ev_pool.push_back(e);
-    }
-    return ev_pool[ev_next++];
-}
-
-void HEVM::invalidate_graph()
-{
-    if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
-    if (graph) (void)hipGraphDestroy(graph);
-    graph_exec = nullptr;
-    graph = nullptr;
-}
-
 void HEVM::dispatch(const WireOp &op)
 {
     switch (op.opcode) {
@@ -1359,22 +1476,14 @@ void HEVM::dispatch(const WireOp &op)
     }
 }
 
-// The dispatch loop of SEAL_HEVM::run (SEAL_HEVM.cpp:336-401).  multi_lane: ops are spread over the lanes; the
-// only ordering enforced between lanes is the program's own register dataflow (RAW, WAR and WAW on cipher
-// registers -- ReuseBuffer recycles registers, so all three occur); plaintext registers are read-only here.
-void HEVM::execute(bool multi_lane)
+// The dispatch loop of SEAL_HEVM::run (SEAL_HEVM.cpp:336-401): one instruction at a time, in program order, on one stream.
+void HEVM::execute()
 {
     memset(op_counts, 0, sizeof(op_counts));
     n_keyswitch = n_ntt = 0;
     t_bootstrap = 0.0;
-    deps.assign(ciphers.size(), RegDeps{});
-    ev_next = 0;
-    for (Lane &l : lanes) l.load = 0, l.tail_op = -1, l.used = false, l.last_ev = nullptr;
-    lanes[0].used = true;
     int i = (int)((header.hevm_header_size + config.config_body_length) / 8), j = 0;
-    int opi = -1;
     for (const WireOp &op : ops) {
-        opi++;
         if (debug) {
             std::cout << std::endl;
             std::cout << std::oct << i++ << " " << std::dec << j++ << std::endl;
@@ -1383,85 +1492,14 @@ void HEVM::execute(bool multi_lane)
         }
         if (op.opcode <= 10) op_counts[op.opcode]++;
         if (op.opcode == 0 || op.opcode > 10) continue;
-        if (!multi_lane) {
-            cur = 0;
-            dispatch(op);
-            continue;
-        }
-        const bool rhs_is_reg = op.opcode == 6 || op.opcode == 8;
-        const int srcs[2] = { (int)op.lhs, rhs_is_reg ? (int)op.rhs : -1 };
-        const int dst = op.dst;
-        if ((size_t)std::max({ dst, srcs[0], srcs[1] }) >= deps.size()) deps.resize((size_t)std::max({ dst, srcs[0], srcs[1] }) + 1);
-        // lane choice: continue the producer's chain when it is still the tail of its lane, else the least loaded lane
-        int lane = -1;
-        for (int sidx = 0; sidx < 2 && lane < 0; sidx++) {
-            if (srcs[sidx] < 0) continue;
-            const Dep &w = deps[(size_t)srcs[sidx]].writer;
-            if (w.lane >= 0 && lanes[(size_t)w.lane].tail_op == w.op) lane = w.lane;
-        }
-        if (lane < 0) {
-            lane = 0;
-            for (int l = 1; l < n_lanes; l++)
-                if (lanes[(size_t)l].load < lanes[(size_t)lane].load) lane = l;
-        }
-        hipStream_t st = lanes[(size_t)lane].stream;
-        static const bool trace = getenv("DACAPO_HEVM_TRACE") != nullptr;
-        if (trace) fprintf(stderr, "op %d opcode %d dst %d lhs %d rhs %d -> lane %d\n", opi, op.opcode, dst, srcs[0], srcs[1], lane);
-        hipEvent_t waited[8];
-        int n_waited = 0;
-        auto wait_for = [&](const Dep &d) {
-            if (!d.ev || d.lane == lane) return;
-            for (int w = 0; w < n_waited; w++)
-                if (waited[w] == d.ev) return; // one edge per producer event
-            if (n_waited < 8) waited[n_waited++] = d.ev;
-            if (trace) fprintf(stderr, "   wait lane %d op %d\n", d.lane, d.op);
-            DC_HIP_CHECK(hipStreamWaitEvent(st, d.ev, 0));
-        };
-        if (!lanes[(size_t)lane].used) { // first work on this lane: branch it off lane 0 (this is what joins it to a capture)
-            lanes[(size_t)lane].used = true;
-            hipEvent_t fork = new_event();
-            DC_HIP_CHECK(hipEventRecord(fork, lanes[0].stream));
-            DC_HIP_CHECK(hipStreamWaitEvent(st, fork, 0));
-        }
-        for (int sidx = 0; sidx < 2; sidx++)
-            if (srcs[sidx] >= 0) wait_for(deps[(size_t)srcs[sidx]].writer); // RAW
-        wait_for(deps[(size_t)dst].writer);                                   // WAW
-        for (const Dep &r : deps[(size_t)dst].readers) wait_for(r);           // WAR
-        cur = lane;
-        const int64_t ntt_before = n_ntt;
         dispatch(op);
-        lanes[(size_t)lane].load += 1 + (long)(n_ntt - ntt_before);
-        lanes[(size_t)lane].tail_op = opi;
-        Dep me{ lane, opi, nullptr };
-        const bool metadata_only = (op.opcode == 4 && (op.dst == op.lhs || (int16_t)op.rhs <= 0)) ||
-                                   (op.opcode == 1 && op.rhs == 0 && op.dst == op.lhs);
-        if (metadata_only && lanes[(size_t)lane].last_ev) {
-            me.ev = lanes[(size_t)lane].last_ev; // metadata-only op (e.g. in-place modswitch): nothing new to wait for
-        } else {
-            me.ev = new_event();
-            DC_HIP_CHECK(hipEventRecord(me.ev, st));
-            lanes[(size_t)lane].last_ev = me.ev;
-        }
-        for (int sidx = 0; sidx < 2; sidx++)
-            if (srcs[sidx] >= 0 && srcs[sidx] != dst) deps[(size_t)srcs[sidx]].readers.push_back(me);
-        deps[(size_t)dst].writer = me;
-        deps[(size_t)dst].readers.clear();
     }
-    cur = 0;
-    if (multi_lane) { // join every lane that received work into lane 0
-        for (int l = 1; l < n_lanes; l++) {
-            if (!lanes[(size_t)l].used) continue;
-            hipEvent_t e = new_event();
-            DC_HIP_CHECK(hipEventRecord(e, lanes[(size_t)l].stream));
-            DC_HIP_CHECK(hipStreamWaitEvent(lanes[0].stream, e, 0));
-        }
-    }
-    hipLaunchKernelGGL(bump_epoch_kernel, dim3(1), dim3(1), 0, lanes[0].stream, d_epoch);
+    bump_epoch(S());
 }
 
 void HEVM::run()
 {
-    if (use_plan && !debug && n_lanes == 1 && !use_graph) {
+    if (use_plan && !debug) {
         run_plan();
         return;
     }
@@ -1469,36 +1507,8 @@ void HEVM::run()
         fprintf(stderr, "[dacapo_amd] several ciphertext streams need the batched plan (DACAPO_HEVM_PLAN=1, no debug)\n");
         abort();
     }
-    const bool multi = n_lanes > 1 && !debug;
-    if (!use_graph || debug) {
-        execute(multi);
-        DC_HIP_CHECK(hipStreamSynchronize(lanes[0].stream)); // the caller's timer stops when run() returns
-        return;
-    }
-    if (!graph_exec) { // first run of this program: record it once ...
-        hipStream_t s0 = lanes[0].stream;
-        DC_HIP_CHECK(hipStreamBeginCapture(s0, hipStreamCaptureModeRelaxed));
-        execute(multi);
-        if (getenv("DACAPO_HEVM_TRACE")) fprintf(stderr, "ending capture\n");
-        DC_HIP_CHECK(hipStreamEndCapture(s0, &graph));
-        if (getenv("DACAPO_HEVM_TRACE")) fprintf(stderr, "capture ended\n");
-        if (const char *dot = getenv("DACAPO_HEVM_DUMP_DOT")) {
-            size_t nn = 0;
-            (void)hipGraphGetNodes(graph, nullptr, &nn);
-            fprintf(stderr, "[dacapo_amd] captured graph: %zu nodes, dumping to %s\n", nn, dot);
-            (void)hipGraphDebugDotPrint(graph, dot, 0);
-        }
-        DC_HIP_CHECK(hipGraphInstantiate(&graph_exec, graph, nullptr, nullptr, 0));
-        final_meta.resize(ciphers.size());
-        for (size_t r = 0; r < ciphers.size(); r++) final_meta[r] = RegMeta{ ciphers[r].level, ciphers[r].scale };
-    }
-    // ... then replay it: one launch for the whole program
-    DC_HIP_CHECK(hipGraphLaunch(graph_exec, lanes[0].stream));
-    DC_HIP_CHECK(hipStreamSynchronize(lanes[0].stream)); // the caller's timer stops when run() returns
-    for (size_t r = 0; r < final_meta.size() && r < ciphers.size(); r++) {
-        ciphers[r].level = final_meta[r].level;
-        ciphers[r].scale = final_meta[r].scale;
-    }
+    execute();
+    DC_HIP_CHECK(hipStreamSynchronize(S())); // the caller's timer stops when run() returns
 }
 
 } // namespace dacapo
@@ -1555,12 +1565,7 @@ void create_context(char *dir)
     env_params(logN, K);
     HEVM vm;
     vm.init_context(logN, K, nullptr);
-    dacapo::u64 seed = 0x4845564D;
-    if (FILE *f = fopen("/dev/urandom", "rb")) {
-        if (fread(&seed, 8, 1, f) != 1) seed = 0x4845564D;
-        fclose(f);
-    }
-    vm.generate_keys(seed, true, true, true);
+    vm.generate_keys(dacapo::rng_keys_from_os(), true, true, true);
     vm.save_keys(dir);
 }
 void load(void *vm, char *constant, char *vmfile)
@@ -1605,7 +1610,7 @@ void *hevm_init_seeded(int logN, int num_primes, uint64_t seed)
     env_params(dl, dk);
     auto vm = new HEVM();
     vm->init_context(logN > 0 ? logN : dl, num_primes > 0 ? num_primes : dk, nullptr);
-    vm->generate_keys(seed, true, true, true);
+    vm->generate_keys(dacapo::rng_keys_from_test_seed(seed), true, true, true); // reproducible and therefore insecure: tests / bench only
     return vm;
 }
 void *hevm_context(void *vm)
@@ -1639,6 +1644,84 @@ void hevm_load_mem(void *vm, const void *cst, uint64_t cst_len, const void *hevm
 void hevm_set_streams(void *vm, int n) { static_cast<HEVM *>(vm)->set_streams(n); }
 void hevm_select_stream(void *vm, int s) { static_cast<HEVM *>(vm)->select_stream(s); }
 double hevm_last_run_bootstrap_seconds(void *vm) { return static_cast<HEVM *>(vm)->t_bootstrap; }
+void hevm_save_ctxt(void *vm, int64_t reg, const char *path) { static_cast<HEVM *>(vm)->save_ctxt((size_t)reg, path); }
+void hevm_load_ctxt(void *vm, int64_t reg, const char *path) { static_cast<HEVM *>(vm)->load_ctxt((size_t)reg, path); }
+
+// ---- host-only entry points (no GPU involved) ---------------------------------------------------------------
+void hevm_seal_parms_id(uint64_t poly_modulus_degree, const uint64_t *primes, int count, uint64_t out[4])
+{
+    const dacapo::sealio::ParmsId id = dacapo::sealio::parms_id(poly_modulus_degree, primes, (size_t)count);
+    memcpy(out, id.data(), 32);
+}
+void hevm_seal_save_parms(const char *path, int compr_mode, uint64_t poly_modulus_degree, const uint64_t *primes, int count)
+{
+    namespace sio = dacapo::sealio;
+    sio::Writer w;
+    sio::Params p;
+    p.N = poly_modulus_degree, p.primes.assign(primes, primes + count);
+    put_params(w, p);
+    write_object_file(path, w.buf, (sio::Compr)compr_mode);
+}
+int hevm_seal_load_parms(const char *path, uint64_t *poly_modulus_degree, uint64_t *primes, int capacity)
+{
+    namespace sio = dacapo::sealio;
+    const std::vector<uint8_t> file = sio::read_file(path);
+    std::vector<uint8_t> owned;
+    sio::Reader outer(file.data(), file.size(), path);
+    sio::Reader m = open_object(outer, owned);
+    const sio::Params p = get_params(m);
+    if (p.scheme != sio::kSchemeCkks) m.fail("scheme is not CKKS");
+    *poly_modulus_degree = p.N;
+    for (size_t i = 0; i < p.primes.size() && (int)i < capacity; i++) primes[i] = p.primes[i];
+    return (int)p.primes.size();
+}
+void hevm_seal_save_ciphertext(const char *path, int compr_mode, uint64_t poly_modulus_degree, const uint64_t *primes, int limbs, int size,
+                               int is_ntt, double scale, const uint64_t *data)
+{
+    namespace sio = dacapo::sealio;
+    sio::Writer w;
+    sio::CtHeader h;
+    h.id = sio::parms_id(poly_modulus_degree, primes, (size_t)limbs);
+    h.is_ntt = is_ntt != 0, h.size = (uint64_t)size, h.N = poly_modulus_degree, h.limbs = (uint64_t)limbs, h.scale = scale;
+    put_ciphertext(w, h, data);
+    write_object_file(path, w.buf, (sio::Compr)compr_mode);
+}
+int64_t hevm_seal_load_ciphertext(const char *path, uint64_t *poly_modulus_degree, int *limbs, int *size, int *is_ntt, double *scale,
+                                  uint64_t parms_id[4], uint64_t *data, uint64_t capacity)
+{
+    namespace sio = dacapo::sealio;
+    const std::vector<uint8_t> file = sio::read_file(path);
+    std::vector<uint8_t> owned;
+    sio::Reader outer(file.data(), file.size(), path);
+    sio::Reader m = open_object(outer, owned);
+    const uint64_t *src = nullptr;
+    const sio::CtHeader h = get_ciphertext(m, src);
+    *poly_modulus_degree = h.N, *limbs = (int)h.limbs, *size = (int)h.size, *is_ntt = h.is_ntt ? 1 : 0, *scale = h.scale;
+    memcpy(parms_id, h.id.data(), 32);
+    const uint64_t words = h.size * h.N * h.limbs;
+    if (data && words <= capacity) memcpy(data, src, (size_t)words * 8);
+    return (int64_t)words;
+}
+int hevm_seal_zstd_available(void) { return dacapo::sealio::zstd_available() ? 1 : 0; }
+void hevm_chacha20_block(const uint32_t key[8], uint64_t counter, uint64_t nonce, uint32_t out[16])
+{
+    dacapo::ChaChaKey k;
+    memcpy(k.w, key, 32);
+    uint32_t o[16];
+    dacapo::chacha20_block(k, counter, nonce, o);
+    memcpy(out, o, 64);
+}
+void hevm_chacha20_blocks_device(const uint32_t key[8], uint64_t counter, uint64_t nonce, int blocks, uint32_t *out_host)
+{ // the same block function as the samplers run it, on the GPU (parity test of the device code path)
+    dacapo::ChaChaKey k;
+    memcpy(k.w, key, 32);
+    uint32_t *d = nullptr;
+    DC_HIP_CHECK(hipMalloc(&d, (size_t)blocks * 64));
+    hipLaunchKernelGGL(dacapo::chacha_blocks_kernel, dim3((unsigned)((blocks + 63) / 64)), dim3(64), 0, 0, d, k, counter, nonce, blocks);
+    DC_HIP_CHECK(hipMemcpy(out_host, d, (size_t)blocks * 64, hipMemcpyDeviceToHost));
+    (void)hipFree(d);
+}
+
 void hevm_last_run_stats(void *vm, int64_t *op_counts, int64_t *keyswitches, int64_t *ntts)
 {
     auto h = static_cast<HEVM *>(vm);

@@ -10,6 +10,8 @@
 #include <vector>
 
 #include "../../include/hevm_abi.h"
+#include "chacha.hpp"
+#include "seal_serial.hpp"
 #include "kernels.hpp"
 #include "encoder.hpp"
 #include "plan.hpp"
@@ -75,51 +77,22 @@ class HEVM {
     KeySet keys;
     bool debug = false;
     void *ckks_handle = nullptr; // dc_context* handed out by hevm_context()
-    u64 seed = 0, enc_counter = 0;
+    RngKeys rng;          // ChaCha20 keys of this VM's randomness (chacha.hpp)
+    u64 enc_counter = 0;  // encryptions made so far: the `object` of the next one
     u64 *d_epoch = nullptr; // run() counter in HBM, mixed into the encryption randomness (graph replays stay fresh)
 
-    // Execution lanes: one HIP stream + one scratch workspace each.  run() spreads independent ops of the program
-    // over the lanes (register-level dependency tracking with events) and captures the result into one HIP graph.
+    // The VM's HIP stream and the scratch of one in-flight composite op.  run() executes the batched plan (plan.hpp); with
+    // DACAPO_HEVM_PLAN=0 or setDebug(true) it is the reference's loop instead: one instruction at a time, in program order.
     struct Lane {
         hipStream_t stream = nullptr;
         Workspace ws;
         Plain boot_plain; // staging plaintext of opcode 10
-        long load = 0;    // scheduled work estimate (NTT-equivalents)
-        int tail_op = -1; // index of the last op issued on this lane
-        bool used = false;        // has work in the current execute()
-        hipEvent_t last_ev = nullptr; // event after the last op issued here
     };
-    std::vector<Lane> lanes;
-    int cur = 0; // lane the handlers currently issue to
+    std::vector<Lane> lanes; // one entry
+    int cur = 0;
     hipStream_t S() const { return lanes[cur].stream; }
     const Workspace &W() const { return lanes[cur].ws; }
-    // defaults: one lane, eager.  More lanes / graph capture are opt-in (DACAPO_HEVM_LANES / DACAPO_HEVM_GRAPH): on
-    // ROCm 7.2 hipStreamEndCapture overflows its stack on captures with >= 3 mutually waiting streams
-    // (tools/graph_repro.hip), and eager multi-stream issue is host-bound (DESIGN.md "Scheduling").
-    int n_lanes = 1;
-    bool use_graph = false;
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t graph_exec = nullptr;
-    struct RegMeta {
-        int32_t level;
-        double scale;
-    };
-    std::vector<RegMeta> final_meta; // register metadata after a captured run
-    struct Dep {
-        int lane = -1, op = -1;
-        hipEvent_t ev = nullptr;
-    };
-    struct RegDeps {
-        Dep writer;
-        std::vector<Dep> readers;
-    };
-    std::vector<RegDeps> deps;
-    std::vector<hipEvent_t> ev_pool;
-    size_t ev_next = 0;
-    hipEvent_t new_event();
-    void invalidate_graph();
-    void execute(bool multi_lane);
-    bool capturing = false;
+    void execute();
     void dispatch(const WireOp &op);
 
     // program
@@ -236,11 +209,14 @@ class HEVM {
     HEVM() = default;
     size_t key_elems() const { return (size_t)(ctx->K - 1) * 2 * ctx->K * ctx->N; }
     void init_context(int logN, int K, const u64 *primes);
-    void generate_keys(u64 seed, bool secret, bool pub, bool eval);
-    void gen_kswitch_key(u64 *key, const u64 *new_key, u64 stream_id);
+    void generate_keys(const RngKeys &rng, bool secret, bool pub, bool eval);
+    void gen_kswitch_key(u64 *key, const u64 *new_key, u64 key_id);
     void add_galois_key(u32 elt);
     void save_keys(const std::string &dir);
     void load_keys(const std::string &dir, bool need_secret, bool need_public, bool need_eval);
+    sealio::ParmsId parms_id_at(int limbs) const; // SEAL parms_id of the chain truncated to `limbs` primes (limbs = K: key level)
+    void save_ctxt(size_t reg, const std::string &path);
+    void load_ctxt(size_t reg, const std::string &path);
 
     void load_constants(const void *data, size_t len);
     void load_program(const void *data, size_t len, bool header_only);

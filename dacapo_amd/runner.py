@@ -71,6 +71,8 @@ def reinit_lw():  # runner.py:73-117
     lw.hevm_select_stream.argtypes = [ctypes.c_void_p, ctypes.c_int]
     lw.hevm_last_run_bootstrap_seconds.argtypes = [ctypes.c_void_p]
     lw.hevm_last_run_bootstrap_seconds.restype = ctypes.c_double
+    lw.hevm_save_ctxt.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_char_p]
+    lw.hevm_load_ctxt.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_char_p]
     return lw
 
 
@@ -173,6 +175,16 @@ class HEVM:
             lw.decrypt_result(self.vm, i, carr)
             result[i] = data
         return result
+
+    def saveCtxt(self, reg: int, path):
+        """extension: seal::Ciphertext::save of a cipher register (SEAL 4.0 bytes) -- what a client / server pair exchanges"""
+        lw.hevm_save_ctxt(self.vm, reg, str(path).encode("utf-8"))
+
+    def loadCtxt(self, reg: int, path):
+        lw.hevm_load_ctxt(self.vm, reg, str(path).encode("utf-8"))
+
+    def getResIdx(self, i: int) -> int:
+        return int(lw.getResIdx(self.vm, i))
 
     def getCtxt(self, reg: int) -> hevm_ctxt:
         return hevm_ctxt.from_address(lw.getCtxt(self.vm, reg))

@@ -25,8 +25,10 @@ void *initFullVM(char *dir, bool device);
 void *initClientVM(char *dir);
 /* SEAL_HEVM.cpp:415 */
 void *initServerVM(char *dir);
-/* SEAL_HEVM.cpp:421  -- writes parm/pub/sec/relin/gal ".seal" files (this runtime's own raw-limb container,
- * not SEAL's serialization: SURVEY.md 8f row f1) */
+/* SEAL_HEVM.cpp:421  -- writes parm/pub/sec/relin/gal ".seal" files in Microsoft SEAL 4.0's binary serialization
+ * (SEAL_HEVM.cpp:55-88): a key directory written here loads in the reference's runtime and vice versa.  Keys and all
+ * encryption randomness come from ChaCha20 keyed by 512 bits of getrandom(2); the call aborts if that fails.
+ * DACAPO_HEVM_SEAL_COMPR = none (default) | zlib | zstd selects the compr_mode of the written files. */
 void create_context(char *dir);
 /* SEAL_HEVM.cpp:424 */
 void load(void *vm, char *constant, char *vmfile);
@@ -69,7 +71,8 @@ struct hevm_ctxt {
 
 /* ---- extensions (not in the reference) used by this repo's tests and bench ------------------------------- */
 /* Generate parameters + the reference's key set in HBM without touching disk.  logN/num_primes = 0 take the
- * reference's hard-coded N = 2^15, 14 primes (SEAL_HEVM.cpp:39-40). */
+ * reference's hard-coded N = 2^15, 14 primes (SEAL_HEVM.cpp:39-40).  TEST / BENCH ONLY: all randomness is expanded from
+ * the 64-bit `seed` so that runs are reproducible -- such keys are NOT secure.  create_context() is the secure path. */
 void *hevm_init_seeded(int logN, int num_primes, uint64_t seed);
 /* the kernel-level context (dc_context*, include/dacapo_ckks.h) behind a VM */
 void *hevm_context(void *vm);
@@ -91,6 +94,28 @@ void hevm_set_streams(void *vm, int n);
 void hevm_select_stream(void *vm, int s);
 /* wall seconds the last run() spent inside opcode 10 (decrypt / re-encode / encrypt) */
 double hevm_last_run_bootstrap_seconds(void *vm);
+/* seal::Ciphertext::save / ::load of cipher register `reg` (the reference hands out seal::Ciphertext* through getCtxt "to
+ * implement communication", SEAL_HEVM.cpp:463-473): SEAL 4.0 bytes, parms_id of the register's level, its scale. */
+void hevm_save_ctxt(void *vm, int64_t reg, const char *path);
+void hevm_load_ctxt(void *vm, int64_t reg, const char *path);
+
+/* ---- host-only helpers: SEAL 4.0 serialization and the PRNG's block function, no GPU touched --------------- */
+/* EncryptionParameters::parms_id of CKKS parameters (poly_modulus_degree, primes[0..count)): BLAKE2b-256 */
+void hevm_seal_parms_id(uint64_t poly_modulus_degree, const uint64_t *primes, int count, uint64_t out[4]);
+/* EncryptionParameters::save / ::load (compr_mode 0 none, 1 zlib, 2 zstd); load returns the number of primes */
+void hevm_seal_save_parms(const char *path, int compr_mode, uint64_t poly_modulus_degree, const uint64_t *primes, int count);
+int hevm_seal_load_parms(const char *path, uint64_t *poly_modulus_degree, uint64_t *primes, int capacity);
+/* Ciphertext::save / ::load on host limbs [size][limbs][N]; the parms_id written is that of primes[0..limbs).
+ * load returns the number of 64-bit words of the data array and copies them when `capacity` allows. */
+void hevm_seal_save_ciphertext(const char *path, int compr_mode, uint64_t poly_modulus_degree, const uint64_t *primes, int limbs, int size,
+                               int is_ntt, double scale, const uint64_t *data);
+int64_t hevm_seal_load_ciphertext(const char *path, uint64_t *poly_modulus_degree, int *limbs, int *size, int *is_ntt, double *scale,
+                                  uint64_t parms_id[4], uint64_t *data, uint64_t capacity);
+int hevm_seal_zstd_available(void);
+/* ChaCha20 block function (RFC 8439 2.3; 64-bit counter in state words 12-13, 64-bit nonce in 14-15) on the host and,
+ * for the parity test of the samplers' code path, on the GPU */
+void hevm_chacha20_block(const uint32_t key[8], uint64_t counter, uint64_t nonce, uint32_t out[16]);
+void hevm_chacha20_blocks_device(const uint32_t key[8], uint64_t counter, uint64_t nonce, int blocks, uint32_t *out_host);
 
 #ifdef __cplusplus
 }

@@ -9,58 +9,21 @@ pytestmark = pytest.mark.gpu
 from oracle.oracle import Ciphertext, Oracle, OracleVM, Plaintext, read_cst, read_hevm
 
 
-def _import_keys(o: Oracle, hevm, ll):
-    """pull the GPU VM's key material into the oracle so both interpret the program on identical limbs"""
-    from dacapo_amd import runner
-
-    lw = runner.lw
-    K, N = o.K, o.N
-    o.sk = ll.read_device(lw.hevm_secret_key(hevm.vm), (K, N))
-    o.pk = ll.read_device(lw.hevm_public_key(hevm.vm), (2, K, N))
-    o.relin = ll.read_device(lw.hevm_relin_key(hevm.vm), (K - 1, 2, K, N))
-    o.galois = {}
-    for elt in o.default_galois_elts():
-        p = lw.hevm_galois_key(hevm.vm, elt)
-        assert p, f"default Galois key {elt} missing"
-        o.galois[elt] = ll.read_device(p, (K - 1, 2, K, N))
+from gpu_helpers import _get_ct, _import_keys, _mirror_vm  # noqa: E402
 
 
-def _get_ct(hevm, ll, reg):
-    c = hevm.getCtxt(reg)
-    full = ll.read_device(c.data, (2, c.poly_stride // hevm.N, hevm.N))
-    return Ciphertext(np.ascontiguousarray(full[:, : c.level]), c.scale)
-
-
-def _mirror_vm(hevm, ll, o, cst, hv, tmp_path):
-    import ctypes
-
-    from dacapo_amd import runner
-
-    (tmp_path / "p.cst").write_bytes(cst)
-    (tmp_path / "p.hevm").write_bytes(hv)
-    ovm = OracleVM(o)
-    ovm.load(tmp_path / "p.cst", tmp_path / "p.hevm")
-    for i in range(ovm.prog.num_ptxt):
-        lvl, sc = ctypes.c_int32(), ctypes.c_double()
-        p = runner.lw.hevm_plain(hevm.vm, i, ctypes.byref(lvl), ctypes.byref(sc))
-        if p:
-            ovm.plains[i] = Plaintext(ll.read_device(p, (lvl.value, o.N)), sc.value)
-    return ovm
-
-
-@pytest.fixture(scope="module", params=["plan", "eager1", "eager4", "graph2"])
+@pytest.fixture(scope="module", params=["plan", "eager", "plan2g"])
 def vm13(request):
     """plan   = default: the batched execution plan (SSA-renamed registers, one batched launch sequence per wave);
-    eager1 = the reference's dispatch loop, one op at a time on one stream;
-    eager4 = 4 lanes issued eagerly (event-based register dependency tracking);
-    graph2 = 2 lanes captured into a HIP graph and replayed."""
+    eager  = the reference's dispatch loop, one instruction at a time on one stream (DACAPO_HEVM_PLAN=0);
+    plan2g = the plan with independent steps of a wave on an auxiliary stream, replayed as one HIP graph."""
     import os
 
     from dacapo_amd import lowlevel as ll
     from dacapo_amd import runner
 
-    env = {"plan": {}, "eager1": {"DACAPO_HEVM_PLAN": "0"}, "eager4": {"DACAPO_HEVM_PLAN": "0", "DACAPO_HEVM_LANES": "4"},
-           "graph2": {"DACAPO_HEVM_PLAN": "0", "DACAPO_HEVM_LANES": "2", "DACAPO_HEVM_GRAPH": "1"}}[request.param]
+    env = {"plan": {}, "eager": {"DACAPO_HEVM_PLAN": "0"},
+           "plan2g": {"DACAPO_HEVM_PLAN_LANES": "2", "DACAPO_HEVM_PLAN_GRAPH": "1"}}[request.param]
     os.environ.update(env)
     try:
         hevm = runner.HEVM(seed=0x4845564D, logN=13, num_primes=7)
@@ -128,7 +91,7 @@ def test_sobel_program_bit_exact_and_rms(vm13, tmp_path):
     assert got.ell == want.ell and got.scale == want.scale
     assert (got.data == want.data).all()  # program-level bit-exactness
     res = hevm.getOutput()
-    # a second run() on the same inputs (graph replay in graph mode) reproduces the same limbs
+    # a second run() on the same inputs (a graph replay in plan2g mode) reproduces the same limbs
     hevm.run()
     again = _get_ct(hevm, ll, ovm.prog.res_dst[0])
     assert (again.data == want.data).all() and again.scale == want.scale and again.ell == want.ell
@@ -163,8 +126,6 @@ def test_rotation_by_arbitrary_offsets_and_bootstrap_opcode(vm13, tmp_path):
     from dacapo_amd import hevm_asm as ha
 
     hevm, o, ll = vm13
-    if hevm.mode == "graph2":
-        pytest.skip("opcode 10 inside a stream capture aborts on ROCm 7.2; the graph path is experimental and opt-in")
     rng = np.random.default_rng(7)
     x = rng.uniform(-1, 1, o.slots)
     b = ha.Builder(slots=o.slots, init_level=6)
@@ -436,8 +397,6 @@ def test_rescale_operand_expressions_bit_exact(vm13, tmp_path):
     from dacapo_amd import hevm_asm as ha
 
     hevm, o, ll = vm13
-    if getattr(hevm, "mode", "plan") == "graph2":
-        pytest.skip("covered by the other three modes")
     rng = np.random.default_rng(23)
     xv, yv = rng.uniform(-1, 1, o.slots), rng.uniform(-1, 1, o.slots)
     b = ha.Builder(slots=o.slots, init_level=6, shadow=True)
@@ -485,8 +444,6 @@ def test_random_programs_bit_exact(vm13, tmp_path, seed):
     from dacapo_amd import hevm_asm as ha
 
     hevm, o, ll = vm13
-    if getattr(hevm, "mode", "plan") == "graph2" and seed > 2:
-        pytest.skip("graph capture mode: two seeds are enough")
     rng = np.random.default_rng(1000 + seed)
     b = ha.Builder(slots=o.slots, init_level=6, shadow=True)
     ins = [b.input(rng.uniform(-1, 1, o.slots)) for _ in range(2)]
@@ -561,8 +518,6 @@ def test_random_lazy_programs_with_bootstraps(vm13, seed):
     from dacapo_amd import hevm_asm as ha
 
     hevm, o, ll = vm13
-    if getattr(hevm, "mode", "plan") == "graph2":
-        pytest.skip("the experimental op-by-op graph capture does not support opcode 10 (DESIGN.md, scheduling notes)")
     rng = np.random.default_rng(2000 + seed)
     b = ha.Builder(slots=o.slots, init_level=3, policy="lazy", boot_level=3, shadow=True)
     ins = [b.input(rng.uniform(-1, 1, o.slots)) for _ in range(2)]

@@ -13,7 +13,7 @@ from pathlib import Path
 
 from oracle.oracle import Oracle
 
-from test_gpu_hevm import _get_ct, _import_keys, _mirror_vm
+from gpu_helpers import _get_ct, _import_keys, _mirror_vm
 
 GOLDEN = Path(__file__).resolve().parent / "golden" / "resnet20"
 

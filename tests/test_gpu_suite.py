@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 
 from oracle.oracle import Oracle
 
-from test_gpu_hevm import _get_ct, _import_keys, _mirror_vm
+from gpu_helpers import _get_ct, _import_keys, _mirror_vm
 
 SUITE = Path(__file__).resolve().parent / "golden" / "suite"
 NAMES = ["SobelFilter", "HarrisCornerDetection", "LinearRegression", "PolynomialRegression", "Multivariate", "MLP"]
