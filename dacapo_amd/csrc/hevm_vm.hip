@@ -772,12 +772,19 @@ void HEVM::load_constants(const void *data, size_t len)
     need(8);
     int64_t count;
     memcpy(&count, p, 8), p += 8;
+    if (count < 0 || (uint64_t)count > (uint64_t)(end - p) / 8) { // every vector needs at least its 8-byte length
+        fprintf(stderr, "[dacapo_amd] .cst file: implausible constant count %lld\n", (long long)count);
+        abort();
+    }
     buffer.assign((size_t)count, {});
     for (int64_t i = 0; i < count; i++) {
         need(8);
         int64_t veclen;
         memcpy(&veclen, p, 8), p += 8;
-        need((size_t)veclen * 8);
+        if (veclen < 0 || (uint64_t)veclen > (uint64_t)(end - p) / 8) {
+            fprintf(stderr, "[dacapo_amd] truncated .cst file (constant %lld claims %lld values)\n", (long long)i, (long long)veclen);
+            abort();
+        }
         buffer[i].resize((size_t)veclen);
         memcpy(buffer[i].data(), p, (size_t)veclen * 8), p += veclen * 8;
     }
@@ -800,6 +807,11 @@ void HEVM::load_program(const void *data, size_t len, bool header_only)
         abort();
     }
     const size_t na = header.arg_length, nr = header.res_length;
+    if (na > (size_t)(end - p) / 16 || nr > (size_t)(end - p) / 24 || config.num_operations > (size_t)(end - p) / sizeof(WireOp) ||
+        config.num_ctxt_buffer > 65536 || config.num_ptxt_buffer > 65536) { // operands are 16-bit register numbers
+        fprintf(stderr, "[dacapo_amd] .hevm header claims more arguments / results / operations / registers than the file can hold\n");
+        abort();
+    }
     arg_scale.resize(na), arg_level.resize(na), res_scale.resize(nr), res_level.resize(nr), res_dst.resize(nr);
     take(arg_scale.data(), na * 8), take(arg_level.data(), na * 8);
     take(res_scale.data(), nr * 8), take(res_level.data(), nr * 8), take(res_dst.data(), nr * 8);
@@ -810,6 +822,31 @@ void HEVM::load_program(const void *data, size_t len, bool header_only)
         nct = std::max<size_t>(nct, config.num_ctxt_buffer);
         free_plains();
         plains.assign(config.num_ptxt_buffer, Plain{});
+        // Operand validation, once: the reference indexes its register vectors unchecked (SEAL_HEVM.cpp:268-334); here a program
+        // may name cipher registers beyond num_ctxt_buffer (the file grows with them) but never a plaintext register that does not exist.
+        for (const WireOp &op : ops) {
+            if (op.opcode > 10) continue;
+            if (op.opcode == 0) {
+                if (op.dst >= plains.size()) {
+                    fprintf(stderr, "[dacapo_amd] .hevm: encode into plaintext register %u of %zu\n", (unsigned)op.dst, plains.size());
+                    abort();
+                }
+                continue;
+            }
+            nct = std::max<size_t>(nct, (size_t)std::max(op.dst, op.lhs) + 1);
+            if (op.opcode == 6 || op.opcode == 8) nct = std::max<size_t>(nct, (size_t)op.rhs + 1);
+            if ((op.opcode == 7 || op.opcode == 9) && op.rhs >= plains.size()) {
+                fprintf(stderr, "[dacapo_amd] .hevm: opcode %u reads plaintext register %u of %zu\n", (unsigned)op.opcode, (unsigned)op.rhs, plains.size());
+                abort();
+            }
+        }
+        for (uint64_t r : res_dst) {
+            if (r >= 65536) {
+                fprintf(stderr, "[dacapo_amd] .hevm: result register %llu outside the 16-bit register space\n", (unsigned long long)r);
+                abort();
+            }
+            nct = std::max<size_t>(nct, (size_t)r + 1);
+        }
     }
     while (ciphers.size() < nct) ciphers.push_back(hevm_ctxt{ nullptr, 0, 0, 0, 1.0 });
     for (size_t i = 0; i < nct; i++) reg(i); // allocate now: nothing may call hipMalloc while run() is being captured

@@ -83,7 +83,13 @@ void HEVM::build_plan()
                 P.n_keyswitch++, P.n_ntt += ks_ntts(s.level);
                 v = nv;
             }
-            cur[op.dst] = v; // zero hops: dst simply names the same value
+            if (v == cur[op.lhs] && op.dst != op.lhs) { // no hop at all: rotate_vector copies (SEAL_HEVM.cpp:273), so dst gets a value of its
+                const Val s = P.vals[(size_t)v];            // own -- a later scale overwrite on one register (:301,:308) must not reach the other
+                const int nv = new_val(s.level, s.scale);
+                add_pop(P_COPY, s.level, { v }, nv);
+                v = nv;
+            }
+            cur[op.dst] = v;
             break;
         }
         case 2: {

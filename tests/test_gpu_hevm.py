@@ -551,3 +551,65 @@ def test_random_lazy_programs_with_bootstraps(vm13, seed):
     res = hevm.getOutput()
     for k, ref in enumerate(b.expected()):
         assert np.sqrt(np.mean((res[k] - ref) ** 2)) < 2e-5 * max(1.0, float(np.abs(ref).max())), (seed, k, info["op_mix"])
+
+
+@pytest.mark.parametrize("plan", ["1", "0"])
+def test_zero_hop_rotate_is_a_copy_not_an_alias(monkeypatch, plan):
+    """rotate by 0 into ANOTHER register copies (rotate_vector, SEAL_HEVM.cpp:273).  The reference's addcp then overwrites the
+    scale of its lhs register only (:308): the copy must keep the old scale, in the plan (SSA values) as in the eager loop."""
+    from dacapo_amd import hevm_asm as ha
+    from dacapo_amd import runner
+
+    monkeypatch.setenv("DACAPO_HEVM_PLAN", plan)
+    hevm = runner.HEVM(seed=7, logN=12, num_primes=4)
+    E, ROT, ADDCP = ha.OP_ENCODE, ha.OP_ROTATE, ha.OP_ADDCP
+    ops = [(E, 0, 0, (3 << 10) + 20),   # plaintext at scale 2^20
+           (ROT, 1, 0, 0),              # r1 = copy of r0 (scale 2^30)
+           (ADDCP, 2, 0, 0)]            # r2 = r0 + pt: r0.scale := 2^20 (r1 must not follow)
+    hv = ha.pack_hevm([30], [3], [30, 20], [3, 3], [1, 2], 3, 1, 3, np.array(ops, dtype=np.uint16))
+    hevm.load_mem(ha.pack_cst([np.array([0.5])]), hv)
+    x = np.linspace(-1, 1, hevm.slots)
+    hevm.setInput(0, x)
+    hevm.run()
+    assert hevm.getCtxt(1).scale == 2.0**30 and hevm.getCtxt(2).scale == 2.0**20
+    res = hevm.getOutput()
+    assert np.abs(res[0] - x).max() < 1e-5
+
+
+@pytest.mark.parametrize("case", ["cst_count", "cst_veclen", "hevm_nops", "plain_reg", "res_dst"])
+def test_malformed_program_files_abort_with_a_message(tmp_path, case):
+    """hostile / truncated .cst and .hevm images stop at load with a diagnostic (the reference reads them unchecked,
+    SEAL_HEVM.cpp:182-234): negative or overflowing counts, an operation count the file cannot hold, operands naming
+    registers that do not exist."""
+    import struct
+    import subprocess
+    import sys
+
+    from dacapo_amd import hevm_asm as ha
+
+    cst = ha.pack_cst([np.array([0.5])])
+    ops = [(ha.OP_ENCODE, 0, 0, (3 << 10) + 20), (ha.OP_ADDCP, 1, 0, 0)]
+    hv = ha.pack_hevm([30], [3], [20], [3], [1], 2, 1, 3, np.array(ops, dtype=np.uint16))
+    if case == "cst_count":
+        cst = struct.pack("<q", -1) + cst[8:]
+    elif case == "cst_veclen":
+        cst = cst[:8] + struct.pack("<q", (1 << 61) + 1) + cst[16:]
+    elif case == "hevm_nops":
+        hv = hv[:32] + struct.pack("<Q", 1 << 40) + hv[40:]
+    elif case == "plain_reg":
+        bad = [(ha.OP_ENCODE, 0, 0, (3 << 10) + 20), (ha.OP_MULCP, 1, 0, 7)]
+        hv = ha.pack_hevm([30], [3], [20], [3], [1], 2, 1, 3, np.array(bad, dtype=np.uint16))
+    elif case == "res_dst":
+        hv = ha.pack_hevm([30], [3], [20], [3], [1 << 20], 2, 1, 3, np.array(ops, dtype=np.uint16))
+    (tmp_path / "p.cst").write_bytes(cst)
+    (tmp_path / "p.hevm").write_bytes(hv)
+    code = f"""
+import sys
+sys.path.insert(0, {str(__import__('pathlib').Path(__file__).resolve().parent.parent)!r})
+from dacapo_amd import runner
+h = runner.HEVM(seed=1, logN=12, num_primes=4)
+h.load({str(tmp_path / 'p.cst')!r}, {str(tmp_path / 'p.hevm')!r})
+print("loaded", flush=True)
+"""
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "loaded" not in r.stdout and "[dacapo_amd]" in r.stderr, (r.stdout, r.stderr[-500:])
