@@ -1069,6 +1069,12 @@ void HEVM::encrypt_plain(hevm_ctxt &dst, const Plain &pt)
         fprintf(stderr, "[dacapo_amd] encrypt: this VM has no public key\n");
         abort();
     }
+    if (test_zero_enc) { // TEST HOOK: (plaintext, 0)
+        DC_HIP_CHECK(hipMemcpyAsync(dst.data, pt.d, (size_t)ell * N * 8, hipMemcpyDeviceToDevice, S()));
+        DC_HIP_CHECK(hipMemsetAsync(dst.data + dst.poly_stride, 0, (size_t)ell * N * 8, S()));
+        dst.level = ell, dst.scale = pt.scale;
+        return;
+    }
     u64 *ue = W().ks_ext; // [3][cnt][N]: u, e0, e1
     const CtView tmp{ dst.data, (long)dst.poly_stride };
     // one object per encryption of this VM's lifetime (opcode-10 items of a plan use the range above 2^32)
@@ -1681,6 +1687,11 @@ void hevm_load_mem(void *vm, const void *cst, uint64_t cst_len, const void *hevm
 void hevm_set_streams(void *vm, int n) { static_cast<HEVM *>(vm)->set_streams(n); }
 void hevm_select_stream(void *vm, int s) { static_cast<HEVM *>(vm)->select_stream(s); }
 double hevm_last_run_bootstrap_seconds(void *vm) { return static_cast<HEVM *>(vm)->t_bootstrap; }
+void hevm_test_zero_encryption(void *vm, bool on)
+{
+    if (on) fprintf(stderr, "[dacapo_amd] TEST HOOK: encryptions of zero are (0, 0) from now on -- this VM offers NO security\n");
+    static_cast<HEVM *>(vm)->test_zero_enc = on;
+}
 void hevm_save_ctxt(void *vm, int64_t reg, const char *path) { static_cast<HEVM *>(vm)->save_ctxt((size_t)reg, path); }
 void hevm_load_ctxt(void *vm, int64_t reg, const char *path) { static_cast<HEVM *>(vm)->load_ctxt((size_t)reg, path); }
 

@@ -169,6 +169,7 @@ class HEVM {
         // opcode 10: item table, the divide-and-round items of the zero-encryptions, the zero-encryption arena and scratch
         BootItem *d_boot = nullptr;
         RsItem *d_boot_rs = nullptr;
+        size_t zenc_bytes = 0;
         u64 *zenc = nullptr, *boot_ue = nullptr, *boot_tmp = nullptr, *boot_pt[2] = { nullptr, nullptr }, *boot_ptx[2] = { nullptr, nullptr };
         struct BootChunk { int first, count, target; };
         std::vector<BootChunk> boot_chunks; // zero-encryption launches at the start of every run
@@ -183,6 +184,7 @@ class HEVM {
     bool plan_graph = false; // DACAPO_HEVM_PLAN_GRAPH=1: replay the plan's launch sequence as one HIP graph
     void issue_plan(hipStream_t s);
     bool use_plan = true;
+    bool test_zero_enc = false; // hevm_test_zero_encryption: encryptions of zero are (0, 0) -- INSECURE, parity tests of opcode 10 only
     int max_batch = 128;
     std::vector<u64 *> home; // permanent buffer block of every architectural register (program inputs live here)
     // Throughput mode: `streams` independent ciphertext streams share the program, keys and plaintexts; every buffer is a

@@ -477,6 +477,7 @@ void HEVM::build_plan()
     if (!h_boot_pops.empty()) {
         const size_t nb = h_boot_pops.size(), slot = (size_t)2 * boot_tmax * N;
         DC_HIP_CHECK(hipMalloc(&P.zenc, nb * slot * sizeof(u64)));
+        P.zenc_bytes = nb * slot * sizeof(u64);
         std::vector<int> order(nb); // boot items sorted by target level (stable): chunks are ranges of the sorted tables
         for (size_t i = 0; i < nb; i++) order[i] = (int)i;
         std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
@@ -597,7 +598,10 @@ void HEVM::issue_plan(hipStream_t s)
 {
     Context &c = *ctx;
     Plan &P = plan;
-    for (const Plan::BootChunk &bc : P.boot_chunks) plan_zero_encrypt(bc.first, bc.count, bc.target, s);
+    if (test_zero_enc) { // TEST HOOK (hevm_test_zero_encryption): Enc(0) := (0, 0), so opcode 10 leaves its re-encoded plaintext in c0
+        if (P.zenc) DC_HIP_CHECK(hipMemsetAsync(P.zenc, 0, P.zenc_bytes, s));
+    } else
+        for (const Plan::BootChunk &bc : P.boot_chunks) plan_zero_encrypt(bc.first, bc.count, bc.target, s);
     size_t ev = 0;
     for (size_t a = 0; a < P.steps.size();) {
         size_t b = a;

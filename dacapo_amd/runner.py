@@ -71,6 +71,7 @@ def reinit_lw():  # runner.py:73-117
     lw.hevm_select_stream.argtypes = [ctypes.c_void_p, ctypes.c_int]
     lw.hevm_last_run_bootstrap_seconds.argtypes = [ctypes.c_void_p]
     lw.hevm_last_run_bootstrap_seconds.restype = ctypes.c_double
+    lw.hevm_test_zero_encryption.argtypes = [ctypes.c_void_p, ctypes.c_bool]
     lw.hevm_save_ctxt.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_char_p]
     lw.hevm_load_ctxt.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_char_p]
     return lw

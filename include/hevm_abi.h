@@ -94,6 +94,10 @@ void hevm_set_streams(void *vm, int n);
 void hevm_select_stream(void *vm, int s);
 /* wall seconds the last run() spent inside opcode 10 (decrypt / re-encode / encrypt) */
 double hevm_last_run_bootstrap_seconds(void *vm);
+/* TEST HOOK, INSECURE: while on, every encryption of zero (encrypt(), opcode 10) is the pair (0, 0), so a ciphertext is
+ * (plaintext, 0) and opcode 10's deterministic half -- decrypt, decode, re-encode (SEAL_HEVM.cpp:328-333) -- can be compared
+ * limb by limb with the oracle.  Prints a warning when switched on. */
+void hevm_test_zero_encryption(void *vm, bool on);
 /* seal::Ciphertext::save / ::load of cipher register `reg` (the reference hands out seal::Ciphertext* through getCtxt "to
  * implement communication", SEAL_HEVM.cpp:463-473): SEAL 4.0 bytes, parms_id of the register's level, its scale. */
 void hevm_save_ctxt(void *vm, int64_t reg, const char *path);
