@@ -107,6 +107,19 @@ static bool fuse_mac()
     static const bool v = !(getenv("DACAPO_KS_FUSE_MAC") && atoi(getenv("DACAPO_KS_FUSE_MAC")) == 0);
     return v;
 }
+// work (in 1024-coefficient tiles of lifted digits) from which a key switch takes the large-batch launch sequence
+static long big_threshold()
+{
+    static const long v = getenv("DACAPO_KS_BIG_TILES") ? atol(getenv("DACAPO_KS_BIG_TILES")) : 4096;
+    return v;
+}
+// ... and up to which the second NTT phase, the inner products and the special prime's first inverse phase stay one launch
+// (always, by default: at N = 2^16 / 24 primes the fused launch is 17 % faster than three, at the HEVM sizes it is even)
+static long fuse_mac_threshold()
+{
+    static const long v = getenv("DACAPO_KS_FUSE_MAC_TILES") ? atol(getenv("DACAPO_KS_FUSE_MAC_TILES")) : (1L << 40);
+    return v;
+}
 
 // L2..L7 of the key-switch pipeline (fused_ks.hip) once the digits' inverse ROWS phase (L1) has been issued
 template <int MODE>
@@ -117,7 +130,8 @@ static void b_ks_tail(Context &c, const BatchWs &w, const KsItem *items, const v
     const int K = c.K, sp = K - 1;
     // small batches: one launch that recomputes the inverse COLS phase per target modulus (latency); large batches: run it
     // once per limb, then a base-change + forward launch (25-35 % less work in these two steps)
-    const bool big = (long)(N >> 10) * B * ell * ell >= 4096;
+    const long tiles = (long)(N >> 10) * B * ell * ell;
+    const bool big = tiles >= big_threshold(), fused_mac = fuse_mac() && tiles < fuse_mac_threshold();
     if (big) {
         launch_ntt_cols_inv(c, w.digits, (long)N, B * ell, nullptr, 0, ell, s);
         f_ks_lift_fcols(c, w.digits, w.ext, B, ell, s);
@@ -125,7 +139,7 @@ static void b_ks_tail(Context &c, const BatchWs &w, const KsItem *items, const v
         f_ks_icols_lift_fcols(c, w.digits, w.ext, B, ell, s);
     u64 *acc_last = w.acc + (size_t)ell * N;
     const long acc_ps = (long)(ell + 1) * (long)N;
-    if (big || !fuse_mac()) {
+    if (!fused_mac) {
         launch_ntt_rows_fwd(c, w.ext, (long)N, B * ell * ell, c.ks_prime_idx(ell), 0, ell * ell, s);
         hipLaunchKernelGGL(b_ks_mac_kernel<MODE>, dim3((unsigned)(N / (2 * kBT)), ell + 1, B), dim3(kBT), 0, s, w.acc, w.ext, w.target, items,
                            shared_key, ell, K, N, c.logN, c.d_mods);
@@ -138,7 +152,7 @@ static void b_ks_tail(Context &c, const BatchWs &w, const KsItem *items, const v
         f_dr_lift_fcols(c, acc_last, acc_ps, w.tmp, 2 * B, ell, sp, s);
     } else
         f_dr_icols_lift_fcols(c, acc_last, acc_ps, w.tmp, 2 * B, ell, sp, s);
-    f_frows_final(c, (MODE == 1 && !big && fuse_mac()) ? 4 : MODE, w.tmp, final_items, w.acc, 2 * B, ell, sp, s);
+    f_frows_final(c, (MODE == 1 && fused_mac) ? 4 : MODE, w.tmp, final_items, w.acc, 2 * B, ell, sp, s);
 }
 
 void b_rotate_hops(Context &c, const BatchWs &w, const KsItem *d_items, int B, int ell, hipStream_t s)
@@ -150,8 +164,8 @@ void b_rotate_hops(Context &c, const BatchWs &w, const KsItem *d_items, int B, i
 void b_mul_relin(Context &c, const BatchWs &w, const MulItem *d_items, const u64 *relin_key, int B, int ell, hipStream_t s)
 {
     const size_t N = c.N;
-    const bool big = (long)(N >> 10) * B * ell * ell >= 4096; // same split as b_ks_tail
-    if (big || !fuse_mac()) {
+    const bool fused_mac = fuse_mac() && (long)(N >> 10) * B * ell * ell < fuse_mac_threshold(); // same split as b_ks_tail
+    if (!fused_mac) {
         hipLaunchKernelGGL(b_tensor_kernel, dim3((unsigned)(N / (2 * kBT)), ell, B), dim3(kBT), 0, s, d_items, w.target, ell, N, c.d_mods);
         f_irows_strided(c, w.target, (long)N, 0, ell, w.digits, (long)N, B * ell, s);
     } else // small batches: a1*b1 is formed in the loaders and a0*b0, a0*b1 + a1*b0 in the last kernel's epilogue

@@ -181,7 +181,9 @@ class HEVM {
         hipGraph_t graph = nullptr;
         hipGraphExec_t graph_exec = nullptr;
     } plan;
-    bool plan_graph = false; // DACAPO_HEVM_PLAN_GRAPH=1: replay the plan's launch sequence as one HIP graph
+    bool plan_graph = true; // replay the plan's launch sequence as one HIP graph (DACAPO_HEVM_PLAN_GRAPH=0: issue it launch by launch)
+    void capture_plan();
+    void drop_plan_graph();
     void issue_plan(hipStream_t s);
     bool use_plan = true;
     bool test_zero_enc = false; // hevm_test_zero_encryption: encryptions of zero are (0, 0) -- INSECURE, parity tests of opcode 10 only
@@ -200,7 +202,7 @@ class HEVM {
     void plan_boot_step(int first, int B, int ell, int t, int lane, hipStream_t s);
     hipStream_t aux_stream = nullptr;
     bool fold_rescale_into_boot = false; // DACAPO_HEVM_FOLD_RESCALE_BOOT=1: do a rescale that only feeds an opcode 10 inside its re-encoder
-    int plan_lanes = 1; // DACAPO_HEVM_PLAN_LANES=2: independent steps of a wave also use an auxiliary stream (pays off only with PLAN_GRAPH)
+    int plan_lanes = 2; // independent steps of a wave also use an auxiliary stream (pays off only inside the graph; DACAPO_HEVM_PLAN_LANES=1: one stream)
     void bump_epoch(hipStream_t s);
 
     // statistics of the last run()

@@ -5,6 +5,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <map>
 #include <queue>
 #include <tuple>
@@ -561,6 +562,7 @@ void HEVM::build_plan()
     }
     P.n_keyswitch *= S, P.n_ntt *= S;
     P.ready = true;
+    if (plan_graph) capture_plan(); // part of the (untimed) preparation, like the plan itself
     if (getenv("DACAPO_HEVM_TRACE")) {
         static const char *kn[] = { "rot", "mulcc", "rescale", "sum", "neg", "mulp", "addp", "copy", "boot" };
         size_t nsteps[9] = { 0 }, nitems[9] = { 0 };
@@ -602,6 +604,10 @@ void HEVM::issue_plan(hipStream_t s)
         if (P.zenc) DC_HIP_CHECK(hipMemsetAsync(P.zenc, 0, P.zenc_bytes, s));
     } else
         for (const Plan::BootChunk &bc : P.boot_chunks) plan_zero_encrypt(bc.first, bc.count, bc.target, s);
+    // DACAPO_HEVM_STEP_PROFILE=1: synchronise after every step and attribute wall time to (kind, level, batch size) -- a
+    // diagnosis mode (every step then pays a full launch round trip, as the steps of a dependent chain do anyway)
+    static const bool step_profile = getenv("DACAPO_HEVM_STEP_PROFILE") && atoi(getenv("DACAPO_HEVM_STEP_PROFILE")) && !plan_graph;
+    std::map<std::tuple<int, int, int>, std::pair<int, double>> prof;
     size_t ev = 0;
     for (size_t a = 0; a < P.steps.size();) {
         size_t b = a;
@@ -627,6 +633,19 @@ void HEVM::issue_plan(hipStream_t s)
             case P_ADDP: b_add_plain(c, P.d_ew + st.first, st.count, st.level, q); break;
             case P_BOOT: plan_boot_step(st.first, st.count, st.level, st.target, st.lane, q); break;
             }
+            if (step_profile) {
+                static auto t_prev = std::chrono::steady_clock::now();
+                if (i == 0) {
+                    DC_HIP_CHECK(hipStreamSynchronize(s));
+                    t_prev = std::chrono::steady_clock::now();
+                }
+                DC_HIP_CHECK(hipStreamSynchronize(q));
+                const auto t1 = std::chrono::steady_clock::now();
+                const int bucket = st.count <= 1 ? 1 : st.count <= 2 ? 2 : st.count <= 4 ? 4 : st.count <= 8 ? 8 : st.count <= 32 ? 32 : 128;
+                auto &e = prof[std::make_tuple((int)st.kind, st.level, bucket)];
+                e.first++, e.second += std::chrono::duration<double>(t1 - t_prev).count();
+                t_prev = t1;
+            }
         }
         if (has_aux) { // join
             DC_HIP_CHECK(hipEventRecord(P.events[ev], aux_stream));
@@ -636,6 +655,38 @@ void HEVM::issue_plan(hipStream_t s)
         a = b;
     }
     bump_epoch(s);
+    if (step_profile) {
+        static const char *kn[] = { "rot", "mulcc", "rescale", "sum", "neg", "mulp", "addp", "copy", "boot" };
+        double total = 0;
+        for (auto &kv : prof) total += kv.second.second;
+        fprintf(stderr, "[dacapo_amd] step profile (synchronised after every step): %.2f ms in %zu steps\n", total * 1e3, P.steps.size());
+        for (auto &kv : prof)
+            fprintf(stderr, "[dacapo_amd]   %-8s level %2d  batch<=%-3d  %5d steps  %8.3f ms  %7.2f us/step\n", kn[std::get<0>(kv.first)],
+                    std::get<1>(kv.first), std::get<2>(kv.first), kv.second.first, kv.second.second * 1e3,
+                    kv.second.second * 1e6 / kv.second.first);
+    }
+}
+
+// Record the plan's launch sequence (main + auxiliary stream) into a HIP graph.  Nothing executes here; kernel arguments are
+// the plan's own device tables and pool buffers, which live as long as the plan does.
+void HEVM::capture_plan()
+{
+    Plan &P = plan;
+    if (P.graph_exec) return;
+    if (!P.boot_chunks.empty() && (!keys.sk || !keys.pk)) return; // opcode 10 on a VM without the keys: run() reports it, eagerly
+    hipStream_t s = S();
+    DC_HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
+    issue_plan(s);
+    DC_HIP_CHECK(hipStreamEndCapture(s, &P.graph));
+    DC_HIP_CHECK(hipGraphInstantiate(&P.graph_exec, P.graph, nullptr, nullptr, 0));
+}
+
+void HEVM::drop_plan_graph()
+{
+    Plan &P = plan;
+    if (P.graph_exec) (void)hipGraphExecDestroy(P.graph_exec);
+    if (P.graph) (void)hipGraphDestroy(P.graph);
+    P.graph_exec = nullptr, P.graph = nullptr;
 }
 
 void HEVM::run_plan()
@@ -651,14 +702,12 @@ void HEVM::run_plan()
     n_keyswitch = P.n_keyswitch, n_ntt = P.n_ntt;
     t_bootstrap = 0.0;
     const long ps = (long)c.K * (long)c.N;
-    if (plan_graph) { // the plan is a fixed launch sequence on one stream: record it once, replay it as one graph launch
-        if (!P.graph_exec) {
-            DC_HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
+    if (plan_graph) { // the plan is a fixed launch sequence: recorded once (normally by preprocess()), replayed as one graph launch
+        capture_plan();
+        if (P.graph_exec)
+            DC_HIP_CHECK(hipGraphLaunch(P.graph_exec, s));
+        else
             issue_plan(s);
-            DC_HIP_CHECK(hipStreamEndCapture(s, &P.graph));
-            DC_HIP_CHECK(hipGraphInstantiate(&P.graph_exec, P.graph, nullptr, nullptr, 0));
-        }
-        DC_HIP_CHECK(hipGraphLaunch(P.graph_exec, s));
     } else
         issue_plan(s);
     DC_HIP_CHECK(hipStreamSynchronize(s)); // the caller's timer stops when run() returns

@@ -12,18 +12,19 @@ from oracle.oracle import Ciphertext, Oracle, OracleVM, Plaintext, read_cst, rea
 from gpu_helpers import _get_ct, _import_keys, _mirror_vm  # noqa: E402
 
 
-@pytest.fixture(scope="module", params=["plan", "eager", "plan2g"])
+@pytest.fixture(scope="module", params=["plan", "eager", "plan1"])
 def vm13(request):
-    """plan   = default: the batched execution plan (SSA-renamed registers, one batched launch sequence per wave);
+    """plan   = default: the batched execution plan (SSA-renamed registers, one batched launch sequence per wave; independent
+             steps of a wave on an auxiliary stream; the whole sequence replayed as one HIP graph);
     eager  = the reference's dispatch loop, one instruction at a time on one stream (DACAPO_HEVM_PLAN=0);
-    plan2g = the plan with independent steps of a wave on an auxiliary stream, replayed as one HIP graph."""
+    plan1  = the plan issued launch by launch on one stream (no graph, no auxiliary stream)."""
     import os
 
     from dacapo_amd import lowlevel as ll
     from dacapo_amd import runner
 
     env = {"plan": {}, "eager": {"DACAPO_HEVM_PLAN": "0"},
-           "plan2g": {"DACAPO_HEVM_PLAN_LANES": "2", "DACAPO_HEVM_PLAN_GRAPH": "1"}}[request.param]
+           "plan1": {"DACAPO_HEVM_PLAN_LANES": "1", "DACAPO_HEVM_PLAN_GRAPH": "0"}}[request.param]
     os.environ.update(env)
     try:
         hevm = runner.HEVM(seed=0x4845564D, logN=13, num_primes=7)
@@ -91,7 +92,7 @@ def test_sobel_program_bit_exact_and_rms(vm13, tmp_path):
     assert got.ell == want.ell and got.scale == want.scale
     assert (got.data == want.data).all()  # program-level bit-exactness
     res = hevm.getOutput()
-    # a second run() on the same inputs (a graph replay in plan2g mode) reproduces the same limbs
+    # a second run() on the same inputs (a graph replay in plan mode) reproduces the same limbs
     hevm.run()
     again = _get_ct(hevm, ll, ovm.prog.res_dst[0])
     assert (again.data == want.data).all() and again.scale == want.scale and again.ell == want.ell

@@ -55,13 +55,13 @@ def test_resnet20_first_layer_bit_exact(vm15, fixture20, tmp_path):
     assert (got.data == want.data).all()
 
 
-def test_resnet20_two_lane_graph_replay(fixture20):
-    """opt-in execution mode: independent steps of a wave on an auxiliary stream, whole plan replayed as one HIP graph"""
+def test_resnet20_single_stream_no_graph(fixture20):
+    """the plan issued launch by launch on one stream (the default replays it as one HIP graph with an auxiliary stream)"""
     import os
 
     from dacapo_amd import runner
 
-    env = {"DACAPO_HEVM_PLAN_LANES": "2", "DACAPO_HEVM_PLAN_GRAPH": "1"}
+    env = {"DACAPO_HEVM_PLAN_LANES": "1", "DACAPO_HEVM_PLAN_GRAPH": "0"}
     os.environ.update(env)
     try:
         hevm = runner.HEVM(seed=0x4845564D + 1, logN=15, num_primes=14)
@@ -70,7 +70,7 @@ def test_resnet20_two_lane_graph_replay(fixture20):
             os.environ.pop(k)
     hevm.load_mem(fixture20["cst"], fixture20["hevm"])
     hevm.setInput(0, fixture20["packed"])
-    for _ in range(2):  # capture + replay
+    for _ in range(2):
         hevm.run()
         out = hevm.getOutput()[0]
         assert float(np.sqrt(np.mean((out - fixture20["expected"]) ** 2))) < 1e-3
