@@ -122,9 +122,12 @@ static long fuse_mac_threshold()
 }
 
 // L2..L7 of the key-switch pipeline (fused_ks.hip) once the digits' inverse ROWS phase (L1) has been issued
+bool chain_fusion_supported() { return fuse_mac(); }
+
+// `digits`: output of the inverse ROWS phase of the key-switch target [B][l][N] (w.digits, or the buffer a fused producer filled)
 template <int MODE>
-static void b_ks_tail(Context &c, const BatchWs &w, const KsItem *items, const void *final_items, const u64 *shared_key, int B, int ell,
-                      hipStream_t s)
+static void b_ks_tail(Context &c, const BatchWs &w, u64 *digits, const KsItem *items, const void *final_items, const u64 *shared_key, int B,
+                      int ell, hipStream_t s, const Handoff &h)
 {
     const size_t N = c.N;
     const int K = c.K, sp = K - 1;
@@ -133,10 +136,10 @@ static void b_ks_tail(Context &c, const BatchWs &w, const KsItem *items, const v
     const long tiles = (long)(N >> 10) * B * ell * ell;
     const bool big = tiles >= big_threshold(), fused_mac = fuse_mac() && tiles < fuse_mac_threshold();
     if (big) {
-        launch_ntt_cols_inv(c, w.digits, (long)N, B * ell, nullptr, 0, ell, s);
-        f_ks_lift_fcols(c, w.digits, w.ext, B, ell, s);
+        launch_ntt_cols_inv(c, digits, (long)N, B * ell, nullptr, 0, ell, s);
+        f_ks_lift_fcols(c, digits, w.ext, B, ell, s);
     } else
-        f_ks_icols_lift_fcols(c, w.digits, w.ext, B, ell, s);
+        f_ks_icols_lift_fcols(c, digits, w.ext, B, ell, s);
     u64 *acc_last = w.acc + (size_t)ell * N;
     const long acc_ps = (long)(ell + 1) * (long)N;
     if (!fused_mac) {
@@ -152,34 +155,40 @@ static void b_ks_tail(Context &c, const BatchWs &w, const KsItem *items, const v
         f_dr_lift_fcols(c, acc_last, acc_ps, w.tmp, 2 * B, ell, sp, s);
     } else
         f_dr_icols_lift_fcols(c, acc_last, acc_ps, w.tmp, 2 * B, ell, sp, s);
-    f_frows_final(c, (MODE == 1 && fused_mac) ? 4 : MODE, w.tmp, final_items, w.acc, 2 * B, ell, sp, s);
+    f_frows_final(c, (MODE == 1 && fused_mac) ? 4 : MODE, w.tmp, final_items, w.acc, 2 * B, ell, sp, s, RsItem{}, nullptr, nullptr, h);
 }
 
-void b_rotate_hops(Context &c, const BatchWs &w, const KsItem *d_items, int B, int ell, hipStream_t s)
+void b_rotate_hops(Context &c, const BatchWs &w, const KsItem *d_items, int B, int ell, hipStream_t s, const Handoff &h)
 {
     f_irows_rot_c1(c, d_items, ell, w.digits, B, s);
-    b_ks_tail<0>(c, w, d_items, d_items, nullptr, B, ell, s);
+    b_ks_tail<0>(c, w, w.digits, d_items, d_items, nullptr, B, ell, s, h);
 }
 
-void b_mul_relin(Context &c, const BatchWs &w, const MulItem *d_items, const u64 *relin_key, int B, int ell, hipStream_t s)
+void b_mul_relin(Context &c, const BatchWs &w, const MulItem *d_items, const u64 *relin_key, int B, int ell, hipStream_t s, const Handoff &h)
 {
     const size_t N = c.N;
     const bool fused_mac = fuse_mac() && (long)(N >> 10) * B * ell * ell < fuse_mac_threshold(); // same split as b_ks_tail
-    if (!fused_mac) {
+    u64 *digits = w.digits;
+    if (h.in) // a fused producer already ran the inverse ROWS phase of a1*b1 (the plan only links steps when fuse_mac() holds)
+        digits = const_cast<u64 *>(h.in);
+    else if (!fused_mac) {
         hipLaunchKernelGGL(b_tensor_kernel, dim3((unsigned)(N / (2 * kBT)), ell, B), dim3(kBT), 0, s, d_items, w.target, ell, N, c.d_mods);
         f_irows_strided(c, w.target, (long)N, 0, ell, w.digits, (long)N, B * ell, s);
     } else // small batches: a1*b1 is formed in the loaders and a0*b0, a0*b1 + a1*b0 in the last kernel's epilogue
         f_irows_tensor_c2(c, d_items, ell, w.digits, B, s);
-    b_ks_tail<1>(c, w, nullptr, d_items, relin_key, B, ell, s);
+    b_ks_tail<1>(c, w, digits, nullptr, d_items, relin_key, B, ell, s, h);
 }
 
-void b_rescale(Context &c, const BatchWs &w, const RsItem *d_items, int B, int ell, hipStream_t s, const SumSrc *d_srcs)
+void b_rescale(Context &c, const BatchWs &w, const RsItem *d_items, int B, int ell, hipStream_t s, const SumSrc *d_srcs, const Handoff &h)
 {
     const int l = ell - 1;
-    u64 *last = w.digits; // [B][2][N]
-    f_irows_rs_last(c, d_items, d_srcs, l, last, B, s);
+    const u64 *last = w.digits; // [B][2][N]
+    if (h.in)
+        last = h.in;
+    else
+        f_irows_rs_last(c, d_items, d_srcs, l, w.digits, B, s);
     f_dr_icols_lift_fcols(c, last, (long)c.N, w.tmp, 2 * B, l, l, s);
-    f_frows_final(c, 2, w.tmp, d_items, nullptr, 2 * B, l, l, s, RsItem{}, nullptr, d_srcs);
+    f_frows_final(c, 2, w.tmp, d_items, nullptr, 2 * B, l, l, s, RsItem{}, nullptr, d_srcs, h);
 }
 
 void rescale_fused(Context &c, const Workspace &w, CtView dst, CtView src, int ell, const u64 *plain, hipStream_t s)

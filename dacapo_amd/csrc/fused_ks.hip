@@ -398,6 +398,134 @@ __global__ __launch_bounds__(kTileThreads) void f_frows_final_kernel(const u64 *
     }
 }
 
+// ---- L7 / R3 with a continuation into the consumer's first phase (plan.hpp Handoff) ---------------------------------------------------
+// Output polynomial p, limb i of item b at this tile's coefficients g[] (pass NP-1 layout of a ROWS tile): computed exactly as
+// f_frows_final_kernel does for the same MODE, stored to the item's destination, and left in v[] (canonical).
+template <int K, int LOGE, int MODE>
+__device__ __forceinline__ void final_value(u64 (&v)[1 << LOGE], const int (&g)[1 << LOGE], const u64 *__restrict__ in, const void *__restrict__ items_,
+                                            const SumSrc *__restrict__ srcs, const u64 *__restrict__ acc, int b, int p, int i, int cnt,
+                                            const DModulus &M, u64 inv, const u64 *__restrict__ tw, int logN, u64 *__restrict__ lds)
+{
+    constexpr int E = 1 << LOGE;
+    const size_t N = (size_t)1 << logN;
+    auto nost = [](int, u64) {};
+    u64 x[E];
+    ntt_tile_x<K, LOGE, false, false, true, false, true>(x, M, tw + ((size_t)i << logN), logN, blockIdx.x, [=](int gi) { return in[gi]; }, nost, lds);
+    if (MODE == 4) {
+        const MulItem it = reinterpret_cast<const MulItem *>(items_)[b];
+        const u64 *ac = acc + (((size_t)(b * 2 + p)) * (cnt + 1) + i) * N;
+        const u64 *a0 = it.a.limb(0, i, N), *a1 = it.a.limb(1, i, N), *b0 = it.b.limb(0, i, N), *b1 = it.b.limb(1, i, N);
+        u64 *o = it.dst.limb(p, i, N);
+#pragma unroll
+        for (int j = 0; j < E; j++) {
+            u64 base;
+            if (p == 0)
+                base = mulmod(a0[g[j]], b0[g[j]], M);
+            else {
+                Acc128 t;
+                t.clear();
+                t.mac(a0[g[j]], b1[g[j]]);
+                t.mac(a1[g[j]], b0[g[j]]);
+                base = t.reduce(M);
+            }
+            v[j] = addmod(base, mulmod(submod(ac[g[j]], x[j], M.q), inv, M), M.q);
+            o[g[j]] = v[j];
+        }
+    } else if (MODE == 0) {
+        const KsItem it = reinterpret_cast<const KsItem *>(items_)[b];
+        const u64 *ac = acc + (((size_t)(b * 2 + p)) * (cnt + 1) + i) * N;
+        const u64 *c0 = it.src.limb(0, i, N);
+        u64 *o = it.dst.limb(p, i, N);
+#pragma unroll
+        for (int j = 0; j < E; j++) {
+            const u64 base = p == 0 ? c0[galois_idx((u32)g[j], it.elt, logN)] : 0;
+            v[j] = addmod(base, mulmod(submod(ac[g[j]], x[j], M.q), inv, M), M.q);
+            o[g[j]] = v[j];
+        }
+    } else { // MODE 2: rescale
+        const RsItem it = reinterpret_cast<const RsItem *>(items_)[b];
+        u64 *o = it.dst.limb(p, i, N);
+        u64 op[E];
+        rs_operand<E>(op, g, it, srcs, p, i, N, M);
+#pragma unroll
+        for (int j = 0; j < E; j++) {
+            v[j] = mulmod(submod(op[j], x[j], M.q), inv, M);
+            o[g[j]] = v[j];
+        }
+    }
+}
+
+// CONT_RS / CONT_MUL: grid = (tiles, 2B * cnt), z = (b*2 + p)*cnt + i as in f_frows_final_kernel; the workgroups that hold what the
+// consumer's first phase reads carry on.  CONT_BOOT: grid = (tiles, B * cnt), z = b*cnt + i, both polynomials in one workgroup
+// (the consumer decrypts: c0 + c1*s).
+template <int K, int LOGE, int MODE, int CONT>
+__global__ __launch_bounds__(kTileThreads) void f_frows_final_cont_kernel(const u64 *__restrict__ tmp, const void *__restrict__ items_,
+                                                                           const SumSrc *__restrict__ srcs, const u64 *__restrict__ acc, int cnt,
+                                                                           int l, int Kp, const DModulus *__restrict__ mods,
+                                                                           const u64 *__restrict__ inv_last, const u64 *__restrict__ tw,
+                                                                           const u64 *__restrict__ itw, int logN, Handoff h)
+{
+    __shared__ __attribute__((aligned(16))) u64 lds[TileGeo<LOGE>::LDS_ELEMS];
+    constexpr int E = 1 << LOGE, NP = num_passes<LOGE>(K);
+    const size_t N = (size_t)1 << logN;
+    int g[E];
+#pragma unroll
+    for (int j = 0; j < E; j++) g[j] = tile_gidx<K, LOGE, false>(NP - 1, logN, blockIdx.x, j);
+    auto nold = [](int) -> u64 { return 0; };
+    if (CONT == CONT_BOOT) {
+        const int z = blockIdx.y, i = z % cnt, b = z / cnt;
+        const DModulus M = mods[i];
+        const u64 inv = inv_last[(size_t)l * Kp + i];
+        u64 v0[E], v1[E];
+        final_value<K, LOGE, MODE>(v0, g, tmp + ((size_t)(b * 2 + 0) * cnt + i) * N, items_, srcs, acc, b, 0, i, cnt, M, inv, tw, logN, lds);
+        __syncthreads(); // the tile's last LDS image has been read by everyone
+        final_value<K, LOGE, MODE>(v1, g, tmp + ((size_t)(b * 2 + 1) * cnt + i) * N, items_, srcs, acc, b, 1, i, cnt, M, inv, tw, logN, lds);
+        const u64 *sk = h.sk + (size_t)i * N;
+#pragma unroll
+        for (int j = 0; j < E; j++) v0[j] = addmod(v0[j], mulmod(v1[j], sk[g[j]], M), M.q);
+        __syncthreads();
+        u64 *o = h.out + (size_t)z * N;
+        ntt_tile_x<K, LOGE, false, true, false, true, false>(v0, M, itw + ((size_t)i << logN), logN, blockIdx.x, nold, [=](int gi, u64 v) { o[gi] = v; }, lds);
+    } else {
+        const int z = blockIdx.y, i = z % cnt, bp = z / cnt, b = bp >> 1, p = bp & 1;
+        const DModulus M = mods[i];
+        const u64 inv = inv_last[(size_t)l * Kp + i];
+        u64 v[E];
+        final_value<K, LOGE, MODE>(v, g, tmp + (size_t)z * N, items_, srcs, acc, b, p, i, cnt, M, inv, tw, logN, lds);
+        if (CONT == CONT_RS) {
+            if (i != cnt - 1) return; // the consumer drops the last limb: only its workgroups continue (uniform per workgroup)
+            const RsItem cit = h.rs_items[b]; // single-use "+ plaintext" / "* plaintext" folded into the consumer (rs_operand's order)
+            if (cit.add && p == 0) {
+                const u64 *w = cit.add + (size_t)i * N;
+#pragma unroll
+                for (int j = 0; j < E; j++) v[j] = addmod(v[j], w[g[j]], M.q);
+            }
+            if (cit.mul) {
+                const u64 *w = cit.mul + (size_t)i * N;
+#pragma unroll
+                for (int j = 0; j < E; j++) v[j] = mulmod(v[j], w[g[j]], M);
+            }
+            __syncthreads();
+            u64 *o = h.out + (size_t)bp * N;
+            ntt_tile_x<K, LOGE, false, true, false, true, false>(v, M, itw + ((size_t)i << logN), logN, blockIdx.x, nold, [=](int gi, u64 y) { o[gi] = y; }, lds);
+        } else { // CONT_MUL
+            if (p != 1) return;
+            const CtView other = h.other[b];
+            if (other.p) {
+                const u64 *o1 = other.limb(1, i, N);
+#pragma unroll
+                for (int j = 0; j < E; j++) v[j] = mulmod(v[j], o1[g[j]], M);
+            } else {
+#pragma unroll
+                for (int j = 0; j < E; j++) v[j] = mulmod(v[j], v[j], M);
+            }
+            __syncthreads();
+            u64 *o = h.out + ((size_t)b * cnt + i) * N;
+            ntt_tile_x<K, LOGE, false, true, false, true, false>(v, M, itw + ((size_t)i << logN), logN, blockIdx.x, nold, [=](int gi, u64 y) { o[gi] = y; }, lds);
+        }
+    }
+}
+
 // L3 + L4 + L5 in one launch (latency path): grid = (tiles, l + 2, B).  Workgroup (tile, y, b) owns one ROWS-phase tile of
 // output modulus slot m (y < l: prime y, both accumulators; y = l, l + 1: the special prime, accumulator y - l).  For every
 // digit j it finishes the NTT of the lifted digit (forward ROWS phase, result kept in registers) -- or, for j == m, reads the
@@ -536,7 +664,11 @@ __global__ __launch_bounds__(kTileThreads) void f_frows_boot_final_kernel(const 
     }
 // CALL sees KK (phase size) and LE (log2 coefficients per thread); grid.x = tiles of that geometry
 #define DC_GEO_SWITCH(Kval, limbs, ...)                                                                   \
-    if (use_small_tiles(c.N, (limbs))) {                                                                  \
+    if (use_tiny_tiles(c.N, (limbs))) {                                                                   \
+        constexpr int LE = 1;                                                                             \
+        const dim3 grid((unsigned)(c.N >> TileGeo<LE>::LOG), (unsigned)(limbs));                          \
+        DC_K_SWITCH(Kval, __VA_ARGS__)                                                                         \
+    } else if (use_small_tiles(c.N, (limbs))) {                                                           \
         constexpr int LE = 2;                                                                             \
         const dim3 grid((unsigned)(c.N >> TileGeo<LE>::LOG), (unsigned)(limbs));                          \
         DC_K_SWITCH(Kval, __VA_ARGS__)                                                                         \
@@ -606,15 +738,19 @@ void f_frows_boot_final(const Context &c, const u64 *ptx, const BootItem *items,
 void f_ks_frows_mac(const Context &c, int mode, const u64 *ext, const u64 *target, const KsItem *items, const u64 *shared_key, u64 *acc,
                     int B, int ell, hipStream_t s)
 {
-    constexpr int LE = 2; // latency geometry only: large batches keep the three separate launches
-    const dim3 grid((unsigned)(c.N >> TileGeo<LE>::LOG), (unsigned)(ell + 2), (unsigned)B);
-    if (mode == 0) {
-        DC_K_SWITCH(c.k2, hipLaunchKernelGGL((f_ks_frows_mac_kernel<KK, LE, 0>), grid, dim3(kTileThreads), 0, s, ext, target, items, shared_key,
-                                             acc, ell, c.K, c.d_mods, c.d_tw, c.d_itw, c.logN));
-    } else {
-        DC_K_SWITCH(c.k2, hipLaunchKernelGGL((f_ks_frows_mac_kernel<KK, LE, 1>), grid, dim3(kTileThreads), 0, s, ext, target, items, shared_key,
-                                             acc, ell, c.K, c.d_mods, c.d_tw, c.d_itw, c.logN));
+#define DC_FMAC(LEV, MD)                                                                                                                  \
+    {                                                                                                                                     \
+        constexpr int LE = LEV;                                                                                                           \
+        const dim3 grid((unsigned)(c.N >> TileGeo<LE>::LOG), (unsigned)(ell + 2), (unsigned)B);                                          \
+        DC_K_SWITCH(c.k2, hipLaunchKernelGGL((f_ks_frows_mac_kernel<KK, LE, MD>), grid, dim3(kTileThreads), 0, s, ext, target, items, shared_key, \
+                                             acc, ell, c.K, c.d_mods, c.d_tw, c.d_itw, c.logN));                                          \
     }
+    if (use_tiny_tiles(c.N, (long)(ell + 2) * B)) {
+        if (mode == 0) DC_FMAC(1, 0) else DC_FMAC(1, 1)
+    } else {
+        if (mode == 0) DC_FMAC(2, 0) else DC_FMAC(2, 1)
+    }
+#undef DC_FMAC
 }
 
 void f_ks_icols_lift_fcols(const Context &c, const u64 *digits, u64 *ext, int B, int ell, hipStream_t s)
@@ -642,8 +778,28 @@ void f_dr_lift_fcols(const Context &c, const u64 *last, long last_stride, u64 *t
 }
 
 void f_frows_final(const Context &c, int mode, const u64 *tmp, const void *items, const u64 *acc, int polys, int cnt, int l,
-                   hipStream_t s, RsItem single, const u64 *plain, const SumSrc *srcs)
+                   hipStream_t s, RsItem single, const u64 *plain, const SumSrc *srcs, const Handoff &h)
 {
+    if (h.cont != CONT_NONE) {
+        const int groups = h.cont == CONT_BOOT ? polys / 2 : polys; // CONT_BOOT: one workgroup per (item, limb) does both polynomials
+#define DC_CONT(MD, CT)                                                                                                                \
+    DC_GEO_SWITCH(c.k2, groups * cnt, hipLaunchKernelGGL((f_frows_final_cont_kernel<KK, LE, MD, CT>), grid, dim3(kTileThreads), 0, s, tmp, items, \
+                                                         srcs, acc, cnt, l, c.K, c.d_mods, c.d_inv_last, c.d_tw, c.d_itw, c.logN, h))
+        if (mode == 4 && h.cont == CONT_RS) {
+            DC_CONT(4, CONT_RS);
+        } else if (mode == 2 && h.cont == CONT_MUL) {
+            DC_CONT(2, CONT_MUL);
+        } else if (mode == 2 && h.cont == CONT_BOOT) {
+            DC_CONT(2, CONT_BOOT);
+        } else if (mode == 0 && h.cont == CONT_BOOT) {
+            DC_CONT(0, CONT_BOOT);
+        } else {
+            fprintf(stderr, "[dacapo_amd] f_frows_final: no continuation kernel for mode %d -> consumer kind %d\n", mode, h.cont);
+            abort();
+        }
+#undef DC_CONT
+        return;
+    }
 #define DC_FINAL(MD)                                                                                                                   \
     DC_GEO_SWITCH(c.k2, polys * cnt, hipLaunchKernelGGL((f_frows_final_kernel<KK, LE, MD>), grid, dim3(kTileThreads), 0, s, tmp, items, single, \
                                                         plain, srcs, acc, cnt, l, c.K, c.d_mods, c.d_inv_last, c.d_tw, c.logN))

@@ -453,6 +453,7 @@ void HEVM::init_context(int logN, int K, const u64 *primes)
     if (const char *e = getenv("DACAPO_HEVM_HOST_ENCODER")) host_encoder = atoi(e) != 0;
     if (const char *e = getenv("DACAPO_HEVM_FOLD_RESCALE_BOOT")) fold_rescale_into_boot = atoi(e) != 0;
     if (const char *e = getenv("DACAPO_HEVM_MAX_BATCH")) max_batch = std::max(1, atoi(e));
+    if (const char *e = getenv("DACAPO_HEVM_CHAIN_FUSION")) chain_fusion = atoi(e) != 0;
     lanes.resize(1);
     DC_HIP_CHECK(hipStreamCreateWithFlags(&lanes[0].stream, hipStreamNonBlocking));
     lanes[0].ws = ctx->ws0;
@@ -1477,7 +1478,7 @@ void HEVM::plan_zero_encrypt(int first, int B, int t, hipStream_t s)
 }
 
 // batched opcode 10, data half: B items at `ell` primes -> `t` primes.  5 launches.
-void HEVM::plan_boot_step(int first, int B, int ell, int t, int lane, hipStream_t s)
+void HEVM::plan_boot_step(int first, int B, int ell, int t, int lane, hipStream_t s, const Handoff &h)
 {
     Context &c = *ctx;
     const size_t N = c.N;
@@ -1490,7 +1491,10 @@ void HEVM::plan_boot_step(int first, int B, int ell, int t, int lane, hipStream_
     const CrtTables &tb = crt_tables(ell);
     const CrtDev cd{ tb.inv, tb.mmod, tb.hmod, tb.hdig, tb.mdbl };
     u64 *pt = P.boot_pt[lane], *ptx = P.boot_ptx[lane];
-    f_irows_decrypt_items(c, items, P.d_sum_srcs, keys.sk, ell, pt, B, s);
+    if (h.in) // the producer's last kernel already decrypted into the first inverse phase (plan.hpp Handoff)
+        pt = const_cast<u64 *>(h.in);
+    else
+        f_irows_decrypt_items(c, items, P.d_sum_srcs, keys.sk, ell, pt, B, s);
     launch_ntt_cols_inv(c, pt, (long)N, B * ell, nullptr, 0, ell, s);
     if (ell == 1) // trivial composition: re-encode inside the first forward phase's loader (4 launches per batch)
         f_boot_reencode_fcols(c, pt, ptx, items, B, ell, t, cd, s);

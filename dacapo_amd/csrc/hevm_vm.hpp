@@ -153,6 +153,8 @@ class HEVM {
         int level = 0, first = 0, count = 0; // range in the kind's device item table
         int target = 0;                     // P_BOOT: primes of the result
         int wave = 0, lane = 0;             // steps of one wave are independent: lane 1 runs on the auxiliary stream
+        Handoff h;                          // link to a fused producer (h.in) / consumer (h.cont, h.out) step, plan.hpp
+        int fused_consumer = -1;            // index of the step whose first phase this step's last kernel computes
     };
     struct Plan {
         bool ready = false;
@@ -166,6 +168,9 @@ class HEVM {
         EwItem *d_ew = nullptr;
         SumItem *d_sum = nullptr;
         SumSrc *d_sum_srcs = nullptr;
+        CtView *d_cont_other = nullptr;      // CONT_MUL links: the consumers' other operands
+        std::vector<u64 *> handoff_bufs;     // first-phase buffers of fused consumer steps
+        size_t n_fused = 0;
         // opcode 10: item table, the divide-and-round items of the zero-encryptions, the zero-encryption arena and scratch
         BootItem *d_boot = nullptr;
         RsItem *d_boot_rs = nullptr;
@@ -199,7 +204,8 @@ class HEVM {
     void run_plan();
     void boot_item(CtView src, int src_level, double src_scale, hevm_ctxt &dst, int target_level);
     void plan_zero_encrypt(int first, int B, int t, hipStream_t s);
-    void plan_boot_step(int first, int B, int ell, int t, int lane, hipStream_t s);
+    void plan_boot_step(int first, int B, int ell, int t, int lane, hipStream_t s, const Handoff &h);
+    bool chain_fusion = true; // DACAPO_HEVM_CHAIN_FUSION=0: every step runs all of its own launches
     hipStream_t aux_stream = nullptr;
     bool fold_rescale_into_boot = false; // DACAPO_HEVM_FOLD_RESCALE_BOOT=1: do a rescale that only feeds an opcode 10 inside its re-encoder
     int plan_lanes = 2; // independent steps of a wave also use an auxiliary stream (pays off only inside the graph; DACAPO_HEVM_PLAN_LANES=1: one stream)

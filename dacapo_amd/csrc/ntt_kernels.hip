@@ -34,10 +34,12 @@ template <bool COLS, bool INV, bool CANON>
 static void launch_phase_k(int K, const Context &c, u64 *data, long limb_stride, int count, const int *d_prime_idx,
                            int prime_base, int prime_period, hipStream_t s)
 {
-    const bool small = use_small_tiles(c.N, count);
+    const bool small = use_small_tiles(c.N, count), tiny = use_tiny_tiles(c.N, count);
 #define DC_PHASE(KK)                                                                                                           \
     case KK:                                                                                                                   \
-        if (small)                                                                                                             \
+        if (tiny)                                                                                                              \
+            launch_phase<KK, 1, COLS, INV, CANON>(c, data, limb_stride, count, d_prime_idx, prime_base, prime_period, s);       \
+        else if (small)                                                                                                        \
             launch_phase<KK, 2, COLS, INV, CANON>(c, data, limb_stride, count, d_prime_idx, prime_base, prime_period, s);       \
         else                                                                                                                   \
             launch_phase<KK, 3, COLS, INV, CANON>(c, data, limb_stride, count, d_prime_idx, prime_base, prime_period, s);       \

@@ -12,16 +12,22 @@
 //   inverse (Gentleman-Sande, bit-reversed in, natural out): ROWS phase first, then COLS, same tiles and the
 //     same table indices with inverse twiddles; N^{-1} is merged into the very last stage.
 //
-// Two geometries (template parameter LOGE = log2 of the coefficients a thread keeps in registers):
+// Three geometries (template parameter LOGE = log2 of the coefficients a thread keeps in registers):
 //   LOGE = 3 : 2048-coefficient tiles, radix-8 passes (3 stages per pass)  -- throughput: fewest LDS exchanges
 //   LOGE = 2 : 1024-coefficient tiles, radix-4 passes (2 stages per pass)  -- latency: twice the workgroups, half
 //              the butterflies per thread; used when a launch has too few tiles to occupy the chip (a lone wave per
 //              SIMD is bound by its own instruction latency, so halving its work nearly halves the phase).
-// Between passes the tile is transposed through LDS.  The LDS image is laid out for the READER: element j of thread
-// t lives at j*(T+pad)+t, so every ds_read_b64 is lane-contiguous.
+//   LOGE = 1 :  512-coefficient tiles, radix-2 passes, ONE butterfly per thread and stage -- single-ciphertext steps, where
+//              even the radix-4 tiles leave half the SIMDs without a wave.  A pass boundary is then a 2 x 2 transpose between
+//              a register pair and one lane bit: when the partner lane sits in the same wavefront (distance < 64) it is a
+//              lane_swap (lane_xchg.hpp: v_permlane32/16_swap, masked DPP moves) -- no LDS, no barrier; only the first one
+//              or two boundaries of a tile cross wavefronts and go through LDS.
+// Between the other passes the tile is transposed through LDS.  The LDS image is laid out for the READER: element j of
+// thread t lives at j*(T+pad)+t, so every ds_read_b64 is lane-contiguous.
 #pragma once
 #include <stdlib.h>
 
+#include "lane_xchg.hpp"
 #include "modarith.hpp"
 
 namespace dacapo {
@@ -127,9 +133,9 @@ __device__ __forceinline__ void ntt_tile_x(u64 (&x)[1 << LOGE], const DModulus M
     const int lane_id = tile * B + b;
     const u32 twroot = COLS ? 1u : ((1u << sh) + (u32)lane_id);
     auto gidx = [&](int idx) -> int { return COLS ? ((idx << sh) + lane_id) : ((lane_id << K) + idx); };
-    // Latency geometry: fetch every pass's twiddles (<= E - 1 per pass) before the first butterfly.  The barriers between
+    // Latency geometries: fetch every pass's twiddles (<= E - 1 per pass) before the first butterfly.  The barriers between
     // passes pin memory operations in place, so otherwise each pass starts by waiting for its own twiddle loads.
-    constexpr bool PF = (LOGE == 2);
+    constexpr bool PF = (LOGE <= 2);
     u64 wpre[PF ? NP : 1][E];
     if (PF) {
 #pragma unroll
@@ -150,6 +156,7 @@ __device__ __forceinline__ void ntt_tile_x(u64 (&x)[1 << LOGE], const DModulus M
         }
     }
 
+    bool lds_dirty = false, from_lds = false; // compile-time after unrolling: an LDS image exists / the next pass reads it
 #pragma unroll
     for (int pp = 0; pp < NP; pp++) {
         const int p = INV ? (NP - 1 - pp) : pp;
@@ -161,9 +168,10 @@ __device__ __forceinline__ void ntt_tile_x(u64 (&x)[1 << LOGE], const DModulus M
 #pragma unroll
                 for (int j = 0; j < E; j++) x[j] = ld(gidx(PassMap<K, LOGE>::idx_of(p, s, j)));
             }
-        } else {
+        } else if (from_lds) {
 #pragma unroll
             for (int j = 0; j < E; j++) x[j] = lds[j * stride + t];
+            from_lds = false;
         }
         // ---- butterflies: 2^(LOGE-r) independent radix-2^r networks per thread
 #pragma unroll
@@ -208,15 +216,32 @@ __device__ __forceinline__ void ntt_tile_x(u64 (&x)[1 << LOGE], const DModulus M
             }
         } else {
             const int pn = INV ? p - 1 : p + 1;
-            if (!first) exchange_sync(); // everyone has finished reading the previous image
+            // LOGE = 1: the boundary between passes q and q + 1 exchanges register bit and thread-index bit K - q - 2, i.e. lanes
+            // at distance 2^(K-q-2) (times the column interleave of a COLS tile)
+            const int lane_dist = LOGE == 1 ? ((1 << (K - (INV ? pn : p) - 2)) << (COLS ? LOGB : 0)) : 64;
+            if (LOGE == 1 && lane_dist < 64) {
+                if constexpr (LOGE == 1) { // (x[] has two elements only in this instantiation)
+                    switch (lane_dist) { // a constant once the pass loop is unrolled
+                    case 32: lane_swap<32>(x[0], x[1]); break;
+                    case 16: lane_swap<16>(x[0], x[1]); break;
+                    case 8: lane_swap<8>(x[0], x[1]); break;
+                    case 4: lane_swap<4>(x[0], x[1]); break;
+                    case 2: lane_swap<2>(x[0], x[1]); break;
+                    default: lane_swap<1>(x[0], x[1]); break;
+                    }
+                }
+            } else {
+                if (lds_dirty) exchange_sync(); // everyone has finished reading the previous image
 #pragma unroll
-            for (int j = 0; j < E; j++) {
-                int s2, j2;
-                PassMap<K, LOGE>::sj_of(pn, PassMap<K, LOGE>::idx_of(p, s, j), s2, j2);
-                const int t2 = COLS ? ((s2 << LOGB) | b) : (b * SUBT + s2);
-                lds[j2 * stride + t2] = x[j];
+                for (int j = 0; j < E; j++) {
+                    int s2, j2;
+                    PassMap<K, LOGE>::sj_of(pn, PassMap<K, LOGE>::idx_of(p, s, j), s2, j2);
+                    const int t2 = COLS ? ((s2 << LOGB) | b) : (b * SUBT + s2);
+                    lds[j2 * stride + t2] = x[j];
+                }
+                exchange_sync();
+                lds_dirty = true, from_lds = true;
             }
-            exchange_sync();
         }
     }
 }
@@ -243,12 +268,18 @@ __device__ __forceinline__ void ntt_tile(const DModulus M, const u64 *__restrict
 }
 
 // geometry choice for a launch of `limbs` limb-phases: the latency geometry while the throughput one would leave most
-// of the 256 CUs without a workgroup
+// of the 256 CUs without a workgroup, the one-butterfly geometry while even that leaves SIMDs without a wave
 inline long small_tile_threshold()
 {
     static const long v = getenv("DACAPO_SMALL_TILE_WGS") ? atol(getenv("DACAPO_SMALL_TILE_WGS")) : 20000;
     return v;
 }
 inline bool use_small_tiles(size_t N, long limbs) { return (long)(N >> kTileLog) * limbs < small_tile_threshold(); }
+inline long tiny_tile_threshold()
+{ // in 512-coefficient workgroups (4 waves each): 256 = one wave on each of the 1024 SIMDs
+    static const long v = getenv("DACAPO_TINY_TILE_WGS") ? atol(getenv("DACAPO_TINY_TILE_WGS")) : 512;
+    return v;
+}
+inline bool use_tiny_tiles(size_t N, long limbs) { return (long)(N >> TileGeo<1>::LOG) * limbs <= tiny_tile_threshold(); }
 
 } // namespace dacapo

@@ -52,6 +52,26 @@ struct BootItem { // opcode 10: dst = Enc(re-encode(Dec(src))) = zenc + (plainte
     const u64 *add = nullptr, *mul = nullptr;
 };
 
+// A step's link to a fused neighbour.  The last kernel of every composite op is a forward ROWS phase and the first kernel of
+// every composite op an inverse ROWS phase over the SAME tiles (ntt_tile.hpp: the last pass of one and the first pass of the
+// other use the same thread <-> coefficient map).  When the plan sees that step B only consumes what step A produces, A's last
+// kernel keeps going: it stores its result, forms B's first-phase operand from the values still in registers and runs B's
+// inverse ROWS phase, writing B's first-phase buffer -- one launch (and one trip through HBM) fewer per link.
+enum ContKind : int {
+    CONT_NONE = 0,
+    CONT_RS = 1,   // consumer is a rescale: inverse phase of the limb it drops (both polynomials)
+    CONT_MUL = 2,  // consumer is a ct x ct multiply: inverse phase of out.c1 * other.c1 (the tensor product's c2), every limb
+    CONT_BOOT = 3, // consumer is an opcode 10: inverse phase of out.c0 + out.c1 * s (Decryptor::decrypt), every limb
+};
+struct Handoff {
+    int cont = CONT_NONE;          // what this step's last kernel also computes ...
+    u64 *out = nullptr;            // ... into the consumer's first-phase buffer ([B][2][N], [B][l][N], [B][l][N])
+    const CtView *other = nullptr; // CONT_MUL: device table [B] of the consumer's other operand (p == nullptr: a square)
+    const struct RsItem *rs_items = nullptr; // CONT_RS: the consumer's items (a "+ plaintext" / "* plaintext" folded into it applies first)
+    const u64 *sk = nullptr;       // CONT_BOOT: secret key [K][N]
+    const u64 *in = nullptr;       // this step's own first phase was computed by its producer: read it here instead of launching it
+};
+
 // scratch of one batched step, sized for the largest batch of the plan
 struct BatchWs {
     u64 *target = nullptr; // [B][l][N]     key-switch target, NTT form
@@ -61,9 +81,12 @@ struct BatchWs {
     u64 *tmp = nullptr;    // [B][2][l][N]
 };
 
-void b_rotate_hops(Context &c, const BatchWs &w, const KsItem *d_items, int B, int ell, hipStream_t s);
-void b_mul_relin(Context &c, const BatchWs &w, const MulItem *d_items, const u64 *relin_key, int B, int ell, hipStream_t s);
-void b_rescale(Context &c, const BatchWs &w, const RsItem *d_items, int B, int ell, hipStream_t s, const SumSrc *d_srcs = nullptr);
+void b_rotate_hops(Context &c, const BatchWs &w, const KsItem *d_items, int B, int ell, hipStream_t s, const Handoff &h = Handoff{});
+void b_mul_relin(Context &c, const BatchWs &w, const MulItem *d_items, const u64 *relin_key, int B, int ell, hipStream_t s,
+                 const Handoff &h = Handoff{});
+void b_rescale(Context &c, const BatchWs &w, const RsItem *d_items, int B, int ell, hipStream_t s, const SumSrc *d_srcs = nullptr,
+               const Handoff &h = Handoff{});
+bool chain_fusion_supported(); // the continuation kernels exist for the default launch sequences only
 // op: Neg / Mul (ct * plain) / Copy ; b_polys as in launch_ew
 void b_ew(Context &c, EwOp op, const EwItem *d_items, int B, int polys, int b_polys, int ell, hipStream_t s);
 void b_add_plain(Context &c, const EwItem *d_items, int B, int ell, hipStream_t s);
@@ -99,7 +122,8 @@ void f_dr_lift_fcols(const Context &c, const u64 *last, long last_stride, u64 *t
 // mode 0 rotation / 1 relinearisation / 2 rescale items / 3 one rescale by value (+ optional plaintext added to c0) /
 // 4 relinearisation with the c0, c1 tensor terms computed in the epilogue (small batches: no tensor launch)
 void f_frows_final(const Context &c, int mode, const u64 *tmp, const void *items, const u64 *acc, int polys, int cnt, int l,
-                   hipStream_t s, RsItem single = RsItem{}, const u64 *plain = nullptr, const SumSrc *srcs = nullptr);
+                   hipStream_t s, RsItem single = RsItem{}, const u64 *plain = nullptr, const SumSrc *srcs = nullptr,
+                   const Handoff &h = Handoff{});
 // a single rescale_to_next of `src` (level ell) into dst, optionally adding a level-(ell-1) plaintext to c0: 3 launches
 void rescale_fused(Context &c, const Workspace &w, CtView dst, CtView src, int ell, const u64 *plain, hipStream_t s);
 

@@ -30,6 +30,9 @@ void HEVM::build_plan()
     Context &c = *ctx;
     const size_t N = c.N;
     Plan &P = plan;
+    for (u64 *b : P.handoff_bufs) (void)hipFree(b);
+    P.handoff_bufs.clear();
+    if (P.d_cont_other) (void)hipFree(P.d_cont_other), P.d_cont_other = nullptr;
     for (void *p : { (void *)P.d_ks, (void *)P.d_mul, (void *)P.d_rs, (void *)P.d_ew, (void *)P.d_sum, (void *)P.d_sum_srcs, (void *)P.d_boot,
                      (void *)P.d_boot_rs, (void *)P.zenc, (void *)P.boot_ue, (void *)P.boot_tmp, (void *)P.boot_pt[0], (void *)P.boot_ptx[0],
                      (void *)P.boot_pt[1], (void *)P.boot_ptx[1] })
@@ -318,6 +321,75 @@ void HEVM::build_plan()
             }
         }
     }
+    // ---- 4b. chain fusion (plan.hpp Handoff): step B's first phase computed by the last kernel of step A -----------------------------
+    // A link needs: B reads A's results and nothing else as its first-phase operand, item for item; no operand expression folded
+    // into B; for a multiply, the other operand is A's result too (a square) or older than A.
+    P.n_fused = 0;
+    std::vector<CtView> h_cont_other;            // filled with stream views in section 6
+    std::vector<std::pair<int, int>> cont_other; // (value or -1 for a square, unused) per CONT_MUL item slot, pop order
+    std::vector<int> mul_fused_src((size_t)O.size(), -1); // consumer multiply pop -> which operand (0 / 1) comes from the producer
+    if (chain_fusion && chain_fusion_supported()) {
+        auto def_step_of = [&](int v) -> int { // step defining value v when v is a plain (non-view) pop result, else -1
+            const Val &sv = V[(size_t)v];
+            if (sv.root != v || sv.def_pop < 0 || O[(size_t)sv.def_pop].dead || O[(size_t)sv.def_pop].dst != v) return -1;
+            return O[(size_t)sv.def_pop].step;
+        };
+        auto wave_of_value = [&](int v) -> int { // wave in which v (or the buffer it views) is complete; 0 for program inputs
+            const Val &r = V[(size_t)V[(size_t)v].root];
+            return r.def_pop >= 0 ? O[(size_t)r.def_pop].wave : 0;
+        };
+        for (size_t bi = 0; bi < P.steps.size(); bi++) {
+            Step &B = P.steps[bi];
+            if (B.kind != P_RESCALE && B.kind != P_BOOT && B.kind != P_MULCC) continue;
+            std::vector<int> &bp = step_pops[bi];
+            int ai = -1;
+            bool ok = true;
+            std::vector<int> which(bp.size(), 0);
+            for (size_t k = 0; k < bp.size() && ok; k++) {
+                const Pop &p = O[(size_t)bp[k]];
+                if (p.rs_sum || p.boot_drop >= 0 || (B.kind != P_RESCALE && (p.rs_add >= 0 || p.rs_mul >= 0))) ok = false;
+                int found = -1;
+                for (size_t w = 0; w < (B.kind == P_MULCC ? 2u : 1u) && ok && found < 0; w++) {
+                    const int st = def_step_of(p.srcs[w]);
+                    if (st < 0 || (ai >= 0 && st != ai)) continue;
+                    const Step &A = P.steps[(size_t)st];
+                    const bool kinds = (B.kind == P_RESCALE && A.kind == P_MULCC && A.level == B.level) ||
+                                       (B.kind == P_BOOT && ((A.kind == P_RESCALE && A.level - 1 == B.level) || (A.kind == P_ROT && A.level == B.level))) ||
+                                       (B.kind == P_MULCC && A.kind == P_RESCALE && A.level - 1 == B.level);
+                    if (!kinds || A.fused_consumer >= 0 || A.wave >= B.wave) continue;
+                    if (B.kind == P_MULCC) { // the other operand: the same value, or complete before A starts
+                        const int other = p.srcs[1 - w];
+                        if (other != p.srcs[w] && wave_of_value(other) >= A.wave) continue;
+                    }
+                    found = st, which[k] = (int)w;
+                }
+                if (found < 0) ok = false;
+                ai = found;
+            }
+            if (!ok || ai < 0 || step_pops[(size_t)ai].size() != bp.size()) continue;
+            // item for item: reorder B's pops to follow A's; every A result must be consumed by exactly one pop of B here
+            std::vector<int> order(bp.size(), -1);
+            std::vector<int> which2(bp.size(), 0);
+            for (size_t k = 0; k < bp.size() && ok; k++) {
+                const int src = O[(size_t)bp[k]].srcs[(size_t)which[k]];
+                const std::vector<int> &apops = step_pops[(size_t)ai];
+                size_t pos = 0;
+                while (pos < apops.size() && O[(size_t)apops[pos]].dst != src) pos++;
+                if (pos == apops.size() || order[pos] >= 0)
+                    ok = false;
+                else
+                    order[pos] = bp[k], which2[pos] = which[k];
+            }
+            if (!ok) continue;
+            bp = order;
+            Step &A = P.steps[(size_t)ai];
+            A.fused_consumer = (int)bi;
+            A.h.cont = B.kind == P_RESCALE ? CONT_RS : B.kind == P_BOOT ? CONT_BOOT : CONT_MUL;
+            if (B.kind == P_MULCC)
+                for (size_t k = 0; k < bp.size(); k++) mul_fused_src[(size_t)bp[k]] = which2[k];
+            P.n_fused++;
+        }
+    }
     // steps of one wave are mutually independent: the costliest stays on the main stream, the rest is balanced over
     // (main, auxiliary) when the auxiliary share is worth a fork/join (>= 3 launches)
     if (plan_lanes >= 2) {
@@ -535,6 +607,35 @@ void HEVM::build_plan()
     }
     P.d_ks = upload(h_ks), P.d_mul = upload(h_mul), P.d_rs = upload(h_rs), P.d_ew = upload(h_ew), P.d_sum = upload(h_sum);
     P.d_sum_srcs = upload(h_srcs);
+    // fused links: the consumer's first-phase buffer (owned by the link, so the two steps may sit on different streams / waves)
+    // and, for multiplies, the table of the consumers' other operands in item order
+    {
+        std::vector<size_t> other_first(P.steps.size(), 0);
+        for (size_t ai = 0; ai < P.steps.size(); ai++) {
+            Step &A = P.steps[ai];
+            if (A.fused_consumer < 0) continue;
+            Step &B = P.steps[(size_t)A.fused_consumer];
+            const size_t items = (size_t)B.count, limbs = A.h.cont == CONT_RS ? 2 : (size_t)B.level;
+            u64 *buf = nullptr;
+            DC_HIP_CHECK(hipMalloc(&buf, items * limbs * N * sizeof(u64)));
+            P.handoff_bufs.push_back(buf);
+            A.h.out = buf, B.h.in = buf;
+            A.h.sk = keys.sk;
+            if (A.h.cont == CONT_RS) A.h.rs_items = P.d_rs + B.first;
+            if (A.h.cont == CONT_MUL) {
+                other_first[ai] = h_cont_other.size();
+                for (int pi : step_pops[(size_t)A.fused_consumer])
+                    for (int q = 0; q < S; q++) {
+                        const Pop &mp = O[(size_t)pi];
+                        const int w = mul_fused_src[(size_t)pi], other = mp.srcs[(size_t)(1 - w)];
+                        h_cont_other.push_back(other == mp.srcs[(size_t)w] ? CtView{ nullptr, 0 } : view(other, q));
+                    }
+            }
+        }
+        P.d_cont_other = upload(h_cont_other);
+        for (size_t ai = 0; ai < P.steps.size(); ai++)
+            if (P.steps[ai].fused_consumer >= 0 && P.steps[ai].h.cont == CONT_MUL) P.steps[ai].h.other = P.d_cont_other + other_first[ai];
+    }
     auto alloc = [&](size_t limbs) {
         u64 *d = nullptr;
         DC_HIP_CHECK(hipMalloc(&d, std::max<size_t>(limbs, 1) * N * sizeof(u64)));
@@ -586,13 +687,30 @@ void HEVM::build_plan()
         }
         for (int k = 0; k < 9; k++)
             if (nsteps[k]) fprintf(stderr, "[dacapo_amd] plan:   %-8s %5zu steps %6zu items\n", kn[k], nsteps[k], nitems[k]);
+        { // who consumes what: candidates for handing a result to its consumer's first phase inside one launch
+            std::map<std::tuple<int, int, int, int>, int> edges; // (producer kind, consumer kind, uses, same level) -> count
+            std::vector<std::vector<int>> users(V.size());
+            for (size_t i = 0; i < O.size(); i++)
+                if (!O[i].dead)
+                    for (int sv : O[i].srcs) users[(size_t)sv].push_back((int)i);
+            for (size_t i = 0; i < O.size(); i++) {
+                if (O[i].dead) continue;
+                const int d = O[i].dst;
+                const int nu = (int)users[(size_t)d].size() + (V[(size_t)d].pinned ? 100 : 0);
+                if (users[(size_t)d].empty()) edges[std::make_tuple((int)O[i].kind, -1, nu, 0)]++;
+                for (int u : users[(size_t)d]) edges[std::make_tuple((int)O[i].kind, (int)O[(size_t)u].kind, nu, O[(size_t)u].wave - O[i].wave)]++;
+            }
+            for (auto &kv : edges)
+                fprintf(stderr, "[dacapo_amd] plan edge: %-8s -> %-8s uses %3d wave distance %3d : %d\n", kn[std::get<0>(kv.first)],
+                        std::get<1>(kv.first) < 0 ? "(none)" : kn[std::get<1>(kv.first)], std::get<2>(kv.first), std::get<3>(kv.first), kv.second);
+        }
         for (auto &kv : ks)
             fprintf(stderr, "[dacapo_amd] plan:   %-8s level %2d: %5zu steps %6zu items\n", kn[kv.first.first], kv.first.second,
                     kv.second.first, kv.second.second);
     }
     if (getenv("DACAPO_HEVM_TRACE"))
-        fprintf(stderr, "[dacapo_amd] plan: %zu ops -> %zu pseudo-ops -> %zu steps (%zu on the auxiliary stream) in %d waves, ~%zu launches, %zu live buffers (%.1f GB pool)\n",
-                ops.size(), O.size(), P.steps.size(), (size_t)std::count_if(P.steps.begin(), P.steps.end(), [](const Step &st) { return st.lane == 1; }),
+        fprintf(stderr, "[dacapo_amd] plan: %zu ops -> %zu pseudo-ops -> %zu steps (%zu on the auxiliary stream, %zu fused into their producer's last kernel) in %d waves, ~%zu launches, %zu live buffers (%.1f GB pool)\n",
+                ops.size(), O.size(), P.steps.size(), (size_t)std::count_if(P.steps.begin(), P.steps.end(), [](const Step &st) { return st.lane == 1; }), P.n_fused,
                 max_wave, P.launches, P.max_live, (double)P.pool.size() * buf_elems * 8 / 1e9);
 }
 
@@ -623,15 +741,15 @@ void HEVM::issue_plan(hipStream_t s)
             hipStream_t q = st.lane ? aux_stream : s;
             const BatchWs &w = P.ws[st.lane];
             switch (st.kind) {
-            case P_ROT: b_rotate_hops(c, w, P.d_ks + st.first, st.count, st.level, q); break;
-            case P_MULCC: b_mul_relin(c, w, P.d_mul + st.first, keys.relin, st.count, st.level, q); break;
-            case P_RESCALE: b_rescale(c, w, P.d_rs + st.first, st.count, st.level, q, P.d_sum_srcs); break;
+            case P_ROT: b_rotate_hops(c, w, P.d_ks + st.first, st.count, st.level, q, st.h); break;
+            case P_MULCC: b_mul_relin(c, w, P.d_mul + st.first, keys.relin, st.count, st.level, q, st.h); break;
+            case P_RESCALE: b_rescale(c, w, P.d_rs + st.first, st.count, st.level, q, P.d_sum_srcs, st.h); break;
             case P_SUM: b_sum(c, P.d_sum + st.first, P.d_sum_srcs, st.count, st.level, q); break;
             case P_NEG: b_ew(c, EwOp::Neg, P.d_ew + st.first, st.count, 2, 2, st.level, q); break;
             case P_COPY: b_ew(c, EwOp::Copy, P.d_ew + st.first, st.count, 2, 2, st.level, q); break;
             case P_MULP: b_ew(c, EwOp::Mul, P.d_ew + st.first, st.count, 2, 1, st.level, q); break;
             case P_ADDP: b_add_plain(c, P.d_ew + st.first, st.count, st.level, q); break;
-            case P_BOOT: plan_boot_step(st.first, st.count, st.level, st.target, st.lane, q); break;
+            case P_BOOT: plan_boot_step(st.first, st.count, st.level, st.target, st.lane, q, st.h); break;
             }
             if (step_profile) {
                 static auto t_prev = std::chrono::steady_clock::now();
