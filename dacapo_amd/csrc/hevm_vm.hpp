@@ -192,7 +192,7 @@ class HEVM {
     void issue_plan(hipStream_t s);
     bool use_plan = true;
     bool test_zero_enc = false; // hevm_test_zero_encryption: encryptions of zero are (0, 0) -- INSECURE, parity tests of opcode 10 only
-    int max_batch = 128;
+    int max_batch = 64; // items per heavy step (DACAPO_HEVM_MAX_BATCH): 64 measured best on the ResNet-20 program (16 ... 256 tried)
     std::vector<u64 *> home; // permanent buffer block of every architectural register (program inputs live here)
     // Throughput mode: `streams` independent ciphertext streams share the program, keys and plaintexts; every buffer is a
     // block of `streams` slices and encrypt/decrypt/getCtxt address the slice selected by hevm_select_stream().

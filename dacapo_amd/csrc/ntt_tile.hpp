@@ -271,7 +271,7 @@ __device__ __forceinline__ void ntt_tile(const DModulus M, const u64 *__restrict
 // of the 256 CUs without a workgroup, the one-butterfly geometry while even that leaves SIMDs without a wave
 inline long small_tile_threshold()
 {
-    static const long v = getenv("DACAPO_SMALL_TILE_WGS") ? atol(getenv("DACAPO_SMALL_TILE_WGS")) : 20000;
+    static const long v = getenv("DACAPO_SMALL_TILE_WGS") ? atol(getenv("DACAPO_SMALL_TILE_WGS")) : 5000;
     return v;
 }
 inline bool use_small_tiles(size_t N, long limbs) { return (long)(N >> kTileLog) * limbs < small_tile_threshold(); }
