@@ -63,17 +63,73 @@ def roofline_leg(ll, ctx, limbs=4096, iters=10):
     L.dc_event_record(e1, None)
     copy_gbs = 2.0 * buf.nbytes / (L.dc_event_elapsed_ms(e0, e1) / iters * 1e-3) / 1e9
     del buf, dst
-    # HBM bytes per forward NTT of this batch from the PMC passes committed under profiles/ (FETCH_SIZE doubled per the
-    # gfx950 correction + WRITE_SIZE, separate rocprofv3 --pmc runs of tools/ntt_only.py); bench.py cannot read counters itself
-    traffic = None
-    tf = ROOT / "profiles" / "r01_ntt_hbm_traffic.json"
+    # HBM bytes per launch pair: rocprofv3 --pmc passes cannot run inside this process (they need their own runs with the program
+    # directly after `--`, tools/ntt_only.py).  profiles/r02_ntt_hbm_traffic.json holds FETCH_SIZE (x2, the gfx950 correction) +
+    # WRITE_SIZE for the same launches; it is reported only when it was collected on exactly this build of the library.
+    traffic, traffic_source = None, "not collected for this build (recipe: profiles/README.md, `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE`)"
+    tf = ROOT / "profiles" / "r02_ntt_hbm_traffic.json"
     if tf.exists() and limbs == 4096 and N == 32768:
-        traffic = json.loads(tf.read_text()).get("forward_ntt_hbm_bytes")
+        rec = json.loads(tf.read_text())
+        if rec.get("lib_sha256") == lib_sha256():
+            traffic, traffic_source = rec.get("forward_ntt_hbm_bytes"), "profiles/r02_ntt_hbm_traffic.json (PMC passes on this build)"
+        else:
+            traffic_source = "profiles/r02_ntt_hbm_traffic.json was collected on another build of the library: not reported"
+    # integer-VALU issue ceiling of the butterfly code (profiles/r01_intbench_gfx950.txt: 16 lanes/clk/SIMD, 34 T lane-ops/s
+    # chip-wide, v_mad_u64_u32 2.4x an add): 29.6 VALU instructions per butterfly, 8.25 of them v_mad_u64_u32 (ISA listing)
+    valu_ceiling = 4.5e6 * (32768.0 * 15) / (N * ctx.logN)  # NTT/s; 4.5 M/s at N = 2^15
     return {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-            "traffic": traffic, "kernel": "ntt_phase_kernel<7,COLS,fwd> + ntt_phase_kernel<8,ROWS,fwd> (one forward NTT = both launches)",
+            "traffic": traffic, "traffic_source": traffic_source,
+            "kernel": "ntt_phase_kernel<7,COLS,fwd> + ntt_phase_kernel<8,ROWS,fwd> (one forward NTT = both launches)",
             "launch": {"limbs": limbs, "N": N, "algorithmic_bytes": alg_bytes, "avg_us": round(ms * 1e3, 2),
                        "ntt_per_s": round(limbs / (ms * 1e-3))},
+            "limiting_resource": "valu-int",
+            "valu": {"instructions_per_butterfly": 29.6, "v_mad_u64_u32_per_butterfly": 8.25,
+                     "issue_ceiling_ntt_per_s": round(valu_ceiling), "frac_of_issue_ceiling": round(limbs / (ms * 1e-3) / valu_ceiling, 4),
+                     "source": "profiles/r01_intbench_gfx950.txt + ISA listing (tools/isa_mix.py); the byte roofline above is what the "
+                               "contract asks for, this is the resource the kernel actually saturates (profiles/r01_ntt_pmc_lds_valu.txt)"},
             "copy_kernel_gbs": round(copy_gbs, 1), "frac_of_copy": round(gbs / copy_gbs, 4)}
+
+
+def lib_sha256():
+    import hashlib
+
+    from dacapo_amd import LIB_PATH
+
+    return hashlib.sha256(Path(LIB_PATH).read_bytes()).hexdigest()
+
+
+def per_op_leg(ll, ell=13, iters=20):
+    """the three expensive opcodes alone at the reference's top level (13 primes, N = 2^15), next to the reference's own
+    per-op table for SEAL on a CPU (profiled_SEAL_CPU.json:10-45); algorithmic bytes per SURVEY.md 8(d)"""
+    L = ll.lib()
+    ctx = ll.Context(15, 14)
+    N, K = ctx.N, ctx.K
+    a, b, d = ll.DeviceBuffer((2, ell, N)), ll.DeviceBuffer((2, ell, N)), ll.DeviceBuffer((2, ell, N))
+    key = ll.DeviceBuffer((K - 1, 2, K, N))
+    for buf, v in ((a, 1), (b, 2), (key, 3)):
+        L.dc_memset(buf.ptr, v, buf.nbytes)
+    st = ell * N
+    e0, e1 = L.dc_event_create(), L.dc_event_create()
+    p_limb = 8 * N
+    ops = {
+        "rotate_hop": (lambda: L.dc_ct_rotate_hop(ctx.h, d.ptr, st, a.ptr, st, 3, key.ptr, ell, None), (2 * ell * ell + 7 * ell) * p_limb, 150699),
+        "mulcc_relin": (lambda: L.dc_ct_mul_relin(ctx.h, d.ptr, st, a.ptr, st, b.ptr, st, key.ptr, ell, None),
+                        (4 * ell + 2 * ell * ell + 7 * ell) * p_limb, 160732),
+        "rescale": (lambda: L.dc_ct_rescale(ctx.h, d.ptr, st, a.ptr, st, ell, None), (2 * ell + 2 * (ell - 1)) * p_limb, 17418),
+    }
+    out = {}
+    for name, (fn, nbytes, ref_us) in ops.items():
+        fn()
+        L.dc_event_record(e0, None)
+        for _ in range(iters):
+            fn()
+        L.dc_event_record(e1, None)
+        us = L.dc_event_elapsed_ms(e0, e1) / iters * 1e3
+        out[name] = {"us": round(us, 1), "algorithmic_bytes": nbytes, "achieved_gbs": round(nbytes / (us * 1e-6) / 1e9, 1),
+                     "frac_of_hbm_peak": round(nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), "reference_seal_cpu_us": ref_us}
+    out["level"] = ell
+    out["reference_table"] = "profiled_SEAL_CPU.json:10-45 (hardware unstated)"
+    return out
 
 
 def ntt_micro_leg(ll, iters=200):
@@ -307,10 +363,55 @@ def main():
 
     ms_per_step = elapsed / args.steps * 1e3
     value = total_ntts / elapsed
+    from dacapo_amd import progstats
+
+    pst = progstats.walk(hv)
+    # ---- the other lowerings of the same trace (same constants, same input): bootstraps to 6 and to 13 primes -------------
+    lowerings = [{"boot_level": fx["meta"].get("boot_level") if fx else None, "headline": True, "ms_per_step": round(ms_per_step, 3),
+                  "ntt_per_s": round(ntts_per_step * 1e3 / ms_per_step), "ntt_equivalents": pst["ntt_equivalents"],
+                  "key_switch_level_histogram": pst["key_switch_level_histogram"], "opcode10": pst["opcode10_histogram"],
+                  "algorithmic_bytes": pst["algorithmic_bytes"]}]
+    if fx is not None and world == 1 and args.streams == 1 and not args.no_lowerings and not args.hevm_gz:
+        import gzip
+
+        for tag in ("b6", "b13"):
+            f = ROOT / "tests" / "golden" / f"resnet20.{tag}.hevm.gz"
+            if not f.exists():
+                continue
+            hv2 = gzip.open(f).read()
+            hevm.load_mem(cst, hv2)
+            hevm.setInput(0, image)
+            hevm.run()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                hevm.run()
+            dt = (time.perf_counter() - t1) / args.steps
+            out2 = hevm.getOutput()[0]
+            st2, p2 = hevm.stats(), progstats.walk(hv2)
+            lowerings.append({"boot_level": int(tag[1:]), "headline": False, "ms_per_step": round(dt * 1e3, 3),
+                              "ntt_per_s": round(st2["ntts"] / dt), "ntt_equivalents": p2["ntt_equivalents"],
+                              "key_switch_level_histogram": p2["key_switch_level_histogram"], "opcode10": p2["opcode10_histogram"],
+                              "algorithmic_bytes": p2["algorithmic_bytes"],
+                              "achieved_gbs": round(p2["algorithmic_bytes"] / dt / 1e9, 1),
+                              "rms_vs_torch": float(np.sqrt(np.mean((out2[:10] * 32 - fx["torch_result"]) ** 2)))})
     ctx = ll.Context(15, 14)
     roof = roofline_leg(ll, ctx)
+    # the timed step's own place on the byte roofline: SURVEY.md 8(d)'s table walked over the bytecode (progstats.walk)
+    step_gbs = pst["algorithmic_bytes"] / (ms_per_step * 1e-3) / 1e9
+    top = None
+    tk = ROOT / "profiles" / "r02_top_kernels.json"
+    if tk.exists():
+        rec = json.loads(tk.read_text())
+        top = rec if rec.get("lib_sha256") == lib_sha256() else {"note": "profiles/r02_top_kernels.json was collected on another build"}
+    roof["step"] = {"what": "one run() of the headline program", "algorithmic_bytes": pst["algorithmic_bytes"],
+                    "achieved_gbs": round(step_gbs, 1), "frac": round(step_gbs / HBM_PEAK_GBS, 4),
+                    "ntt_equivalents": pst["ntt_equivalents"], "bytes_by_opcode": pst["algorithmic_bytes_by_opcode"],
+                    "top_kernels": top,
+                    "note": "latency-bound: ~5 300 dependent launches of 4-30 us (tools/timeline_gaps.py over a --kernel-trace of this "
+                            "command: profiles/r02_*_timeline.txt); 62 % of these bytes belong to elementwise ops the plan folds away"}
     micro = ntt_micro_leg(ll)
     cfg3 = cfg3_leg(ll)
+    per_op = per_op_leg(ll)
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline_leg(cst, hv, image)
@@ -325,6 +426,7 @@ def main():
                                "independent ciphertext stream per GPU",
                    "ops": info["op_mix"], "key_switches_per_step": stats["keyswitches"], "ntt_equivalents_per_step": ntts_per_step,
                    "streams_per_gpu": args.streams,
+                   "lowerings": lowerings,
                    "parallelism": f"replicas x{world} (no collective in the op path)"},
         "hevm_wall_s": round(ms_per_step / 1e3, 4),
         "hevm_bootstrap_s_per_step": round(stats["bootstrap_s"], 4),
@@ -333,6 +435,7 @@ def main():
         "roofline": roof,
         "ntt_micro": micro,
         "cfg3_mul_relin": cfg3,
+        "per_op_13_primes": per_op,
         "cpu_baseline": cpu,
     }
     if cpu:

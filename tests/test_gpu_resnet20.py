@@ -142,3 +142,22 @@ def test_resnet20_encrypted_inference_matches_torch(vm15, fixture20):
     hevm.run()
     again = hevm.getOutput()[0]
     assert np.abs(again - out).max() < 1e-3
+
+
+@pytest.mark.parametrize("tag", ["b6", "b13"])
+def test_resnet20_other_lowerings_decrypt_to_the_same_logits(fixture20, tag):
+    """the same trace with opcode 10 re-encrypting to 6 / 13 primes (key switches at up to 13 primes, the reference's top level):
+    the encrypted inference still decrypts to the torch model's logits"""
+    import gzip
+    from pathlib import Path
+
+    from dacapo_amd import runner
+
+    hv = gzip.open(Path(__file__).resolve().parent / "golden" / f"resnet20.{tag}.hevm.gz").read()
+    hevm = runner.HEVM(seed=0x4845564D + 9, logN=15, num_primes=14)
+    hevm.load_mem(fixture20["cst"], hv)
+    hevm.setInput(0, fixture20["packed"])
+    hevm.run()
+    out = hevm.getOutput()[0]
+    assert float(np.sqrt(np.mean((out - fixture20["expected"]) ** 2))) < 1e-3
+    assert float(np.sqrt(np.mean((out[:10] * 32 - fixture20["torch_result"]) ** 2))) < 5e-3

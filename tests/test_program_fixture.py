@@ -9,6 +9,8 @@ from oracle.oracle import OracleVM, read_cst, read_hevm
 
 import pytest
 
+ROOT = Path(__file__).resolve().parent.parent
+
 GOLDEN = Path(__file__).resolve().parent / "golden" / "resnet20"
 
 
@@ -139,3 +141,30 @@ def test_sobel_suite_program_on_oracle_at_reference_parameters(oracle_ref, tmp_p
     vm.run()
     got = vm.decrypt_result(0)
     assert np.abs(got - fx["expected"][0]).max() < 1e-5 * max(1.0, np.abs(fx["expected"][0]).max())
+
+
+def test_other_lowerings_of_the_resnet_trace_share_constants_and_compute_the_same_function():
+    """tests/golden/resnet20.b6 / .b13: the same traced op stream lowered with opcode 10 re-encrypting to 6 and to 13 primes
+    (DaCapo's bootstrapLevelUpperBound for SEAL is 13, profiled_SEAL_CPU.json:7-8).  Same constants file (sha recorded by the
+    tracer), same rotations / multiplications, same cleartext result; what differs is where rescales, modswitches and opcode 10 sit
+    and therefore the prime count the key switches run at."""
+    import gzip
+    import json
+
+    from dacapo_amd import hevm_asm as ha
+    from dacapo_amd import progstats
+
+    base = ha.read_fixture(ROOT / "tests" / "golden" / "resnet20")
+    ref = progstats.walk(base["hevm"])
+    want = ha.plain_eval(base["hevm"], base["cst"], [base["packed"]])[0]
+    for tag, boots, top in (("b6", 383, 6), ("b13", 192, 13)):
+        meta = json.loads((ROOT / "tests" / "golden" / f"resnet20.{tag}.json").read_text())
+        hv = gzip.open(ROOT / "tests" / "golden" / f"resnet20.{tag}.hevm.gz").read()
+        assert meta["cst_sha256"] == base["meta"]["cst_sha256"] and meta["boot_level"] == top
+        st = progstats.walk(hv)
+        assert st["key_switches"] == ref["key_switches"] == 4271                 # same rotations (3 910 hops) + 361 ct x ct
+        assert sum(st["opcode10_histogram"].values()) == boots
+        assert max(int(k) for k in st["key_switch_level_histogram"]) == top
+        assert st["ntt_equivalents"] > ref["ntt_equivalents"]                    # more primes per key switch
+        got = ha.plain_eval(hv, base["cst"], [base["packed"]])[0]
+        assert np.abs(got - want).max() < 1e-9
