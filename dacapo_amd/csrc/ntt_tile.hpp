@@ -78,26 +78,41 @@ struct PassMap {
     }
 };
 
-// Cooley-Tukey butterfly, values < 2^63 in and out:  (x, y) -> (x + w y, x - w y)
-__device__ __forceinline__ void ct_bfly(u64 &x, u64 &y, u64 w, const DModulus &M)
+// Lazy-reduction schedule.  mulmod_lazy(w, y) takes any w < 2^60 and y < 1.875 * 2^63 (its middle term a0*b1 + a1*b0 + carry
+// word then stays below 2^64 and the product below 2^124) and returns a value < 2^62; fold60 takes any 64-bit value.  So a
+// butterfly's "x" input only has to be folded often enough for the sums to fit 64 bits and the next multiplicand to stay under
+// 1.875 * 2^63 = 3.75 * 2^62:
+//   forward (Cooley-Tukey):  F stage  x' , y' = fold60(x) +- w y      -> every output < 1.25 * 2^62 (+2^32)
+//                            N stage  x' , y' = x +- w y (no fold)     -> bound grows by 2^62 per stage: 2.25, 3.25 (* 2^62) < 2^64
+//                            schedule F N N F N N ... from the first stage of every phase (inputs from memory are canonical or
+//                            a previous phase's outputs, < 3.25 * 2^62: fine for an F stage)
+//   inverse (Gentleman-Sande): x' = fold60(x + y), y' = w (x + 4q - y) at every stage.  The subtraction needs 4q > y, so every
+//                            value must stay below 4q: the sum is folded each time (an unfolded x + y could be the next
+//                            stage's subtrahend, and a larger multiple of q in its place would push the multiplicand past
+//                            its bound).  Forward has no such constraint: its subtrahend is always the fresh product w y < 4q.
+// Every value stored as a RESULT is canonical; intermediate (phase-to-phase) limbs may hold any of the lazy ranges above.
+__device__ __forceinline__ constexpr bool fwd_stage_folds(int stage_in_phase) { return stage_in_phase % 3 == 0; }
+
+// Cooley-Tukey butterfly:  (x, y) -> (x + w y, x - w y)
+__device__ __forceinline__ void ct_bfly(u64 &x, u64 &y, u64 w, const DModulus &M, bool fold)
 {
-    u64 xf = fold60(x, M.delta);            // < 2^60 + 2^31
-    u64 t = mulmod_lazy(w, y, M.delta);     // < 4q (w < 2^60, y < 2^63)
-    x = xf + t;                             // < 2^63
-    y = xf + (M.q << 2) - t;                // 4q > t : < 2^60 + 2^31 + 2^62
+    const u64 xf = fold ? fold60(x, M.delta) : x;
+    const u64 t = mulmod_lazy(w, y, M.delta); // < 4q < 2^62
+    x = xf + t;
+    y = xf + (M.q << 2) - t;                  // 4q > t
 }
 // Gentleman-Sande butterfly, values < 4q (< 2^62) in and out:  (x, y) -> (x + y, (x - y) w)
 // (every value here is a canonical input, a fold60 result or a mulmod_lazy result, all < 4q = 2^62 - 4 delta)
 __device__ __forceinline__ void gs_bfly(u64 &x, u64 &y, u64 w, const DModulus &M)
 {
-    u64 s = x + y;                          // < 2^63
-    u64 d = x + (M.q << 2) - y;             // 4q > y ; < 2^62 + 2^62 = 2^63
+    const u64 s = x + y;                      // < 2^63
+    const u64 d = x + (M.q << 2) - y;         // 4q > y ; < 2^63
     x = fold60(s, M.delta);
-    y = mulmod_lazy(w, d, M.delta);         // w < 2^60, d < 2^63 ; result < 4q
+    y = mulmod_lazy(w, d, M.delta);           // < 4q
 }
 
-// Ld: u64 operator()(int gidx)            coefficient gidx (0..N-1) of this limb, value < 2^62
-// St: void operator()(int gidx, u64 v)    v canonical if CANON else lazy (< 2^63)
+// Ld: u64 operator()(int gidx)            coefficient gidx (0..N-1) of this limb: canonical, or what a previous phase stored
+// St: void operator()(int gidx, u64 v)    v canonical if CANON else lazy (any of the ranges of the schedule above)
 // PRELOADED: x[] already holds the first pass's coefficients (register j <-> idx_of(first pass, s, j)); ld unused.
 // KEEP     : leave the result in x[] (canonical if CANON) instead of calling st.  The last pass of an inverse phase and
 //            the first pass of a forward phase of the same shape use the same thread<->coefficient map, so an inverse
@@ -191,7 +206,7 @@ __device__ __forceinline__ void ntt_tile_x(u64 (&x)[1 << LOGE], const DModulus M
                     for (int e = 0; e < half; e++) {
                         const int j0 = (u << r) | (g << (r - st_)) | e, j1 = j0 | half;
                         if (!INV)
-                            ct_bfly(x[j0], x[j1], w, M);
+                            ct_bfly(x[j0], x[j1], w, M, fwd_stage_folds(gs));
                         else if (COLS && gs == 0) { // very last inverse stage: fold N^{-1} in
                             u64 sv = x[j0] + x[j1];
                             u64 d = x[j0] + (M.q << 2) - x[j1];
