@@ -10,6 +10,8 @@ dacapo_amd/csrc by `__graft_entry__.build()`); this package only holds ctypes bi
 There is no CPU fallback: importing the bindings without the built library, or creating a context without
 a GPU, fails loudly.
 """
+import os
 from pathlib import Path
 
-LIB_PATH = Path(__file__).resolve().parent / "lib" / "libSEAL_HEVM.so"
+# DACAPO_AMD_LIB: another build of the same library (kernel-tuning sweeps: tools/sweep_lds_pad.sh); never a different backend
+LIB_PATH = Path(os.environ.get("DACAPO_AMD_LIB") or Path(__file__).resolve().parent / "lib" / "libSEAL_HEVM.so")

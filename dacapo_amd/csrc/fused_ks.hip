@@ -745,6 +745,8 @@ void f_ks_frows_mac(const Context &c, int mode, const u64 *ext, const u64 *targe
         DC_K_SWITCH(c.k2, hipLaunchKernelGGL((f_ks_frows_mac_kernel<KK, LE, MD>), grid, dim3(kTileThreads), 0, s, ext, target, items, shared_key, \
                                              acc, ell, c.K, c.d_mods, c.d_tw, c.d_itw, c.logN));                                          \
     }
+    // (the radix-8 geometry was measured for this kernel too: 8 coefficients x two 128-bit accumulators per thread cost more in
+    // occupancy than the saved LDS exchange returns -- config 3: 520 us against 455 us; profiles/r02_experiments.txt)
     if (use_tiny_tiles(c.N, (long)(ell + 2) * B)) {
         if (mode == 0) DC_FMAC(1, 0) else DC_FMAC(1, 1)
     } else {

@@ -33,7 +33,10 @@
 namespace dacapo {
 
 constexpr int kTileThreads = 256;
-constexpr int kLdsPad = 4;
+#ifndef DC_LDS_PAD
+#define DC_LDS_PAD 4
+#endif
+constexpr int kLdsPad = DC_LDS_PAD; // u64 words between the LDS rows of consecutive register indices (measured: profiles/r02_lds_pad_sweep.txt)
 template <int LOGE>
 struct TileGeo {
     static constexpr int E = 1 << LOGE;            // coefficients per thread
