@@ -394,6 +394,26 @@ def main():
                               "algorithmic_bytes": p2["algorithmic_bytes"],
                               "achieved_gbs": round(p2["algorithmic_bytes"] / dt / 1e9, 1),
                               "rms_vs_torch": float(np.sqrt(np.mean((out2[:10] * 32 - fx["torch_result"]) ** 2)))})
+    # ---- the same headline program with a direct Galois key for each of its rotation offsets (KeyGenerator::create_galois_keys(steps);
+    # the reference's HEaaN runtime keeps such a list, HEAAN_HEVM.cpp:58-64): every rotation one key switch.  NOT the headline: the
+    # reference's SEAL runtime only has the default key set (SEAL_HEVM.cpp:82-83), which the headline reproduces hop for hop.
+    direct = None
+    if fx is not None and world == 1 and args.streams == 1 and not args.no_lowerings and not args.hevm_gz:
+        offs = sorted({(int(r) - 65536 if r >= 32768 else int(r)) for o, _, _, r in ha.unpack_hevm(hv)["ops"].tolist() if o == ha.OP_ROTATE} - {0})
+        t1 = time.time()
+        hevm.addRotationKeys(offs)
+        t_keys = time.time() - t1
+        hevm.load_mem(cst, hv)
+        hevm.setInput(0, image)
+        hevm.run()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            hevm.run()
+        dt = (time.perf_counter() - t1) / args.steps
+        out3, st3 = hevm.getOutput()[0], hevm.stats()
+        direct = {"distinct_offsets": len(offs), "extra_key_bytes": len(offs) * 13 * 2 * 14 * 32768 * 8, "keygen_s": round(t_keys, 2),
+                  "ms_per_step": round(dt * 1e3, 3), "key_switches_per_step": st3["keyswitches"], "ntt_equivalents_per_step": st3["ntts"],
+                  "ntt_per_s": round(st3["ntts"] / dt), "rms_vs_torch": float(np.sqrt(np.mean((out3[:10] * 32 - fx["torch_result"]) ** 2)))}
     ctx = ll.Context(15, 14)
     roof = roofline_leg(ll, ctx)
     # the timed step's own place on the byte roofline: SURVEY.md 8(d)'s table walked over the bytecode (progstats.walk)
@@ -427,6 +447,7 @@ def main():
                    "ops": info["op_mix"], "key_switches_per_step": stats["keyswitches"], "ntt_equivalents_per_step": ntts_per_step,
                    "streams_per_gpu": args.streams,
                    "lowerings": lowerings,
+                   "with_direct_rotation_keys": direct,
                    "parallelism": f"replicas x{world} (no collective in the op path)"},
         "hevm_wall_s": round(ms_per_step / 1e3, 4),
         "hevm_bootstrap_s_per_step": round(stats["bootstrap_s"], 4),

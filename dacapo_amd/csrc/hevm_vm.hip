@@ -4,6 +4,7 @@
 // [SEAL-upstream keygenerator.cpp, rlwe.cpp, encryptor.cpp, decryptor.cpp, ckks.cpp].
 #include "hevm_vm.hpp"
 
+#include "../../include/dacapo_ckks.h"
 #include "c_api_types.hpp"
 #include "chacha.hpp"
 #include "seal_serial.hpp"
@@ -1691,6 +1692,26 @@ void hevm_load_mem(void *vm, const void *cst, uint64_t cst_len, const void *hevm
 void hevm_set_streams(void *vm, int n) { static_cast<HEVM *>(vm)->set_streams(n); }
 void hevm_select_stream(void *vm, int s) { static_cast<HEVM *>(vm)->select_stream(s); }
 double hevm_last_run_bootstrap_seconds(void *vm) { return static_cast<HEVM *>(vm)->t_bootstrap; }
+void hevm_add_rotation_keys(void *vm, const int64_t *offsets, int count)
+{ // KeyGenerator::create_galois_keys(steps): a direct key per slot offset (left = positive), next to the default +-2^k set
+    auto h = static_cast<HEVM *>(vm);
+    if (!h->keys.sk) {
+        fprintf(stderr, "[dacapo_amd] hevm_add_rotation_keys: this VM holds no secret key\n");
+        abort();
+    }
+    const int64_t slots = (int64_t)(h->ctx->N >> 1);
+    for (int i = 0; i < count; i++) {
+        int64_t st = offsets[i] % slots; // the HEaaN runtime lists left rotations in [1, slots) (HEAAN_HEVM.cpp:58-64)
+        if (st > slots / 2) st -= slots;
+        if (st < -slots / 2) st += slots;
+        if (st == 0) continue;
+        const uint32_t elt = dc_galois_elt_from_step(static_cast<dc_context *>(hevm_context(vm)), (int)st);
+        h->add_galois_key(elt);
+    }
+    DC_HIP_CHECK(hipStreamSynchronize(h->S()));
+    h->plan.ready = false; // rotations by these offsets are single hops from now on: the plan of a loaded program is rebuilt
+    h->drop_plan_graph();
+}
 void hevm_test_zero_encryption(void *vm, bool on)
 {
     if (on) fprintf(stderr, "[dacapo_amd] TEST HOOK: encryptions of zero are (0, 0) from now on -- this VM offers NO security\n");

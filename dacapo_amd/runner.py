@@ -71,6 +71,7 @@ def reinit_lw():  # runner.py:73-117
     lw.hevm_select_stream.argtypes = [ctypes.c_void_p, ctypes.c_int]
     lw.hevm_last_run_bootstrap_seconds.argtypes = [ctypes.c_void_p]
     lw.hevm_last_run_bootstrap_seconds.restype = ctypes.c_double
+    lw.hevm_add_rotation_keys.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64), ctypes.c_int]
     lw.hevm_test_zero_encryption.argtypes = [ctypes.c_void_p, ctypes.c_bool]
     lw.hevm_save_ctxt.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_char_p]
     lw.hevm_load_ctxt.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_char_p]
@@ -176,6 +177,11 @@ class HEVM:
             lw.decrypt_result(self.vm, i, carr)
             result[i] = data
         return result
+
+    def addRotationKeys(self, offsets):
+        """extension: direct Galois keys for these slot offsets (create_galois_keys(steps) in SEAL; HEAAN_HEVM.cpp:58-64's key list)"""
+        arr = (ctypes.c_int64 * len(offsets))(*[int(o) for o in offsets])
+        lw.hevm_add_rotation_keys(self.vm, arr, len(offsets))
 
     def saveCtxt(self, reg: int, path):
         """extension: seal::Ciphertext::save of a cipher register (SEAL 4.0 bytes) -- what a client / server pair exchanges"""

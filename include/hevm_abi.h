@@ -94,6 +94,12 @@ void hevm_set_streams(void *vm, int n);
 void hevm_select_stream(void *vm, int s);
 /* wall seconds the last run() spent inside opcode 10 (decrypt / re-encode / encrypt) */
 double hevm_last_run_bootstrap_seconds(void *vm);
+/* Direct Galois keys for the given slot offsets (left rotation = positive), what KeyGenerator::create_galois_keys(steps, ...)
+ * makes in SEAL and what the reference's HEaaN runtime loads for its fixed offset list (HEAAN_HEVM.cpp:58-64,124-126).  A
+ * rotation by such an offset is then ONE key switch instead of one per non-zero NAF digit (Evaluator::rotate_internal uses a
+ * direct key when it exists).  Needs the secret key; call before load()/preprocess() or re-run preprocess() afterwards.
+ * The reference's SEAL runtime only ever has the default set (SEAL_HEVM.cpp:82-83): programs run identically without this. */
+void hevm_add_rotation_keys(void *vm, const int64_t *offsets, int count);
 /* TEST HOOK, INSECURE: while on, every encryption of zero (encrypt(), opcode 10) is the pair (0, 0), so a ciphertext is
  * (plaintext, 0) and opcode 10's deterministic half -- decrypt, decode, re-encode (SEAL_HEVM.cpp:328-333) -- can be compared
  * limb by limb with the oracle.  Prints a warning when switched on. */

@@ -614,3 +614,46 @@ print("loaded", flush=True)
 """
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert r.returncode != 0 and "loaded" not in r.stdout and "[dacapo_amd]" in r.stderr, (r.stdout, r.stderr[-500:])
+
+
+def test_direct_rotation_keys_make_rotations_single_hops(tmp_path):
+    """hevm_add_rotation_keys = KeyGenerator::create_galois_keys(steps): with a key for the offset itself, rotate_vector is one key
+    switch (Evaluator::rotate_internal takes the direct key; the HEaaN runtime's key list, HEAAN_HEVM.cpp:58-64, exists for that).
+    Limbs equal the oracle's with the same keys; without the extra keys the same program takes one hop per NAF digit."""
+    from dacapo_amd import hevm_asm as ha
+    from dacapo_amd import lowlevel as ll
+    from dacapo_amd import runner
+
+    hevm = runner.HEVM(seed=11, logN=13, num_primes=5)
+    o = Oracle(13, 5)
+    rng = np.random.default_rng(4)
+    x = rng.uniform(-1, 1, o.slots)
+    b = ha.Builder(slots=o.slots, init_level=4)
+    v = b.input(x)
+    y = b.add(b.rotate(v, 37), b.rotate(v, -100))      # NAF: 3 + 3 hops under the default key set
+    b.output(b.add(y, b.rotate(y, 1000)))              # 1000 = 1024 - 32 + 8: 3 hops
+    cst, hv, _ = b.assemble()
+    hevm.load_mem(cst, hv)
+    hevm.setInput(0, x)
+    hevm.run()
+    assert hevm.stats()["keyswitches"] == 9
+    base = hevm.getOutput()[0]
+    hevm.addRotationKeys([37, -100, o.slots + 1000])   # offsets are taken modulo the slot count
+    _import_keys(o, hevm, ll)
+    for step in (37, -100, 1000):
+        elt = o.elt_from_step(step)
+        p = runner.lw.hevm_galois_key(hevm.vm, elt)
+        assert p, f"no direct key for step {step}"
+        o.galois[elt] = ll.read_device(p, (o.K - 1, 2, o.K, o.N))
+    hevm.load_mem(cst, hv)
+    ovm = _mirror_vm(hevm, ll, o, cst, hv, tmp_path)
+    hevm.setInput(0, x)
+    ovm.ciphers[0] = _get_ct(hevm, ll, 0)
+    hevm.run()
+    ovm.run()
+    assert hevm.stats()["keyswitches"] == 3
+    r = ovm.prog.res_dst[0]
+    got, want = _get_ct(hevm, ll, r), ovm.ciphers[r]
+    assert got.ell == want.ell and (got.data == want.data).all()
+    res = hevm.getOutput()[0]
+    assert np.sqrt(np.mean((res - b.expected()[0]) ** 2)) < 1e-5 and np.abs(res - base).max() < 1e-4
