@@ -1,0 +1,33 @@
+#!/bin/bash
+# Everything under profiles/ for one round, collected on the GPU box in one gpurun call:
+#   gpurun --timeout 1500 -- 'bash tools/collect_profiles.sh r02'
+# Outputs go to gpurun_out/<round>/ (merged back by gpurun); copy the summaries into profiles/ afterwards.
+set -u
+R=${1:-r02}
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$ROOT/gpurun_out/$R
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+# A. kernel trace + stats of the bench command (program directly after `--`)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-lowerings > $OUT/bench_under_profiler.json 2> $OUT/kt.err
+KT=$(ls $OUT/kt/*/*kernel_trace.csv | head -1)
+cp $(ls $OUT/kt/*/*kernel_stats.csv | head -1) $OUT/${R}_kernel_stats.csv
+cd $ROOT
+python tools/summarize_trace.py $KT > $OUT/${R}_by_kernel_and_grid.txt
+python tools/summarize_trace.py $KT 4096 > $OUT/${R}_roofline_leg_launches.txt
+python tools/timeline_gaps.py $KT > $OUT/${R}_timeline.txt
+python tools/top_kernels.py $KT > $OUT/${R}_top_kernels.json
+rm -rf $OUT/kt
+# B. HBM traffic of the NTT phase kernels: FETCH_SIZE and WRITE_SIZE need separate passes
+cd /tmp
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pf -- python3 $ROOT/tools/ntt_only.py 15 4096 2 > /dev/null 2> $OUT/pf.err
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pw -- python3 $ROOT/tools/ntt_only.py 15 4096 2 > /dev/null 2> $OUT/pw.err
+cd $ROOT
+python tools/collect_traffic.py $(ls $OUT/pf/*/*counter_collection.csv | head -1) $(ls $OUT/pw/*/*counter_collection.csv | head -1) > $OUT/${R}_ntt_hbm_traffic.json
+rm -rf $OUT/pf $OUT/pw
+# C. latency of dependent chains, D. several ciphertext streams on one GPU, E. the bench line itself, F. per-op table for the reference's planner
+python tools/chain_bench.py > $OUT/${R}_chain_latency.txt 2>/dev/null
+for s in 2 4 8; do python bench.py --streams $s --no-cpu-baseline --no-lowerings 2>/dev/null | python tools/bench_brief.py; done > $OUT/${R}_streams.txt
+python tools/profile_backend.py --out $OUT/${R}_profiled_SEAL_MI355X.json > $OUT/profile_backend.log 2>&1
+python bench.py > $OUT/${R}_bench.json 2> $OUT/bench.err
+tail -c 400 $OUT/${R}_bench.json
