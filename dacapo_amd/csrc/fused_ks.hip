@@ -589,6 +589,14 @@ __global__ __launch_bounds__(kTileThreads) void f_ks_frows_mac_kernel(const u64 
 #pragma unroll
             for (int e = 0; e < E; e++) a1[e].mac(x[e], k1[g[e]]);
         }
+        if ((j & 15) == 15 && j + 1 < ell) { // a 128-bit accumulator holds 16 products of canonical residues (Acc128): fold it into a word
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                const u64 f0 = a0[e].reduce(M), f1 = a1[e].reduce(M);
+                a0[e].clear(), a1[e].clear();
+                a0[e].lo = f0, a1[e].lo = f1; // the folded sum counts as one more (tiny) term: 16 products + 2^60 < 2^124
+            }
+        }
     }
     if (m < ell) {
         u64 *ac = acc + (size_t)b * 2 * (ell + 1) * N;
