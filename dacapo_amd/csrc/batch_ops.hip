@@ -295,6 +295,57 @@ __global__ __launch_bounds__(kBT) void b_sum_kernel(const SumItem *__restrict__ 
     *reinterpret_cast<u64x2 *>(it.dst.limb(p, i, N) + k) = r;
 }
 
+// ---- ModRaise -----------------------------------------------------------------------------------------------------------------
+// scratch[b*2 + p][k] = limb 0 of polynomial p of item b (NTT form; the caller then takes it to the coefficient domain)
+__global__ __launch_bounds__(kBT) void b_modraise_gather_kernel(u64 *__restrict__ scratch, const EwItem *__restrict__ items, size_t N)
+{
+    const int z = blockIdx.y, b = z >> 1, p = z & 1;
+    const size_t k = ((size_t)blockIdx.x * kBT + threadIdx.x) * 2;
+    *reinterpret_cast<u64x2 *>(scratch + (size_t)z * N + k) = *reinterpret_cast<const u64x2 *>(items[b].a.limb(p, 0, N) + k);
+}
+// dst[p][i][k] = centred(scratch[b*2+p][k] mod q_0) mod q_i : the integer in (-q_0/2, q_0/2] read modulo every prime of the target level
+// grid = (N/512, target, 2B)
+__global__ __launch_bounds__(kBT) void b_modraise_lift_kernel(const u64 *__restrict__ scratch, const EwItem *__restrict__ items, size_t N,
+                                                               const DModulus *__restrict__ mods)
+{
+    const int i = blockIdx.y, z = blockIdx.z, b = z >> 1, p = z & 1;
+    const u64 q0 = mods[0].q, qi = mods[i].q, half = q0 >> 1;
+    const size_t k = ((size_t)blockIdx.x * kBT + threadIdx.x) * 2;
+    const u64x2 v = *reinterpret_cast<const u64x2 *>(scratch + (size_t)z * N + k);
+    u64x2 r;
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
+        if (v[e] > half) { // negative: -(q0 - v) mod q_i ; all primes lie in (2^60 - 2^28, 2^60), so one conditional subtraction reduces
+            u64 m = q0 - v[e];
+            m = m >= qi ? m - qi : m;
+            r[e] = m ? qi - m : 0;
+        } else
+            r[e] = v[e] >= qi ? v[e] - qi : v[e];
+    }
+    *reinterpret_cast<u64x2 *>(items[b].dst.limb(p, i, N) + k) = r;
+}
+
+void modraise(Context &c, u64 *scratch, const EwItem *h_items, int B, int target, hipStream_t s, const EwItem *d_items)
+{
+    const size_t N = c.N;
+    EwItem *tmp = nullptr;
+    if (!d_items) { // eager path: one item by value
+        DC_HIP_CHECK(hipMalloc(&tmp, (size_t)B * sizeof(EwItem)));
+        DC_HIP_CHECK(hipMemcpyAsync(tmp, h_items, (size_t)B * sizeof(EwItem), hipMemcpyHostToDevice, s));
+        d_items = tmp;
+    }
+    hipLaunchKernelGGL(b_modraise_gather_kernel, dim3((unsigned)(N / (2 * kBT)), (unsigned)(2 * B)), dim3(kBT), 0, s, scratch, d_items, N);
+    launch_ntt(c, true, scratch, (long)N, 2 * B, nullptr, 0, 1, s);
+    hipLaunchKernelGGL(b_modraise_lift_kernel, dim3((unsigned)(N / (2 * kBT)), (unsigned)target, (unsigned)(2 * B)), dim3(kBT), 0, s, scratch,
+                       d_items, N, c.d_mods);
+    for (int b = 0; b < B; b++)
+        for (int p = 0; p < 2; p++) launch_ntt(c, false, h_items[b].dst.limb(p, 0, N), (long)N, target, nullptr, 0, 0, s);
+    if (tmp) {
+        DC_HIP_CHECK(hipStreamSynchronize(s));
+        (void)hipFree(tmp);
+    }
+}
+
 void b_sum(Context &c, const SumItem *d_items, const SumSrc *d_srcs, int B, int ell, hipStream_t s)
 {
     hipLaunchKernelGGL(b_sum_kernel, dim3((unsigned)(c.N / (2 * kBT)), (unsigned)ell, (unsigned)(2 * B)), dim3(kBT), 0, s, d_items, d_srcs,

@@ -19,9 +19,10 @@ __global__ __launch_bounds__(kEncThreads) void enc_scatter_kernel(double2 *__res
     const size_t slots = N >> 1, i = (size_t)blockIdx.x * kEncThreads + threadIdx.x;
     const EncItem it = items[blockIdx.y];
     const double x = it.len ? consts[it.src_off + i % it.len] : 1.0; // len 0: the all-ones "upscale" constant
+    const double y = it.cplx ? consts[it.src_off + it.len + i % it.len] : 0.0;
     double2 *o = v + (size_t)blockIdx.y * N;
-    o[slot_map[i]] = make_double2(x, 0.0);
-    o[slot_map[slots | i]] = make_double2(x, 0.0);
+    o[slot_map[i]] = make_double2(x, y);
+    o[slot_map[slots | i]] = make_double2(x, -y); // the conjugate half (CKKSEncoder::encode_internal)
 }
 
 __device__ __forceinline__ double2 cmul(double2 a, double2 b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }

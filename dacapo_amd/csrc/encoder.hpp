@@ -7,7 +7,7 @@ namespace dacapo {
 struct EncItem {
     size_t src_off; // offset (in doubles) of the source vector in the device constant arena
     u32 len;        // its length; 0 = the all-ones constant of an upscale (EmitHEVM.cpp: lhs 0xFFFF)
-    u32 pad;
+    u32 cplx;       // 1: the source holds `len` real parts followed by `len` imaginary parts (extension opcode 16, ckks_boot.py)
     double fix;     // scale / N
 };
 struct EncTables {

@@ -455,6 +455,7 @@ void HEVM::init_context(int logN, int K, const u64 *primes)
     if (const char *e = getenv("DACAPO_HEVM_FOLD_RESCALE_BOOT")) fold_rescale_into_boot = atoi(e) != 0;
     if (const char *e = getenv("DACAPO_HEVM_MAX_BATCH")) max_batch = std::max(1, atoi(e));
     if (const char *e = getenv("DACAPO_HEVM_CHAIN_FUSION")) chain_fusion = atoi(e) != 0;
+    if (const char *e = getenv("DACAPO_HEVM_SECRET_HW")) secret_weight = atoi(e);
     lanes.resize(1);
     DC_HIP_CHECK(hipStreamCreateWithFlags(&lanes[0].stream, hipStreamNonBlocking));
     lanes[0].ws = ctx->ws0;
@@ -506,7 +507,32 @@ void HEVM::generate_keys(const RngKeys &rng_, bool secret, bool pub, bool eval)
     const dim3 gu((unsigned)(N / (kRngCoefs * kVmThreads)), (unsigned)K), gs((unsigned)(N / (kRngCoefs * kVmThreads))),
         g2((unsigned)(N / (2 * kVmThreads)), (unsigned)K);
     keys.sk = dalloc((size_t)K * N);
-    hipLaunchKernelGGL(sample_small_kernel, gs, dim3(kVmThreads), 0, S(), keys.sk, N, K, 0, rng.secret, (u64)0, (u32)RNG_SK, c.d_mods);
+    if (secret_weight > 0) {
+        // Sparse ternary secret with exactly `secret_weight` non-zero coefficients (what bootstrappable parameter sets use: the ModRaise
+        // overflow I of ckks_boot.py is ~ sqrt(h / 12) wide).  Positions and signs from the secret ChaCha20 key, drawn on the host.
+        if ((size_t)secret_weight > N / 2) {
+            fprintf(stderr, "[dacapo_amd] DACAPO_HEVM_SECRET_HW=%d is not sparse for N = %zu\n", secret_weight, N);
+            abort();
+        }
+        std::vector<int8_t> coef(N, 0);
+        u64 w[8];
+        int placed = 0;
+        for (u64 blk = 0; placed < secret_weight; blk++) {
+            rng_words8(rng.secret, 0, blk, 0, 1, RNG_SK, w);
+            for (int e = 0; e < 8 && placed < secret_weight; e++) {
+                const size_t idx = (size_t)((w[e] >> 8) % N); // N is a power of two: unbiased
+                if (coef[idx]) continue;
+                coef[idx] = (w[e] & 1) ? 1 : -1;
+                placed++;
+            }
+        }
+        std::vector<u64> h((size_t)K * N);
+        for (int i = 0; i < K; i++)
+            for (size_t k = 0; k < N; k++) h[(size_t)i * N + k] = coef[k] == 0 ? 0 : coef[k] > 0 ? 1 : c.primes[(size_t)i] - 1;
+        DC_HIP_CHECK(hipMemcpyAsync(keys.sk, h.data(), h.size() * 8, hipMemcpyHostToDevice, S()));
+        DC_HIP_CHECK(hipStreamSynchronize(S()));
+    } else
+        hipLaunchKernelGGL(sample_small_kernel, gs, dim3(kVmThreads), 0, S(), keys.sk, N, K, 0, rng.secret, (u64)0, (u32)RNG_SK, c.d_mods);
     launch_ntt(c, false, keys.sk, (long)N, K, nullptr, 0, 0, S());
     if (pub) {
         keys.pk = dalloc((size_t)2 * K * N);
@@ -827,8 +853,12 @@ void HEVM::load_program(const void *data, size_t len, bool header_only)
         // Operand validation, once: the reference indexes its register vectors unchecked (SEAL_HEVM.cpp:268-334); here a program
         // may name cipher registers beyond num_ctxt_buffer (the file grows with them) but never a plaintext register that does not exist.
         for (const WireOp &op : ops) {
-            if (op.opcode > 10) continue;
-            if (op.opcode == 0) {
+            if (op.opcode > 10 && (op.opcode < kOpEncodeComplex || op.opcode > kOpSetScale)) continue;
+            if (op.opcode == kOpSetScale && op.rhs >= buffer.size()) {
+                fprintf(stderr, "[dacapo_amd] .hevm: setscale reads constant %u of %zu\n", (unsigned)op.rhs, buffer.size());
+                abort();
+            }
+            if (op.opcode == 0 || op.opcode == kOpEncodeComplex) {
                 if (op.dst >= plains.size()) {
                     fprintf(stderr, "[dacapo_amd] .hevm: encode into plaintext register %u of %zu\n", (unsigned)op.dst, plains.size());
                     abort();
@@ -978,10 +1008,10 @@ void HEVM::preprocess_device()
     std::map<int, std::vector<std::pair<int, EncItem>>> by_level; // level -> (plain register, item)
     std::vector<long> last_write(plains.size(), -1); // a register encoded more than once keeps its last value
     for (size_t k = 0; k < ops.size(); k++)
-        if (ops[k].opcode == 0) last_write.at(ops[k].dst) = (long)k;
+        if (ops[k].opcode == 0 || ops[k].opcode == kOpEncodeComplex) last_write.at(ops[k].dst) = (long)k;
     for (size_t k = 0; k < ops.size(); k++) {
         const WireOp &op = ops[k];
-        if (op.opcode != 0 || last_write[op.dst] != (long)k) continue;
+        if ((op.opcode != 0 && op.opcode != kOpEncodeComplex) || last_write[op.dst] != (long)k) continue;
         const int level = op.rhs >> 10, scale_bits = op.rhs & 0x3FF;
         if (level < 1 || level > c.max_level()) {
             fprintf(stderr, "[dacapo_amd] encode: level %d outside 1..%d\n", level, c.max_level());
@@ -999,6 +1029,16 @@ void HEVM::preprocess_device()
                 host.insert(host.end(), src.begin(), src.end());
             }
             it.src_off = off[op.lhs], it.len = (u32)src.size();
+            if (op.opcode == kOpEncodeComplex) {
+                if (src.size() < 2 || (src.size() & 1)) {
+                    fprintf(stderr, "[dacapo_amd] encode (complex): constant %u must hold real parts then imaginary parts\n", (unsigned)op.lhs);
+                    abort();
+                }
+                it.len = (u32)(src.size() / 2), it.cplx = 1;
+            }
+        } else if (op.opcode == kOpEncodeComplex) {
+            fprintf(stderr, "[dacapo_amd] encode (complex): needs a constant\n");
+            abort();
         }
         Plain &pl = plains.at(op.dst);
         pl.level = level, pl.scale = pow(2.0, (double)scale_bits), pl.arena = true;
@@ -1050,7 +1090,10 @@ void HEVM::preprocess()
     else {
         const std::vector<double> identity(1, 1.0); // tiled to all ones, like the reference's identity vector
         for (const WireOp &op : ops)
-            if (op.opcode == 0) {
+            if (op.opcode == kOpEncodeComplex) {
+                fprintf(stderr, "[dacapo_amd] complex plaintexts (extension opcode 16) need the device encoder\n");
+                abort();
+            } else if (op.opcode == 0) {
                 const std::vector<double> &src = (op.lhs == 0xFFFF) ? identity : buffer.at(op.lhs);
                 encode_internal(plains.at(op.dst), src.data(), src.size(), op.rhs >> 10, op.rhs & 0x3FF);
             }
@@ -1356,6 +1399,40 @@ void HEVM::op_mulcp(int dst, int lhs, int rhs)
     const double sc = a.scale * p.scale;
     d.level = a.level, d.scale = sc;
 }
+// ---- extension opcodes 17-19 (hevm_asm.OP_CONJ / OP_MODRAISE / OP_SETSCALE: the pieces real CKKS bootstrapping needs, ckks_boot.py) ----
+void HEVM::op_conj(int dst, int src)
+{ // complex conjugation of the slots = the Galois automorphism X -> X^(2N-1), a key of the default set
+    hevm_ctxt &s = reg(src);
+    hevm_ctxt &d = reg(dst);
+    const u32 elt = (u32)(2 * ctx->N - 1);
+    if (!keys.galois.count(elt)) {
+        fprintf(stderr, "[dacapo_amd] conj: no Galois key for the conjugation\n");
+        abort();
+    }
+    rotate_hop(*ctx, W(), view(d), view(s), elt, keys.galois.at(elt), s.level, S());
+    n_keyswitch++, n_ntt += ks_ntts(s.level);
+    d.level = s.level, d.scale = s.scale;
+}
+void HEVM::op_modraise(int dst, int src, int target)
+{
+    hevm_ctxt &s = reg(src);
+    hevm_ctxt &d = reg(dst);
+    if (s.level != 1 || target < 1 || target > ctx->max_level()) {
+        fprintf(stderr, "[dacapo_amd] modraise: the operand must sit at 1 prime (has %d) and the target within 1..%d\n", s.level, ctx->max_level());
+        abort();
+    }
+    const EwItem it{ view(d), view(s), view(s) };
+    modraise(*ctx, W().ks_digits, &it, 1, target, S());
+    d.level = target, d.scale = s.scale;
+}
+void HEVM::op_setscale(int dst, int src, int const_idx)
+{
+    hevm_ctxt &s = reg(src);
+    hevm_ctxt &d = reg(dst);
+    if (dst != src) launch_ew(*ctx, EwOp::Copy, view(d), view(s), view(s), 2, 2, s.level, S());
+    d.level = s.level, d.scale = buffer.at((size_t)const_idx).at(0);
+}
+
 // host-side constants of the device CRT for level ell (built once per level)
 const HEVM::CrtTables &HEVM::crt_tables(int ell)
 {
@@ -1520,6 +1597,9 @@ void HEVM::dispatch(const WireOp &op)
     case 8: op_mulcc(op.dst, op.lhs, op.rhs); break;
     case 9: op_mulcp(op.dst, op.lhs, op.rhs); break;
     case 10: op_bootstrap(op.dst, op.lhs, op.rhs); break;
+    case kOpConj: op_conj(op.dst, op.lhs); break;
+    case kOpModRaise: op_modraise(op.dst, op.lhs, op.rhs); break;
+    case kOpSetScale: op_setscale(op.dst, op.lhs, op.rhs); break;
     default: break; // 0 = Encode (done in preprocess), 0xFFFF buffer marker and unknown opcodes are no-ops
     }
 }
@@ -1539,7 +1619,7 @@ void HEVM::execute()
                       << std::endl;
         }
         if (op.opcode <= 10) op_counts[op.opcode]++;
-        if (op.opcode == 0 || op.opcode > 10) continue;
+        if (op.opcode == 0 || (op.opcode > 10 && (op.opcode < kOpConj || op.opcode > kOpSetScale))) continue;
         dispatch(op);
     }
     bump_epoch(S());

@@ -35,6 +35,8 @@ struct WireConfigBody {
 struct WireOp {
     uint16_t opcode, dst, lhs, rhs;
 };
+// extension opcodes (dacapo_amd/hevm_asm.py OP_ENCODE_COMPLEX ...): not emitted by the reference's compiler, skipped by its VMs
+constexpr uint16_t kOpEncodeComplex = 16, kOpConj = 17, kOpModRaise = 18, kOpSetScale = 19;
 static_assert(sizeof(WireHeader) == 24 && sizeof(WireConfigBody) == 40 && sizeof(WireOp) == 8, "HEVM wire format");
 
 // CKKSEncoder restated on the host (encode/decode are untimed set-up work in the reference: SEAL_HEVM.cpp:242-267,
@@ -120,7 +122,7 @@ class HEVM {
     const CrtTables &crt_tables(int ell);
 
     // ---- batched plan (plan.hpp): built on the first run() of a loaded program -----------------------------
-    enum PopKind { P_ROT, P_MULCC, P_RESCALE, P_SUM, P_NEG, P_MULP, P_ADDP, P_COPY, P_BOOT };
+    enum PopKind { P_ROT, P_MULCC, P_RESCALE, P_SUM, P_NEG, P_MULP, P_ADDP, P_COPY, P_BOOT, P_MODRAISE };
     struct Val {
         int level = 0;
         double scale = 1.0;
@@ -169,6 +171,7 @@ class HEVM {
         SumItem *d_sum = nullptr;
         SumSrc *d_sum_srcs = nullptr;
         CtView *d_cont_other = nullptr;      // CONT_MUL links: the consumers' other operands
+        std::vector<EwItem> h_ew;            // host copy of the elementwise item table (modraise launches its NTTs per item)
         std::vector<u64 *> handoff_bufs;     // first-phase buffers of fused consumer steps
         size_t n_fused = 0;
         // opcode 10: item table, the divide-and-round items of the zero-encryptions, the zero-encryption arena and scratch
@@ -205,6 +208,7 @@ class HEVM {
     void boot_item(CtView src, int src_level, double src_scale, hevm_ctxt &dst, int target_level);
     void plan_zero_encrypt(int first, int B, int t, hipStream_t s);
     void plan_boot_step(int first, int B, int ell, int t, int lane, hipStream_t s, const Handoff &h);
+    int secret_weight = 0; // DACAPO_HEVM_SECRET_HW=h: key generation draws a ternary secret with exactly h non-zero coefficients (0: uniform ternary, SEAL's)
     bool chain_fusion = true; // DACAPO_HEVM_CHAIN_FUSION=0: every step runs all of its own launches
     hipStream_t aux_stream = nullptr;
     bool fold_rescale_into_boot = false; // DACAPO_HEVM_FOLD_RESCALE_BOOT=1: do a rescale that only feeds an opcode 10 inside its re-encoder
@@ -249,6 +253,9 @@ class HEVM {
     void op_mulcc(int dst, int lhs, int rhs);
     void op_mulcp(int dst, int lhs, int rhs);
     void op_bootstrap(int dst, int src, int target_level);
+    void op_conj(int dst, int src);
+    void op_modraise(int dst, int src, int target);
+    void op_setscale(int dst, int src, int const_idx);
     std::vector<u32> rotate_hops(int steps) const;
 
     CtView view(const hevm_ctxt &c) const { return CtView{ c.data, (long)c.poly_stride }; }

@@ -91,6 +91,9 @@ bool chain_fusion_supported(); // the continuation kernels exist for the default
 void b_ew(Context &c, EwOp op, const EwItem *d_items, int B, int polys, int b_polys, int ell, hipStream_t s);
 void b_add_plain(Context &c, const EwItem *d_items, int B, int ell, hipStream_t s);
 void b_sum(Context &c, const SumItem *d_items, const SumSrc *d_srcs, int B, int ell, hipStream_t s);
+// ModRaise (extension opcode 18): items[b].a at 1 prime -> items[b].dst at `target` primes, the centred residues mod q_0 re-read
+// modulo every prime.  `scratch` holds [B][2][N]; h_items is the host copy of the items (the forward NTTs are launched per item).
+void modraise(Context &c, u64 *scratch, const EwItem *h_items, int B, int target, hipStream_t s, const EwItem *d_items = nullptr);
 
 // fused phase launchers (fused_ks.hip)
 void f_irows_strided(const Context &c, const u64 *base, long stride, int prime_base, int period, u64 *out, long out_stride, int count,

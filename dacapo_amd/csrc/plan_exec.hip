@@ -194,6 +194,44 @@ void HEVM::build_plan()
             cur[op.dst] = nv;
             break;
         }
+        case kOpConj: { // one key switch with the conjugation key
+            const int a = need(op.lhs, "conj");
+            const Val s = P.vals[(size_t)a];
+            const u32 elt = (u32)(2 * N - 1);
+            if (!keys.galois.count(elt)) {
+                fprintf(stderr, "[dacapo_amd] conj: no Galois key for the conjugation\n");
+                abort();
+            }
+            const int nv = new_val(s.level, s.scale);
+            Pop &p = add_pop(P_ROT, s.level, { a }, nv);
+            p.elt = elt, p.key = keys.galois.at(elt);
+            P.n_keyswitch++, P.n_ntt += ks_ntts(s.level);
+            cur[op.dst] = nv;
+            break;
+        }
+        case kOpModRaise: {
+            const int a = need(op.lhs, "modraise");
+            const Val s = P.vals[(size_t)a];
+            if (s.level != 1 || op.rhs < 1 || (int)op.rhs > c.max_level()) {
+                fprintf(stderr, "[dacapo_amd] modraise: the operand must sit at 1 prime (has %d) and the target within 1..%d\n", s.level, c.max_level());
+                abort();
+            }
+            const int nv = new_val((int)op.rhs, s.scale);
+            add_pop(P_MODRAISE, 1, { a }, nv).target_level = op.rhs;
+            P.n_ntt += 2 + 2 * (int)op.rhs;
+            cur[op.dst] = nv;
+            break;
+        }
+        case kOpSetScale: { // a relabelled view of the same buffer
+            const int a = need(op.lhs, "setscale");
+            const Val s = P.vals[(size_t)a];
+            const int nv = new_val(s.level, buffer.at(op.rhs).at(0));
+            P.vals[(size_t)nv].root = s.root;
+            P.vals[(size_t)nv].def_pop = P.vals[(size_t)s.root].def_pop;
+            P.vals[(size_t)a].uses++;
+            cur[op.dst] = nv;
+            break;
+        }
         default: break;
         }
     }
@@ -512,6 +550,9 @@ void HEVM::build_plan()
                     }
                 }
             break;
+        case P_MODRAISE:
+            need_d = std::max(need_d, B * 2);
+            [[fallthrough]];
         case P_NEG:
         case P_COPY:
             st.first = (int)h_ew.size();
@@ -606,6 +647,7 @@ void HEVM::build_plan()
         P.d_boot = upload(h_boot), P.d_boot_rs = upload(h_brs);
     }
     P.d_ks = upload(h_ks), P.d_mul = upload(h_mul), P.d_rs = upload(h_rs), P.d_ew = upload(h_ew), P.d_sum = upload(h_sum);
+    P.h_ew = h_ew;
     P.d_sum_srcs = upload(h_srcs);
     // fused links: the consumer's first-phase buffer (owned by the link, so the two steps may sit on different streams / waves)
     // and, for multiplies, the table of the consumers' other operands in item order
@@ -665,8 +707,8 @@ void HEVM::build_plan()
     P.ready = true;
     if (plan_graph) capture_plan(); // part of the (untimed) preparation, like the plan itself
     if (getenv("DACAPO_HEVM_TRACE")) {
-        static const char *kn[] = { "rot", "mulcc", "rescale", "sum", "neg", "mulp", "addp", "copy", "boot" };
-        size_t nsteps[9] = { 0 }, nitems[9] = { 0 };
+        static const char *kn[] = { "rot", "mulcc", "rescale", "sum", "neg", "mulp", "addp", "copy", "boot", "modraise" };
+        size_t nsteps[10] = { 0 }, nitems[10] = { 0 };
         std::map<std::pair<int, int>, std::pair<size_t, size_t>> ks; // (kind, level) -> steps, items
         for (const Step &st : P.steps) {
             nsteps[st.kind]++, nitems[st.kind] += (size_t)st.count;
@@ -685,7 +727,7 @@ void HEVM::build_plan()
             }
             fprintf(stderr, "\n");
         }
-        for (int k = 0; k < 9; k++)
+        for (int k = 0; k < 10; k++)
             if (nsteps[k]) fprintf(stderr, "[dacapo_amd] plan:   %-8s %5zu steps %6zu items\n", kn[k], nsteps[k], nitems[k]);
         { // who consumes what: candidates for handing a result to its consumer's first phase inside one launch
             std::map<std::tuple<int, int, int, int>, int> edges; // (producer kind, consumer kind, uses, same level) -> count
@@ -747,6 +789,7 @@ void HEVM::issue_plan(hipStream_t s)
             case P_SUM: b_sum(c, P.d_sum + st.first, P.d_sum_srcs, st.count, st.level, q); break;
             case P_NEG: b_ew(c, EwOp::Neg, P.d_ew + st.first, st.count, 2, 2, st.level, q); break;
             case P_COPY: b_ew(c, EwOp::Copy, P.d_ew + st.first, st.count, 2, 2, st.level, q); break;
+            case P_MODRAISE: modraise(c, w.digits, P.h_ew.data() + st.first, st.count, st.target, q, P.d_ew + st.first); break;
             case P_MULP: b_ew(c, EwOp::Mul, P.d_ew + st.first, st.count, 2, 1, st.level, q); break;
             case P_ADDP: b_add_plain(c, P.d_ew + st.first, st.count, st.level, q); break;
             case P_BOOT: plan_boot_step(st.first, st.count, st.level, st.target, st.lane, q, st.h); break;
@@ -774,7 +817,7 @@ void HEVM::issue_plan(hipStream_t s)
     }
     bump_epoch(s);
     if (step_profile) {
-        static const char *kn[] = { "rot", "mulcc", "rescale", "sum", "neg", "mulp", "addp", "copy", "boot" };
+        static const char *kn[] = { "rot", "mulcc", "rescale", "sum", "neg", "mulp", "addp", "copy", "boot", "modraise" };
         double total = 0;
         for (auto &kv : prof) total += kv.second.second;
         fprintf(stderr, "[dacapo_amd] step profile (synchronised after every step): %.2f ms in %zu steps\n", total * 1e3, P.steps.size());

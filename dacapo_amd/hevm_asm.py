@@ -27,6 +27,12 @@ MAGIC = 0x4845564D
 OP_ENCODE, OP_ROTATE, OP_NEGATE, OP_RESCALE, OP_MODSWITCH, OP_UPSCALE = 0, 1, 2, 3, 4, 5
 OP_ADDCC, OP_ADDCP, OP_MULCC, OP_MULCP, OP_BOOTSTRAP = 6, 7, 8, 9, 10
 OP_NAMES = ["encode", "rotate", "negate", "rescale", "modswitch", "upscale", "addcc", "addcp", "mulcc", "mulcp", "bootstrap"]
+# Extension opcodes of this runtime (not emitted by the reference's compiler; its VMs skip unknown opcodes, SEAL_HEVM.cpp:351-399).
+# They exist so that real CKKS bootstrapping (dacapo_amd/ckks_boot.py; HEAAN_HEVM.cpp:386-399) is an instruction sequence like any other:
+OP_ENCODE_COMPLEX = 16  # dst = plain reg, lhs = constant index (vector [re..., im...]), rhs = (level << 10) + scale: complex slot values
+OP_CONJ = 17            # dst = complex conjugate of lhs (Galois element 2N - 1, a key of the default set)
+OP_MODRAISE = 18        # dst = lhs (1 prime) re-read modulo the first rhs primes: decrypts to p + q0 * I
+OP_SETSCALE = 19        # dst = lhs with its scale label set to constants[rhs][0]
 
 
 def write_cst(path, constants):
@@ -446,8 +452,8 @@ class Builder:
             next_reg += 1
         wire = np.zeros((len(self.ops), 4), dtype=np.uint16)
         for idx, op in enumerate(self.ops):
-            if op.opcode == OP_ENCODE:
-                wire[idx] = (OP_ENCODE, op.dst, op.lhs, op.rhs)
+            if op.opcode in (OP_ENCODE, OP_ENCODE_COMPLEX):
+                wire[idx] = (op.opcode, op.dst, op.lhs, op.rhs)
                 continue
             lhs_reg = reg_of[op.lhs]
             rhs = reg_of[op.rhs] if op.rhs_is_value else op.rhs

@@ -797,6 +797,8 @@ static void fft_to_rev(const orc_ctx *c, double complex *v)
 
 /* values: nvals (<= N/2) real numbers (imaginary part 0 -- HEVM only ever encodes reals);
  * out: [ell][N] NTT form.  Returns 0, or -1 if a coefficient does not fit in 127 bits. */
+static int encode_from_slots(const orc_ctx *c, double complex *cv, double scale, int ell, u64 *out);
+
 int orc_encode(const orc_ctx *c, const double *values, size_t nvals, double scale, int ell, u64 *out)
 {
     size_t N = c->N, slots = N >> 1;
@@ -806,6 +808,25 @@ int orc_encode(const orc_ctx *c, const double *values, size_t nvals, double scal
         cv[c->slot_map[i]] = values[i];
         cv[c->slot_map[slots + i]] = values[i]; /* conj of a real */
     }
+    return encode_from_slots(c, cv, scale, ell, out);
+}
+
+/* complex slot values (extension opcode 16 of this repo's VM; CKKSEncoder::encode of a complex vector [SEAL-upstream]) */
+int orc_encode_complex(const orc_ctx *c, const double *re, const double *im, size_t nvals, double scale, int ell, u64 *out)
+{
+    size_t N = c->N, slots = N >> 1;
+    if (nvals > slots) return -1;
+    double complex *cv = (double complex *)calloc(N, sizeof(double complex));
+    for (size_t i = 0; i < nvals; i++) {
+        cv[c->slot_map[i]] = CMPLX(re[i], im[i]);
+        cv[c->slot_map[slots + i]] = CMPLX(re[i], -im[i]);
+    }
+    return encode_from_slots(c, cv, scale, ell, out);
+}
+
+static int encode_from_slots(const orc_ctx *c, double complex *cv, double scale, int ell, u64 *out)
+{
+    size_t N = c->N;
     fft_from_rev(c, cv, scale / (double)N);
     int rc = 0;
     for (size_t j = 0; j < N; j++) {

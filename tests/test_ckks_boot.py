@@ -1,0 +1,102 @@
+"""CPU: real CKKS bootstrapping as an instruction sequence (dacapo_amd/ckks_boot.py; what `bootstrap` is in the reference's HEaaN
+runtime, /root/reference/lib/Runtime/HEAAN_HEVM.cpp:386-399, and what opcode 10 only stands in for in its SEAL runtime).
+  * the radix-2 factorisation of the special DFT for SEAL's slot order (generator 3) against the dense matrix;
+  * the whole construction on cleartext slot vectors with the VM's exact scale semantics (ModRaise adds q0 * I);
+  * the same program on REAL ciphertexts through the CPU oracle (its own NTT / key switch / rescale, plus the four extension
+    opcodes): a ciphertext at 1 prime comes back at 3 primes, scale exactly 2^40, decrypting to the message."""
+import numpy as np
+import pytest
+
+from dacapo_amd import ckks_boot as cb
+from dacapo_amd import hevm_asm as ha
+
+
+def _brev(i, bits):
+    return int(format(i, f"0{bits}b")[::-1], 2) if bits else 0
+
+
+@pytest.mark.parametrize("logN", [3, 4, 6])
+def test_special_dft_factorisation_for_generator_3(logN):
+    N, n = 1 << logN, 1 << (logN - 1)
+    e = cb.slot_exponents(logN)
+    zeta = np.exp(2j * np.pi / (2 * N))
+    A0 = np.array([[zeta ** ((int(p) * j) % (2 * N)) for j in range(n)] for p in e])
+    rng = np.random.default_rng(1)
+    t = rng.normal(size=N)
+    z = cb.embed(t, logN)
+    assert np.abs(z - np.array([np.sum(t * zeta ** ((int(p) * np.arange(N)) % (2 * N))) for p in e])).max() < 1e-10
+    P = [_brev(i, logN - 1) for i in range(n)]
+    ms = [1 << i for i in range(1, logN)]
+    m0 = rng.normal(size=n) + 0j
+    x = m0[P].copy()
+    for m in ms:                                             # SlotToCoeff direction: A0 m = S_n ... S_2 (m in bit-reversed order)
+        x = cb.dft_factor(m, logN, herm=False).apply(x)
+    assert np.abs(x - A0 @ m0).max() < 1e-10
+    Dp = zeta ** ((e * n) % (2 * N))                         # zeta_k^(N/2) = +-i
+    for half, pre in ((t[:n], np.ones(n)), (t[n:], np.conj(Dp))):  # CoeffToSlot: t = (2 / N) Re(A0^H [conj(D)] z)
+        y = pre * z
+        for m in reversed(ms):
+            y = cb.dft_factor(m, logN, herm=True).apply(y)
+        assert np.abs((2 / N) * y.real - half[P]).max() < 1e-10
+
+
+def _boot_program(logN, r=5, target=3, in_level=1):
+    K = target + 16 + 1
+    b = ha.Builder(slots=1 << (logN - 1), init_level=in_level, shadow=False)
+    x = b.input(None, level=in_level, scale_bits=40)
+    em = cb.BootstrapEmitter(b, logN, K, target, r=r)
+    y, label = em.bootstrap(x, 2.0**40)
+    b.output(y)
+    cst, hv, info = b.assemble()
+    return em, cst, hv, info, label
+
+
+def test_prime_chain_is_the_runtime_s():
+    from oracle.oracle import Oracle
+
+    assert cb.seal_prime_chain(12, 6) == Oracle(12, 6).primes     # CoeffModulus::Create order, special prime last
+
+
+def test_bootstrap_on_cleartext_slots_with_exact_scale_semantics():
+    logN = 11
+    em, cst, hv, info, label = _boot_program(logN)
+    assert label == 2.0**40
+    mix = info["op_mix"]
+    assert mix["mulcc"] == 32 and mix["rescale"] == 60 and mix["bootstrap"] == 0       # 2 x (1 + 10 + 5) squarings/products, no stand-in
+    msg = np.random.default_rng(3).uniform(-1, 1, 1 << (logN - 1))
+    outs, trace = cb.simulate(hv, cst, [msg], logN, em.primes, secret_weight=64, return_trace=True)
+    assert np.abs(outs[0] - msg).max() < 1e-7 and np.abs(outs[0].imag).max() < 1e-7
+    assert trace[-1][2] == 3 and trace[-1][3] == 2.0**40                                   # 3 primes left, label exactly 2^40
+    assert max(t[2] for t in trace) == 19                                                  # ModRaise to the top of a 20-prime chain
+
+
+def test_bootstrap_of_a_real_ciphertext_on_the_cpu_oracle(tmp_path):
+    from oracle.oracle import Oracle, OracleVM
+
+    logN = 10
+    em, cst, hv, info, _ = _boot_program(logN)
+    o = Oracle(logN, 20)
+    assert o.primes == em.primes
+    offs = sorted({(int(q) - 65536 if q >= 32768 else int(q)) for op, _, _, q in ha.unpack_hevm(hv)["ops"].tolist() if op == ha.OP_ROTATE} - {0})
+    o.keygen_sparse(32, seed=3, galois_elts=sorted(set(o.default_galois_elts()) | {o.elt_from_step(s) for s in offs}))
+    (tmp_path / "p.cst").write_bytes(cst)
+    (tmp_path / "p.hevm").write_bytes(hv)
+    vm = OracleVM(o)
+    vm.load(tmp_path / "p.cst", tmp_path / "p.hevm")
+    vm.preprocess()
+    msg = np.random.default_rng(1).uniform(-1, 1, o.slots)
+    vm.encrypt(0, msg)
+    assert vm.ciphers[0].ell == 1
+    vm.run()
+    out_ct = vm.ciphers[vm.prog.res_dst[0]]
+    assert out_ct.ell == 3 and out_ct.scale == 2.0**40
+    assert np.abs(vm.decrypt_result(0) - msg).max() < 1e-6
+
+
+def test_vm_scale_mirror_follows_the_reference_semantics():
+    b = ha.Builder(slots=64, init_level=3, shadow=False)
+    x = b.input(None, level=3, scale_bits=40)
+    y = b.rescale(b.mul_plain(x, [0.5], scale_bits=60, normalise=False))
+    primes = cb.seal_prime_chain(7, 4)
+    sc = cb.vm_scales(b, primes)
+    assert sc[y.id] == 2.0**40 * 2.0**60 / float(primes[2])                                # rescale divides by the dropped prime, as a double

@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Real CKKS bootstrapping on the MI355X: one ciphertext at 1 prime -> `target` primes, through the extension opcodes and
+dacapo_amd/ckks_boot.py.   python tools/boot_demo.py [logN=15] [r=5] [direct_keys=1]"""
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+os.environ.setdefault("DACAPO_HEVM_SECRET_HW", "64")
+from dacapo_amd import ckks_boot as cb  # noqa: E402
+from dacapo_amd import hevm_asm as ha  # noqa: E402
+from dacapo_amd import runner  # noqa: E402
+
+logN = int(sys.argv[1]) if len(sys.argv) > 1 else 15
+r = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+direct = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+target = 3
+K = target + (6 + 5 + r) + 1
+slots = 1 << (logN - 1)
+b = ha.Builder(slots=slots, init_level=1, shadow=False)
+x = b.input(None, level=1, scale_bits=40)
+em = cb.BootstrapEmitter(b, logN, K, target, r=r)
+y, _ = em.bootstrap(x, 2.0**40)
+b.output(y)
+cst, hv, info = b.assemble()
+print(f"N=2^{logN}, {K} primes, r={r}: {info['num_ops']} instructions, {info['num_ptxt']} plaintexts, {len(cst)/1e6:.0f} MB of constants")
+msg = np.random.default_rng(3).uniform(-1, 1, slots)
+sim = cb.simulate(hv, cst, [msg], logN, em.primes)[0]
+print("cleartext simulation: max error", np.abs(sim - msg).max())
+t0 = time.time()
+hevm = runner.HEVM(seed=5, logN=logN, num_primes=K)
+print(f"context + keys: {time.time()-t0:.1f} s")
+if direct:
+    offs = sorted({(int(q) - 65536 if q >= 32768 else int(q)) for o, _, _, q in ha.unpack_hevm(hv)["ops"].tolist() if o == ha.OP_ROTATE} - {0})
+    t0 = time.time()
+    hevm.addRotationKeys(offs)
+    print(f"{len(offs)} direct rotation keys: {time.time()-t0:.1f} s")
+t0 = time.time()
+hevm.load_mem(cst, hv)
+print(f"load + preprocess: {time.time()-t0:.1f} s")
+hevm.setInput(0, msg)
+hevm.run()
+for _ in range(2):
+    t0 = time.perf_counter()
+    hevm.run()
+    dt = time.perf_counter() - t0
+out = hevm.getOutput()[0]
+err = np.abs(out - msg)
+st = hevm.stats()
+c = hevm.getCtxt(hevm.getResIdx(0))
+print(f"bootstrap: {dt*1e3:.2f} ms, {st['keyswitches']} key switches, result at {c.level} primes, scale 2^{np.log2(c.scale):.3f}")
+print(f"decrypted vs message: max error {err.max():.3e}, rms {np.sqrt(np.mean(err**2)):.3e}  ({-np.log2(err.max()):.1f} bits)")
