@@ -229,7 +229,7 @@ class BootstrapEmitter:
         """x + c exactly: the plaintext is encoded at a power of two near the true scale, with the value compensating the difference"""
         bits = int(round(math.log2(x.s)))
         val = c * x.s / 2.0**bits
-        reg = self.b._encode(self.b._const(np.array([val])), x.level, bits)
+        reg = self._plain_reg(("const", val), np.array([val]), x.level, bits, False)  # shared by every bootstrap of the program
         return self._op(OP_ADDCP, x, x.level, x.s, reg)
 
     def set_scale(self, x: Ct, label: float) -> Ct:
@@ -363,47 +363,68 @@ class BootstrapEmitter:
             yhi = self.linear(yhi, M["stc"][gi], f"stc{gi}")
         q_last = float(self.primes[ylo.level - 1])
         s_after = ylo.s * 2.0**self.diag_bits / q_last          # true scale after the last group without kappa
-        kappa = 2.0**self.out_bits * q0 / (s_after * 2.0 * math.pi * delta)
-        last = M["stc"][-1].scaled(kappa)
-        zlo = self.linear(ylo, last, "stcL")
-        zhi = self.linear(yhi, last.times_diag_left(M["Dp"]), "stcLh")
+        # kappa is fixed for the NOMINAL input scale 2^boot_in_bits, so that every bootstrap of a program shares these plaintexts; the
+        # instance's own scale (2^-35-level drift of the rescales before it) goes into the final label instead
+        delta_nom = 2.0**self.boot_in_bits
+        kappa = 2.0**self.out_bits * q0 / (s_after * 2.0 * math.pi * delta_nom)
+        if "stcL" not in M:
+            M["stcL"] = M["stc"][-1].scaled(kappa)
+            M["stcLh"] = M["stcL"].times_diag_left(M["Dp"])
+        zlo = self.linear(ylo, M["stcL"], "stcL")
+        zhi = self.linear(yhi, M["stcLh"], "stcLh")
         z = self.add(zlo, zhi)
         assert z.level == self.target, (z.level, self.target)
-        out = self.set_scale(z, 2.0**self.out_bits)
-        return out.v, 2.0**self.out_bits
+        label = 2.0**self.out_bits * (delta / delta_nom)
+        out = self.set_scale(z, label)
+        return out.v, label
 
 
 # ---- exact scale labels of a Builder's values (what the VM computes at run time) -------------------------------------------------
+class ScaleMirror:
+    """value id -> the double the VM holds as that ciphertext's scale (SEAL_HEVM.cpp:268-334 semantics, in program order); incremental:
+    `upto()` processes the instructions emitted since the last call"""
+
+    def __init__(self, b: ha.Builder, primes):
+        self.b, self.primes, self.done = b, primes, 0
+        self.sc, self.lv, self.ps = {}, {}, {}
+
+    def upto(self) -> dict:
+        b, primes, sc, lv, ps = self.b, self.primes, self.sc, self.lv, self.ps
+        for a in b.args:
+            if a.id not in sc:
+                sc[a.id], lv[a.id] = 2.0**a.scale_bits, a.level
+        ops = b.ops
+        for k in range(self.done, len(ops)):
+            op = ops[k]
+            if op.opcode in (OP_ENCODE, OP_ENCODE_COMPLEX):
+                ps[op.dst] = 2.0 ** (op.rhs & 0x3FF)
+                continue
+            s, l = sc[op.lhs], lv[op.lhs]
+            if op.opcode == OP_RESCALE:
+                s, l = s / float(primes[l - 1]), l - 1
+            elif op.opcode == OP_MODSWITCH:
+                l -= op.rhs
+            elif op.opcode == OP_ADDCC:
+                s = sc[op.rhs]
+            elif op.opcode == OP_ADDCP:
+                s = ps[op.rhs]
+            elif op.opcode == OP_MULCC:
+                s *= sc[op.rhs]
+            elif op.opcode == OP_MULCP:
+                s *= ps[op.rhs]
+            elif op.opcode == OP_BOOTSTRAP:
+                s, l = 2.0 ** int(math.log2(s)), op.rhs
+            elif op.opcode == OP_MODRAISE:
+                l = op.rhs
+            elif op.opcode == OP_SETSCALE:
+                s = float(b.constants[op.rhs][0])
+            sc[op.dst], lv[op.dst] = s, l
+        self.done = len(ops)
+        return sc
+
+
 def vm_scales(b: ha.Builder, primes) -> dict:
-    """value id -> the double the VM holds as that ciphertext's scale (SEAL_HEVM.cpp:268-334 semantics, in program order)"""
-    sc = {a.id: 2.0**a.scale_bits for a in b.args}
-    lv = {a.id: a.level for a in b.args}
-    ps = {}
-    for op in b.ops:
-        if op.opcode in (OP_ENCODE, OP_ENCODE_COMPLEX):
-            ps[op.dst] = 2.0 ** (op.rhs & 0x3FF)
-            continue
-        s, l = sc[op.lhs], lv[op.lhs]
-        if op.opcode == OP_RESCALE:
-            s, l = s / float(primes[l - 1]), l - 1
-        elif op.opcode == OP_MODSWITCH:
-            l -= op.rhs
-        elif op.opcode == OP_ADDCC:
-            s = sc[op.rhs]
-        elif op.opcode == OP_ADDCP:
-            s = ps[op.rhs]
-        elif op.opcode == OP_MULCC:
-            s *= sc[op.rhs]
-        elif op.opcode == OP_MULCP:
-            s *= ps[op.rhs]
-        elif op.opcode == OP_BOOTSTRAP:
-            s, l = 2.0 ** int(math.log2(s)), op.rhs
-        elif op.opcode == OP_MODRAISE:
-            l = op.rhs
-        elif op.opcode == OP_SETSCALE:
-            s = float(b.constants[op.rhs][0])
-        sc[op.dst], lv[op.dst] = s, l
-    return sc
+    return ScaleMirror(b, primes).upto()
 
 
 def _quantise(raw, logN: int):
@@ -480,3 +501,21 @@ def simulate(hevm: bytes, cst: bytes, inputs, logN: int, primes, secret_weight: 
             trace.append((opc, dst, l, s))
     outs = [reg[d][0] / reg[d][1] for d in h["res_dst"]]
     return (outs, trace) if return_trace else outs
+
+
+# ---- a bootstrap on its own (tools/boot_demo.py, bench.py, tests) ------------------------------------------------------------------
+def single_bootstrap_program(logN: int, target: int = 3, r: int = 5, msg_bits: int = 0):
+    """(num_primes, cst, hevm, rotation offsets, emitter) of the program `one ciphertext at 1 prime, scale 2^40 -> bootstrap -> output`"""
+    K = target + 2 * 3 + 5 + r + 1
+    b = ha.Builder(slots=1 << (logN - 1), init_level=1, shadow=False)
+    x = b.input(None, level=1, scale_bits=40)
+    em = BootstrapEmitter(b, logN, K, target, r=r, msg_bits=msg_bits)
+    y, _ = em.bootstrap(x, 2.0**40)
+    b.output(y)
+    cst, hv, _ = b.assemble()
+    return K, cst, hv, rotation_offsets(hv), em
+
+
+def rotation_offsets(hevm: bytes):
+    """distinct non-zero slot offsets a program rotates by (for hevm_add_rotation_keys)"""
+    return sorted({(int(q) - 65536 if q >= 32768 else int(q)) for o, _, _, q in ha.unpack_hevm(hevm)["ops"].tolist() if o == OP_ROTATE} - {0})

@@ -199,7 +199,7 @@ class _Op:
 
 class Builder:
     def __init__(self, slots=1 << 14, waterline=40, init_level=13, rescale_bits=60, min_level=1, shadow=True,
-                 policy="eager", boot_level=None, headroom=16, rotate_reserve=0, carry_scale=False):
+                 policy="eager", boot_level=None, headroom=16, rotate_reserve=0, carry_scale=False, real_boot=None):
         """policy "eager": rescale a product as soon as its scale allows (EVA's waterline rule; the caller places
         bootstraps).  policy "lazy": products keep their scale, sums of products are rescaled ONCE when the sum is next
         multiplied or rotated (what the reference's scale-management passes achieve by moving rescales below
@@ -215,6 +215,9 @@ class Builder:
         # at 2^80 is not upscaled to 2^100 just to be rescaled): ~2/3 of the rescales and bootstraps of the exact rule
         self.carry_scale = carry_scale
         self.boot_level = init_level if boot_level is None else boot_level
+        # real_boot = dict(num_primes=K, r=5, msg_bits=7): `bootstrap` emits REAL CKKS bootstrapping (dacapo_amd/ckks_boot.py: ModRaise,
+        # CoeffToSlot, EvalMod, SlotToCoeff over extension opcodes 16-19) instead of opcode 10, the SEAL VM's decrypt / re-encrypt stand-in
+        self.real_boot, self._boot_emitter, self._scale_mirror = real_boot, None, None
         self._memo: dict = {}  # lazy policy: (kind, value id, arg) -> value, so a shared operand is rescaled/bootstrapped once
         self.values: list[Value] = []
         self.ops: list[_Op] = []
@@ -317,9 +320,32 @@ class Builder:
 
     def bootstrap(self, x: Value, target_level=None) -> Value:
         t = self.init_level if target_level is None else target_level
+        if self.real_boot is not None:
+            return self._real_bootstrap(x, t)
         out = self._new(t, x.scale_bits, x.plain)
         self._emit(OP_BOOTSTRAP, out, x, t)
         return out
+
+    def _real_bootstrap(self, x: Value, t: int) -> Value:
+        from . import ckks_boot
+
+        rb = self.real_boot
+        logN = self.slots.bit_length()  # slots = N / 2
+        if self._boot_emitter is None:
+            self._boot_emitter = ckks_boot.BootstrapEmitter(self, logN, rb["num_primes"], t, r=rb.get("r", 5), msg_bits=rb.get("msg_bits", 0),
+                                                            out_bits=self.waterline)
+            self._scale_mirror = ckks_boot.ScaleMirror(self, self._boot_emitter.primes)
+        em = self._boot_emitter
+        assert t == em.target, "every real bootstrap of a program restores the same number of primes"
+        assert x.scale_bits <= em.boot_in_bits, f"a value at scale 2^{x.scale_bits} cannot enter a bootstrap (limit 2^{em.boot_in_bits})"
+        if self.shadow and x.plain is not None:
+            peak = float(np.max(np.abs(x.plain)))
+            assert peak < 2.0 ** rb.get("msg_bits", 0), f"message of magnitude {peak:.3g} exceeds real_boot['msg_bits']"
+            rb["peak_seen"] = max(rb.get("peak_seen", 0.0), peak)
+        scale = self._scale_mirror.upto()[x.id]
+        v, _ = em.bootstrap(x, scale)
+        v.scale_bits, v.plain = self.waterline, x.plain
+        return v
 
     def _normalise(self, x: Value) -> Value:
         while x.scale_bits - self.rescale_bits >= self.waterline and x.level > self.min_level:

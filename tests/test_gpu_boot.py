@@ -131,3 +131,24 @@ def test_bootstrap_at_the_reference_ring_restores_levels_and_message():
     assert c.level == 3 and c.scale == 2.0**40
     err = np.abs(hevm.getOutput()[0] - msg)
     assert err.max() < 2e-4 and np.sqrt(np.mean(err**2)) < 1e-5              # measured: 1e-5 / 4e-7
+
+
+def test_resnet20_with_real_bootstraps_decrypts_to_the_torch_logits():
+    """tests/golden/resnet20.rb3: the reference's ResNet-20 trace with all 526 bootstrap sites lowered to REAL bootstrapping (783 k
+    instructions, 94 k key switches): the encrypted inference still produces the torch model's logits (BASELINE config 4 in spirit)."""
+    from pathlib import Path
+
+    from dacapo_amd import ckks_boot as cb
+    from dacapo_amd import hevm_asm as ha
+
+    fx = ha.read_fixture(Path(__file__).resolve().parent / "golden" / "resnet20.rb3")
+    ops = ha.unpack_hevm(fx["hevm"])["ops"]
+    assert int((ops[:, 0] == ha.OP_MODRAISE).sum()) == 526 and int((ops[:, 0] == ha.OP_BOOTSTRAP).sum()) == 0
+    hevm = _vm(15, 20, 64, cb.rotation_offsets(fx["hevm"]))
+    hevm.load_mem(fx["cst"], fx["hevm"])
+    hevm.setInput(0, fx["packed"])
+    hevm.run()
+    out = hevm.getOutput()[0]
+    assert float(np.sqrt(np.mean((out - fx["expected"]) ** 2))) < 2e-4                     # measured 2e-5
+    assert float(np.sqrt(np.mean((out[:10] * 32 - fx["torch_result"]) ** 2))) < 0.05        # measured 0.01 (logits are x32)
+    assert int(np.argmax(out[:10])) == int(np.argmax(fx["torch_result"]))

@@ -17,15 +17,9 @@ from dacapo_amd import runner  # noqa: E402
 logN = int(sys.argv[1]) if len(sys.argv) > 1 else 15
 r = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 direct = int(sys.argv[3]) if len(sys.argv) > 3 else 1
-target = 3
-K = target + (6 + 5 + r) + 1
+K, cst, hv, offs_all, em = cb.single_bootstrap_program(logN, r=r)
 slots = 1 << (logN - 1)
-b = ha.Builder(slots=slots, init_level=1, shadow=False)
-x = b.input(None, level=1, scale_bits=40)
-em = cb.BootstrapEmitter(b, logN, K, target, r=r)
-y, _ = em.bootstrap(x, 2.0**40)
-b.output(y)
-cst, hv, info = b.assemble()
+info = {'num_ops': len(ha.unpack_hevm(hv)['ops']), 'num_ptxt': ha.unpack_hevm(hv)['num_ptxt']}
 print(f"N=2^{logN}, {K} primes, r={r}: {info['num_ops']} instructions, {info['num_ptxt']} plaintexts, {len(cst)/1e6:.0f} MB of constants")
 msg = np.random.default_rng(3).uniform(-1, 1, slots)
 sim = cb.simulate(hv, cst, [msg], logN, em.primes)[0]
@@ -34,7 +28,7 @@ t0 = time.time()
 hevm = runner.HEVM(seed=5, logN=logN, num_primes=K)
 print(f"context + keys: {time.time()-t0:.1f} s")
 if direct:
-    offs = sorted({(int(q) - 65536 if q >= 32768 else int(q)) for o, _, _, q in ha.unpack_hevm(hv)["ops"].tolist() if o == ha.OP_ROTATE} - {0})
+    offs = offs_all
     t0 = time.time()
     hevm.addRotationKeys(offs)
     print(f"{len(offs)} direct rotation keys: {time.time()-t0:.1f} s")

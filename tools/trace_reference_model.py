@@ -378,6 +378,10 @@ def main():
     ap.add_argument("--no-shadow", action="store_true")
     ap.add_argument("--full", action="store_true", help="also write the real constants (<out>.cst, not committed)")
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--real-boot-primes", type=int, default=0,
+                    help="K > 0: every bootstrap is REAL CKKS bootstrapping (dacapo_amd/ckks_boot.py) on a chain of K primes "
+                         "(K = boot-level + 17 with the default r = 5) instead of opcode 10")
+    ap.add_argument("--msg-bits", type=int, default=7, help="--real-boot-primes: bound 2^msg_bits on the magnitude of a bootstrapped value")
     ap.add_argument("--suite", action="store_true", help="trace the small benchmarks (%s) into <out>/<name>.*" % ", ".join(SUITE))
     a = ap.parse_args()
     if a.suite:
@@ -399,7 +403,8 @@ def main():
 
     slots = 1 << a.slots_log
     b = hevm_asm.Builder(slots=slots, waterline=a.waterline, init_level=a.init_level, policy="lazy", boot_level=a.boot_level, rotate_reserve=a.rotate_reserve, carry_scale=a.carry_scale,
-                         shadow=not a.no_shadow)
+                         shadow=not a.no_shadow,
+                         real_boot=dict(num_primes=a.real_boot_primes, msg_bits=a.msg_bits) if a.real_boot_primes else None)
     stub_torchvision()
     sys.path.insert(0, str(REF / "python/poly"))
     os.environ.setdefault("HECATE", str(REF))
@@ -425,6 +430,7 @@ def main():
         "bootstraps": boots,
         "ntt_equivalents": ntt_equivalents(b),
         "bootstrap_hints_dropped": sys.modules["hecate"]._state["hints"],
+        "real_boot": ({k: v for k, v in b.real_boot.items()} if b.real_boot else None),
         "hevm_sha256": hashlib.sha256(hevm).hexdigest(),
         "cst_sha256": hashlib.sha256(cst).hexdigest(),
     }
