@@ -456,6 +456,7 @@ void HEVM::init_context(int logN, int K, const u64 *primes)
     if (const char *e = getenv("DACAPO_HEVM_MAX_BATCH")) max_batch = std::max(1, atoi(e));
     if (const char *e = getenv("DACAPO_HEVM_CHAIN_FUSION")) chain_fusion = atoi(e) != 0;
     if (const char *e = getenv("DACAPO_HEVM_SECRET_HW")) secret_weight = atoi(e);
+    if (const char *e = getenv("DACAPO_HEVM_ONLINE_ENCODE")) online_encode = atoi(e) != 0 && use_plan && !host_encoder;
     lanes.resize(1);
     DC_HIP_CHECK(hipStreamCreateWithFlags(&lanes[0].stream, hipStreamNonBlocking));
     lanes[0].ws = ctx->ws0;
@@ -974,6 +975,8 @@ void HEVM::encode_internal(Plain &dst, const double *src, size_t len, int level,
 
 void HEVM::free_plains()
 {
+    if (online.d_consts) (void)hipFree(online.d_consts);
+    online.d_consts = nullptr, online.items.clear();
     for (auto &pl : plains)
         if (pl.d && !pl.arena) (void)hipFree(pl.d);
     for (u64 *a : plain_arenas) (void)hipFree(a);
@@ -1043,11 +1046,19 @@ void HEVM::preprocess_device()
         Plain &pl = plains.at(op.dst);
         pl.level = level, pl.scale = pow(2.0, (double)scale_bits), pl.arena = true;
         by_level[level].push_back({ (int)op.dst, it });
+        if (online_encode) online.items[(int)op.dst] = it;
     }
     if (by_level.empty()) return;
     double *d_consts = nullptr;
     DC_HIP_CHECK(hipMalloc(&d_consts, std::max<size_t>(host.size(), 1) * sizeof(double)));
     if (!host.empty()) DC_HIP_CHECK(hipMemcpy(d_consts, host.data(), host.size() * sizeof(double), hipMemcpyHostToDevice));
+    if (online_encode) {
+        // On-line encode (the HEaaN runtime's mode, HEAAN_HEVM.cpp:266-281,353-363): only the constants stay resident, as doubles;
+        // the plan encodes every plaintext register into a recycled window right before the wave that first reads it
+        // (build_plan: Plan::enc_groups).  Registers get their addresses there.
+        online.d_consts = d_consts, online.const_bytes = host.size() * sizeof(double);
+        return;
+    }
     const int chunk = 1024;
     double2 *scratch = nullptr;
     EncItem *d_items = nullptr;
@@ -1772,6 +1783,14 @@ void hevm_load_mem(void *vm, const void *cst, uint64_t cst_len, const void *hevm
 void hevm_set_streams(void *vm, int n) { static_cast<HEVM *>(vm)->set_streams(n); }
 void hevm_select_stream(void *vm, int s) { static_cast<HEVM *>(vm)->select_stream(s); }
 double hevm_last_run_bootstrap_seconds(void *vm) { return static_cast<HEVM *>(vm)->t_bootstrap; }
+uint64_t hevm_plaintext_bytes(void *vm)
+{ // HBM held for the program's plaintexts: the pre-encoded pool, or (on-line encode) the resident constants + the encode window
+    auto h = static_cast<HEVM *>(vm);
+    if (h->online_encode) return h->online.const_bytes + h->plan.enc_arena_bytes + h->plan.enc_scratch_bytes;
+    uint64_t total = 0;
+    for (const dacapo::Plain &p : h->plains) total += (uint64_t)p.level * h->ctx->N * 8;
+    return total;
+}
 void hevm_add_rotation_keys(void *vm, const int64_t *offsets, int count)
 { // KeyGenerator::create_galois_keys(steps): a direct key per slot offset (left = positive), next to the default +-2^k set
     auto h = static_cast<HEVM *>(vm);

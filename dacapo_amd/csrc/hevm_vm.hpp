@@ -102,6 +102,13 @@ class HEVM {
     // batched device encoder (encoder.hip): tables, and the arenas the plaintext registers of the loaded program live in
     EncTables enc_tables;
     std::vector<u64 *> plain_arenas;
+    // DACAPO_HEVM_ONLINE_ENCODE=1: plaintexts are encoded at use from the resident constants instead of being kept pre-encoded
+    bool online_encode = false;
+    struct OnlineEncode {
+        double *d_consts = nullptr;
+        size_t const_bytes = 0;
+        std::map<int, EncItem> items; // plaintext register -> what to encode
+    } online;
     bool host_encoder = false; // DACAPO_HEVM_HOST_ENCODER=1: encode on the host (HostEncoder), one plaintext at a time
     void ensure_enc_tables();
     void preprocess_device();
@@ -171,6 +178,14 @@ class HEVM {
         SumItem *d_sum = nullptr;
         SumSrc *d_sum_srcs = nullptr;
         CtView *d_cont_other = nullptr;      // CONT_MUL links: the consumers' other operands
+        // on-line encode: per wave, the plaintext registers first read in it, encoded into a window recycled at wave granularity
+        struct EncGroup { int wave, level, first, count; u64 *out; };
+        std::vector<EncGroup> enc_groups;
+        EncItem *d_enc_items = nullptr;
+        u64 *enc_arena = nullptr;
+        double2 *enc_scratch = nullptr;
+        int *d_enc_overflow = nullptr;
+        size_t enc_arena_bytes = 0, enc_scratch_bytes = 0;
         std::vector<EwItem> h_ew;            // host copy of the elementwise item table (modraise launches its NTTs per item)
         std::vector<u64 *> handoff_bufs;     // first-phase buffers of fused consumer steps
         size_t n_fused = 0;

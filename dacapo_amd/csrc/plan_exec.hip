@@ -32,6 +32,10 @@ void HEVM::build_plan()
     Plan &P = plan;
     for (u64 *b : P.handoff_bufs) (void)hipFree(b);
     P.handoff_bufs.clear();
+    for (void *p : { (void *)P.d_enc_items, (void *)P.enc_arena, (void *)P.enc_scratch, (void *)P.d_enc_overflow })
+        if (p) (void)hipFree(p);
+    P.d_enc_items = nullptr, P.enc_arena = nullptr, P.enc_scratch = nullptr, P.d_enc_overflow = nullptr;
+    P.enc_groups.clear(), P.enc_arena_bytes = P.enc_scratch_bytes = 0;
     if (P.d_cont_other) (void)hipFree(P.d_cont_other), P.d_cont_other = nullptr;
     for (void *p : { (void *)P.d_ks, (void *)P.d_mul, (void *)P.d_rs, (void *)P.d_ew, (void *)P.d_sum, (void *)P.d_sum_srcs, (void *)P.d_boot,
                      (void *)P.d_boot_rs, (void *)P.zenc, (void *)P.boot_ue, (void *)P.boot_tmp, (void *)P.boot_pt[0], (void *)P.boot_ptx[0],
@@ -448,6 +452,91 @@ void HEVM::build_plan()
             a = b;
         }
     }
+    // ---- 4c. on-line encode: every plaintext register is encoded right before the wave that first reads it, into a window whose
+    // blocks are recycled once the last reader's wave is over; the item tables below then see ordinary device pointers -----------
+    if (online_encode && !online.items.empty()) {
+        const int NW = max_wave + 2;
+        std::map<int, std::pair<int, int>> use; // plain register -> (first wave, last wave)
+        auto touch = [&](int reg, int w) {
+            if (reg < 0) return;
+            auto it = use.find(reg);
+            if (it == use.end())
+                use[reg] = { w, w };
+            else
+                it->second.first = std::min(it->second.first, w), it->second.second = std::max(it->second.second, w);
+        };
+        for (size_t si = 0; si < P.steps.size(); si++) {
+            const Step &st = P.steps[si];
+            // a fused producer evaluates its consumer's folded "+ pt" / "* pt" one step early (Handoff::rs_items)
+            const int early = st.fused_consumer >= 0 ? st.wave : -1;
+            for (int pi : step_pops[si]) {
+                const Pop &p = O[(size_t)pi];
+                touch(p.plain, p.wave), touch(p.rs_add, p.wave), touch(p.rs_mul, p.wave);
+                for (int pl : p.src_plain) touch(pl, p.wave);
+            }
+            if (early >= 0)
+                for (int pi : step_pops[(size_t)st.fused_consumer]) touch(O[(size_t)pi].rs_add, early), touch(O[(size_t)pi].rs_mul, early);
+        }
+        std::map<std::pair<int, int>, std::vector<int>> groups; // (first wave, level) -> registers
+        for (auto &kv : use) groups[{ kv.second.first, plains.at((size_t)kv.first).level }].push_back(kv.first);
+        struct Block { size_t off, size; int release; };
+        std::vector<Block> live, freeb;
+        size_t high = 0, max_cnt = 0;
+        std::vector<EncItem> h_items;
+        std::vector<std::pair<size_t, size_t>> placed; // per group: (offset, first item)
+        const int chunk = 256;
+        int cur_wave = -1;
+        for (auto &kv : groups) {
+            const int w = kv.first.first, level = kv.first.second;
+            if (w != cur_wave) { // blocks whose readers are done are free again
+                for (size_t i = 0; i < live.size();)
+                    if (live[i].release < w) {
+                        freeb.push_back(live[i]);
+                        live[i] = live.back(), live.pop_back();
+                    } else
+                        i++;
+                cur_wave = w;
+            }
+            for (size_t k0 = 0; k0 < kv.second.size(); k0 += (size_t)chunk) {
+                const size_t cnt = std::min<size_t>((size_t)chunk, kv.second.size() - k0), size = cnt * (size_t)level * N;
+                int release = w;
+                for (size_t k = 0; k < cnt; k++) release = std::max(release, use[kv.second[k0 + k]].second);
+                size_t off = (size_t)-1;
+                for (size_t i = 0; i < freeb.size(); i++)
+                    if (freeb[i].size >= size) { // first fit; the remainder stays free
+                        off = freeb[i].off;
+                        if (freeb[i].size > size)
+                            freeb[i].off += size, freeb[i].size -= size;
+                        else
+                            freeb[i] = freeb.back(), freeb.pop_back();
+                        break;
+                    }
+                if (off == (size_t)-1) off = high, high += size;
+                live.push_back({ off, size, release });
+                P.enc_groups.push_back({ w, level, (int)h_items.size(), (int)cnt, nullptr });
+                placed.push_back({ off, h_items.size() });
+                for (size_t k = 0; k < cnt; k++) h_items.push_back(online.items.at(kv.second[k0 + k]));
+                max_cnt = std::max(max_cnt, cnt);
+            }
+            (void)NW;
+        }
+        DC_HIP_CHECK(hipMalloc(&P.enc_arena, std::max<size_t>(high, 1) * sizeof(u64)));
+        P.enc_arena_bytes = high * sizeof(u64);
+        P.enc_scratch_bytes = max_cnt * N * sizeof(double2);
+        DC_HIP_CHECK(hipMalloc(&P.enc_scratch, std::max<size_t>(P.enc_scratch_bytes, 16)));
+        DC_HIP_CHECK(hipMalloc(&P.d_enc_overflow, sizeof(int)));
+        DC_HIP_CHECK(hipMemset(P.d_enc_overflow, 0, sizeof(int)));
+        P.d_enc_items = upload(h_items);
+        size_t gi = 0;
+        for (auto &kv : groups)
+            for (size_t k0 = 0; k0 < kv.second.size(); k0 += (size_t)chunk, gi++) {
+                Plan::EncGroup &g = P.enc_groups[gi];
+                g.out = P.enc_arena + placed[gi].first;
+                for (int k = 0; k < g.count; k++) plains.at((size_t)kv.second[k0 + (size_t)k]).d = g.out + (size_t)k * (size_t)g.level * N;
+            }
+        for (auto &kv : online.items)
+            if (!use.count(kv.first)) plains.at((size_t)kv.first).d = P.enc_arena; // never read: any valid address
+    }
     // ---- 5. lifetimes and pool buffers ---------------------------------------------------------------------------------
     for (const Pop &p : O) {
         if (p.dead) continue;
@@ -768,11 +857,15 @@ void HEVM::issue_plan(hipStream_t s)
     // diagnosis mode (every step then pays a full launch round trip, as the steps of a dependent chain do anyway)
     static const bool step_profile = getenv("DACAPO_HEVM_STEP_PROFILE") && atoi(getenv("DACAPO_HEVM_STEP_PROFILE")) && !plan_graph;
     std::map<std::tuple<int, int, int>, std::pair<int, double>> prof;
-    size_t ev = 0;
+    size_t ev = 0, eg = 0;
     for (size_t a = 0; a < P.steps.size();) {
         size_t b = a;
         bool has_aux = false;
         while (b < P.steps.size() && P.steps[b].wave == P.steps[a].wave) has_aux |= P.steps[b].lane == 1, b++;
+        for (; eg < P.enc_groups.size() && P.enc_groups[eg].wave <= P.steps[a].wave; eg++) { // on-line encode of this wave's plaintexts
+            const Plan::EncGroup &g = P.enc_groups[eg];
+            enc_batch(c, enc_tables, online.d_consts, P.d_enc_items + g.first, g.count, g.level, P.enc_scratch, g.out, P.d_enc_overflow, s);
+        }
         if (has_aux) { // fork: the auxiliary stream sees everything the main stream has been given so far
             DC_HIP_CHECK(hipEventRecord(P.events[ev], s));
             DC_HIP_CHECK(hipStreamWaitEvent(aux_stream, P.events[ev], 0));
@@ -835,6 +928,9 @@ void HEVM::capture_plan()
     Plan &P = plan;
     if (P.graph_exec) return;
     if (!P.boot_chunks.empty() && (!keys.sk || !keys.pk)) return; // opcode 10 on a VM without the keys: run() reports it, eagerly
+    // ROCm 7.2's capture walks the recorded nodes recursively: beyond roughly 1.5e5 of them hipStreamEndCapture overflows its stack
+    // (seen with the 783 k-instruction real-bootstrap ResNet in on-line encode mode).  Such plans are issued launch by launch.
+    if (P.launches + P.enc_groups.size() * (size_t)(ctx->logN + 4) > 120000) return;
     hipStream_t s = S();
     DC_HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
     issue_plan(s);
@@ -872,6 +968,14 @@ void HEVM::run_plan()
     } else
         issue_plan(s);
     DC_HIP_CHECK(hipStreamSynchronize(s)); // the caller's timer stops when run() returns
+    if (P.d_enc_overflow) { // on-line encode: the range check preprocess() makes for the pre-encoded pool happens here
+        int overflow = 0;
+        DC_HIP_CHECK(hipMemcpy(&overflow, P.d_enc_overflow, sizeof(int), hipMemcpyDeviceToHost));
+        if (overflow) {
+            fprintf(stderr, "[dacapo_amd] encode: coefficient does not fit 120 bits (scale too large)\n");
+            abort();
+        }
+    }
     for (size_t r = 0; r < P.final_val.size() && r < ciphers.size(); r++) {
         const int v = P.final_val[r];
         if (v < 0) continue;

@@ -71,6 +71,8 @@ def reinit_lw():  # runner.py:73-117
     lw.hevm_select_stream.argtypes = [ctypes.c_void_p, ctypes.c_int]
     lw.hevm_last_run_bootstrap_seconds.argtypes = [ctypes.c_void_p]
     lw.hevm_last_run_bootstrap_seconds.restype = ctypes.c_double
+    lw.hevm_plaintext_bytes.argtypes = [ctypes.c_void_p]
+    lw.hevm_plaintext_bytes.restype = ctypes.c_uint64
     lw.hevm_add_rotation_keys.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64), ctypes.c_int]
     lw.hevm_test_zero_encryption.argtypes = [ctypes.c_void_p, ctypes.c_bool]
     lw.hevm_save_ctxt.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_char_p]
@@ -177,6 +179,10 @@ class HEVM:
             lw.decrypt_result(self.vm, i, carr)
             result[i] = data
         return result
+
+    def plaintextBytes(self) -> int:
+        """extension: HBM held for the program's plaintexts (pre-encoded pool, or constants + window with DACAPO_HEVM_ONLINE_ENCODE=1)"""
+        return int(lw.hevm_plaintext_bytes(self.vm))
 
     def addRotationKeys(self, offsets):
         """extension: direct Galois keys for these slot offsets (create_galois_keys(steps) in SEAL; HEAAN_HEVM.cpp:58-64's key list)"""

@@ -94,6 +94,9 @@ void hevm_set_streams(void *vm, int n);
 void hevm_select_stream(void *vm, int s);
 /* wall seconds the last run() spent inside opcode 10 (decrypt / re-encode / encrypt) */
 double hevm_last_run_bootstrap_seconds(void *vm);
+/* HBM bytes held for the loaded program's plaintexts (pre-encoded pool, or constants + encode window with
+ * DACAPO_HEVM_ONLINE_ENCODE=1: plaintexts encoded at use, HEAAN_HEVM.cpp:266-281) */
+uint64_t hevm_plaintext_bytes(void *vm);
 /* Direct Galois keys for the given slot offsets (left rotation = positive), what KeyGenerator::create_galois_keys(steps, ...)
  * makes in SEAL and what the reference's HEaaN runtime loads for its fixed offset list (HEAAN_HEVM.cpp:58-64,124-126).  A
  * rotation by such an offset is then ONE key switch instead of one per non-zero NAF digit (Evaluator::rotate_internal uses a

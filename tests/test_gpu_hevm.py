@@ -657,3 +657,38 @@ def test_direct_rotation_keys_make_rotations_single_hops(tmp_path):
     assert got.ell == want.ell and (got.data == want.data).all()
     res = hevm.getOutput()[0]
     assert np.sqrt(np.mean((res - b.expected()[0]) ** 2)) < 1e-5 and np.abs(res - base).max() < 1e-4
+
+
+def test_online_encode_is_bit_identical_to_the_pre_encoded_pool(monkeypatch):
+    """DACAPO_HEVM_ONLINE_ENCODE=1 (the HEaaN runtime's way, HEAAN_HEVM.cpp:266-281,353-363): constants stay resident as doubles
+    and every plaintext register is encoded right before the wave that first reads it, into a window recycled wave by wave.  Same
+    seed, same program, same input: the result limbs equal the pre-encoded run's bit for bit, and the plaintext footprint shrinks."""
+    from dacapo_amd import hevm_asm as ha
+    from dacapo_amd import lowlevel as ll
+    from dacapo_amd import runner
+
+    rng = np.random.default_rng(31)
+    slots = 1 << 12
+    b = ha.Builder(slots=slots, init_level=6, policy="lazy", boot_level=3, shadow=True)
+    x = b.input(rng.uniform(-1, 1, slots))
+    acc = None
+    for k in range(24):                                   # a convolution-like layer: rotations x plaintext masks, summed, then squared
+        t = b.mul_plain(b.rotate(x, [1, -1, 2, -2, 8, -8][k % 6] * (1 + k // 6)), rng.uniform(-0.2, 0.2, slots))
+        acc = t if acc is None else b.add(acc, t)
+    y = b.add_plain(b.mul(acc, acc), rng.uniform(-0.1, 0.1, slots))
+    z = b.mul_plain(b.mul(y, x), [0.5])
+    b.output(b.finish(b.add(z, b.mul_plain(y, rng.uniform(-1, 1, 7)))))
+    cst, hv, info = b.assemble()
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("DACAPO_HEVM_ONLINE_ENCODE", mode)
+        hevm = runner.HEVM(seed=77, logN=13, num_primes=7)
+        hevm.load_mem(cst, hv)
+        hevm.setInput(0, x.plain)
+        hevm.run()
+        hevm.run()                                        # graph replay re-encodes into the same window
+        res[mode] = (_get_ct(hevm, ll, hevm.getResIdx(0)), hevm.plaintextBytes(), hevm.getOutput()[0])
+    a, bb = res["0"][0], res["1"][0]
+    assert a.ell == bb.ell and a.scale == bb.scale and (a.data == bb.data).all()
+    assert res["1"][1] > 0 and res["0"][1] > 0   # (this program reads all its plaintexts in two waves: the footprint test is the ResNet one)
+    assert np.sqrt(np.mean((res["1"][2] - b.expected()[0]) ** 2)) < 1e-4

@@ -161,3 +161,23 @@ def test_resnet20_other_lowerings_decrypt_to_the_same_logits(fixture20, tag):
     out = hevm.getOutput()[0]
     assert float(np.sqrt(np.mean((out - fixture20["expected"]) ** 2))) < 1e-3
     assert float(np.sqrt(np.mean((out[:10] * 32 - fixture20["torch_result"]) ** 2))) < 5e-3
+
+
+def test_resnet20_online_encode_shrinks_the_plaintext_footprint(fixture20):
+    """DACAPO_HEVM_ONLINE_ENCODE=1: the 5 894 plaintext registers are encoded at use from the resident constants (0.5 GB of doubles)
+    into a recycled window instead of living pre-encoded in HBM (6 GB); same logits"""
+    import os
+
+    from dacapo_amd import runner
+
+    os.environ["DACAPO_HEVM_ONLINE_ENCODE"] = "1"
+    try:
+        hevm = runner.HEVM(seed=0x4845564D + 6, logN=15, num_primes=14)
+    finally:
+        os.environ.pop("DACAPO_HEVM_ONLINE_ENCODE")
+    hevm.load_mem(fixture20["cst"], fixture20["hevm"])
+    hevm.setInput(0, fixture20["packed"])
+    hevm.run()
+    out = hevm.getOutput()[0]
+    assert float(np.sqrt(np.mean((out - fixture20["expected"]) ** 2))) < 1e-3
+    assert hevm.plaintextBytes() < 2.0e9      # constants 0.49 GB + window + scratch = 1.7 GB, against 4 GB pre-encoded
