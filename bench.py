@@ -120,9 +120,11 @@ def real_bootstrap_leg(ll, runner, steps=3, resnet=True):
                                   "key_switches": st["keyswitches"], "ntt_equivalents": st["ntts"], "ntt_per_s": round(st["ntts"] / dt),
                                   "max_error": float(err.max()), "rms_error": float(np.sqrt(np.mean(err**2))),
                                   "precision_bits": round(float(-np.log2(err.max())), 1)})
-        f = ROOT / "tests" / "golden" / "resnet20.rb3"
-        if resnet and Path(str(f) + ".hevm.gz").exists():
-            fx = ha.read_fixture(f)
+        if resnet:
+            fx = ha.read_fixture(ROOT / "tests" / "golden" / "resnet20")
+            t0 = time.time()
+            fx["hevm"], fx["cst"] = cb.lower_bootstraps(fx["hevm"], fx["cst"], 15, 20, msg_bits=4)  # every opcode 10 -> real bootstrapping
+            t_lower = time.time() - t0
             hevm = runner.HEVM(seed=0x4845564D, logN=15, num_primes=20)
             hevm.addRotationKeys(cb.rotation_offsets(fx["hevm"]))
             hevm.load_mem(fx["cst"], fx["hevm"])
@@ -133,7 +135,8 @@ def real_bootstrap_leg(ll, runner, steps=3, resnet=True):
             o, st = hevm.getOutput()[0], hevm.stats()
             ops = ha.unpack_hevm(fx["hevm"])["ops"]
             out["resnet20_with_real_bootstraps"] = {
-                "program": "tests/golden/resnet20.rb3 (the headline trace, every bootstrap site lowered to ModRaise/CoeffToSlot/EvalMod/SlotToCoeff)",
+                "program": "the headline program, every opcode 10 lowered to ModRaise/CoeffToSlot/EvalMod/SlotToCoeff by ckks_boot.lower_bootstraps",
+                "lowering_s": round(t_lower, 1),
                 "instructions": int(len(ops)), "real_bootstraps": int((ops[:, 0] == ha.OP_MODRAISE).sum()), "run_s": round(dt, 3),
                 "key_switches": st["keyswitches"], "ntt_equivalents": st["ntts"], "ntt_per_s": round(st["ntts"] / dt),
                 "rms_vs_torch": float(np.sqrt(np.mean((o[:10] * 32 - fx["torch_result"]) ** 2))),

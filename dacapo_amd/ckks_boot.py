@@ -519,3 +519,65 @@ def single_bootstrap_program(logN: int, target: int = 3, r: int = 5, msg_bits: i
 def rotation_offsets(hevm: bytes):
     """distinct non-zero slot offsets a program rotates by (for hevm_add_rotation_keys)"""
     return sorted({(int(q) - 65536 if q >= 32768 else int(q)) for o, _, _, q in ha.unpack_hevm(hevm)["ops"].tolist() if o == OP_ROTATE} - {0})
+
+
+# ---- compiled programs: opcode 10 -> real bootstrapping ------------------------------------------------------------------------------
+def lower_bootstraps(hevm: bytes, cst: bytes, logN: int, num_primes: int, msg_bits: int = 4, r: int = 5):
+    """Rewrites a program (e.g. one emitted by the reference's compiler) so that every opcode 10 -- `bootstrap`, a decrypt / re-encrypt
+    stand-in in the SEAL runtime (SEAL_HEVM.cpp:324-334), the real thing in the HEaaN runtime (HEAAN_HEVM.cpp:386-399) -- becomes the
+    real bootstrapping sequence of this module.  Everything else is re-emitted unchanged (same instructions, same constants, registers
+    re-allocated).  All opcode 10 of the program must restore the same number of primes t, and the chain must hold num_primes =
+    t + 17 primes (r = 5).  Returns (hevm', cst')."""
+    h = ha.unpack_hevm(hevm)
+    consts = ha.unpack_cst(cst)
+    slots = 1 << (logN - 1)
+    b = ha.Builder(slots=slots, init_level=int(h["init_level"]), shadow=False, real_boot=dict(num_primes=num_primes, msg_bits=msg_bits, r=r))
+    b.constants = [np.asarray(c, dtype=np.float64) for c in consts]
+    b._const_index = {c.tobytes(): i for i, c in enumerate(b.constants)}
+    cur = {}
+    for i, (sb, lv) in enumerate(zip(h["arg_scale"], h["arg_level"])):
+        cur[i] = b.input(None, level=int(lv), scale_bits=int(sb))
+    plain_of, plain_bits = {}, {}
+    for opc, dst, lhs, rhs in h["ops"].tolist():
+        if opc in (OP_ENCODE, OP_ENCODE_COMPLEX):
+            reg = b.num_plain
+            b.num_plain += 1
+            b.ops.append(ha._Op(opc, reg, lhs, rhs, False, False))
+            plain_of[dst], plain_bits[dst] = reg, rhs & 0x3FF
+            continue
+        if opc > OP_SETSCALE or opc == 5 or (10 < opc < OP_CONJ):
+            continue
+        x = cur[lhs]
+        lvl, bits = x.level, x.scale_bits
+        if opc == OP_BOOTSTRAP:
+            cur[dst] = b.bootstrap(x, int(rhs))
+            continue
+        if opc == OP_MODSWITCH:
+            d = rhs - 65536 if rhs >= 32768 else rhs
+            if d <= 0:
+                continue
+            lvl -= d
+        elif opc == OP_RESCALE:
+            lvl, bits = lvl - 1, bits - 60
+        elif opc == OP_ADDCC:
+            bits = cur[rhs].scale_bits
+        elif opc == OP_ADDCP:
+            bits = plain_bits[rhs]
+        elif opc == OP_MULCC:
+            bits += cur[rhs].scale_bits
+        elif opc == OP_MULCP:
+            bits += plain_bits[rhs]
+        elif opc == OP_MODRAISE:
+            lvl = rhs
+        out = b._new(lvl, bits, None)
+        if opc in (OP_ADDCC, OP_MULCC):
+            b._emit(opc, out, x, cur[rhs].id, True)
+        elif opc in (OP_ADDCP, OP_MULCP):
+            b._emit(opc, out, x, plain_of[rhs])
+        else:
+            b._emit(opc, out, x, rhs)
+        cur[dst] = out
+    for d in h["res_dst"]:
+        b.output(cur[int(d)])
+    cst2, hv2, _ = b.assemble()
+    return hv2, cst2

@@ -100,3 +100,23 @@ def test_vm_scale_mirror_follows_the_reference_semantics():
     primes = cb.seal_prime_chain(7, 4)
     sc = cb.vm_scales(b, primes)
     assert sc[y.id] == 2.0**40 * 2.0**60 / float(primes[2])                                # rescale divides by the dropped prime, as a double
+
+
+def test_lowering_opcode_10_of_a_compiled_program_to_real_bootstrapping():
+    """ckks_boot.lower_bootstraps: a program with opcode 10 (what the reference's compiler emits for `bootstrap`) re-emitted with every
+    opcode 10 replaced by the real sequence; on cleartext slots (ModRaise overflow simulated) it still computes the same function"""
+    logN, slots = 11, 1 << 10
+    rng = np.random.default_rng(5)
+    b = ha.Builder(slots=slots, init_level=3, policy="lazy", boot_level=3, shadow=True)
+    x = b.input(rng.uniform(-1, 1, slots))
+    y = x
+    for _ in range(4):                                   # enough multiplications to run out of primes twice
+        y = b.add_plain(b.mul(y, y), [0.1])
+    b.output(b.finish(b.add(y, b.rotate(x, 3))))
+    cst, hv, info = b.assemble()
+    assert info["op_mix"]["bootstrap"] >= 2
+    hv2, cst2 = cb.lower_bootstraps(hv, cst, logN, 20, msg_bits=1)
+    ops = ha.unpack_hevm(hv2)["ops"]
+    assert int((ops[:, 0] == ha.OP_BOOTSTRAP).sum()) == 0 and int((ops[:, 0] == ha.OP_MODRAISE).sum()) == info["op_mix"]["bootstrap"]
+    out = cb.simulate(hv2, cst2, [x.plain], logN, cb.seal_prime_chain(logN, 20))[0]
+    assert np.abs(out.real - b.expected()[0]).max() < 1e-5 and np.abs(out.imag).max() < 1e-5

@@ -134,18 +134,19 @@ def test_bootstrap_at_the_reference_ring_restores_levels_and_message():
 
 
 def test_resnet20_with_real_bootstraps_decrypts_to_the_torch_logits():
-    """tests/golden/resnet20.rb3: the reference's ResNet-20 trace with all 526 bootstrap sites lowered to REAL bootstrapping (783 k
-    instructions, 94 k key switches): the encrypted inference still produces the torch model's logits (BASELINE config 4 in spirit)."""
+    """the headline ResNet-20 program with all 526 opcode 10 rewritten to REAL bootstrapping by ckks_boot.lower_bootstraps (783 k
+    instructions, 94 k key switches): the encrypted inference still produces the torch model's logits (BASELINE config 4 in spirit)"""
     from pathlib import Path
 
     from dacapo_amd import ckks_boot as cb
     from dacapo_amd import hevm_asm as ha
 
-    fx = ha.read_fixture(Path(__file__).resolve().parent / "golden" / "resnet20.rb3")
-    ops = ha.unpack_hevm(fx["hevm"])["ops"]
+    fx = ha.read_fixture(Path(__file__).resolve().parent / "golden" / "resnet20")
+    hv, cst = cb.lower_bootstraps(fx["hevm"], fx["cst"], 15, 20, msg_bits=4)
+    ops = ha.unpack_hevm(hv)["ops"]
     assert int((ops[:, 0] == ha.OP_MODRAISE).sum()) == 526 and int((ops[:, 0] == ha.OP_BOOTSTRAP).sum()) == 0
-    hevm = _vm(15, 20, 64, cb.rotation_offsets(fx["hevm"]))
-    hevm.load_mem(fx["cst"], fx["hevm"])
+    hevm = _vm(15, 20, 64, cb.rotation_offsets(hv))
+    hevm.load_mem(cst, hv)
     hevm.setInput(0, fx["packed"])
     hevm.run()
     out = hevm.getOutput()[0]

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""The reference's ResNet-20 with REAL CKKS bootstrapping at every bootstrap site (tests/golden/resnet20.rb3.*: the same trace as the
-headline program, `bootstrap` lowered by dacapo_amd/ckks_boot.py instead of opcode 10): BASELINE config 4 in spirit -- the reference
+"""The reference's ResNet-20 with REAL CKKS bootstrapping at every bootstrap site (the headline program tests/golden/resnet20.*, every
+opcode 10 rewritten by dacapo_amd/ckks_boot.lower_bootstraps): BASELINE config 4 in spirit -- the reference
 runs it on HEaaN (HEAAN_HEVM.cpp:386-399) at N = 2^17; here on SEAL-style 60-bit primes, N = 2^15, 20 primes, sparse secret.
     python tools/resnet_real_boot.py [direct_keys=1]"""
 import json
@@ -15,10 +15,14 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 os.environ.setdefault("DACAPO_HEVM_SECRET_HW", "64")
 from dacapo_amd import hevm_asm as ha  # noqa: E402
-from dacapo_amd import progstats, runner  # noqa: E402
+from dacapo_amd import ckks_boot as cb  # noqa: E402
+from dacapo_amd import runner  # noqa: E402
 
 direct = int(sys.argv[1]) if len(sys.argv) > 1 else 1
-fx = ha.read_fixture(ROOT / "tests" / "golden" / "resnet20.rb3")
+fx = ha.read_fixture(ROOT / "tests" / "golden" / "resnet20")
+t0 = time.time()
+fx["hevm"], fx["cst"] = cb.lower_bootstraps(fx["hevm"], fx["cst"], 15, 20, msg_bits=4)
+print(f"opcode 10 -> real bootstrapping: {time.time()-t0:.1f} s", flush=True)
 h = ha.unpack_hevm(fx["hevm"])
 ops = h["ops"]
 print(f"{len(ops)} instructions, {h['num_ptxt']} plaintext registers, {int((ops[:, 0] == ha.OP_MODRAISE).sum())} real bootstraps", flush=True)
