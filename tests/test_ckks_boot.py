@@ -110,8 +110,8 @@ def test_lowering_opcode_10_of_a_compiled_program_to_real_bootstrapping():
     b = ha.Builder(slots=slots, init_level=3, policy="lazy", boot_level=3, shadow=True)
     x = b.input(rng.uniform(-1, 1, slots))
     y = x
-    for _ in range(4):                                   # enough multiplications to run out of primes twice
-        y = b.add_plain(b.mul(y, y), [0.1])
+    for _ in range(7):                                   # enough multiplications to run out of primes more than once
+        y = b.add_plain(b.mul_plain(b.mul(y, y), [0.5]), [0.1])
     b.output(b.finish(b.add(y, b.rotate(x, 3))))
     cst, hv, info = b.assemble()
     assert info["op_mix"]["bootstrap"] >= 2
