@@ -116,7 +116,12 @@ def real_bootstrap_leg(ll, runner, steps=3, resnet=True):
             dt = (time.perf_counter() - t0) / steps
             err = np.abs(hevm.getOutput()[0] - msg)
             st = hevm.stats()
+            from dacapo_amd import progstats
+
+            pst = progstats.walk(hv, logN, direct_keys=True)
             out["single"].append({"N": 1 << logN, "ms": round(dt * 1e3, 2), "instructions": int(len(ha.unpack_hevm(hv)["ops"])),
+                                  "algorithmic_bytes": pst["algorithmic_bytes"], "achieved_gbs": round(pst["algorithmic_bytes"] / dt / 1e9, 1),
+                                  "frac_of_hbm_peak": round(pst["algorithmic_bytes"] / dt / 1e9 / HBM_PEAK_GBS, 4),
                                   "key_switches": st["keyswitches"], "ntt_equivalents": st["ntts"], "ntt_per_s": round(st["ntts"] / dt),
                                   "max_error": float(err.max()), "rms_error": float(np.sqrt(np.mean(err**2))),
                                   "precision_bits": round(float(-np.log2(err.max())), 1)})

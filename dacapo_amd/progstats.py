@@ -21,8 +21,8 @@ from __future__ import annotations
 
 from collections import Counter
 
-from .hevm_asm import (OP_ADDCC, OP_ADDCP, OP_BOOTSTRAP, OP_ENCODE, OP_MODSWITCH, OP_MULCC, OP_MULCP, OP_NEGATE, OP_RESCALE,
-                       OP_ROTATE, unpack_hevm)
+from .hevm_asm import (OP_ADDCC, OP_ADDCP, OP_BOOTSTRAP, OP_CONJ, OP_ENCODE, OP_ENCODE_COMPLEX, OP_MODRAISE, OP_MODSWITCH, OP_MULCC, OP_MULCP,
+                       OP_NEGATE, OP_RESCALE, OP_ROTATE, OP_SETSCALE, unpack_hevm)
 
 
 def naf(value: int):
@@ -50,7 +50,13 @@ def rotate_hops(offset: int, slots: int) -> int:
     return sum(rotate_hops(d, slots) for d in naf(offset) if abs(d) != slots)
 
 
-def walk(hevm: bytes, logN: int = 15) -> dict:
+def BOOTSTRAP_GAP(opc: int) -> bool:
+    """opcode numbers 11-15 are unassigned (10 = bootstrap, 16-19 = this runtime's extension opcodes)"""
+    return OP_BOOTSTRAP < opc < OP_ENCODE_COMPLEX
+
+
+def walk(hevm: bytes, logN: int = 15, direct_keys: bool = False) -> dict:
+    """direct_keys: a Galois key exists for every rotation offset of the program (hevm_add_rotation_keys): one hop per rotation"""
     h = unpack_hevm(hevm)
     N, slots = 1 << logN, 1 << (logN - 1)
     p_limb = 8 * N
@@ -59,12 +65,13 @@ def walk(hevm: bytes, logN: int = 15) -> dict:
     limbs = 0  # algorithmic bytes in units of P_limb
     ks_hist, rs_hist, boot_hist, op_bytes = Counter(), Counter(), Counter(), Counter()
     for opc, dst, lhs, rhs in h["ops"].tolist():
-        if opc == OP_ENCODE or opc > OP_BOOTSTRAP:
+        if opc in (OP_ENCODE, OP_ENCODE_COMPLEX) or opc > OP_SETSCALE or BOOTSTRAP_GAP(opc):
             continue
         l = lvl[lhs]
         out_l, b = l, 0
         if opc == OP_ROTATE:
-            hops = rotate_hops(rhs - 65536 if rhs >= 32768 else rhs, slots)
+            off = rhs - 65536 if rhs >= 32768 else rhs
+            hops = (1 if off % slots else 0) if direct_keys else rotate_hops(off, slots)
             ks += hops
             ks_hist[l] += hops
             ntts += hops * (l + 1) * (l + 2)
@@ -95,6 +102,17 @@ def walk(hevm: bytes, logN: int = 15) -> dict:
             out_l = rhs
             boot_hist[(l, rhs)] += 1
             b = 2 * l + 2 * rhs
+        elif opc == OP_CONJ:      # extension: conjugation = one key switch with the key of Galois element 2N - 1
+            ks += 1
+            ks_hist[l] += 1
+            ntts += (l + 1) * (l + 2)
+            b = 2 * l * l + 7 * l
+        elif opc == OP_MODRAISE:  # extension: 2 inverse NTTs of one limb, 2 * rhs forward NTTs
+            out_l = rhs
+            ntts += 2 + 2 * rhs
+            b = 2 * l + 2 * rhs
+        elif opc == OP_SETSCALE:
+            b = 0
         limbs += b
         op_bytes[opc] += b * p_limb
         lvl[dst] = out_l
