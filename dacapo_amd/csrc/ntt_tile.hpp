@@ -204,9 +204,17 @@ __device__ __forceinline__ void ntt_tile_x(u64 (&x)[1 << LOGE], const DModulus M
 #pragma unroll
                 for (int g = 0; g < (1 << st_); g++) {
                     const u32 twi = (twroot << gs) + (u32)((hi << st_) | g);
+#if defined(DC_EXP_NO_TWLOAD) // timing experiment only (wrong results; profiles/r02_experiments.txt): twiddles from registers, not memory
+                    const u64 w = M.inv_n + twi;
+#else
                     const u64 w = PF ? wpre[PF ? pp : 0][(u << r) | ((1 << st_) + g)] : tw[twi];
+#endif
 #pragma unroll
+#if defined(DC_EXP_NO_BFLY) // timing experiment only (wrong results): loads, exchanges and stores without the arithmetic
+                    for (int e = 0; e < 0; e++) {
+#else
                     for (int e = 0; e < half; e++) {
+#endif
                         const int j0 = (u << r) | (g << (r - st_)) | e, j1 = j0 | half;
                         if (!INV)
                             ct_bfly(x[j0], x[j1], w, M, fwd_stage_folds(gs));
