@@ -74,19 +74,23 @@ def roofline_leg(ll, ctx, limbs=4096, iters=10):
             traffic, traffic_source = rec.get("forward_ntt_hbm_bytes"), "profiles/r02_ntt_hbm_traffic.json (PMC passes on this build)"
         else:
             traffic_source = "profiles/r02_ntt_hbm_traffic.json was collected on another build of the library: not reported"
-    # integer-VALU issue ceiling of the butterfly code (profiles/r01_intbench_gfx950.txt: 16 lanes/clk/SIMD, 34 T lane-ops/s
-    # chip-wide, v_mad_u64_u32 2.4x an add): 29.6 VALU instructions per butterfly, 8.25 of them v_mad_u64_u32 (ISA listing)
-    valu_ceiling = 4.5e6 * (32768.0 * 15) / (N * ctx.logN)  # NTT/s; 4.5 M/s at N = 2^15
+    # What bounds this launch pair (profiles/r02_experiments.txt items 8-10): every limb crosses HBM twice (one read + one write per
+    # phase), and the same kernels with the arithmetic compiled out run at the copy kernel's bandwidth, so the memory side is at the
+    # floor of the two-launch structure, 2 x (algorithmic bytes / copy bandwidth); the arithmetic (27.7 VALU instructions per forward
+    # butterfly, 7.6 of them v_mad_u64_u32; about 270 + 410 us of pure issue time) is only partly hidden behind that traffic.  A multiply
+    # with 22 % fewer instructions did not change the time: the kernels are not VALU-issue bound.
+    floor_us = 2.0 * alg_bytes / (copy_gbs * 1e9) * 1e6
     return {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
             "traffic": traffic, "traffic_source": traffic_source,
             "kernel": "ntt_phase_kernel<7,COLS,fwd> + ntt_phase_kernel<8,ROWS,fwd> (one forward NTT = both launches)",
             "launch": {"limbs": limbs, "N": N, "algorithmic_bytes": alg_bytes, "avg_us": round(ms * 1e3, 2),
                        "ntt_per_s": round(limbs / (ms * 1e-3))},
-            "limiting_resource": "valu-int",
-            "valu": {"instructions_per_butterfly": 29.6, "v_mad_u64_u32_per_butterfly": 8.25,
-                     "issue_ceiling_ntt_per_s": round(valu_ceiling), "frac_of_issue_ceiling": round(limbs / (ms * 1e-3) / valu_ceiling, 4),
-                     "source": "profiles/r01_intbench_gfx950.txt + ISA listing (tools/isa_mix.py); the byte roofline above is what the "
-                               "contract asks for, this is the resource the kernel actually saturates (profiles/r01_ntt_pmc_lds_valu.txt)"},
+            "limiting_resource": "two HBM crossings per limb + partly exposed integer arithmetic",
+            "two_launch_structure": {"hbm_crossings_per_limb": 2, "memory_floor_us": round(floor_us, 1),
+                                     "frac_of_memory_floor": round(floor_us / (ms * 1e3), 4),
+                                     "valu_instructions_per_butterfly": 27.7, "v_mad_u64_u32_per_butterfly": 7.6,
+                                     "source": "profiles/r02_experiments.txt items 8-10 (kernel variants without arithmetic / without "
+                                               "twiddle loads, twiddle-pair multiply, slices, software pipelining); tools/isa_mix.py"},
             "copy_kernel_gbs": round(copy_gbs, 1), "frac_of_copy": round(gbs / copy_gbs, 4)}
 
 
