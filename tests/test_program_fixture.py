@@ -168,3 +168,25 @@ def test_other_lowerings_of_the_resnet_trace_share_constants_and_compute_the_sam
         assert st["ntt_equivalents"] > ref["ntt_equivalents"]                    # more primes per key switch
         got = ha.plain_eval(hv, base["cst"], [base["packed"]])[0]
         assert np.abs(got - want).max() < 1e-9
+
+
+def test_resnet20_trace_at_the_reference_scripts_own_slot_count():
+    """tests/golden/resnet20_nt16.*: the same model traced at nt = 2^16 (examples/benchmarks/ResNet.py:50, the HEaaN runtime's slot
+    count, HEAAN_HEVM.cpp:55-56) -- the program tools/resnet_real_boot.py runs at N = 2^17 with real bootstrapping (BASELINE config 4)."""
+    from dacapo_amd import progstats
+
+    f16 = ha.read_fixture(GOLDEN.parent / "resnet20_nt16")
+    meta = f16["meta"]
+    assert hashlib.sha256(f16["hevm"]).hexdigest() == meta["hevm_sha256"] and hashlib.sha256(f16["cst"]).hexdigest() == meta["cst_sha256"]
+    assert meta["slots"] == 65536 and len(f16["packed"]) == 65536
+    h = ha.unpack_hevm(f16["hevm"])
+    mix = {ha.OP_NAMES[k]: int((h["ops"][:, 0] == k).sum()) for k in range(11)}
+    assert mix == meta["info"]["op_mix"] and mix["mulcc"] == 361 and mix["bootstrap"] == meta["bootstraps"]
+    # rotation offsets are (int16) fields: at 2^16 slots they span the whole range and stay inside it
+    offs = [(r - 65536 if r >= 32768 else r) for o, _, _, r in h["ops"].tolist() if o == ha.OP_ROTATE]
+    assert min(offs) >= -32768 and max(offs) <= 32767 and all(o % 65536 for o in offs)
+    st = progstats.walk(f16["hevm"], logN=17)
+    assert st["key_switches"] == sum(meta["hops_per_level"].values()) + sum(meta["mulcc_per_level"].values())  # NAF hops + relinearisations
+    # same model, same input image as the nt = 2^14 trace: the cleartext evaluation of both traces gives the torch logits
+    assert meta["plain_vs_torch_rms"] < 1e-3
+    np.testing.assert_allclose(meta["torch_result"], ha.read_fixture(GOLDEN)["meta"]["torch_result"], rtol=0, atol=1e-12)

@@ -2,7 +2,9 @@
 """The reference's ResNet-20 with REAL CKKS bootstrapping at every bootstrap site (the headline program tests/golden/resnet20.*, every
 opcode 10 rewritten by dacapo_amd/ckks_boot.lower_bootstraps): BASELINE config 4 in spirit -- the reference
 runs it on HEaaN (HEAAN_HEVM.cpp:386-399) at N = 2^17; here on SEAL-style 60-bit primes, N = 2^15, 20 primes, sparse secret.
-    python tools/resnet_real_boot.py [direct_keys=1]"""
+    python tools/resnet_real_boot.py [direct_keys=1|2] [fixture=resnet20] [logN=15] [msg_bits=4]
+With fixture resnet20_nt16 (the same model traced at the reference script's own nt = 2^16 slots, examples/benchmarks/ResNet.py:50) and
+logN 17 this is the HEaaN runtime's ring (HEAAN_HEVM.cpp:55-56): ~100 GB of one-prime-per-digit Galois keys, sized for one MI355X."""
 import json
 import os
 import sys
@@ -19,17 +21,23 @@ from dacapo_amd import ckks_boot as cb  # noqa: E402
 from dacapo_amd import runner  # noqa: E402
 
 direct = int(sys.argv[1]) if len(sys.argv) > 1 else 1
-fx = ha.read_fixture(ROOT / "tests" / "golden" / "resnet20")
+name = sys.argv[2] if len(sys.argv) > 2 else "resnet20"
+logN = int(sys.argv[3]) if len(sys.argv) > 3 else 15
+msg_bits = int(sys.argv[4]) if len(sys.argv) > 4 else 4
+fx = ha.read_fixture(ROOT / "tests" / "golden" / name)
+assert fx["meta"]["slots"] == 1 << (logN - 1), "the fixture was traced for another slot count"
 t0 = time.time()
-fx["hevm"], fx["cst"] = cb.lower_bootstraps(fx["hevm"], fx["cst"], 15, 20, msg_bits=4)
+fx["hevm"], fx["cst"] = cb.lower_bootstraps(fx["hevm"], fx["cst"], logN, 20, msg_bits=msg_bits)
 print(f"opcode 10 -> real bootstrapping: {time.time()-t0:.1f} s", flush=True)
 h = ha.unpack_hevm(fx["hevm"])
 ops = h["ops"]
 print(f"{len(ops)} instructions, {h['num_ptxt']} plaintext registers, {int((ops[:, 0] == ha.OP_MODRAISE).sum())} real bootstraps", flush=True)
 t0 = time.time()
-hevm = runner.HEVM(seed=0x4845564D, logN=15, num_primes=20)
+hevm = runner.HEVM(seed=0x4845564D, logN=logN, num_primes=20)
 if direct:
-    offs = sorted({(int(q) - 65536 if q >= 32768 else int(q)) for o, _, _, q in ops.tolist() if o == ha.OP_ROTATE} - {0})
+    offs = cb.rotation_offsets(fx["hevm"])
+    if direct == 2:  # direct keys for the bootstraps' own rotations only (they run at up to 19 primes); the model's rotations run at 1-3 primes,
+        offs = cb.rotation_offsets(cb.single_bootstrap_program(logN)[2])  # where a NAF hop pair under the default keys costs little
     hevm.addRotationKeys(offs)
     print(f"{len(offs)} direct rotation keys", flush=True)
 print(f"context + keys {time.time()-t0:.1f} s", flush=True)
@@ -42,7 +50,7 @@ hevm.run()
 dt = time.perf_counter() - t0
 out = hevm.getOutput()[0]
 st = hevm.stats()
-res = {"run_s": round(dt, 3), "key_switches": st["keyswitches"], "ntt_equivalents": st["ntts"], "ntt_per_s": round(st["ntts"] / dt),
+res = {"fixture": name, "N": 1 << logN, "slots": 1 << (logN - 1), "primes": 20, "msg_bits": msg_bits, "instructions": int(len(ops)), "run_s": round(dt, 3), "key_switches": st["keyswitches"], "ntt_equivalents": st["ntts"], "ntt_per_s": round(st["ntts"] / dt),
        "real_bootstraps": int((ops[:, 0] == ha.OP_MODRAISE).sum()),
        "rms_vs_torch": float(np.sqrt(np.mean((out[:10] * 32 - fx["torch_result"]) ** 2))),
        "rms_vs_plaintext_evaluation": float(np.sqrt(np.mean((out - fx["expected"]) ** 2))),
