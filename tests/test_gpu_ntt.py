@@ -79,3 +79,27 @@ def test_linearity_and_convolution_at_full_size():
     shifted = np.roll(x, 1, axis=1)
     shifted[:, 0] = (q[:, 0] - x[:, -1]) % q[:, 0]
     assert (dp.to_host() == shifted).all()
+
+
+@pytest.mark.parametrize("logN,K,limbs", [(15, 14, 520), (17, 3, 136)])
+def test_large_batch_uses_the_throughput_tiles_and_matches_oracle(logN, K, limbs):
+    """>= 5000 workgroups per launch: the radix-8 (2048-coefficient) tile geometry, the one bench.py's roofline leg times.
+    Forward == oracle on a spread of limbs, repeated launches agree, forward/inverse round trips are exact."""
+    ll, ctx = _ctx(logN, K)
+    o = Oracle(logN, K)
+    N = 1 << logN
+    assert (N >> 11) * limbs >= 5000
+    pidx = [b % K for b in range(limbs)]
+    a = np.stack([splitmix_fill(0x4845564D + b, N) % np.uint64(o.primes[p]) for b, p in enumerate(pidx)])
+    d = ll.DeviceBuffer.from_host(a)
+    check = sorted(set(list(range(0, limbs, limbs // 24)) + [limbs - 1, limbs - 2, 7, 8]))
+    want = o.ntt_fwd(a[check], [pidx[b] for b in check])
+    first = None
+    for _ in range(2):
+        ctx.ntt(d, limbs, prime_base=0, prime_period=K)
+        got = d.to_host()
+        assert (got[check] == want).all()
+        first = got if first is None else first
+        assert (got == first).all()
+        ctx.ntt(d, limbs, inverse=True, prime_base=0, prime_period=K)
+        assert (d.to_host() == a).all()
