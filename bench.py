@@ -94,7 +94,7 @@ def roofline_leg(ll, ctx, limbs=4096, iters=10):
             "copy_kernel_gbs": round(copy_gbs, 1), "frac_of_copy": round(gbs / copy_gbs, 4)}
 
 
-def real_bootstrap_leg(ll, runner, steps=3, resnet=True, config4=False):
+def real_bootstrap_leg(ll, runner, steps=3, resnet=True):
     """Real CKKS bootstrapping (dacapo_amd/ckks_boot.py; the reference's HEaaN runtime's `bootstrap`, HEAAN_HEVM.cpp:386-399, for which
     its SEAL runtime's opcode 10 is a stand-in): one ciphertext 1 prime -> 3 primes at the reference's two ring sizes, and the ResNet-20
     trace with a real bootstrap at every bootstrap site (lowered here from tests/golden/resnet20.*).  20 x 60-bit primes, secret of Hamming weight 64,
@@ -148,30 +148,6 @@ def real_bootstrap_leg(ll, runner, steps=3, resnet=True, config4=False):
                 "lowering_s": round(t_lower, 1),
                 "instructions": int(len(ops)), "real_bootstraps": int((ops[:, 0] == ha.OP_MODRAISE).sum()), "run_s": round(dt, 3),
                 "key_switches": st["keyswitches"], "ntt_equivalents": st["ntts"], "ntt_per_s": round(st["ntts"] / dt),
-                "rms_vs_torch": float(np.sqrt(np.mean((o[:10] * 32 - fx["torch_result"]) ** 2))),
-                "rms_vs_plaintext_evaluation": float(np.sqrt(np.mean((o - fx["expected"]) ** 2)))}
-        if config4:
-            # BASELINE config 4's shape (--config4, about two minutes): the model traced at the reference script's own nt = 2^16 slots
-            # (examples/benchmarks/ResNet.py:50), run on N = 2^17 (HEAAN_HEVM.cpp:55-56) with a real bootstrap at every bootstrap site.
-            # Default Galois keys for the model's rotations (1-3 primes), direct keys for the bootstraps' own 50 offsets: ~63 GB of keys.
-            fx = ha.read_fixture(ROOT / "tests" / "golden" / "resnet20_nt16")
-            t0 = time.time()
-            fx["hevm"], fx["cst"] = cb.lower_bootstraps(fx["hevm"], fx["cst"], 17, 20, msg_bits=3)
-            t_lower = time.time() - t0
-            hevm = runner.HEVM(seed=0x4845564D, logN=17, num_primes=20)
-            hevm.addRotationKeys(cb.rotation_offsets(cb.single_bootstrap_program(17)[2]))
-            hevm.load_mem(fx["cst"], fx["hevm"])
-            hevm.setInput(0, fx["packed"])
-            t0 = time.perf_counter()
-            hevm.run()
-            dt = time.perf_counter() - t0
-            o, st = hevm.getOutput()[0], hevm.stats()
-            ops = ha.unpack_hevm(fx["hevm"])["ops"]
-            out["config4_resnet20_nt65536_N131072"] = {
-                "program": "tests/golden/resnet20_nt16.* (nt = 2^16), every opcode 10 lowered to a real bootstrap; msg_bits 3",
-                "reference": "README.md:131-136: DaCapo's cost model estimates 13.6 s for its 19-bootstrap HEaaN plan (not measured)",
-                "lowering_s": round(t_lower, 1), "instructions": int(len(ops)), "real_bootstraps": int((ops[:, 0] == ha.OP_MODRAISE).sum()),
-                "run_s": round(dt, 3), "key_switches": st["keyswitches"], "ntt_equivalents": st["ntts"], "ntt_per_s": round(st["ntts"] / dt),
                 "rms_vs_torch": float(np.sqrt(np.mean((o[:10] * 32 - fx["torch_result"]) ** 2))),
                 "rms_vs_plaintext_evaluation": float(np.sqrt(np.mean((o - fx["expected"]) ** 2)))}
     finally:
@@ -332,6 +308,25 @@ def build_parser():
     return ap
 
 
+def config4_child():
+    """--config4: BASELINE config 4's shape -- ResNet-20 traced at the reference script's own nt = 2^16 slots (examples/benchmarks/
+    ResNet.py:50), run on N = 2^17 (HEAAN_HEVM.cpp:55-56) with a real bootstrap at every bootstrap site (tools/resnet_real_boot.py).
+    About 70 GB of keys and plaintexts: it runs in a CHILD process started before this one touches the GPU (the reference's ABI has no
+    destroy symbol, so the other legs' VMs stay resident until exit), about two minutes."""
+    import subprocess
+
+    cmd = [sys.executable, str(ROOT / "tools" / "resnet_real_boot.py"), "2", "resnet20_nt16", "17", "3"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    last = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or not last:
+        return {"error": f"tools/resnet_real_boot.py exited with {r.returncode}", "stderr_tail": r.stderr[-400:]}
+    res = json.loads(last[-1])
+    res["command"] = "python tools/resnet_real_boot.py 2 resnet20_nt16 17 3"
+    res["keys"] = "default Galois set for the model's rotations (1-3 primes) + 50 direct keys for the bootstraps' own offsets"
+    res["reference"] = "README.md:131-136: DaCapo's cost model estimates 13.6 s for its 19-bootstrap HEaaN plan (not measured)"
+    return res
+
+
 def spawn_ranks(args, argv) -> int:
     """`python bench.py --gpus N` outside a launcher: start N ranks as a CHILD torch.distributed.run (this parent has not touched the
     GPU and never does -- a process that has initialised HIP must not exec another program on this pool) and hand its exit code back."""
@@ -379,6 +374,8 @@ def main():
     args = build_parser().parse_args(argv)
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(spawn_ranks(args, argv))
+
+    config4 = config4_child() if (args.config4 and args.gpus == 1 and not args.dry_run) else None
 
     from dacapo_amd.dist import Group
 
@@ -523,7 +520,9 @@ def main():
     micro = ntt_micro_leg(ll)
     cfg3 = cfg3_leg(ll)
     per_op = per_op_leg(ll)
-    real_boot = real_bootstrap_leg(ll, runner, config4=args.config4) if (world == 1 and not args.no_lowerings) else None
+    real_boot = real_bootstrap_leg(ll, runner) if (world == 1 and not args.no_lowerings) else None
+    if real_boot is not None and config4 is not None:
+        real_boot["config4_resnet20_nt65536_N131072"] = config4
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline_leg(cst, hv, image)
