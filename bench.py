@@ -129,6 +129,7 @@ def real_bootstrap_leg(ll, runner, steps=3, resnet=True):
                                   "key_switches": st["keyswitches"], "ntt_equivalents": st["ntts"], "ntt_per_s": round(st["ntts"] / dt),
                                   "max_error": float(err.max()), "rms_error": float(np.sqrt(np.mean(err**2))),
                                   "precision_bits": round(float(-np.log2(err.max())), 1)})
+            hevm.close()  # hevm_destroy: the next VM gets this one's HBM back
         if resnet:
             fx = ha.read_fixture(ROOT / "tests" / "golden" / "resnet20")
             t0 = time.time()
@@ -150,6 +151,7 @@ def real_bootstrap_leg(ll, runner, steps=3, resnet=True):
                 "key_switches": st["keyswitches"], "ntt_equivalents": st["ntts"], "ntt_per_s": round(st["ntts"] / dt),
                 "rms_vs_torch": float(np.sqrt(np.mean((o[:10] * 32 - fx["torch_result"]) ** 2))),
                 "rms_vs_plaintext_evaluation": float(np.sqrt(np.mean((o - fx["expected"]) ** 2)))}
+            hevm.close()
     finally:
         os.environ.pop("DACAPO_HEVM_SECRET_HW", None)
     return out
@@ -502,6 +504,7 @@ def main():
         direct = {"distinct_offsets": len(offs), "extra_key_bytes": len(offs) * 13 * 2 * 14 * 32768 * 8, "keygen_s": round(t_keys, 2),
                   "ms_per_step": round(dt * 1e3, 3), "key_switches_per_step": st3["keyswitches"], "ntt_equivalents_per_step": st3["ntts"],
                   "ntt_per_s": round(st3["ntts"] / dt), "rms_vs_torch": float(np.sqrt(np.mean((out3[:10] * 32 - fx["torch_result"]) ** 2)))}
+    hevm.close()  # the timed VM (and its direct keys) is no longer needed: return its HBM before the other legs allocate
     ctx = ll.Context(15, 14)
     roof = roofline_leg(ll, ctx)
     # the timed step's own place on the byte roofline: SURVEY.md 8(d)'s table walked over the bytecode (progstats.walk)

@@ -81,6 +81,13 @@ void dc_stream_sync(void *stream) { DC_HIP_CHECK(hipStreamSynchronize(S(stream))
 
 void dc_set_device(int device) { DC_HIP_CHECK(hipSetDevice(device)); }
 void dc_device_sync(void) { DC_HIP_CHECK(hipDeviceSynchronize()); }
+void dc_mem_info(uint64_t *free_bytes, uint64_t *total_bytes)
+{
+    size_t f = 0, t = 0;
+    DC_HIP_CHECK(hipMemGetInfo(&f, &t));
+    if (free_bytes) *free_bytes = f;
+    if (total_bytes) *total_bytes = t;
+}
 int dc_device_count(void)
 {
     int n = 0;

@@ -434,7 +434,7 @@ RngKeys rng_keys_from_test_seed(uint64_t seed)
 static u64 *dalloc(size_t elems)
 {
     u64 *p = nullptr;
-    DC_HIP_CHECK(hipMalloc(&p, elems * sizeof(u64)));
+    DC_HIP_CHECK(vm_malloc(&p, elems * sizeof(u64)));
     return p;
 }
 
@@ -462,7 +462,7 @@ void HEVM::init_context(int logN, int K, const u64 *primes)
     lanes[0].ws = ctx->ws0;
     lanes[0].boot_plain.d = dalloc((size_t)ctx->max_level() * ctx->N);
     lanes[0].boot_plain.level = ctx->max_level();
-    DC_HIP_CHECK(hipMalloc(&d_epoch, 8));
+    DC_HIP_CHECK(vm_malloc(&d_epoch, 8));
     DC_HIP_CHECK(hipMemset(d_epoch, 0, 8));
     cur = 0;
 }
@@ -734,7 +734,7 @@ void HEVM::load_keys(const std::string &dir, bool need_secret, bool need_public,
                 if (index == 0)
                     keys.relin = key;
                 else
-                    (void)hipFree(key); // keys for higher powers of s: the HEVM path never multiplies without relinearising
+                    (void)vm_free(key); // keys for higher powers of s: the HEVM path never multiplies without relinearising
             });
             if (!keys.relin) m.fail("no relinearisation key for s^2");
         }
@@ -914,8 +914,8 @@ void HEVM::set_streams(int n)
     if (n == streams) return;
     DC_HIP_CHECK(hipDeviceSynchronize());
     for (u64 *&p : home)
-        if (p) (void)hipFree(p), p = nullptr;
-    for (u64 *p : plan.pool) (void)hipFree(p);
+        if (p) (void)vm_free(p), p = nullptr;
+    for (u64 *p : plan.pool) (void)vm_free(p);
     plan.pool.clear();
     plan.ready = false;
     for (auto &r : ciphers) r.data = nullptr;
@@ -961,7 +961,7 @@ void HEVM::encode_internal(Plain &dst, const double *src, size_t len, int level,
     DC_HIP_CHECK(hipMemcpyAsync(stage, lohi.data(), 2 * N * 8, hipMemcpyHostToDevice, S()));
     if (dst.d && (dst.level != level || dst.arena)) {
         DC_HIP_CHECK(hipStreamSynchronize(S()));
-        if (!dst.arena) (void)hipFree(dst.d);
+        if (!dst.arena) (void)vm_free(dst.d);
         dst.d = nullptr, dst.arena = false;
     }
     if (!dst.d) dst.d = dalloc((size_t)level * N);
@@ -975,11 +975,11 @@ void HEVM::encode_internal(Plain &dst, const double *src, size_t len, int level,
 
 void HEVM::free_plains()
 {
-    if (online.d_consts) (void)hipFree(online.d_consts);
+    if (online.d_consts) (void)vm_free(online.d_consts);
     online.d_consts = nullptr, online.items.clear();
     for (auto &pl : plains)
-        if (pl.d && !pl.arena) (void)hipFree(pl.d);
-    for (u64 *a : plain_arenas) (void)hipFree(a);
+        if (pl.d && !pl.arena) (void)vm_free(pl.d);
+    for (u64 *a : plain_arenas) (void)vm_free(a);
     plain_arenas.clear();
     for (auto &pl : plains) pl = Plain{};
 }
@@ -992,9 +992,9 @@ void HEVM::ensure_enc_tables()
     if (!enc_tables.roots) {
         std::vector<double2> r(N);
         for (size_t k = 0; k < N; k++) r[k] = make_double2(encoder->roots()[k].real(), encoder->roots()[k].imag());
-        DC_HIP_CHECK(hipMalloc(&enc_tables.roots, N * sizeof(double2)));
+        DC_HIP_CHECK(vm_malloc(&enc_tables.roots, N * sizeof(double2)));
         DC_HIP_CHECK(hipMemcpy(enc_tables.roots, r.data(), N * sizeof(double2), hipMemcpyHostToDevice));
-        DC_HIP_CHECK(hipMalloc(&enc_tables.slot_map, N * sizeof(u32)));
+        DC_HIP_CHECK(vm_malloc(&enc_tables.slot_map, N * sizeof(u32)));
         DC_HIP_CHECK(hipMemcpy(enc_tables.slot_map, encoder->slot_map().data(), N * sizeof(u32), hipMemcpyHostToDevice));
     }
 }
@@ -1050,7 +1050,7 @@ void HEVM::preprocess_device()
     }
     if (by_level.empty()) return;
     double *d_consts = nullptr;
-    DC_HIP_CHECK(hipMalloc(&d_consts, std::max<size_t>(host.size(), 1) * sizeof(double)));
+    DC_HIP_CHECK(vm_malloc(&d_consts, std::max<size_t>(host.size(), 1) * sizeof(double)));
     if (!host.empty()) DC_HIP_CHECK(hipMemcpy(d_consts, host.data(), host.size() * sizeof(double), hipMemcpyHostToDevice));
     if (online_encode) {
         // On-line encode (the HEaaN runtime's mode, HEAAN_HEVM.cpp:266-281,353-363): only the constants stay resident, as doubles;
@@ -1063,9 +1063,9 @@ void HEVM::preprocess_device()
     double2 *scratch = nullptr;
     EncItem *d_items = nullptr;
     int *d_overflow = nullptr;
-    DC_HIP_CHECK(hipMalloc(&scratch, (size_t)chunk * N * sizeof(double2)));
-    DC_HIP_CHECK(hipMalloc(&d_items, (size_t)chunk * sizeof(EncItem)));
-    DC_HIP_CHECK(hipMalloc(&d_overflow, sizeof(int)));
+    DC_HIP_CHECK(vm_malloc(&scratch, (size_t)chunk * N * sizeof(double2)));
+    DC_HIP_CHECK(vm_malloc(&d_items, (size_t)chunk * sizeof(EncItem)));
+    DC_HIP_CHECK(vm_malloc(&d_overflow, sizeof(int)));
     DC_HIP_CHECK(hipMemset(d_overflow, 0, sizeof(int)));
     for (auto &kv : by_level) {
         const int level = kv.first;
@@ -1086,7 +1086,7 @@ void HEVM::preprocess_device()
     }
     int overflow = 0;
     DC_HIP_CHECK(hipMemcpy(&overflow, d_overflow, sizeof(int), hipMemcpyDeviceToHost));
-    (void)hipFree(d_consts), (void)hipFree(scratch), (void)hipFree(d_items), (void)hipFree(d_overflow);
+    (void)vm_free(d_consts), (void)vm_free(scratch), (void)vm_free(d_items), (void)vm_free(d_overflow);
     if (overflow) {
         fprintf(stderr, "[dacapo_amd] encode: coefficient does not fit 120 bits (scale too large)\n");
         abort();
@@ -1154,7 +1154,7 @@ void HEVM::encrypt(int64_t i, const double *dat, int len)
     r.poly_stride = (int64_t)ctx->K * (int64_t)ctx->N;
     encrypt_plain(r, pt);
     DC_HIP_CHECK(hipStreamSynchronize(S()));
-    (void)hipFree(pt.d);
+    (void)vm_free(pt.d);
 }
 
 void HEVM::decrypt(int64_t i, double *out)
@@ -1499,7 +1499,7 @@ const HEVM::CrtTables &HEVM::crt_tables(int ell)
     CrtTables tb;
     auto up = [&](const void *src, size_t bytes) {
         void *d = nullptr;
-        DC_HIP_CHECK(hipMalloc(&d, bytes));
+        DC_HIP_CHECK(vm_malloc(&d, bytes));
         DC_HIP_CHECK(hipMemcpy(d, src, bytes, hipMemcpyHostToDevice));
         return d;
     };
@@ -1655,7 +1655,32 @@ void HEVM::run()
 // =========================================================================================================
 // the 18 symbols of the reference (SEAL_HEVM.cpp:404-504) + extensions
 // =========================================================================================================
+namespace dacapo {
+thread_local VmAllocs *g_vm_allocs = nullptr;
+
+void HEVM::destroy_device_state()
+{
+    (void)hipDeviceSynchronize();
+    drop_plan_graph();
+    for (Lane &ln : lanes)
+        if (ln.stream) (void)hipStreamDestroy(ln.stream), ln.stream = nullptr;
+    if (aux_stream) (void)hipStreamDestroy(aux_stream), aux_stream = nullptr;
+    for (hipEvent_t e : plan.events) (void)hipEventDestroy(e);
+    plan.events.clear();
+    const std::vector<void *> live(allocs.live.begin(), allocs.live.end());
+    allocs.live.clear();
+    for (void *p : live) (void)hipFree(p);
+}
+} // namespace dacapo
+
 using dacapo::HEVM;
+// every entry point names the VM whose allocations it may create or release
+static HEVM *V(void *vm)
+{
+    HEVM *h = static_cast<HEVM *>(vm);
+    dacapo::g_vm_allocs = &h->allocs;
+    return h;
+}
 
 static std::vector<char> slurp(const char *path)
 {
@@ -1706,35 +1731,37 @@ void create_context(char *dir)
     vm.init_context(logN, K, nullptr);
     vm.generate_keys(dacapo::rng_keys_from_os(), true, true, true);
     vm.save_keys(dir);
+    vm.destroy_device_state(); // a temporary VM: its keys live in the files now
+    dacapo::g_vm_allocs = nullptr;
 }
 void load(void *vm, char *constant, char *vmfile)
 {
-    auto hevm = static_cast<HEVM *>(vm);
+    auto hevm = V(vm);
     std::vector<char> cst = slurp(constant), prog = slurp(vmfile);
     hevm->load_constants(cst.data(), cst.size());
     hevm->load_program(prog.data(), prog.size(), false);
 }
 void loadClient(void *vm, void *is)
 {
-    auto hevm = static_cast<HEVM *>(vm);
+    auto hevm = V(vm);
     std::vector<char> prog = slurp(static_cast<const char *>(is));
     hevm->load_program(prog.data(), prog.size(), true);
     hevm->reset_res_dst();
 }
-void encrypt(void *vm, int64_t i, double *dat, int len) { static_cast<HEVM *>(vm)->encrypt(i, dat, len); }
-void decrypt(void *vm, int64_t i, double *dat) { static_cast<HEVM *>(vm)->decrypt(i, dat); }
+void encrypt(void *vm, int64_t i, double *dat, int len) { V(vm)->encrypt(i, dat, len); }
+void decrypt(void *vm, int64_t i, double *dat) { V(vm)->decrypt(i, dat); }
 void decrypt_result(void *vm, int64_t i, double *dat)
 {
-    auto hevm = static_cast<HEVM *>(vm);
+    auto hevm = V(vm);
     hevm->decrypt((int64_t)hevm->res_dst.at((size_t)i), dat);
 }
-int64_t getResIdx(void *vm, int64_t i) { return (int64_t) static_cast<HEVM *>(vm)->res_dst.at((size_t)i); }
-void *getCtxt(void *vm, int64_t id) { return &static_cast<HEVM *>(vm)->reg((size_t)id); }
-void preprocess(void *vm) { static_cast<HEVM *>(vm)->preprocess(); }
-void run(void *vm) { static_cast<HEVM *>(vm)->run(); }
-int64_t getArgLen(void *vm) { return (int64_t) static_cast<HEVM *>(vm)->header.arg_length; }
-int64_t getResLen(void *vm) { return (int64_t) static_cast<HEVM *>(vm)->header.res_length; }
-void setDebug(void *vm, bool enable) { static_cast<HEVM *>(vm)->debug = enable; }
+int64_t getResIdx(void *vm, int64_t i) { return (int64_t) V(vm)->res_dst.at((size_t)i); }
+void *getCtxt(void *vm, int64_t id) { return &V(vm)->reg((size_t)id); }
+void preprocess(void *vm) { V(vm)->preprocess(); }
+void run(void *vm) { V(vm)->run(); }
+int64_t getArgLen(void *vm) { return (int64_t) V(vm)->header.arg_length; }
+int64_t getResLen(void *vm) { return (int64_t) V(vm)->header.res_length; }
+void setDebug(void *vm, bool enable) { V(vm)->debug = enable; }
 void setToGPU(void *vm, bool ongpu)
 {
     (void)vm;
@@ -1754,38 +1781,38 @@ void *hevm_init_seeded(int logN, int num_primes, uint64_t seed)
 }
 void *hevm_context(void *vm)
 { // borrowed kernel-level handle, one per VM (never freed, like the VM itself)
-    auto h = static_cast<HEVM *>(vm);
+    auto h = V(vm);
     if (!h->ckks_handle) h->ckks_handle = new dc_context{ h->ctx.get(), false };
     return h->ckks_handle;
 }
-const uint64_t *hevm_relin_key(void *vm) { return static_cast<HEVM *>(vm)->keys.relin; }
+const uint64_t *hevm_relin_key(void *vm) { return V(vm)->keys.relin; }
 const uint64_t *hevm_galois_key(void *vm, uint32_t elt)
 {
-    auto &g = static_cast<HEVM *>(vm)->keys.galois;
+    auto &g = V(vm)->keys.galois;
     auto it = g.find(elt);
     return it == g.end() ? nullptr : it->second;
 }
-const uint64_t *hevm_secret_key(void *vm) { return static_cast<HEVM *>(vm)->keys.sk; }
-const uint64_t *hevm_public_key(void *vm) { return static_cast<HEVM *>(vm)->keys.pk; }
+const uint64_t *hevm_secret_key(void *vm) { return V(vm)->keys.sk; }
+const uint64_t *hevm_public_key(void *vm) { return V(vm)->keys.pk; }
 const uint64_t *hevm_plain(void *vm, int64_t i, int32_t *level, double *scale)
 {
-    const dacapo::Plain &p = static_cast<HEVM *>(vm)->plains.at((size_t)i);
+    const dacapo::Plain &p = V(vm)->plains.at((size_t)i);
     if (level) *level = p.level;
     if (scale) *scale = p.scale;
     return p.d;
 }
 void hevm_load_mem(void *vm, const void *cst, uint64_t cst_len, const void *hevm, uint64_t hevm_len)
 {
-    auto h = static_cast<HEVM *>(vm);
+    auto h = V(vm);
     h->load_constants(cst, cst_len);
     h->load_program(hevm, hevm_len, false);
 }
-void hevm_set_streams(void *vm, int n) { static_cast<HEVM *>(vm)->set_streams(n); }
-void hevm_select_stream(void *vm, int s) { static_cast<HEVM *>(vm)->select_stream(s); }
-double hevm_last_run_bootstrap_seconds(void *vm) { return static_cast<HEVM *>(vm)->t_bootstrap; }
+void hevm_set_streams(void *vm, int n) { V(vm)->set_streams(n); }
+void hevm_select_stream(void *vm, int s) { V(vm)->select_stream(s); }
+double hevm_last_run_bootstrap_seconds(void *vm) { return V(vm)->t_bootstrap; }
 uint64_t hevm_plaintext_bytes(void *vm)
 { // HBM held for the program's plaintexts: the pre-encoded pool, or (on-line encode) the resident constants + the encode window
-    auto h = static_cast<HEVM *>(vm);
+    auto h = V(vm);
     if (h->online_encode) return h->online.const_bytes + h->plan.enc_arena_bytes + h->plan.enc_scratch_bytes;
     uint64_t total = 0;
     for (const dacapo::Plain &p : h->plains) total += (uint64_t)p.level * h->ctx->N * 8;
@@ -1793,7 +1820,7 @@ uint64_t hevm_plaintext_bytes(void *vm)
 }
 void hevm_add_rotation_keys(void *vm, const int64_t *offsets, int count)
 { // KeyGenerator::create_galois_keys(steps): a direct key per slot offset (left = positive), next to the default +-2^k set
-    auto h = static_cast<HEVM *>(vm);
+    auto h = V(vm);
     if (!h->keys.sk) {
         fprintf(stderr, "[dacapo_amd] hevm_add_rotation_keys: this VM holds no secret key\n");
         abort();
@@ -1814,11 +1841,11 @@ void hevm_add_rotation_keys(void *vm, const int64_t *offsets, int count)
 void hevm_test_zero_encryption(void *vm, bool on)
 {
     if (on) fprintf(stderr, "[dacapo_amd] TEST HOOK: encryptions of zero are (0, 0) from now on -- this VM offers NO security\n");
-    static_cast<HEVM *>(vm)->test_zero_enc = on;
-    static_cast<HEVM *>(vm)->drop_plan_graph(); // the recorded launch sequence contains (or lacks) the zero-encryption launches
+    V(vm)->test_zero_enc = on;
+    V(vm)->drop_plan_graph(); // the recorded launch sequence contains (or lacks) the zero-encryption launches
 }
-void hevm_save_ctxt(void *vm, int64_t reg, const char *path) { static_cast<HEVM *>(vm)->save_ctxt((size_t)reg, path); }
-void hevm_load_ctxt(void *vm, int64_t reg, const char *path) { static_cast<HEVM *>(vm)->load_ctxt((size_t)reg, path); }
+void hevm_save_ctxt(void *vm, int64_t reg, const char *path) { V(vm)->save_ctxt((size_t)reg, path); }
+void hevm_load_ctxt(void *vm, int64_t reg, const char *path) { V(vm)->load_ctxt((size_t)reg, path); }
 
 // ---- host-only entry points (no GPU involved) ---------------------------------------------------------------
 void hevm_seal_parms_id(uint64_t poly_modulus_degree, const uint64_t *primes, int count, uint64_t out[4])
@@ -1897,10 +1924,21 @@ void hevm_chacha20_blocks_device(const uint32_t key[8], uint64_t counter, uint64
 
 void hevm_last_run_stats(void *vm, int64_t *op_counts, int64_t *keyswitches, int64_t *ntts)
 {
-    auto h = static_cast<HEVM *>(vm);
+    auto h = V(vm);
     if (op_counts) memcpy(op_counts, h->op_counts, sizeof(h->op_counts));
     if (keyswitches) *keyswitches = h->n_keyswitch;
     if (ntts) *ntts = h->n_ntt;
+}
+
+// the reference never frees a VM (no destroy symbol); a long-lived host that creates many can return one's HBM with this
+void hevm_destroy(void *vm)
+{
+    if (!vm) return;
+    HEVM *h = V(vm);
+    h->destroy_device_state();
+    dacapo::g_vm_allocs = nullptr;
+    delete static_cast<dc_context *>(h->ckks_handle);
+    delete h;
 }
 
 } // extern "C"

@@ -7,6 +7,7 @@
 #include <map>
 #include <memory>
 #include <string>
+#include <unordered_set>
 #include <vector>
 
 #include "../../include/hevm_abi.h"
@@ -17,6 +18,27 @@
 #include "plan.hpp"
 
 namespace dacapo {
+
+// Device allocations made on behalf of one VM, so that hevm_destroy (an extension: the reference's ABI never frees a VM) can return
+// them.  The C ABI's entry points name the VM they act on (HEVM::enter); allocation sites call vm_malloc / vm_free instead of
+// hipMalloc / hipFree.  Allocations made with no VM entered are not tracked (and live as long as the process, as before).
+struct VmAllocs {
+    std::unordered_set<void *> live;
+};
+extern thread_local VmAllocs *g_vm_allocs;
+template <class T>
+inline hipError_t vm_malloc(T **p, size_t bytes)
+{
+    const hipError_t e = hipMalloc((void **)p, bytes);
+    if (e == hipSuccess && g_vm_allocs) g_vm_allocs->live.insert((void *)*p);
+    return e;
+}
+inline hipError_t vm_free(void *p)
+{
+    if (p && g_vm_allocs) g_vm_allocs->live.erase(p);
+    return hipFree(p);
+}
+
 
 // wire format of include/hecate/Support/HEVMHeader.h:10-35 (little endian, natural alignment)
 struct WireHeader {
@@ -235,7 +257,9 @@ class HEVM {
     int64_t n_keyswitch = 0, n_ntt = 0;
     double t_bootstrap = 0.0; // host wall time spent inside opcode 10
 
-    HEVM() = default;
+    VmAllocs allocs;   // device memory held by this VM (hevm_destroy)
+    HEVM() { g_vm_allocs = &allocs; }
+    void destroy_device_state(); // streams, events, graph, every tracked allocation; the object is unusable afterwards
     size_t key_elems() const { return (size_t)(ctx->K - 1) * 2 * ctx->K * ctx->N; }
     void init_context(int logN, int K, const u64 *primes);
     void generate_keys(const RngKeys &rng, bool secret, bool pub, bool eval);

@@ -20,7 +20,7 @@ template <class T>
 static T *upload(const std::vector<T> &v)
 {
     T *d = nullptr;
-    DC_HIP_CHECK(hipMalloc(&d, std::max<size_t>(v.size(), 1) * sizeof(T)));
+    DC_HIP_CHECK(vm_malloc(&d, std::max<size_t>(v.size(), 1) * sizeof(T)));
     if (!v.empty()) DC_HIP_CHECK(hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
     return d;
 }
@@ -30,17 +30,17 @@ void HEVM::build_plan()
     Context &c = *ctx;
     const size_t N = c.N;
     Plan &P = plan;
-    for (u64 *b : P.handoff_bufs) (void)hipFree(b);
+    for (u64 *b : P.handoff_bufs) (void)vm_free(b);
     P.handoff_bufs.clear();
     for (void *p : { (void *)P.d_enc_items, (void *)P.enc_arena, (void *)P.enc_scratch, (void *)P.d_enc_overflow })
-        if (p) (void)hipFree(p);
+        if (p) (void)vm_free(p);
     P.d_enc_items = nullptr, P.enc_arena = nullptr, P.enc_scratch = nullptr, P.d_enc_overflow = nullptr;
     P.enc_groups.clear(), P.enc_arena_bytes = P.enc_scratch_bytes = 0;
-    if (P.d_cont_other) (void)hipFree(P.d_cont_other), P.d_cont_other = nullptr;
+    if (P.d_cont_other) (void)vm_free(P.d_cont_other), P.d_cont_other = nullptr;
     for (void *p : { (void *)P.d_ks, (void *)P.d_mul, (void *)P.d_rs, (void *)P.d_ew, (void *)P.d_sum, (void *)P.d_sum_srcs, (void *)P.d_boot,
                      (void *)P.d_boot_rs, (void *)P.zenc, (void *)P.boot_ue, (void *)P.boot_tmp, (void *)P.boot_pt[0], (void *)P.boot_ptx[0],
                      (void *)P.boot_pt[1], (void *)P.boot_ptx[1] })
-        if (p) (void)hipFree(p);
+        if (p) (void)vm_free(p);
     P.d_boot = nullptr, P.d_boot_rs = nullptr, P.zenc = P.boot_ue = P.boot_tmp = nullptr;
     P.boot_pt[0] = P.boot_pt[1] = P.boot_ptx[0] = P.boot_ptx[1] = nullptr;
     P.boot_chunks.clear();
@@ -520,11 +520,11 @@ void HEVM::build_plan()
             }
             (void)NW;
         }
-        DC_HIP_CHECK(hipMalloc(&P.enc_arena, std::max<size_t>(high, 1) * sizeof(u64)));
+        DC_HIP_CHECK(vm_malloc(&P.enc_arena, std::max<size_t>(high, 1) * sizeof(u64)));
         P.enc_arena_bytes = high * sizeof(u64);
         P.enc_scratch_bytes = max_cnt * N * sizeof(double2);
-        DC_HIP_CHECK(hipMalloc(&P.enc_scratch, std::max<size_t>(P.enc_scratch_bytes, 16)));
-        DC_HIP_CHECK(hipMalloc(&P.d_enc_overflow, sizeof(int)));
+        DC_HIP_CHECK(vm_malloc(&P.enc_scratch, std::max<size_t>(P.enc_scratch_bytes, 16)));
+        DC_HIP_CHECK(vm_malloc(&P.d_enc_overflow, sizeof(int)));
         DC_HIP_CHECK(hipMemset(P.d_enc_overflow, 0, sizeof(int)));
         P.d_enc_items = upload(h_items);
         size_t gi = 0;
@@ -568,7 +568,7 @@ void HEVM::build_plan()
                 b = free_list.back();
                 free_list.pop_back();
             } else {
-                DC_HIP_CHECK(hipMalloc(&b, buf_elems * (size_t)S * sizeof(u64))); // one block = the value in all S streams
+                DC_HIP_CHECK(vm_malloc(&b, buf_elems * (size_t)S * sizeof(u64))); // one block = the value in all S streams
                 P.pool.push_back(b);
             }
             V[(size_t)v].buf = b;
@@ -679,7 +679,7 @@ void HEVM::build_plan()
     // the same target level at the start of each run (plan_zero_encrypt)
     if (!h_boot_pops.empty()) {
         const size_t nb = h_boot_pops.size(), slot = (size_t)2 * boot_tmax * N;
-        DC_HIP_CHECK(hipMalloc(&P.zenc, nb * slot * sizeof(u64)));
+        DC_HIP_CHECK(vm_malloc(&P.zenc, nb * slot * sizeof(u64)));
         P.zenc_bytes = nb * slot * sizeof(u64);
         std::vector<int> order(nb); // boot items sorted by target level (stable): chunks are ranges of the sorted tables
         for (size_t i = 0; i < nb; i++) order[i] = (int)i;
@@ -688,11 +688,11 @@ void HEVM::build_plan()
         });
         const size_t bc = std::min<size_t>(nb, (size_t)std::max(max_batch, 1));
         const size_t cmax = (size_t)boot_tmax + 1;
-        DC_HIP_CHECK(hipMalloc(&P.boot_ue, bc * 3 * cmax * N * sizeof(u64)));
-        DC_HIP_CHECK(hipMalloc(&P.boot_tmp, bc * 2 * cmax * N * sizeof(u64)));
+        DC_HIP_CHECK(vm_malloc(&P.boot_ue, bc * 3 * cmax * N * sizeof(u64)));
+        DC_HIP_CHECK(vm_malloc(&P.boot_tmp, bc * 2 * cmax * N * sizeof(u64)));
         for (int ln = 0; ln < plan_lanes; ln++) {
-            DC_HIP_CHECK(hipMalloc(&P.boot_pt[ln], std::max<size_t>(need_bpt, 1) * N * sizeof(u64)));
-            DC_HIP_CHECK(hipMalloc(&P.boot_ptx[ln], std::max<size_t>(need_bptx, 1) * N * sizeof(u64)));
+            DC_HIP_CHECK(vm_malloc(&P.boot_pt[ln], std::max<size_t>(need_bpt, 1) * N * sizeof(u64)));
+            DC_HIP_CHECK(vm_malloc(&P.boot_ptx[ln], std::max<size_t>(need_bptx, 1) * N * sizeof(u64)));
         }
         std::vector<BootItem> h_boot(nb);
         std::vector<RsItem> h_brs(nb);
@@ -748,7 +748,7 @@ void HEVM::build_plan()
             Step &B = P.steps[(size_t)A.fused_consumer];
             const size_t items = (size_t)B.count, limbs = A.h.cont == CONT_RS ? 2 : (size_t)B.level;
             u64 *buf = nullptr;
-            DC_HIP_CHECK(hipMalloc(&buf, items * limbs * N * sizeof(u64)));
+            DC_HIP_CHECK(vm_malloc(&buf, items * limbs * N * sizeof(u64)));
             P.handoff_bufs.push_back(buf);
             A.h.out = buf, B.h.in = buf;
             A.h.sk = keys.sk;
@@ -769,13 +769,13 @@ void HEVM::build_plan()
     }
     auto alloc = [&](size_t limbs) {
         u64 *d = nullptr;
-        DC_HIP_CHECK(hipMalloc(&d, std::max<size_t>(limbs, 1) * N * sizeof(u64)));
+        DC_HIP_CHECK(vm_malloc(&d, std::max<size_t>(limbs, 1) * N * sizeof(u64)));
         return d;
     };
     for (int ln = 0; ln < 2; ln++) {
         BatchWs &w = P.ws[ln];
         for (void *p : { (void *)w.target, (void *)w.digits, (void *)w.ext, (void *)w.acc, (void *)w.tmp })
-            if (p) (void)hipFree(p);
+            if (p) (void)vm_free(p);
         w = BatchWs{};
         if (ln >= plan_lanes) continue;
         w.target = alloc(need_t), w.digits = alloc(need_d), w.ext = alloc(need_e);

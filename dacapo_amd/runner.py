@@ -73,6 +73,8 @@ def reinit_lw():  # runner.py:73-117
     lw.hevm_last_run_bootstrap_seconds.restype = ctypes.c_double
     lw.hevm_plaintext_bytes.argtypes = [ctypes.c_void_p]
     lw.hevm_plaintext_bytes.restype = ctypes.c_uint64
+    lw.hevm_destroy.argtypes = [ctypes.c_void_p]
+    lw.hevm_destroy.restype = None
     lw.hevm_add_rotation_keys.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64), ctypes.c_int]
     lw.hevm_test_zero_encryption.argtypes = [ctypes.c_void_p, ctypes.c_bool]
     lw.hevm_save_ctxt.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_char_p]
@@ -179,6 +181,12 @@ class HEVM:
             lw.decrypt_result(self.vm, i, carr)
             result[i] = data
         return result
+
+    def close(self):
+        """extension: return this VM's HBM (hevm_destroy).  The reference's runner never frees its VM; neither does this class unless asked."""
+        if getattr(self, "vm", None):
+            lw.hevm_destroy(self.vm)
+            self.vm = None
 
     def plaintextBytes(self) -> int:
         """extension: HBM held for the program's plaintexts (pre-encoded pool, or constants + window with DACAPO_HEVM_ONLINE_ENCODE=1)"""

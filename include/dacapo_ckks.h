@@ -47,6 +47,8 @@ void dc_stream_sync(void *stream);
 void dc_set_device(int device);  /* hipSetDevice: one process per GPU, call before creating contexts/VMs */
 void dc_device_sync(void);       /* hipDeviceSynchronize */
 int dc_device_count(void);
+/* free and total HBM of the current device in bytes (hipMemGetInfo) */
+void dc_mem_info(uint64_t *free_bytes, uint64_t *total_bytes);
 /* HIP events on `stream`, for timing the kernels where they are launched (bench.py) */
 void *dc_event_create(void);
 void dc_event_destroy(void *event);

@@ -97,6 +97,10 @@ double hevm_last_run_bootstrap_seconds(void *vm);
 /* HBM bytes held for the loaded program's plaintexts (pre-encoded pool, or constants + encode window with
  * DACAPO_HEVM_ONLINE_ENCODE=1: plaintexts encoded at use, HEAAN_HEVM.cpp:266-281) */
 uint64_t hevm_plaintext_bytes(void *vm);
+/* Frees a VM: its keys, registers, plaintext pool, plan, streams and graph.  The reference's ABI has no such symbol (its VM handles are
+ * allocated with `new` and never freed, SEAL_HEVM.cpp:404-419): a host that creates VMs repeatedly can call this; the handle (and the
+ * pointers hevm_context / getCtxt returned for it) must not be used afterwards. */
+void hevm_destroy(void *vm);
 /* Direct Galois keys for the given slot offsets (left rotation = positive), what KeyGenerator::create_galois_keys(steps, ...)
  * makes in SEAL and what the reference's HEaaN runtime loads for its fixed offset list (HEAAN_HEVM.cpp:58-64,124-126).  A
  * rotation by such an offset is then ONE key switch instead of one per non-zero NAF digit (Evaluator::rotate_internal uses a

@@ -692,3 +692,51 @@ def test_online_encode_is_bit_identical_to_the_pre_encoded_pool(monkeypatch):
     assert a.ell == bb.ell and a.scale == bb.scale and (a.data == bb.data).all()
     assert res["1"][1] > 0 and res["0"][1] > 0   # (this program reads all its plaintexts in two waves: the footprint test is the ResNet one)
     assert np.sqrt(np.mean((res["1"][2] - b.expected()[0]) ** 2)) < 1e-4
+
+
+def test_destroy_returns_the_vms_memory():
+    """hevm_destroy (extension; the reference's VMs are never freed): after close() the device holds what it held before the VM was
+    created, and a new VM of the same shape works -- five cycles do not accumulate."""
+    import ctypes
+
+    from dacapo_amd import hevm_asm as ha
+    from dacapo_amd import lowlevel as ll
+    from dacapo_amd import runner
+
+    L = ll.lib()
+    L.dc_mem_info.argtypes = [ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
+    L.dc_mem_info.restype = None
+
+    def free_bytes():
+        L.dc_device_sync()
+        f, t = ctypes.c_uint64(), ctypes.c_uint64()
+        L.dc_mem_info(ctypes.byref(f), ctypes.byref(t))
+        return f.value
+
+    rng = np.random.default_rng(9)
+    x = rng.uniform(-1, 1, 1 << 13)
+    b = ha.Builder(slots=1 << 13, init_level=4)
+    v = b.input(x)
+    y = b.mul(v, v)
+    b.output(b.add(y, b.rotate(y, 5)))
+    cst, hv, _ = b.assemble()
+
+    def cycle(seed):
+        hevm = runner.HEVM(seed=seed, logN=14, num_primes=6)
+        hevm.addRotationKeys([5])
+        hevm.load_mem(cst, hv)
+        hevm.setInput(0, x)
+        hevm.run()
+        out = hevm.getOutput()[0]
+        hevm.close()
+        return out
+
+    out = cycle(1)  # the first VM also pays for one-time runtime allocations (code objects, the library's own pools)
+    assert np.sqrt(np.mean((out - b.expected()[0]) ** 2)) < 1e-5
+    free0 = free_bytes()
+    for seed in range(2, 6):
+        out = cycle(seed)
+        assert np.sqrt(np.mean((out - b.expected()[0]) ** 2)) < 1e-5
+    free1 = free_bytes()
+    one_vm = 6 * 2 * 6 * (1 << 14) * 8 * 5  # a lower bound on one VM's keys alone (~35 MB)
+    assert free0 - free1 < one_vm, f"{(free0 - free1) / 1e6:.1f} MB still held after four create/destroy cycles"
