@@ -258,8 +258,9 @@ class BootstrapEmitter:
             self._mats = {"cts": cts, "cts_hi_first": cts[0].times_diag_right(np.conj(Dp)), "stc": stc, "Dp": Dp}
         return self._mats
 
-    def linear(self, x: Ct, mat: DiagMatrix, key: str, bits: int | None = None) -> Ct:
-        """y = mat x by baby-step / giant-step, one plaintext product per diagonal, one rescale"""
+    def linear(self, x: Ct, mat: DiagMatrix, key: str, bits: int | None = None, baby_cache: dict | None = None) -> Ct:
+        """y = mat x by baby-step / giant-step, one plaintext product per diagonal, one rescale.  baby_cache: rotations of x by slot
+        offset, shared between transforms of the same ciphertext (the two first-group CoeffToSlot matrices)"""
         bits = self.diag_bits if bits is None else bits
         offs = sorted(mat.d)
         g = 0
@@ -280,7 +281,12 @@ class BootstrapEmitter:
             inner = None
             for i, o in sorted(by_j[j]):
                 if i not in baby:
-                    baby[i] = self.rotate(x, g * i)
+                    if baby_cache is not None and g * i in baby_cache:
+                        baby[i] = baby_cache[g * i]
+                    else:
+                        baby[i] = self.rotate(x, g * i)
+                        if baby_cache is not None:
+                            baby_cache[g * i] = baby[i]
                 term = self.mul_plain(baby[i], (key, o), np.roll(mat.d[o], G), bits)  # rot(d, -G)[k] = d[k - G]
                 inner = term if inner is None else self.add(inner, term)
             inner = self.rotate(inner, G)
@@ -346,8 +352,9 @@ class BootstrapEmitter:
         # EvalMod at a true scale of ~2^60 (every power of w then sits at ~2^60 too): 2^total N q0 / (q q' q'') kp = 2^60
         total = int(round(60 * self.groups - math.log2(self.k_range + 0.25) - self.logN))
         cbits = [total // self.groups + (1 if i < total % self.groups else 0) for i in range(self.groups)]
-        lo = self.linear(ct, M["cts"][0], "cts0", cbits[0])
-        hi = self.linear(ct, M["cts_hi_first"], "cts0h", cbits[0])
+        shared: dict = {}                                       # both transforms rotate the same ciphertext by the same baby steps
+        lo = self.linear(ct, M["cts"][0], "cts0", cbits[0], shared)
+        hi = self.linear(ct, M["cts_hi_first"], "cts0h", cbits[0], shared)
         for gi in range(1, self.groups):
             lo = self.linear(lo, M["cts"][gi], f"cts{gi}", cbits[gi])
             hi = self.linear(hi, M["cts"][gi], f"cts{gi}", cbits[gi])
