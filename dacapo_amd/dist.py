@@ -20,7 +20,8 @@ class Group:
         self.rank, self.local_rank, self.world = env_rank()
         self.dist = None
         self.device = "cpu"
-        if self.world > 1:
+        # DACAPO_FORCE_DIST=1: build the process group at world size 1 too (exercises the RCCL init / barrier / reduction path on a 1-GPU box)
+        if self.world > 1 or os.environ.get("DACAPO_FORCE_DIST") == "1":
             import torch
             import torch.distributed as dist
 
