@@ -103,7 +103,8 @@ def real_bootstrap_leg(ll, runner, steps=3, resnet=True):
     from dacapo_amd import hevm_asm as ha
 
     os.environ["DACAPO_HEVM_SECRET_HW"] = "64"
-    out = {"parameters": "20 x 60-bit primes (19 data + 1 special), secret Hamming weight 64, r = 5 double angles, 3 + 10 + 3 levels",
+    KB = 3 + cb.boot_levels() + 1
+    out = {"parameters": f"{KB} x 60-bit primes ({KB - 1} data + 1 special), secret Hamming weight 64, r = 5 double angles, 4 + 10 + 3 levels",
            "reference": "profiled_HEAAN_GPU.json earth.bootstrap_single: 0.29-0.46 s at N = 2^17 on HEaaN (its GPU unstated)", "single": []}
     try:
         for logN in (15, 17):
@@ -133,9 +134,9 @@ def real_bootstrap_leg(ll, runner, steps=3, resnet=True):
         if resnet:
             fx = ha.read_fixture(ROOT / "tests" / "golden" / "resnet20")
             t0 = time.time()
-            fx["hevm"], fx["cst"] = cb.lower_bootstraps(fx["hevm"], fx["cst"], 15, 20, msg_bits=4)  # every opcode 10 -> real bootstrapping
+            fx["hevm"], fx["cst"] = cb.lower_bootstraps(fx["hevm"], fx["cst"], 15, KB, msg_bits=4)  # every opcode 10 -> real bootstrapping
             t_lower = time.time() - t0
-            hevm = runner.HEVM(seed=0x4845564D, logN=15, num_primes=20)
+            hevm = runner.HEVM(seed=0x4845564D, logN=15, num_primes=KB)
             hevm.addRotationKeys(cb.rotation_offsets(fx["hevm"]))
             hevm.load_mem(fx["cst"], fx["hevm"])
             hevm.setInput(0, fx["packed"])

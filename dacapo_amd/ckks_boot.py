@@ -16,7 +16,7 @@ already executes, plus four extension opcodes (hevm_asm.OP_ENCODE_COMPLEX / OP_C
                   compensating factor), so the 2^-35 drift of each rescale (q = 2^60 - delta) never appears as an error.
     SlotToCoeff   z' = A0 y_lo + D A0 y_hi: the same factors in the other order, on the bit-reversed inputs EvalMod left.
 
-Levels: 3 (CoeffToSlot) + 5 + r (EvalMod) + 3 (SlotToCoeff).  `simulate` interprets a program (all opcodes, the four extensions
+Levels: 3 + 1 (CoeffToSlot) + 5 + r (EvalMod) + 3 (SlotToCoeff): `boot_levels`.  `simulate` interprets a program (all opcodes, the four extensions
 included) on cleartext slot vectors with the exact scale semantics of the VM -- the reference semantics of the extension opcodes and
 the CPU check of the whole construction (tests/test_ckks_boot.py).
 """
@@ -64,6 +64,11 @@ def seal_prime_chain(logN: int, count: int, bits: int = 60):
         if _is_prime(v):
             found.append(v)
     return found[::-1]
+
+
+def boot_levels(r: int = 5, groups: int = 3, taylor_terms: int = 16) -> int:
+    """primes one bootstrap consumes: CoeffToSlot `groups` + 1, EvalMod 5 + r, SlotToCoeff `groups`"""
+    return 2 * groups + 1 + 5 + r - (1 if taylor_terms == 8 else 0)
 
 
 def _norm_off(o: int, n: int) -> int:
@@ -162,14 +167,15 @@ class BootstrapEmitter:
     """Emits the bootstrap of one ciphertext into `b`.  Plaintext registers of the matrices are shared by all bootstraps of a program."""
 
     def __init__(self, b: ha.Builder, logN: int, num_primes: int, target_level: int, r: int = 5, taylor_terms: int = 16, k_range: float = 16.0,
-                 msg_bits: int = 0, diag_bits: int = 55, out_bits: int = 40, groups: int = 3):
+                 msg_bits: int = 0, diag_bits: int = 55, out_bits: int = 40, groups: int = 3, cts_bits: int = 60):
         self.b, self.logN, self.N, self.n = b, logN, 1 << logN, 1 << (logN - 1)
         self.primes = seal_prime_chain(logN, num_primes)
         self.top = num_primes - 1
         self.target, self.r, self.terms, self.k_range = target_level, r, taylor_terms, k_range
-        self.msg_bits, self.diag_bits, self.out_bits, self.groups = msg_bits, diag_bits, out_bits, groups
+        self.msg_bits, self.diag_bits, self.out_bits, self.groups, self.cts_bits = msg_bits, diag_bits, out_bits, groups, cts_bits
         assert taylor_terms in (8, 16), "the polynomial in theta^2 is evaluated as a complete binary tree"
-        self.levels_needed = 2 * groups + 5 + r - (1 if taylor_terms == 8 else 0)
+        # round 3: one more level than round 2 -- CoeffToSlot now ends with two rescales (see `bootstrap`)
+        self.levels_needed = boot_levels(r, groups, taylor_terms)
         assert self.top - self.levels_needed == target_level, (
             f"{num_primes} primes leave {self.top - self.levels_needed} levels after a bootstrap, not {target_level}")
         self._plain_cache: dict = {}
@@ -258,7 +264,7 @@ class BootstrapEmitter:
             self._mats = {"cts": cts, "cts_hi_first": cts[0].times_diag_right(np.conj(Dp)), "stc": stc, "Dp": Dp}
         return self._mats
 
-    def linear(self, x: Ct, mat: DiagMatrix, key: str, bits: int | None = None, baby_cache: dict | None = None) -> Ct:
+    def linear(self, x: Ct, mat: DiagMatrix, key: str, bits: int | None = None, baby_cache: dict | None = None, rescale: bool = True) -> Ct:
         """y = mat x by baby-step / giant-step, one plaintext product per diagonal, one rescale.  baby_cache: rotations of x by slot
         offset, shared between transforms of the same ciphertext (the two first-group CoeffToSlot matrices)"""
         bits = self.diag_bits if bits is None else bits
@@ -291,7 +297,7 @@ class BootstrapEmitter:
                 inner = term if inner is None else self.add(inner, term)
             inner = self.rotate(inner, G)
             total = inner if total is None else self.add(total, inner)
-        return self.rescale(total)
+        return self.rescale(total) if rescale else total
 
     # -- EvalMod -------------------------------------------------------------------------------------------------------------------
     def eval_sine(self, x: Ct) -> Ct:
@@ -311,9 +317,17 @@ class BootstrapEmitter:
         depth = int(math.log2(T))
         out_level = w.level - depth
         P = self._poly(a, pw, depth, out_level, 2.0**60)
-        for _ in range(r):                                      # cos(2 t) = 2 cos^2 t - 1
-            sq = self.rescale(self.mul(P, P))
-            P = self.add_const(self.add(sq, sq), -1.0)
+        for i in range(r):                                      # cos(2 t) = 2 cos^2 t - 1
+            sq = self.mul(P, P)
+            if i < r - 1:
+                sq = self.rescale(sq)
+                P = self.add_const(self.add(sq, sq), -1.0)
+            else:
+                # the last product stays at ~2^120: SlotToCoeff's baby-step rotations then act on a signal 2^60 above their
+                # key-switch noise (sin(2 pi x) = 2 pi eps is tiny), and the rescale is paid after the last group instead.
+                # The constant is added as -1/2 before the doubling: |-1 * 2^120| is the encoder's limit, 2^119 is not.
+                h = self.add_const(sq, -0.5)
+                P = self.add(h, h)
         return P                                                # cos(2 pi (x - 1/4)) = sin(2 pi x)
 
     def _poly(self, a, pw, k, out_level, S) -> Ct:
@@ -348,28 +362,41 @@ class BootstrapEmitter:
             ct = self._op(OP_MULCP, ct, 1, ct.s * 2.0**up, reg)
         delta = ct.s                                             # p = delta * mu ; after ModRaise t = p + q0 I
         ct = self._op(OP_MODRAISE, ct, self.top, 1.0, self.top)  # from here s is relative to z = slots(t)
-        # CoeffToSlot: lo = A0^H z, hi = A0^H conj(D) z.  The plaintext scales of its groups are chosen so that (x - 1/4) / kp enters
-        # EvalMod at a true scale of ~2^60 (every power of w then sits at ~2^60 too): 2^total N q0 / (q q' q'') kp = 2^60
-        total = int(round(60 * self.groups - math.log2(self.k_range + 0.25) - self.logN))
-        cbits = [total // self.groups + (1 if i < total % self.groups else 0) for i in range(self.groups)]
+        # Noise budget (round 3; measured with the CPU oracle, tools/boot_precision.py).  What a bootstrap must preserve is
+        # eps_j = p_j / q0 ~ 2^-(10 + msg_bits) / sqrt(N) per coefficient next to I_j ~ 2, so three absolute error sources that a
+        # ciphertext at scale 2^40 would never notice decide the result: (a) key-switch noise of the baby-step rotations (~2^17 per slot
+        # at N = 2^15, whatever the scale), (b) the integer rounding of the matrix plaintexts (relative 2^-(bits - 7) of |I|), (c) the
+        # conjugation's key switch on the transform's output.  So: the raised ciphertext is multiplied by the integer 2^boost first
+        # (exact: the all-ones "upscale" constant), the matrices are encoded at 2^60, and the transform ends with conj + add on the
+        # un-rescaled sum followed by TWO rescales -- one level more than round 2, (a)-(c) pushed ~2^6 .. 2^40 further down.
+        total = int(round(60 * (self.groups + 1) - math.log2(self.k_range + 0.25) - self.logN))
+        cbits = [min(60, self.cts_bits)] * self.groups
+        boost = total - sum(cbits)
+        assert 0 < boost < 60, boost
+        reg = b._encode(0xFFFF, self.top, boost)
+        ct = self._op(OP_MULCP, ct, self.top, ct.s * 2.0**boost, reg)
+        # CoeffToSlot: lo = A0^H z, hi = A0^H conj(D) z.  boost and the plaintext scales are chosen so that (x - 1/4) / kp enters
+        # EvalMod at a true scale of ~2^60 (every power of w then sits at ~2^60 too): 2^(boost + sum cbits) N q0 / (4 primes * kp) = 2^60
         shared: dict = {}                                       # both transforms rotate the same ciphertext by the same baby steps
-        lo = self.linear(ct, M["cts"][0], "cts0", cbits[0], shared)
-        hi = self.linear(ct, M["cts_hi_first"], "cts0h", cbits[0], shared)
+        last = self.groups - 1
+        lo = self.linear(ct, M["cts"][0], "cts0", cbits[0], shared, rescale=last != 0)
+        hi = self.linear(ct, M["cts_hi_first"], "cts0h", cbits[0], shared, rescale=last != 0)
         for gi in range(1, self.groups):
-            lo = self.linear(lo, M["cts"][gi], f"cts{gi}", cbits[gi])
-            hi = self.linear(hi, M["cts"][gi], f"cts{gi}", cbits[gi])
+            lo = self.linear(lo, M["cts"][gi], f"cts{gi}", cbits[gi], rescale=gi != last)
+            hi = self.linear(hi, M["cts"][gi], f"cts{gi}", cbits[gi], rescale=gi != last)
         outs = []
         for u in (lo, hi):
             v = self.add(u, self.conj(u))                        # 2 Re u = N t  (slots now hold coefficients, bit-reversed)
+            v = self.rescale(self.rescale(v))
             v = Ct(v.v, v.level, v.s * self.N * q0)              # ... read as x = t / q0
-            outs.append(self.eval_sine(v))                       # sin(2 pi x) = 2 pi p / q0 (+ cubic error)
+            outs.append(self.eval_sine(v))                       # sin(2 pi x) = 2 pi p / q0 (+ cubic error), at ~2^120
         # SlotToCoeff: z' = A0 y_lo + D A0 y_hi.  The last group carries kappa so that the result's label is exactly 2^out_bits.
         ylo, yhi = outs
         for gi in range(self.groups - 1):
             ylo = self.linear(ylo, M["stc"][gi], f"stc{gi}")
             yhi = self.linear(yhi, M["stc"][gi], f"stc{gi}")
-        q_last = float(self.primes[ylo.level - 1])
-        s_after = ylo.s * 2.0**self.diag_bits / q_last          # true scale after the last group without kappa
+        q_last, q_fin = float(self.primes[ylo.level - 1]), float(self.primes[ylo.level - 2])
+        s_after = ylo.s * 2.0**self.diag_bits / (q_last * q_fin)  # true scale after the last group and the deferred rescale, without kappa
         # kappa is fixed for the NOMINAL input scale 2^boot_in_bits, so that every bootstrap of a program shares these plaintexts; the
         # instance's own scale (2^-35-level drift of the rescales before it) goes into the final label instead
         delta_nom = 2.0**self.boot_in_bits
@@ -377,9 +404,9 @@ class BootstrapEmitter:
         if "stcL" not in M:
             M["stcL"] = M["stc"][-1].scaled(kappa)
             M["stcLh"] = M["stcL"].times_diag_left(M["Dp"])
-        zlo = self.linear(ylo, M["stcL"], "stcL")
-        zhi = self.linear(yhi, M["stcLh"], "stcLh")
-        z = self.add(zlo, zhi)
+        zlo = self.linear(ylo, M["stcL"], "stcL", rescale=False)
+        zhi = self.linear(yhi, M["stcLh"], "stcLh", rescale=False)
+        z = self.rescale(self.rescale(self.add(zlo, zhi)))
         assert z.level == self.target, (z.level, self.target)
         label = 2.0**self.out_bits * (delta / delta_nom)
         out = self.set_scale(z, label)
@@ -513,7 +540,7 @@ def simulate(hevm: bytes, cst: bytes, inputs, logN: int, primes, secret_weight: 
 # ---- a bootstrap on its own (tools/boot_demo.py, bench.py, tests) ------------------------------------------------------------------
 def single_bootstrap_program(logN: int, target: int = 3, r: int = 5, msg_bits: int = 0):
     """(num_primes, cst, hevm, rotation offsets, emitter) of the program `one ciphertext at 1 prime, scale 2^40 -> bootstrap -> output`"""
-    K = target + 2 * 3 + 5 + r + 1
+    K = target + boot_levels(r) + 1
     b = ha.Builder(slots=1 << (logN - 1), init_level=1, shadow=False)
     x = b.input(None, level=1, scale_bits=40)
     em = BootstrapEmitter(b, logN, K, target, r=r, msg_bits=msg_bits)
@@ -534,7 +561,7 @@ def lower_bootstraps(hevm: bytes, cst: bytes, logN: int, num_primes: int, msg_bi
     stand-in in the SEAL runtime (SEAL_HEVM.cpp:324-334), the real thing in the HEaaN runtime (HEAAN_HEVM.cpp:386-399) -- becomes the
     real bootstrapping sequence of this module.  Everything else is re-emitted unchanged (same instructions, same constants, registers
     re-allocated).  All opcode 10 of the program must restore the same number of primes t, and the chain must hold num_primes =
-    t + 17 primes (r = 5).  Returns (hevm', cst')."""
+    t + boot_levels(r) + 1 primes.  Returns (hevm', cst')."""
     h = ha.unpack_hevm(hevm)
     consts = ha.unpack_cst(cst)
     slots = 1 << (logN - 1)

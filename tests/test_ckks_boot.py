@@ -41,7 +41,7 @@ def test_special_dft_factorisation_for_generator_3(logN):
 
 
 def _boot_program(logN, r=5, target=3, in_level=1):
-    K = target + 16 + 1
+    K = target + cb.boot_levels(r) + 1
     b = ha.Builder(slots=1 << (logN - 1), init_level=in_level, shadow=False)
     x = b.input(None, level=in_level, scale_bits=40)
     em = cb.BootstrapEmitter(b, logN, K, target, r=r)
@@ -67,7 +67,7 @@ def test_bootstrap_on_cleartext_slots_with_exact_scale_semantics():
     outs, trace = cb.simulate(hv, cst, [msg], logN, em.primes, secret_weight=64, return_trace=True)
     assert np.abs(outs[0] - msg).max() < 1e-7 and np.abs(outs[0].imag).max() < 1e-7
     assert trace[-1][2] == 3 and trace[-1][3] == 2.0**40                                   # 3 primes left, label exactly 2^40
-    assert max(t[2] for t in trace) == 19                                                  # ModRaise to the top of a 20-prime chain
+    assert max(t[2] for t in trace) == 20                                                  # ModRaise to the top of a 21-prime chain
 
 
 def test_bootstrap_of_a_real_ciphertext_on_the_cpu_oracle(tmp_path):
@@ -75,7 +75,7 @@ def test_bootstrap_of_a_real_ciphertext_on_the_cpu_oracle(tmp_path):
 
     logN = 10
     em, cst, hv, info, _ = _boot_program(logN)
-    o = Oracle(logN, 20)
+    o = Oracle(logN, 21)
     assert o.primes == em.primes
     offs = sorted({(int(q) - 65536 if q >= 32768 else int(q)) for op, _, _, q in ha.unpack_hevm(hv)["ops"].tolist() if op == ha.OP_ROTATE} - {0})
     o.keygen_sparse(32, seed=3, galois_elts=sorted(set(o.default_galois_elts()) | {o.elt_from_step(s) for s in offs}))
@@ -115,8 +115,8 @@ def test_lowering_opcode_10_of_a_compiled_program_to_real_bootstrapping():
     b.output(b.finish(b.add(y, b.rotate(x, 3))))
     cst, hv, info = b.assemble()
     assert info["op_mix"]["bootstrap"] >= 2
-    hv2, cst2 = cb.lower_bootstraps(hv, cst, logN, 20, msg_bits=1)
+    hv2, cst2 = cb.lower_bootstraps(hv, cst, logN, 21, msg_bits=1)
     ops = ha.unpack_hevm(hv2)["ops"]
     assert int((ops[:, 0] == ha.OP_BOOTSTRAP).sum()) == 0 and int((ops[:, 0] == ha.OP_MODRAISE).sum()) == info["op_mix"]["bootstrap"]
-    out = cb.simulate(hv2, cst2, [x.plain], logN, cb.seal_prime_chain(logN, 20))[0]
+    out = cb.simulate(hv2, cst2, [x.plain], logN, cb.seal_prime_chain(logN, 21))[0]
     assert np.abs(out.real - b.expected()[0]).max() < 1e-5 and np.abs(out.imag).max() < 1e-5

@@ -18,7 +18,7 @@ def _program(logN, target=3, r=5):
     from dacapo_amd import ckks_boot as cb
     from dacapo_amd import hevm_asm as ha
 
-    K = target + 16 + 1
+    K = target + cb.boot_levels(r) + 1
     b = ha.Builder(slots=1 << (logN - 1), init_level=1, shadow=False)
     x = b.input(None, level=1, scale_bits=40)
     em = cb.BootstrapEmitter(b, logN, K, target, r=r)
@@ -130,7 +130,7 @@ def test_bootstrap_at_the_reference_ring_restores_levels_and_message():
     c = hevm.getCtxt(hevm.getResIdx(0))
     assert c.level == 3 and c.scale == 2.0**40
     err = np.abs(hevm.getOutput()[0] - msg)
-    assert err.max() < 2e-4 and np.sqrt(np.mean(err**2)) < 1e-5              # measured: 1e-5 / 4e-7
+    assert err.max() < 1e-6 and np.sqrt(np.mean(err**2)) < 1e-7              # measured: 7e-8 / 1.5e-8 = 23.7 / 26 bits (round 2: 1e-5 / 4e-7)
 
 
 def test_resnet20_with_real_bootstraps_decrypts_to_the_torch_logits():
@@ -142,14 +142,15 @@ def test_resnet20_with_real_bootstraps_decrypts_to_the_torch_logits():
     from dacapo_amd import hevm_asm as ha
 
     fx = ha.read_fixture(Path(__file__).resolve().parent / "golden" / "resnet20")
-    hv, cst = cb.lower_bootstraps(fx["hevm"], fx["cst"], 15, 20, msg_bits=4)
+    hv, cst = cb.lower_bootstraps(fx["hevm"], fx["cst"], 15, 3 + cb.boot_levels() + 1, msg_bits=4)
     ops = ha.unpack_hevm(hv)["ops"]
     assert int((ops[:, 0] == ha.OP_MODRAISE).sum()) == 526 and int((ops[:, 0] == ha.OP_BOOTSTRAP).sum()) == 0
-    hevm = _vm(15, 20, 64, cb.rotation_offsets(hv))
+    hevm = _vm(15, 3 + cb.boot_levels() + 1, 64, cb.rotation_offsets(hv))
     hevm.load_mem(cst, hv)
     hevm.setInput(0, fx["packed"])
     hevm.run()
     out = hevm.getOutput()[0]
-    assert float(np.sqrt(np.mean((out - fx["expected"]) ** 2))) < 2e-4                     # measured 2e-5
-    assert float(np.sqrt(np.mean((out[:10] * 32 - fx["torch_result"]) ** 2))) < 0.05        # measured 0.01 (logits are x32)
+    assert float(np.sqrt(np.mean((out - fx["expected"]) ** 2))) < 5e-6                     # measured 3.5e-7 (round 2: 2e-5)
+    # the reference's own acceptance figure for its run is 9.5e-4 (README.md:189); the cleartext evaluation of this trace is 5.4e-4 from torch
+    assert float(np.sqrt(np.mean((out[:10] * 32 - fx["torch_result"]) ** 2))) < 2e-3        # measured 6.1e-4 (round 2: 1e-2; logits are x32)
     assert int(np.argmax(out[:10])) == int(np.argmax(fx["torch_result"]))

@@ -24,16 +24,17 @@ direct = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 name = sys.argv[2] if len(sys.argv) > 2 else "resnet20"
 logN = int(sys.argv[3]) if len(sys.argv) > 3 else 15
 msg_bits = int(sys.argv[4]) if len(sys.argv) > 4 else 4
+KB = 3 + cb.boot_levels() + 1  # 3 primes left after a bootstrap + the special prime
 fx = ha.read_fixture(ROOT / "tests" / "golden" / name)
 assert fx["meta"]["slots"] == 1 << (logN - 1), "the fixture was traced for another slot count"
 t0 = time.time()
-fx["hevm"], fx["cst"] = cb.lower_bootstraps(fx["hevm"], fx["cst"], logN, 20, msg_bits=msg_bits)
+fx["hevm"], fx["cst"] = cb.lower_bootstraps(fx["hevm"], fx["cst"], logN, KB, msg_bits=msg_bits)
 print(f"opcode 10 -> real bootstrapping: {time.time()-t0:.1f} s", flush=True)
 h = ha.unpack_hevm(fx["hevm"])
 ops = h["ops"]
 print(f"{len(ops)} instructions, {h['num_ptxt']} plaintext registers, {int((ops[:, 0] == ha.OP_MODRAISE).sum())} real bootstraps", flush=True)
 t0 = time.time()
-hevm = runner.HEVM(seed=0x4845564D, logN=logN, num_primes=20)
+hevm = runner.HEVM(seed=0x4845564D, logN=logN, num_primes=KB)
 if direct:
     offs = cb.rotation_offsets(fx["hevm"])
     if direct == 2:  # direct keys for the bootstraps' own rotations only (they run at up to 19 primes); the model's rotations run at 1-3 primes,
@@ -50,7 +51,7 @@ hevm.run()
 dt = time.perf_counter() - t0
 out = hevm.getOutput()[0]
 st = hevm.stats()
-res = {"fixture": name, "N": 1 << logN, "slots": 1 << (logN - 1), "primes": 20, "msg_bits": msg_bits, "instructions": int(len(ops)), "run_s": round(dt, 3), "key_switches": st["keyswitches"], "ntt_equivalents": st["ntts"], "ntt_per_s": round(st["ntts"] / dt),
+res = {"fixture": name, "N": 1 << logN, "slots": 1 << (logN - 1), "primes": KB, "msg_bits": msg_bits, "instructions": int(len(ops)), "run_s": round(dt, 3), "key_switches": st["keyswitches"], "ntt_equivalents": st["ntts"], "ntt_per_s": round(st["ntts"] / dt),
        "real_bootstraps": int((ops[:, 0] == ha.OP_MODRAISE).sum()),
        "rms_vs_torch": float(np.sqrt(np.mean((out[:10] * 32 - fx["torch_result"]) ** 2))),
        "rms_vs_plaintext_evaluation": float(np.sqrt(np.mean((out - fx["expected"]) ** 2))),
