@@ -121,6 +121,20 @@ void dc_ntt_inverse(dc_context *ctx, uint64_t *data, long limb_stride, int count
     launch_ntt(*ctx->c, true, data, limb_stride, count, d_prime_idx, prime_base, prime_period, S(stream));
 }
 
+// variant 0: the two-launch tiles whatever the batch size; 1: the single-crossing kernel (N = 2^15 only; aborts otherwise)
+void dc_ntt_variant(dc_context *ctx, int variant, int inverse, uint64_t *data, long limb_stride, int count, const int32_t *d_prime_idx,
+                    int prime_base, int prime_period, void *stream)
+{
+    if (variant == 1) {
+        if (!ntt_full_supported(*ctx->c)) {
+            fprintf(stderr, "[dacapo_amd] dc_ntt_variant: the single-crossing transform exists for N = 2^15 only\n");
+            abort();
+        }
+        launch_ntt_full(*ctx->c, inverse != 0, data, limb_stride, count, d_prime_idx, prime_base, prime_period, S(stream));
+    } else
+        launch_ntt_two_phase(*ctx->c, inverse != 0, data, limb_stride, count, d_prime_idx, prime_base, prime_period, S(stream));
+}
+
 void dc_ct_negate(dc_context *ctx, uint64_t *dst, long dst_stride, const uint64_t *a, long a_stride, int ell, void *stream)
 {
     launch_ew(*ctx->c, EwOp::Neg, V(dst, dst_stride), V(a, a_stride), V(a, a_stride), 2, 2, ell, S(stream));

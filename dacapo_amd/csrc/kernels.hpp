@@ -21,6 +21,16 @@ struct CtView {
 void launch_ntt(const Context &c, bool inverse, u64 *data, long limb_stride, int count, const int *d_prime_idx,
                 int prime_base, int prime_period, hipStream_t s);
 
+// the two-launch transform whatever the batch size
+void launch_ntt_two_phase(const Context &c, bool inverse, u64 *data, long limb_stride, int count, const int *d_prime_idx,
+                          int prime_base, int prime_period, hipStream_t s);
+// single-crossing transform (ntt_full.hip): one 1024-thread workgroup per limb, N = 2^15 only.  launch_ntt takes it for launches of
+// at least ntt_full_min_limbs() limbs (DACAPO_NTT_FULL_MIN_LIMBS / DACAPO_NTT_FULL_INV_MIN_LIMBS; 0 = never)
+bool ntt_full_supported(const Context &c);
+long ntt_full_min_limbs(bool inverse);
+void launch_ntt_full(const Context &c, bool inverse, u64 *data, long limb_stride, int count, const int *d_prime_idx, int prime_base,
+                     int prime_period, hipStream_t s);
+
 // second (ROWS) phase of a forward NTT only: the input holds the output of a COLS phase (fused_ks.hip)
 void launch_ntt_rows_fwd(const Context &c, u64 *data, long limb_stride, int count, const int *d_prime_idx, int prime_base,
                          int prime_period, hipStream_t s);

@@ -42,6 +42,7 @@ def lib():
         L.dc_event_elapsed_ms.argtypes = [vp, vp]
         for f in (L.dc_ntt_forward, L.dc_ntt_inverse):
             f.argtypes = [vp, u64p, lng, i32, vp, i32, i32, vp]
+        L.dc_ntt_variant.argtypes = [vp, i32, i32, u64p, lng, i32, vp, i32, i32, vp]
         L.dc_ct_negate.argtypes = [vp, u64p, lng, u64p, lng, i32, vp]
         L.dc_ct_add.argtypes = [vp, u64p, lng, u64p, lng, u64p, lng, i32, vp]
         L.dc_ct_add_plain.argtypes = [vp, u64p, lng, u64p, lng, u64p, i32, vp]
@@ -125,10 +126,14 @@ class Context:
         lib().dc_stream_sync(stream)
 
     def ntt(self, buf: DeviceBuffer, count, inverse=False, prime_idx: DeviceBuffer | None = None, prime_base=0,
-            prime_period=0, limb_stride=None, offset=0, stream=None):
-        f = lib().dc_ntt_inverse if inverse else lib().dc_ntt_forward
-        f(self.h, buf.at(offset), self.N if limb_stride is None else limb_stride, count,
-          prime_idx.ptr if prime_idx is not None else None, prime_base, prime_period, stream)
+            prime_period=0, limb_stride=None, offset=0, stream=None, variant=None):
+        """variant None: the library chooses by batch size; 0 / 1: the two-launch tiles / the single-crossing kernel (dc_ntt_variant)"""
+        args = (buf.at(offset), self.N if limb_stride is None else limb_stride, count,
+                prime_idx.ptr if prime_idx is not None else None, prime_base, prime_period, stream)
+        if variant is None:
+            (lib().dc_ntt_inverse if inverse else lib().dc_ntt_forward)(self.h, *args)
+        else:
+            lib().dc_ntt_variant(self.h, variant, int(inverse), *args)
 
     def elt_from_step(self, step: int) -> int:
         return int(lib().dc_galois_elt_from_step(self.h, step))

@@ -64,6 +64,12 @@ void dc_ntt_forward(dc_context *ctx, uint64_t *data, long limb_stride, int count
 void dc_ntt_inverse(dc_context *ctx, uint64_t *data, long limb_stride, int count, const int32_t *d_prime_idx, int prime_base,
                     int prime_period, void *stream);
 
+/* The same transform with the implementation named (tests and bench.py compare them; dc_ntt_forward/inverse choose by batch size):
+ * variant 0 = two launches per transform (ntt_tile.hpp), 1 = one 1024-thread workgroup per limb, one HBM crossing (ntt_full.hip,
+ * N = 2^15 only). */
+void dc_ntt_variant(dc_context *ctx, int variant, int inverse, uint64_t *data, long limb_stride, int count, const int32_t *d_prime_idx,
+                    int prime_base, int prime_period, void *stream);
+
 /* Evaluator::negate            SEAL_HEVM.cpp:278 */
 void dc_ct_negate(dc_context *ctx, uint64_t *dst, long dst_stride, const uint64_t *a, long a_stride, int ell, void *stream);
 /* Evaluator::add               SEAL_HEVM.cpp:302 */

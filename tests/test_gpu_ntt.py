@@ -83,7 +83,8 @@ def test_linearity_and_convolution_at_full_size():
 
 @pytest.mark.parametrize("logN,K,limbs", [(15, 14, 520), (17, 3, 136)])
 def test_large_batch_uses_the_throughput_tiles_and_matches_oracle(logN, K, limbs):
-    """>= 5000 workgroups per launch: the radix-8 (2048-coefficient) tile geometry, the one bench.py's roofline leg times.
+    """>= 5000 workgroups per launch: the radix-8 (2048-coefficient) tile geometry (round 3: at N = 2^15 the roofline leg's forward
+    transform takes the single-crossing kernel from 1024 limbs on; this batch of 520 stays on the tiles, and N = 2^17 always does).
     Forward == oracle on a spread of limbs, repeated launches agree, forward/inverse round trips are exact."""
     ll, ctx = _ctx(logN, K)
     o = Oracle(logN, K)
@@ -103,3 +104,48 @@ def test_large_batch_uses_the_throughput_tiles_and_matches_oracle(logN, K, limbs
         assert (got == first).all()
         ctx.ntt(d, limbs, inverse=True, prime_base=0, prime_period=K)
         assert (d.to_host() == a).all()
+
+
+def test_single_crossing_kernel_matches_oracle_and_the_two_launch_tiles():
+    """ntt_full.hip (one 1024-thread workgroup per limb of N = 2^15, one HBM crossing) through dc_ntt_variant: forward and inverse ==
+    oracle bit for bit on an irregular prime pattern and on the edge limbs (zeros, q - 1), with a limb stride, and == the two-launch
+    transform on a batch large enough that dc_ntt_forward itself takes the single-crossing kernel (>= 1024 limbs)."""
+    ll, ctx = _ctx(15, 14)
+    o = Oracle(15, 14)
+    N, K = 1 << 15, 14
+    pidx = list(range(K)) + [K - 1, 0, 5]
+    a = np.stack([splitmix_fill(0x51C0 + b, N) % np.uint64(o.primes[p]) for b, p in enumerate(pidx)])
+    a[0, : N // 2] = 0
+    a[1, :] = np.uint64(o.primes[pidx[1]] - 1)
+    di = ll.DeviceBuffer.from_host(np.array(pidx, dtype=np.int32))
+    d = ll.DeviceBuffer.from_host(a)
+    ctx.ntt(d, len(pidx), prime_idx=di, variant=1)
+    assert (d.to_host() == o.ntt_fwd(a, pidx)).all()
+    ctx.ntt(d, len(pidx), inverse=True, prime_idx=di, variant=1)
+    assert (d.to_host() == a).all()
+    d2 = ll.DeviceBuffer.from_host(a)
+    ctx.ntt(d2, len(pidx), inverse=True, prime_idx=di, variant=1)
+    assert (d2.to_host() == o.ntt_inv(a, pidx)).all()
+    # stride 2N, arithmetic prime pattern: the unused halves stay untouched
+    s = np.zeros((6, 2, N), dtype=np.uint64)
+    for b in range(6):
+        s[b, 0] = splitmix_fill(b + 11, N) % np.uint64(o.primes[2 + b % 4])
+        s[b, 1] = np.uint64(0xDEADBEEF)
+    ds = ll.DeviceBuffer.from_host(s)
+    ctx.ntt(ds, 6, prime_base=2, prime_period=4, limb_stride=2 * N, variant=1)
+    got = ds.to_host()
+    assert (got[:, 1] == np.uint64(0xDEADBEEF)).all()
+    assert (got[:, 0] == o.ntt_fwd(s[:, 0], [2 + b % 4 for b in range(6)])).all()
+    # a batch at which the library's own choice is the single-crossing kernel (forward) / the two-launch tiles (inverse)
+    limbs = 1040
+    big = np.stack([splitmix_fill(0x4845564D + b, N) % np.uint64(o.primes[b % K]) for b in range(limbs)])
+    outs = []
+    for variant in (0, 1, None):
+        db = ll.DeviceBuffer.from_host(big)
+        ctx.ntt(db, limbs, prime_base=0, prime_period=K, variant=variant)
+        outs.append(db.to_host())
+        ctx.ntt(db, limbs, inverse=True, prime_base=0, prime_period=K, variant=variant)
+        assert (db.to_host() == big).all()
+    assert (outs[0] == outs[1]).all() and (outs[0] == outs[2]).all()
+    check = [0, 1, 13, 14, 517, limbs - 1]
+    assert (outs[1][check] == o.ntt_fwd(big[check], [b % K for b in check])).all()

@@ -10,7 +10,7 @@ for arg in "$@"; do
   name=${arg%%:*}; flags=${arg#*:}
   B=/tmp/sweep_build_$name
   mkdir -p $B
-  for f in ntt_kernels fused_ks; do
+  for f in ntt_kernels fused_ks ntt_full; do
     /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -Wno-pass-failed $flags -c $f.hip -o $B/$f.o &
   done
   wait
