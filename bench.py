@@ -303,8 +303,11 @@ def build_parser():
     ap.add_argument("--layers", type=int, default=20, help="--program shaped: depth (20 = the traced op mix)")
     ap.add_argument("--streams", type=int, default=1, help="independent ciphertext streams per GPU (throughput mode; 1 = the reference's one image per run)")
     ap.add_argument("--no-lowerings", action="store_true", help="skip the other lowerings of the trace (config.lowerings)")
-    ap.add_argument("--config4", action="store_true",
-                    help="also run BASELINE config 4's shape (ResNet-20 traced at nt = 2^16, N = 2^17, real bootstrapping; ~2 min, ~70 GB of HBM)")
+    ap.add_argument("--no-config4", dest="config4", action="store_false",
+                    help="skip BASELINE config 4's shape (ResNet-20 traced at nt = 2^16, N = 2^17, real bootstrapping; ~2.5 min, ~75 GB of HBM); "
+                         "it runs by default since round 3, in a child process before this one touches the GPU")
+    ap.add_argument("--config4", dest="config4", action="store_true", help="(default)")
+    ap.set_defaults(config4=True)
     ap.add_argument("--dry-run", action="store_true",
                     help="exercise the launch / rank / aggregation path without a GPU: no kernel runs, the step is a sleep, the process "
                          "group uses gloo (tests/test_dist_gloo.py)")
@@ -378,7 +381,8 @@ def main():
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(spawn_ranks(args, argv))
 
-    config4 = config4_child() if (args.config4 and args.gpus == 1 and not args.dry_run) else None
+    # rank 0 of a 1-GPU run only: the other legs of the line are N = 1 figures as well
+    config4 = config4_child() if (args.config4 and args.gpus == 1 and not args.dry_run and "RANK" not in os.environ) else None
 
     from dacapo_amd.dist import Group
 
@@ -525,8 +529,6 @@ def main():
     cfg3 = cfg3_leg(ll)
     per_op = per_op_leg(ll)
     real_boot = real_bootstrap_leg(ll, runner) if (world == 1 and not args.no_lowerings) else None
-    if real_boot is not None and config4 is not None:
-        real_boot["config4_resnet20_nt65536_N131072"] = config4
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline_leg(cst, hv, image)
@@ -553,6 +555,9 @@ def main():
         "cfg3_mul_relin": cfg3,
         "per_op_13_primes": per_op,
         "real_bootstrap": real_boot,
+        # BASELINE config 4's shape (run_s, rms_vs_torch, key switches, ...): tools/resnet_real_boot.py in a child process; null under
+        # --no-config4, --gpus > 1 or an external launcher
+        "config4_resnet20_nt65536_N131072": config4,
         "cpu_baseline": cpu,
     }
     if cpu:
