@@ -58,6 +58,7 @@ typedef struct orc_ctx {
     int logN;
     size_t N;
     int K; /* number of primes in the key-level chain (data primes 0..K-2, special prime K-1) */
+    int ks, alpha; /* grouped-digit extension (orc_set_hybrid): ks special primes K-ks..K-1, digits of alpha data primes; 1, 1 = SEAL */
     orc_mod mod[ORC_MAX_PRIMES];
     u64 psi[ORC_MAX_PRIMES];     /* minimal primitive 2N-th root */
     u64 *rp[ORC_MAX_PRIMES];     /* rp[k]  = psi^{bitrev(k)}           (SEAL NTTTables::root_powers_) */
@@ -244,6 +245,7 @@ orc_ctx *orc_create(int logN, int K, int bit_size, const u64 *primes)
     c->logN = logN;
     c->N = ((size_t)1) << logN;
     c->K = K;
+    c->ks = c->alpha = 1;
     u64 chain[ORC_MAX_PRIMES];
     if (primes)
         memcpy(chain, primes, sizeof(u64) * K);
@@ -752,6 +754,124 @@ void orc_keyswitch_inner_simple(const orc_ctx *c, int ell, const u64 *target, co
 }
 
 /* ------------------------------------------------------------------------------------------------
+ * EXTENSION (not SEAL, not in the reference's SEAL runtime): hybrid key switching with GROUPED digits -- dnum = ceil(L / alpha)
+ * digits of alpha data primes each and ks special primes (Han-Ki 2020; what the reference's HEaaN runtime does inside its closed
+ * library: HEAAN_HEVM.cpp:124-141 keygen, :386-399 bootstrap at 29 levels).  The published algorithm, restated on canonical residues
+ * with the INTEGER fast base conversion (no floating-point correction), so that every implementation agrees bit for bit:
+ *   digit g of the target = its residues modulo S_g = {q_i : g alpha <= i < min((g+1) alpha, ell)} (coefficient domain), raised to
+ *   every other modulus m of {q_0..q_{ell-1}, p_0..p_{ks-1}} as   sum_{i in S_g} [x_i (Q_g/q_i)^{-1}]_{q_i} (Q_g/q_i)  mod m
+ *   (= x + u Q_g, 0 <= u < |S_g|: the overshoot only multiplies the key's error term); inner products with key[g];
+ *   mod-down by P = p_0 ... p_{ks-1} with rounding: r = [acc + floor(P/2)]_P converted the same way to q_i, out_i = (acc_i -
+ *   (conv_i - floor(P/2) mod q_i)) P^{-1} mod q_i  (= round(acc / P) - u', 0 <= u' < ks).
+ * With ks = alpha = 1 every step degenerates to SEAL's switch_key_inplace above (tested: identical limbs).
+ * key: [dnum][2][K][N], digit g = (-(a s + e) + [i in group g] (P mod q_i) s'_i , a).
+ * ---------------------------------------------------------------------------------------------- */
+int orc_set_hybrid(orc_ctx *c, int ks, int alpha)
+{
+    if (ks < 1 || alpha < 1 || alpha > ks || ks >= c->K) return -1; /* P must cover a digit: alpha <= ks */
+    c->ks = ks;
+    c->alpha = alpha;
+    return 0;
+}
+int orc_hybrid_dnum(const orc_ctx *c) { return (c->K - c->ks + c->alpha - 1) / c->alpha; }
+
+static u64 prod_mod_except(const orc_ctx *c, int lo, int hi, int skip, u64 m)
+{ /* product of primes lo..hi-1 except `skip`, modulo m */
+    u64 r = 1 % m;
+    for (int t = lo; t < hi; t++)
+        if (t != skip) r = mulmod_simple(r, c->mod[t].q % m, m);
+    return r;
+}
+
+void orc_keyswitch_hybrid(const orc_ctx *c, int ell, const u64 *target, const u64 *key, u64 *out0, u64 *out1)
+{
+    size_t N = c->N;
+    int K = c->K, ks = c->ks, al = c->alpha, L = K - ks, M = ell + ks;
+    int G = (ell + al - 1) / al;
+    size_t key_poly = (size_t)K * N, key_digit = 2 * key_poly;
+    u64 *coef = (u64 *)malloc((size_t)ell * N * 8);
+    u64 *y = (u64 *)malloc((size_t)al * N * 8);
+    u64 *t = (u64 *)malloc(N * 8);
+    u64 *prod = (u64 *)calloc((size_t)2 * M * N, 8); /* [2][ell + ks][N], canonical running sums */
+    memcpy(coef, target, (size_t)ell * N * 8);
+    for (int j = 0; j < ell; j++) orc_ntt_inv(c, j, coef + (size_t)j * N);
+    for (int g = 0; g < G; g++) {
+        int lo = g * al, hi = lo + al < ell ? lo + al : ell;
+        for (int i = lo; i < hi; i++) { /* y_i = [x_i (Q_g/q_i)^{-1}]_{q_i} */
+            const orc_mod *mi = &c->mod[i];
+            u64 inv = invmod_prime(prod_mod_except(c, lo, hi, i, mi->q), mi->q);
+            for (size_t n = 0; n < N; n++) y[(size_t)(i - lo) * N + n] = mulmod(coef[(size_t)i * N + n], inv, mi);
+        }
+        for (int I = 0; I < M; I++) {
+            int pm = I < ell ? I : L + (I - ell);
+            const orc_mod *m = &c->mod[pm];
+            const u64 *operand;
+            if (I >= lo && I < hi)
+                operand = target + (size_t)I * N; /* a modulus of the digit's own group: the NTT-form limb itself */
+            else {
+                u64 w[ORC_MAX_PRIMES];
+                for (int i = lo; i < hi; i++) w[i - lo] = prod_mod_except(c, lo, hi, i, m->q);
+                for (size_t n = 0; n < N; n++) {
+                    u64 a = 0;
+                    for (int i = lo; i < hi; i++) a = addmod(a, mulmod(barrett64(y[(size_t)(i - lo) * N + n], m), w[i - lo], m), m->q);
+                    t[n] = a;
+                }
+                orc_ntt_fwd(c, pm, t);
+                operand = t;
+            }
+            for (int kc = 0; kc < 2; kc++) {
+                const u64 *kk = key + (size_t)g * key_digit + (size_t)kc * key_poly + (size_t)pm * N;
+                u64 *o = prod + ((size_t)kc * M + I) * N;
+                for (size_t n = 0; n < N; n++) o[n] = addmod(o[n], mulmod(operand[n], kk[n], m), m->q);
+            }
+        }
+    }
+    /* mod-down by P with rounding */
+    u64 *z = (u64 *)malloc((size_t)ks * N * 8);
+    for (int kc = 0; kc < 2; kc++) {
+        u64 *pp = prod + (size_t)kc * M * N;
+        u64 *out = kc ? out1 : out0;
+        for (int j = 0; j < ks; j++) {
+            int pj = L + j;
+            const orc_mod *m = &c->mod[pj];
+            u64 *r = pp + (size_t)(ell + j) * N;
+            orc_ntt_inv(c, pj, r);
+            u64 Pm = prod_mod_except(c, L, K, -1, m->q); /* = 0 */
+            (void)Pm;
+            /* floor(P/2) mod p_j: P is odd and = 0 mod p_j, so floor(P/2) = (P - 1)/2 = -(1/2) mod p_j = (p_j - 1)/2 */
+            u64 half = (m->q - 1) >> 1;
+            u64 inv = invmod_prime(prod_mod_except(c, L, K, pj, m->q), m->q);
+            for (size_t n = 0; n < N; n++) z[(size_t)j * N + n] = mulmod(addmod(r[n], half, m->q), inv, m);
+        }
+        for (int i = 0; i < ell; i++) {
+            const orc_mod *m = &c->mod[i];
+            u64 qi = m->q, w[ORC_MAX_PRIMES];
+            for (int j = 0; j < ks; j++) w[j] = prod_mod_except(c, L, K, L + j, qi);
+            u64 Pq = prod_mod_except(c, L, K, -1, qi);
+            u64 inv2 = (qi + 1) >> 1;                                   /* 2^{-1} mod q_i */
+            u64 half_q = mulmod(submod(Pq, 1 % qi, qi), inv2, m);       /* floor(P/2) = (P - 1)/2 mod q_i */
+            u64 inv_p = invmod_prime(Pq, qi);
+            for (size_t n = 0; n < N; n++) {
+                u64 a = 0;
+                for (int j = 0; j < ks; j++) a = addmod(a, mulmod(barrett64(z[(size_t)j * N + n], m), w[j], m), qi);
+                t[n] = submod(a, half_q, qi);
+            }
+            orc_ntt_fwd(c, i, t);
+            u64 *x = pp + (size_t)i * N;
+            for (size_t n = 0; n < N; n++) {
+                u64 v = mulmod(submod(x[n], t[n], qi), inv_p, m);
+                out[(size_t)i * N + n] = addmod(out[(size_t)i * N + n], v, qi);
+            }
+        }
+    }
+    free(coef);
+    free(y);
+    free(t);
+    free(prod);
+    free(z);
+}
+
+/* ------------------------------------------------------------------------------------------------
  * CKKS encoder / decoder  [SEAL-upstream ckks.h/ckks.cpp CKKSEncoder::encode_internal /
  * decode_internal, dwthandler.h transform_from_rev / transform_to_rev]
  * -- reached from SEAL_HEVM.cpp:262 (encode), :331,:451 (decode).
@@ -1048,6 +1168,26 @@ void orc_gen_kswitch(const orc_ctx *c, const u64 *sk, const u64 *new_key, u64 *s
         for (size_t n = 0; n < N; n++) {
             size_t k = (size_t)j * N + n;
             dj[k] = addmod(dj[k], mulmod(new_key[k], factor, m), m->q);
+        }
+    }
+}
+
+/* grouped-digit key (extension, see orc_keyswitch_hybrid): [dnum][2][K][N] */
+void orc_gen_kswitch_hybrid(const orc_ctx *c, const u64 *sk, const u64 *new_key, u64 *seed, u64 *ksk)
+{
+    size_t N = c->N;
+    int K = c->K, L = K - c->ks, dnum = orc_hybrid_dnum(c);
+    for (int g = 0; g < dnum; g++) {
+        u64 *dg = ksk + (size_t)g * 2 * K * N;
+        encrypt_zero_symmetric(c, sk, K, seed, dg);
+        int lo = g * c->alpha, hi = lo + c->alpha < L ? lo + c->alpha : L;
+        for (int i = lo; i < hi; i++) {
+            const orc_mod *m = &c->mod[i];
+            u64 factor = prod_mod_except(c, L, K, -1, m->q); /* P mod q_i */
+            for (size_t n = 0; n < N; n++) {
+                size_t k = (size_t)i * N + n;
+                dg[k] = addmod(dg[k], mulmod(new_key[k], factor, m), m->q);
+            }
         }
     }
 }

@@ -119,6 +119,23 @@ class Oracle:
         self.rng = C.c_uint64(0x4845564D)
         self.sk = self.pk = self.relin = None
         self.galois = {}
+        self.ks, self.alpha = 1, 1  # SEAL: one special prime, one prime per digit
+
+    def set_hybrid(self, ks: int, alpha: int | None = None):
+        """EXTENSION (not SEAL): grouped-digit hybrid key switching -- the last `ks` primes are special, digits are groups of `alpha`
+        data primes (default alpha = ks); keys become [dnum][2][K][N] (orc_keyswitch_hybrid).  set_hybrid(1, 1) is SEAL's scheme."""
+        alpha = ks if alpha is None else alpha
+        if self.L.orc_set_hybrid(self.ctx, ks, alpha) != 0:
+            raise ValueError("bad hybrid parameters")
+        self.ks, self.alpha = ks, alpha
+
+    @property
+    def max_level(self) -> int:
+        return self.K - self.ks
+
+    @property
+    def dnum(self) -> int:
+        return -(-(self.K - self.ks) // self.alpha)
 
     def __del__(self):
         try:
@@ -253,6 +270,10 @@ class Oracle:
     def keyswitch(self, target: np.ndarray, key: np.ndarray, out0: np.ndarray, out1: np.ndarray):
         """Adds switch_key(target) into (out0, out1) in place. target/out: [ell][N]; key: [K-1][2][K][N]."""
         target = np.ascontiguousarray(target, dtype=np.uint64)
+        if (self.ks, self.alpha) != (1, 1):
+            assert key.flags["C_CONTIGUOUS"] and key.shape == (self.dnum, 2, self.K, self.N) and target.shape[0] <= self.max_level
+            self.L.orc_keyswitch_hybrid(self.ctx, target.shape[0], _p(target), _p(key), _p(out0), _p(out1))
+            return
         assert key.flags["C_CONTIGUOUS"] and key.shape == (self.K - 1, 2, self.K, self.N)
         self.L.orc_keyswitch(self.ctx, target.shape[0], _p(target), _p(key), _p(out0), _p(out1))
 
@@ -340,6 +361,10 @@ class Oracle:
             self.add_galois_key(elt)
 
     def gen_kswitch(self, new_key: np.ndarray) -> np.ndarray:
+        if (self.ks, self.alpha) != (1, 1):
+            ksk = np.zeros((self.dnum, 2, self.K, self.N), dtype=np.uint64)
+            self.L.orc_gen_kswitch_hybrid(self.ctx, _p(self.sk), _p(np.ascontiguousarray(new_key)), C.byref(self.rng), _p(ksk))
+            return ksk
         ksk = np.zeros((self.K - 1, 2, self.K, self.N), dtype=np.uint64)
         self.L.orc_gen_kswitch(self.ctx, _p(self.sk), _p(np.ascontiguousarray(new_key)), C.byref(self.rng), _p(ksk))
         return ksk

@@ -1,0 +1,124 @@
+"""CPU: the grouped-digit hybrid key switch of the oracle (oracle/ckks_oracle.c orc_keyswitch_hybrid; an EXTENSION -- what the reference's
+HEaaN runtime does inside its closed library, HEAAN_HEVM.cpp:124-141 / :386-399 -- not SEAL's scheme):
+  * with one special prime and one prime per digit it IS SEAL's switch_key_inplace: identical key layout and identical limbs;
+  * with real groups (ks special primes, digits of alpha primes, including a partial last digit and levels below the chain's top) a
+    rotation / relinearisation still decrypts to the right message, with noise of the same order as SEAL's scheme;
+  * its closed form: the output equals round(sum_g d~_g key_g / P) limb for limb, recomputed with Python integers on a small ring."""
+import numpy as np
+import pytest
+
+from oracle.oracle import Ciphertext, Oracle
+
+
+def test_degenerate_hybrid_is_seals_key_switch():
+    logN, K = 10, 5
+    a, b = Oracle(logN, K), Oracle(logN, K)
+    b.set_hybrid(1, 1)
+    b.ks, b.alpha = 2, 2          # force the hybrid code path in the wrapper while the C context stays at (1, 1)
+    a.keygen(seed=7, galois_elts=[3])
+    b.rng.value = 0
+    b.sk, b.pk = a.sk, a.pk
+    # same randomness -> same key
+    a2 = Oracle(logN, K)
+    a2.keygen(seed=7, galois_elts=[3])
+    assert (a2.galois[3] == a.galois[3]).all()
+    rng = np.random.default_rng(1)
+    for ell in (1, 2, 4):
+        q = np.array(a.primes[:ell], dtype=np.uint64)[:, None]
+        target = rng.integers(0, 1 << 62, size=(ell, a.N), dtype=np.uint64) % q
+        o0, o1 = np.zeros((ell, a.N), dtype=np.uint64), np.zeros((ell, a.N), dtype=np.uint64)
+        h0, h1 = o0.copy(), o1.copy()
+        a.keyswitch(target, a.galois[3], o0, o1)
+        b.L.orc_keyswitch_hybrid(b.ctx, ell, target.ctypes.data_as(__import__("ctypes").c_void_p), a.galois[3].ctypes.data_as(__import__("ctypes").c_void_p),
+                                 h0.ctypes.data_as(__import__("ctypes").c_void_p), h1.ctypes.data_as(__import__("ctypes").c_void_p))
+        assert (o0 == h0).all() and (o1 == h1).all()
+
+
+# alpha <= ks: P must cover a digit (P >= Q_g) or the switching noise is Q_g / P times too large
+@pytest.mark.parametrize("K,ks,alpha", [(7, 2, 2), (8, 3, 3), (9, 3, 2)])
+def test_grouped_digits_rotate_and_relinearise_correctly(K, ks, alpha):
+    logN = 10
+    o = Oracle(logN, K)
+    o.set_hybrid(ks, alpha)
+    assert o.max_level == K - ks and o.dnum == -(-(K - ks) // alpha)
+    o.keygen(seed=11, galois_elts=[o.elt_from_step(1), o.elt_from_step(-3)])
+    assert o.relin.shape == (o.dnum, 2, K, o.N)
+    rng = np.random.default_rng(2)
+    x, y = rng.uniform(-1, 1, o.slots), rng.uniform(-1, 1, o.slots)
+    for ell in range(1, o.max_level + 1):     # every level, including partial last digits
+        cx, cy = o.encrypt(o.encode(x, 2.0**40, ell)), o.encrypt(o.encode(y, 2.0**40, ell))
+        r = o.decode(o.decrypt(o.rotate(cx, 1)))
+        assert np.abs(r - np.roll(x, -1)).max() < 1e-6, ell
+        r = o.decode(o.decrypt(o.rotate(cx, -3)))
+        assert np.abs(r - np.roll(x, 3)).max() < 1e-6, ell
+        if ell >= 2:
+            m = o.decode(o.decrypt(o.mul_relin(cx, cy)))
+            assert np.abs(m - x * y).max() < 1e-6, ell
+
+
+def test_hybrid_key_switch_closed_form_on_a_small_ring():
+    """out = round-ish(sum_g d~_g key_g / P): the oracle's limbs recomputed from the definition with Python integers (CRT lifts, exact
+    division), independent of the C code's RNS arithmetic: d~_g = sum_i [x_i qhat_i^-1]_{q_i} qhat_i as an INTEGER, the accumulated
+    polynomial product mod Q_ell P, r = [acc + floor(P/2)]_P through the same integer base conversion, out = (acc - (conv - floor(P/2))) / P."""
+    logN, K, ks, alpha = 4, 6, 2, 2
+    o = Oracle(logN, K)
+    o.set_hybrid(ks, alpha)
+    o.keygen(seed=5, galois_elts=[3])
+    N, L = o.N, K - ks
+    key = o.galois[3]
+    rng = np.random.default_rng(3)
+    for ell in (1, 2, 3, 4):
+        q = o.primes[:ell]
+        sp = o.primes[L:]
+        P = 1
+        for p in sp:
+            P *= p
+        target = rng.integers(0, 1 << 62, size=(ell, N), dtype=np.uint64) % np.array(q, dtype=np.uint64)[:, None]
+        out0, out1 = np.zeros((ell, N), dtype=np.uint64), np.zeros((ell, N), dtype=np.uint64)
+        o.keyswitch(target, key, out0, out1)
+        coef = o.ntt_inv(target, list(range(ell)))
+        mods = q + sp
+        pidx = list(range(ell)) + list(range(L, K))
+        # negacyclic product in the coefficient domain, per modulus, with Python ints
+        def negacyclic(u, v, m):
+            res = [0] * N
+            for i in range(N):
+                for j in range(N):
+                    k = i + j
+                    t = u[i] * v[j]
+                    if k >= N:
+                        res[k - N] = (res[k - N] - t) % m
+                    else:
+                        res[k] = (res[k] + t) % m
+            return res
+        acc = [[[0] * N for _ in mods] for _ in range(2)]
+        G = -(-ell // alpha)
+        for g in range(G):
+            lo, hi = g * alpha, min((g + 1) * alpha, ell)
+            Qg = 1
+            for i in range(lo, hi):
+                Qg *= q[i]
+            dt = [0] * N
+            for i in range(lo, hi):
+                qh = Qg // q[i]
+                inv = pow(qh, -1, q[i])
+                for n in range(N):
+                    dt[n] += (int(coef[i][n]) * inv % q[i]) * qh
+            for kc in range(2):
+                for mi, (m, pi) in enumerate(zip(mods, pidx)):
+                    kcoef = [int(v) for v in o.ntt_inv(key[g, kc, pi : pi + 1], [pi])[0]]
+                    prod = negacyclic([d % m for d in dt], kcoef, m)
+                    acc[kc][mi] = [(a + b) % m for a, b in zip(acc[kc][mi], prod)]
+        for kc, out in ((0, out0), (1, out1)):
+            want = np.zeros((ell, N), dtype=np.uint64)
+            for n in range(N):
+                # r = [acc + floor(P/2)]_P via the integer fast base conversion from the special primes
+                conv = 0
+                for j, p in enumerate(sp):
+                    ph = P // p
+                    conv += ((acc[kc][ell + j][n] + (P // 2)) % p * pow(ph, -1, p) % p) * ph
+                for i in range(ell):
+                    t = (conv - P // 2) % q[i]
+                    want[i, n] = (acc[kc][i][n] - t) * pow(P, -1, q[i]) % q[i]
+            got = o.ntt_inv(out, list(range(ell)))
+            assert (got == want).all(), (ell, kc)
