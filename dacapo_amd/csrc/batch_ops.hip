@@ -160,12 +160,20 @@ static void b_ks_tail(Context &c, const BatchWs &w, u64 *digits, const KsItem *i
 
 void b_rotate_hops(Context &c, const BatchWs &w, const KsItem *d_items, int B, int ell, hipStream_t s, const Handoff &h)
 {
+    if (c.hybrid()) { // (the plan links no steps in this mode: h is empty)
+        hyb_rotate_hops(c, w, d_items, B, ell, s);
+        return;
+    }
     f_irows_rot_c1(c, d_items, ell, w.digits, B, s);
     b_ks_tail<0>(c, w, w.digits, d_items, d_items, nullptr, B, ell, s, h);
 }
 
 void b_mul_relin(Context &c, const BatchWs &w, const MulItem *d_items, const u64 *relin_key, int B, int ell, hipStream_t s, const Handoff &h)
 {
+    if (c.hybrid()) {
+        hyb_mul_relin(c, w, d_items, relin_key, B, ell, s);
+        return;
+    }
     const size_t N = c.N;
     const bool fused_mac = fuse_mac() && (long)(N >> 10) * B * ell * ell < fuse_mac_threshold(); // same split as b_ks_tail
     u64 *digits = w.digits;

@@ -46,6 +46,21 @@ dc_context *dc_context_create(int logN, int num_primes, int bit_size, const uint
     c->ensure_scratch();
     return new dc_context{ c, true };
 }
+// EXTENSION: a context whose key switching uses grouped digits (hybrid_ks.hip): the last `special` primes are special, a digit is `alpha`
+// data primes, keys passed to dc_ct_rotate_hop / dc_ct_mul_relin / dc_keyswitch are [ceil((K - special) / alpha)][2][K][N]
+dc_context *dc_context_create_hybrid(int logN, int num_primes, int special, int alpha)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        fprintf(stderr, "[dacapo_amd] no HIP device: the HEVM runtime has no CPU fallback\n");
+        abort();
+    }
+    Context *c = new Context(logN, num_primes, kQBits, nullptr, special, alpha);
+    c->ensure_scratch();
+    return new dc_context{ c, true };
+}
+int dc_context_key_digits(const dc_context *ctx) { return ctx->c->key_digits(); }
+int dc_context_max_level(const dc_context *ctx) { return ctx->c->max_level(); }
 void dc_context_destroy(dc_context *ctx)
 {
     if (ctx && ctx->item_ring) (void)hipFree(ctx->item_ring);

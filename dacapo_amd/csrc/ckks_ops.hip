@@ -6,6 +6,7 @@
 // Algorithms follow SEAL 4.0 [SEAL-upstream evaluator.cpp, rns.cpp]; all intermediate results that SEAL
 // defines on canonical residues are canonical here too, so outputs are bit-identical by construction.
 #include "kernels.hpp"
+#include "plan.hpp"
 
 namespace dacapo {
 
@@ -131,6 +132,10 @@ __global__ __launch_bounds__(kOpThreads) void copy_limbs_kernel(u64 *__restrict_
 void keyswitch(Context &c, const Workspace &w, CtView out, const u64 *base0, const u64 *base1, const u64 *target,
                const u64 *key, int ell, hipStream_t s)
 {
+    if (c.hybrid()) {
+        hyb_keyswitch(c, w, out, base0, base1, target, key, ell, s);
+        return;
+    }
     const size_t N = c.N;
     const int K = c.K, sp = K - 1;
     const unsigned gx = (unsigned)(N / (2 * kOpThreads));

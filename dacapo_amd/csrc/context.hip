@@ -78,7 +78,8 @@ u64 h_min_primitive_root(u64 degree, u64 q)
     return best;
 }
 
-Context::Context(int logN_, int K_, int bits, const u64 *primes_or_null) : logN(logN_), N(1ull << logN_), K(K_)
+Context::Context(int logN_, int K_, int bits, const u64 *primes_or_null, int ksp_, int alpha_)
+    : logN(logN_), N(1ull << logN_), K(K_), ksp(ksp_), alpha(alpha_)
 {
     if (logN < 12 || logN > 17) {
         fprintf(stderr, "[dacapo_amd] ring degree 2^%d unsupported (12..17)\n", logN);
@@ -141,6 +142,65 @@ Context::Context(int logN_, int K_, int bits, const u64 *primes_or_null) : logN(
     DC_HIP_CHECK(hipMalloc(&d_half_mod, half_mod.size() * 8));
     DC_HIP_CHECK(hipMemcpy(d_inv_last, inv_last.data(), inv_last.size() * 8, hipMemcpyHostToDevice));
     DC_HIP_CHECK(hipMemcpy(d_half_mod, half_mod.data(), half_mod.size() * 8, hipMemcpyHostToDevice));
+
+    // ---- key-switching constants that depend on the special primes ------------------------------------------------------------
+    if (ksp < 1 || alpha < 1 || alpha > ksp || ksp >= K || alpha > 16 || (max_level() + alpha - 1) / alpha > 16) {
+        fprintf(stderr, "[dacapo_amd] hybrid key switching needs 1 <= alpha <= ksp < K, alpha <= 16 and at most 16 digits (K = %d, ksp = %d, alpha = %d)\n", K,
+                ksp, alpha);
+        abort();
+    }
+    const int L = max_level();
+    auto prod_except = [&](int lo, int hi, int skip, u64 m) {
+        u64 r = 1 % m;
+        for (int t = lo; t < hi; t++)
+            if (t != skip) r = h_mulmod(r, primes[(size_t)t] % m, m);
+        return r;
+    };
+    std::vector<u64> pmod((size_t)K, 0);
+    for (int i = 0; i < L; i++) pmod[(size_t)i] = prod_except(L, K, -1, primes[(size_t)i]);
+    DC_HIP_CHECK(hipMalloc(&d_pmod, pmod.size() * 8));
+    DC_HIP_CHECK(hipMemcpy(d_pmod, pmod.data(), pmod.size() * 8, hipMemcpyHostToDevice));
+    if (hybrid()) {
+        std::vector<u64> up;
+        std::vector<int> pidx;
+        hyb_up_off.assign((size_t)L + 2, 0), hyb_pidx_off.assign((size_t)L + 2, 0);
+        for (int ell = 1; ell <= L; ell++) {
+            const int M = ell + ksp;
+            hyb_up_off[(size_t)ell] = up.size(), hyb_pidx_off[(size_t)ell] = (int)pidx.size();
+            const size_t base = up.size();
+            up.resize(base + (size_t)ell + (size_t)ell * M, 0);
+            for (int g = 0; g < hyb_groups(ell); g++) {
+                const int lo = g * alpha, hi = std::min(lo + alpha, ell);
+                for (int i = lo; i < hi; i++) {
+                    up[base + (size_t)i] = h_invmod(prod_except(lo, hi, i, primes[(size_t)i]), primes[(size_t)i]);
+                    for (int mi = 0; mi < M; mi++) {
+                        const int pm = mi < ell ? mi : L + (mi - ell);
+                        up[base + (size_t)ell + (size_t)i * M + mi] = prod_except(lo, hi, i, primes[(size_t)pm]);
+                    }
+                }
+                for (int mi = 0; mi < M; mi++)
+                    if (mi < lo || mi >= hi) pidx.push_back(mi < ell ? mi : L + (mi - ell));
+            }
+        }
+        DC_HIP_CHECK(hipMalloc(&d_hyb_up, up.size() * 8));
+        DC_HIP_CHECK(hipMemcpy(d_hyb_up, up.data(), up.size() * 8, hipMemcpyHostToDevice));
+        DC_HIP_CHECK(hipMalloc(&d_hyb_pidx, pidx.size() * sizeof(int)));
+        DC_HIP_CHECK(hipMemcpy(d_hyb_pidx, pidx.data(), pidx.size() * sizeof(int), hipMemcpyHostToDevice));
+        std::vector<u64> dn((size_t)2 * ksp + 2 * L + (size_t)ksp * L, 0);
+        for (int j = 0; j < ksp; j++) {
+            const u64 pj = primes[(size_t)(L + j)];
+            dn[(size_t)j] = h_invmod(prod_except(L, K, L + j, pj), pj);
+            dn[(size_t)(ksp + j)] = (pj - 1) >> 1; // floor(P/2) mod p_j: P = 0 mod p_j and odd
+            for (int i = 0; i < L; i++) dn[(size_t)2 * ksp + 2 * L + (size_t)j * L + i] = prod_except(L, K, L + j, primes[(size_t)i]);
+        }
+        for (int i = 0; i < L; i++) {
+            const u64 qi = primes[(size_t)i], Pq = pmod[(size_t)i];
+            dn[(size_t)(2 * ksp + i)] = h_mulmod((Pq + qi - 1) % qi, (qi + 1) >> 1, qi); // floor(P/2) = (P - 1) / 2 mod q_i
+            dn[(size_t)(2 * ksp + L + i)] = h_invmod(Pq, qi);
+        }
+        DC_HIP_CHECK(hipMalloc(&d_hyb_dn, dn.size() * 8));
+        DC_HIP_CHECK(hipMemcpy(d_hyb_dn, dn.data(), dn.size() * 8, hipMemcpyHostToDevice));
+    }
 }
 
 Workspace Context::new_workspace()
@@ -148,8 +208,9 @@ Workspace Context::new_workspace()
     const size_t L = max_level();
     Workspace w;
     DC_HIP_CHECK(hipMalloc(&w.ks_digits, std::max<size_t>(L, 2) * N * 8));
-    DC_HIP_CHECK(hipMalloc(&w.ks_ext, std::max<size_t>(L * L, 3 * (size_t)K) * N * 8)); // also [3][K][N] encryption staging
-    DC_HIP_CHECK(hipMalloc(&w.ks_acc, 2 * (L + 1) * N * 8));
+    const size_t ext = std::max<size_t>(std::max<size_t>(L * L, 3 * (size_t)K), hybrid() ? (size_t)hyb_ext_max() : 0);
+    DC_HIP_CHECK(hipMalloc(&w.ks_ext, ext * N * 8)); // also [3][K][N] encryption staging
+    DC_HIP_CHECK(hipMalloc(&w.ks_acc, 2 * (L + (size_t)ksp) * N * 8));
     DC_HIP_CHECK(hipMalloc(&w.ks_tmp, 2 * std::max<size_t>(L, 1) * N * 8));
     DC_HIP_CHECK(hipMalloc(&w.ct_tmp, 3 * std::max<size_t>(L, 1) * N * 8));
     workspaces.push_back(w);
@@ -166,7 +227,7 @@ void Context::ensure_scratch()
     for (int ell = 1; ell <= (int)L; ell++) {
         ks_pidx_off[ell] = (int)pidx.size();
         for (int j = 0; j < ell; j++)
-            for (int e = 0; e < ell; e++) pidx.push_back(ks_other_prime(j, e, ell, K - 1));
+            for (int e = 0; e < ell; e++) pidx.push_back(ks_other_prime(j, e, ell, K - ksp));
     }
     DC_HIP_CHECK(hipMalloc(&d_ks_pidx, std::max<size_t>(pidx.size(), 1) * sizeof(int)));
     DC_HIP_CHECK(hipMemcpy(d_ks_pidx, pidx.data(), pidx.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -174,7 +235,8 @@ void Context::ensure_scratch()
 
 Context::~Context()
 {
-    for (void *p : { (void *)d_mods, (void *)d_tw, (void *)d_itw, (void *)d_inv_last, (void *)d_half_mod, (void *)d_ks_pidx })
+    for (void *p : { (void *)d_mods, (void *)d_tw, (void *)d_itw, (void *)d_inv_last, (void *)d_half_mod, (void *)d_ks_pidx, (void *)d_pmod,
+                     (void *)d_hyb_up, (void *)d_hyb_pidx, (void *)d_hyb_dn })
         if (p) (void)hipFree(p);
     for (Workspace &w : workspaces)
         for (void *p : { (void *)w.ks_digits, (void *)w.ks_ext, (void *)w.ks_acc, (void *)w.ks_tmp, (void *)w.ct_tmp })

@@ -62,6 +62,27 @@ struct Context {
     int logN = 0;
     size_t N = 0;
     int K = 0; // primes in the key-level chain; data levels use primes 0..ell-1, special prime = K-1
+    // EXTENSION (hybrid_ks.hip; not SEAL's scheme): grouped-digit hybrid key switching -- the last `ksp` primes are special, a digit is
+    // a group of `alpha` data primes (alpha <= ksp), keys are [key_digits()][2][K][N].  ksp = alpha = 1 is SEAL's switch_key_inplace.
+    int ksp = 1, alpha = 1;
+    bool hybrid() const { return ksp > 1 || alpha > 1; }
+    int key_digits() const { return hybrid() ? (max_level() + alpha - 1) / alpha : K - 1; }
+    int hyb_groups(int ell) const { return (ell + alpha - 1) / alpha; }
+    int hyb_ext(int ell) const { return hyb_groups(ell) * (ell + ksp) - ell; } // raised limbs of one key switch at level ell
+    int hyb_ext_max() const
+    {
+        int m = 0;
+        for (int l = 1; l <= max_level(); l++) m = hyb_ext(l) > m ? hyb_ext(l) : m;
+        return m;
+    }
+    u64 *d_pmod = nullptr;   // [K]: P mod q_i (P = product of the special primes) for the data primes, 0 for the special ones
+    u64 *d_hyb_up = nullptr; // per level ell: qhat_inv[i] (i < ell), then w[i][mi] (mi < ell + ksp) = (Q_g / q_i) mod m_mi
+    std::vector<size_t> hyb_up_off;
+    int *d_hyb_pidx = nullptr; // per level: prime index of every raised limb, group by group
+    std::vector<int> hyb_pidx_off;
+    u64 *d_hyb_dn = nullptr; // phat_inv[ksp], half_p[ksp], half_q[L], pinv[L], w_dn[ksp][L]   (L = max_level())
+    const u64 *hyb_up(int ell) const { return d_hyb_up + hyb_up_off[(size_t)ell]; }
+    const int *hyb_pidx(int ell) const { return d_hyb_pidx + hyb_pidx_off[(size_t)ell]; }
     int k1 = 0, k2 = 0; // NTT split: COLS phase runs k1 stages, ROWS phase k2 = logN - k1
     std::vector<u64> primes, psi;
     std::vector<DModulus> h_mods;
@@ -76,9 +97,9 @@ struct Context {
     std::vector<int> ks_pidx_off;
     const int *ks_prime_idx(int ell) const { return d_ks_pidx + ks_pidx_off[ell]; }
 
-    Context(int logN, int K, int bits, const u64 *primes_or_null);
+    Context(int logN, int K, int bits, const u64 *primes_or_null, int ksp = 1, int alpha = 1);
     ~Context();
-    int max_level() const { return K - 1; }
+    int max_level() const { return K - ksp; }
     void ensure_scratch();
     Workspace new_workspace();
 };

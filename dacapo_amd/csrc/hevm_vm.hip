@@ -133,10 +133,11 @@ __global__ __launch_bounds__(kVmThreads) void lift_i128_kernel(u64 *__restrict__
     out[(size_t)i * N + k] = neg ? negmod(r, M.q) : r;
 }
 
-// encrypt_zero_symmetric tail: c0 = -(c1*s + e) [+ factor_i * newkey on limb `digit`].  grid = (N/512, limbs)
+// encrypt_zero_symmetric tail: c0 = -(c1*s + e) [+ (P mod q_i) * newkey on the limbs digit_lo <= i < digit_hi of the key's digit: one limb
+// in SEAL's scheme, the digit's group with grouped digits].  grid = (N/512, limbs)
 __global__ __launch_bounds__(kVmThreads) void ezs_final_kernel(u64 *__restrict__ c0, const u64 *__restrict__ c1,
                                                                 const u64 *__restrict__ sk, const u64 *__restrict__ newkey,
-                                                                int digit, u64 factor, size_t N,
+                                                                int digit_lo, int digit_hi, const u64 *__restrict__ pmod, size_t N,
                                                                 const DModulus *__restrict__ mods)
 {
     const int i = blockIdx.y;
@@ -147,8 +148,9 @@ __global__ __launch_bounds__(kVmThreads) void ezs_final_kernel(u64 *__restrict__
     u64x2 r;
 #pragma unroll
     for (int t = 0; t < 2; t++) r[t] = negmod(addmod(mulmod(a[t], s[t], M), e[t], M.q), M.q);
-    if (newkey && i == digit) {
+    if (newkey && i >= digit_lo && i < digit_hi) {
         const u64x2 nk = *reinterpret_cast<const u64x2 *>(newkey + k);
+        const u64 factor = pmod[i];
 #pragma unroll
         for (int t = 0; t < 2; t++) r[t] = addmod(r[t], mulmod(nk[t], factor, M), M.q);
     }
@@ -445,7 +447,13 @@ void HEVM::init_context(int logN, int K, const u64 *primes)
         fprintf(stderr, "[dacapo_amd] no HIP device: the HEVM runtime has no CPU fallback\n");
         abort();
     }
-    ctx.reset(new Context(logN, K, kQBits, primes));
+    // EXTENSION: DACAPO_HEVM_KS_SPECIAL = k > 1 switches key switching to grouped digits (hybrid_ks.hip): the last k primes of the chain
+    // are special, a digit is DACAPO_HEVM_KS_ALPHA (default k) data primes.  Not SEAL's key format: a key directory written in this
+    // mode loads only into a VM created with the same two values.
+    int ksp = 1, alpha = 1;
+    if (const char *e = getenv("DACAPO_HEVM_KS_SPECIAL")) ksp = alpha = std::max(1, atoi(e));
+    if (const char *e = getenv("DACAPO_HEVM_KS_ALPHA")) alpha = std::max(1, atoi(e));
+    ctx.reset(new Context(logN, K, kQBits, primes, ksp, alpha));
     ctx->ensure_scratch();
     encoder.reset(new HostEncoder(logN));
     if (const char *e = getenv("DACAPO_HEVM_PLAN")) use_plan = atoi(e) != 0;
@@ -475,14 +483,15 @@ void HEVM::gen_kswitch_key(u64 *key, const u64 *new_key, u64 key_id)
     const int K = c.K;
     const dim3 gu((unsigned)(N / (kRngCoefs * kVmThreads)), (unsigned)K), gs((unsigned)(N / (kRngCoefs * kVmThreads))),
         g2((unsigned)(N / (2 * kVmThreads)), (unsigned)K);
-    for (int j = 0; j < K - 1; j++) {
+    const int L = c.max_level();
+    for (int j = 0; j < c.key_digits(); j++) {
         u64 *c0 = key + (size_t)j * 2 * K * N, *c1 = c0 + (size_t)K * N;
         const u64 object = key_id * 64 + (u64)j; // one object per (key, digit)
         hipLaunchKernelGGL(sample_uniform_kernel, gu, dim3(kVmThreads), 0, S(), c1, N, rng.pub, object, (u32)RNG_KSK_A, c.d_mods);
         hipLaunchKernelGGL(sample_small_kernel, gs, dim3(kVmThreads), 0, S(), c0, N, K, 1, rng.secret, object, (u32)RNG_KSK_E, c.d_mods);
         launch_ntt(c, false, c0, (long)N, K, nullptr, 0, 0, S());
-        const u64 factor = c.primes[K - 1] % c.primes[j];
-        hipLaunchKernelGGL(ezs_final_kernel, g2, dim3(kVmThreads), 0, S(), c0, c1, keys.sk, new_key, j, factor, N, c.d_mods);
+        const int lo = c.hybrid() ? j * c.alpha : j, hi = c.hybrid() ? std::min(lo + c.alpha, L) : j + 1;
+        hipLaunchKernelGGL(ezs_final_kernel, g2, dim3(kVmThreads), 0, S(), c0, c1, keys.sk, new_key, lo, hi, c.d_pmod, N, c.d_mods);
     }
 }
 
@@ -541,7 +550,7 @@ void HEVM::generate_keys(const RngKeys &rng_, bool secret, bool pub, bool eval)
         hipLaunchKernelGGL(sample_uniform_kernel, gu, dim3(kVmThreads), 0, S(), c1, N, rng.pub, (u64)0, (u32)RNG_PK_A, c.d_mods);
         hipLaunchKernelGGL(sample_small_kernel, gs, dim3(kVmThreads), 0, S(), c0, N, K, 1, rng.secret, (u64)0, (u32)RNG_PK_E, c.d_mods);
         launch_ntt(c, false, c0, (long)N, K, nullptr, 0, 0, S());
-        hipLaunchKernelGGL(ezs_final_kernel, g2, dim3(kVmThreads), 0, S(), c0, c1, keys.sk, (const u64 *)nullptr, -1, (u64)0, N,
+        hipLaunchKernelGGL(ezs_final_kernel, g2, dim3(kVmThreads), 0, S(), c0, c1, keys.sk, (const u64 *)nullptr, -1, -1, (const u64 *)nullptr, N,
                            c.d_mods);
     }
     if (eval) {
@@ -594,7 +603,7 @@ static void put_kswitch_keys(sealio::Writer &w, const Context &c, const sealio::
                              const std::map<size_t, const u64 *> &present)
 {
     const size_t per_digit = (size_t)2 * c.K * c.N;
-    w.buf.reserve(w.buf.size() + 64 + dim1 * 8 + present.size() * (size_t)(c.K - 1) * (per_digit * 8 + 128));
+    w.buf.reserve(w.buf.size() + 64 + dim1 * 8 + present.size() * (size_t)c.key_digits() * (per_digit * 8 + 128));
     w.put(key_id);
     w.put<uint64_t>(dim1);
     sealio::CtHeader h;
@@ -605,9 +614,9 @@ static void put_kswitch_keys(sealio::Writer &w, const Context &c, const sealio::
             w.put<uint64_t>(0);
             continue;
         }
-        w.put<uint64_t>((uint64_t)(c.K - 1));
-        const std::vector<u64> key = from_dev(it->second, (size_t)(c.K - 1) * per_digit);
-        for (int j = 0; j < c.K - 1; j++) { // PublicKey::save = Ciphertext::save (own header, compr none)
+        w.put<uint64_t>((uint64_t)c.key_digits());
+        const std::vector<u64> key = from_dev(it->second, (size_t)c.key_digits() * per_digit);
+        for (int j = 0; j < c.key_digits(); j++) { // PublicKey::save = Ciphertext::save (own header, compr none)
             sealio::Writer one;
             one.buf.reserve(per_digit * 8 + 128);
             put_ciphertext(one, h, key.data() + (size_t)j * per_digit);
@@ -678,8 +687,8 @@ static void get_kswitch_keys(sealio::Reader &r, const Context &c, const sealio::
     for (uint64_t index = 0; index < dim1; index++) {
         const uint64_t dim2 = r.get<uint64_t>();
         if (dim2 == 0) continue;
-        if (dim2 != (uint64_t)(c.K - 1)) r.fail("decomposition digit count differs from coeff_modulus_size - 1");
-        u64 *key = dalloc((size_t)(c.K - 1) * per_digit);
+        if (dim2 != (uint64_t)c.key_digits()) r.fail("decomposition digit count differs from this context's (coeff_modulus_size - 1 in SEAL's scheme)");
+        u64 *key = dalloc((size_t)c.key_digits() * per_digit);
         for (uint64_t j = 0; j < dim2; j++) {
             std::vector<uint8_t> owned;
             sealio::Reader m = open_object(r, owned);
@@ -1298,7 +1307,7 @@ std::vector<u32> HEVM::rotate_hops(int steps) const
     return hops;
 }
 
-static inline int64_t ks_ntts(int ell) { return (int64_t)(ell + 1) * (ell + 2); }
+#define ks_ntts(ell) ks_ntt_count(*ctx, (ell))
 
 void HEVM::op_rotate(int dst, int src, int offset)
 {

@@ -260,7 +260,7 @@ class HEVM {
     VmAllocs allocs;   // device memory held by this VM (hevm_destroy)
     HEVM() { g_vm_allocs = &allocs; }
     void destroy_device_state(); // streams, events, graph, every tracked allocation; the object is unusable afterwards
-    size_t key_elems() const { return (size_t)(ctx->K - 1) * 2 * ctx->K * ctx->N; }
+    size_t key_elems() const { return (size_t)ctx->key_digits() * 2 * ctx->K * ctx->N; }
     void init_context(int logN, int K, const u64 *primes);
     void generate_keys(const RngKeys &rng, bool secret, bool pub, bool eval);
     void gen_kswitch_key(u64 *key, const u64 *new_key, u64 key_id);

@@ -1,0 +1,285 @@
+// EXTENSION -- not SEAL's scheme, not reached by the reference's SEAL runtime: hybrid key switching with GROUPED digits (dnum digits of
+// `alpha` data primes, `ksp` special primes; Han-Ki 2020), what the reference's HEaaN runtime gets from its closed library for the
+// N = 2^17 / 29-level configuration (HEAAN_HEVM.cpp:124-141 key generation, :386-399 bootstrap).  With SEAL's one prime per digit a
+// key at N = 2^17 and 30 primes is 1.7 GB and a hop at the top level costs (l+1)(l+2) = 930 NTTs; with digits of 8 primes it is 0.3 GB
+// and 4 (l + 8) + 16 + 2 l = 222.  The algorithm is oracle/ckks_oracle.c orc_keyswitch_hybrid, limb for limb (tests/test_gpu_hybrid.py);
+// with ksp = alpha = 1 it is SEAL's switch_key_inplace and the fused launch sequences of fused_ks.hip stay in charge.
+//
+// Launch sequence of a batch of B key switches at level l (G = ceil(l / alpha) digits, M = l + ksp moduli, E = G M - l raised limbs):
+//   prepare   rotation: dst.c0 = galois(src.c0), target = digits = galois(src.c1)   |   ct x ct: tensor product, target = digits = c2
+//   iNTT      digits [B][l]                                   (batched transforms of ntt_kernels.hip / ntt_full.hip)
+//   mod-up    ext[b][g][e] = sum_{i in S_g} [x_i qhat_i^-1]_{q_i} (Q_g / q_i)  mod m_e   -- the base conversion, a [|S_g| x (M - |S_g|)]
+//             constant matrix applied to every coefficient: 128-bit lazy accumulators, one reduction per output
+//   NTT       ext [B][E]
+//   mac       acc[b][c][m] = sum_g operand_g[m] * key[g][c][m]   (operand = the NTT-form target limb itself when m is in S_g)
+//   iNTT      the 2 ksp special-prime limbs of every item
+//   mod-down  t_i = sum_j [(r_j + floor(P/2)) phat_j^-1]_{p_j} (P / p_j) - floor(P/2)  mod q_i
+//   NTT       t [B][2][l]
+//   final     dst.c += (acc_c - t_c) P^-1
+// HBM-bound element-wise kernels around the transforms; 16-byte accesses, constants through scalar loads.
+#include "plan.hpp"
+
+namespace dacapo {
+
+typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+constexpr int kHT = 256;
+constexpr int kHybMaxAlpha = 16;
+
+__device__ __forceinline__ u32 hyb_galois_src(u32 k, u32 elt, int logN)
+{ // GaloisTool::apply_galois_ntt index map (poly_kernels.hip)
+    const u32 r = (__brev(k) >> (32 - logN)) * 2u + 1u;
+    const u32 idx = ((elt * r) >> 1) & ((1u << logN) - 1u);
+    return __brev(idx) >> (32 - logN);
+}
+
+struct HybSingle { // one key switch by value (the one-instruction-at-a-time loop, the kernel-level C ABI): out = base + KS(target)
+    CtView out;
+    const u64 *base0 = nullptr, *base1 = nullptr, *key = nullptr;
+};
+
+// rotation items: dst.c0 = galois(src.c0); target[b] = digits[b] = galois(src.c1).  grid = (N/512, l, B)
+__global__ __launch_bounds__(kHT) void hyb_prepare_rot_kernel(const KsItem *__restrict__ items, u64 *__restrict__ target, u64 *__restrict__ digits,
+                                                               int ell, size_t N, int logN)
+{
+    const int i = blockIdx.y, b = blockIdx.z;
+    const KsItem it = items[b];
+    const size_t k = ((size_t)blockIdx.x * kHT + threadIdx.x) * 2;
+    const u32 g = hyb_galois_src((u32)k, it.elt, logN); // an aligned pair of outputs reads an aligned pair of inputs, possibly swapped
+    const u64x2 v0 = *reinterpret_cast<const u64x2 *>(it.src.limb(0, i, N) + (g & ~1u));
+    const u64x2 v1 = *reinterpret_cast<const u64x2 *>(it.src.limb(1, i, N) + (g & ~1u));
+    const u64x2 c0 = (g & 1u) ? u64x2{ v0.y, v0.x } : v0, c1 = (g & 1u) ? u64x2{ v1.y, v1.x } : v1;
+    *reinterpret_cast<u64x2 *>(it.dst.limb(0, i, N) + k) = c0;
+    const size_t o = ((size_t)b * ell + i) * N + k;
+    *reinterpret_cast<u64x2 *>(target + o) = c1;
+    *reinterpret_cast<u64x2 *>(digits + o) = c1;
+}
+
+// ct x ct items: dst.c0 = a0 b0, dst.c1 = a0 b1 + a1 b0, target[b] = digits[b] = a1 b1.  grid = (N/512, l, B)
+__global__ __launch_bounds__(kHT) void hyb_prepare_mul_kernel(const MulItem *__restrict__ items, u64 *__restrict__ target, u64 *__restrict__ digits,
+                                                               int ell, size_t N, const DModulus *__restrict__ mods)
+{
+    const int i = blockIdx.y, b = blockIdx.z;
+    const MulItem it = items[b];
+    const DModulus m = mods[i];
+    const size_t k = ((size_t)blockIdx.x * kHT + threadIdx.x) * 2;
+    const u64x2 a0 = *reinterpret_cast<const u64x2 *>(it.a.limb(0, i, N) + k), a1 = *reinterpret_cast<const u64x2 *>(it.a.limb(1, i, N) + k);
+    const u64x2 b0 = *reinterpret_cast<const u64x2 *>(it.b.limb(0, i, N) + k), b1 = *reinterpret_cast<const u64x2 *>(it.b.limb(1, i, N) + k);
+    u64x2 c0, c1, c2;
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
+        c0[e] = mulmod(a0[e], b0[e], m);
+        Acc128 acc;
+        acc.clear();
+        acc.mac(a0[e], b1[e]);
+        acc.mac(a1[e], b0[e]);
+        c1[e] = acc.reduce(m);
+        c2[e] = mulmod(a1[e], b1[e], m);
+    }
+    *reinterpret_cast<u64x2 *>(it.dst.limb(0, i, N) + k) = c0;
+    *reinterpret_cast<u64x2 *>(it.dst.limb(1, i, N) + k) = c1;
+    const size_t o = ((size_t)b * ell + i) * N + k;
+    *reinterpret_cast<u64x2 *>(target + o) = c2;
+    *reinterpret_cast<u64x2 *>(digits + o) = c2;
+}
+
+__global__ __launch_bounds__(kHT) void hyb_copy_kernel(u64 *__restrict__ dst, const u64 *__restrict__ src)
+{
+    const size_t k = ((size_t)blockIdx.x * kHT + threadIdx.x) * 2;
+    *reinterpret_cast<u64x2 *>(dst + k) = *reinterpret_cast<const u64x2 *>(src + k);
+}
+
+// mod-up: digits [B][l][N] (coefficient domain) -> ext [B][E][N].  grid = (N/512, G, B)
+__global__ __launch_bounds__(kHT) void hyb_modup_kernel(const u64 *__restrict__ digits, u64 *__restrict__ ext, int ell, int ksp, int alpha, int L,
+                                                         int E, size_t N, const DModulus *__restrict__ mods, const u64 *__restrict__ up)
+{
+    const int g = blockIdx.y, b = blockIdx.z, M = ell + ksp;
+    const int lo = g * alpha, hi = min(lo + alpha, ell), a = hi - lo;
+    const size_t k = ((size_t)blockIdx.x * kHT + threadIdx.x) * 2;
+    u64x2 y[kHybMaxAlpha];
+#pragma unroll
+    for (int t = 0; t < kHybMaxAlpha; t++) {
+        if (t < a) {
+            const DModulus mi = mods[lo + t];
+            const u64x2 x = *reinterpret_cast<const u64x2 *>(digits + ((size_t)b * ell + lo + t) * N + k);
+            const u64 inv = up[lo + t];
+            y[t].x = mulmod(x.x, inv, mi), y[t].y = mulmod(x.y, inv, mi);
+        }
+    }
+    u64 *out = ext + ((size_t)b * E + (size_t)g * (M - alpha)) * N + k; // every earlier digit is a full one
+    const u64 *w = up + ell;
+    for (int mi = 0; mi < M; mi++) {
+        if (mi >= lo && mi < hi) continue;
+        const DModulus m = mods[mi < ell ? mi : L + (mi - ell)];
+        Acc128 a0, a1;
+        a0.clear(), a1.clear();
+#pragma unroll
+        for (int t = 0; t < kHybMaxAlpha; t++) {
+            if (t < a) {
+                const u64 c = w[(size_t)(lo + t) * M + mi];
+                a0.mac(y[t].x, c);
+                a1.mac(y[t].y, c);
+            }
+        }
+        u64x2 r;
+        r.x = a0.reduce(m), r.y = a1.reduce(m);
+        *reinterpret_cast<u64x2 *>(out) = r;
+        out += N;
+    }
+}
+
+// inner products with the key.  grid = (N/512, M, B).  MODE 0 rotation items (per-item key), 1 ct x ct items (shared key), 2 single
+template <int MODE>
+__global__ __launch_bounds__(kHT) void hyb_mac_kernel(u64 *__restrict__ accq, u64 *__restrict__ accp, const u64 *__restrict__ ext,
+                                                       const u64 *__restrict__ target, const void *__restrict__ items,
+                                                       const u64 *__restrict__ shared_key, int ell, int ksp, int alpha, int L, int K, int E, size_t N,
+                                                       const DModulus *__restrict__ mods)
+{
+    const int mi = blockIdx.y, b = blockIdx.z, M = ell + ksp, pm = mi < ell ? mi : L + (mi - ell);
+    const DModulus Md = mods[pm];
+    const u64 *key = MODE == 0 ? static_cast<const KsItem *>(items)[b].key : shared_key;
+    const size_t k = ((size_t)blockIdx.x * kHT + threadIdx.x) * 2;
+    const int G = (ell + alpha - 1) / alpha;
+    Acc128 a0[2], a1[2];
+#pragma unroll
+    for (int e = 0; e < 2; e++) a0[e].clear(), a1[e].clear();
+    for (int g = 0; g < G; g++) { // G <= 16: the 128-bit sums stay below 2^124
+        const int lo = g * alpha, hi = min(lo + alpha, ell);
+        const u64 *op = (mi >= lo && mi < hi) ? target + ((size_t)b * ell + mi) * N
+                                              : ext + ((size_t)b * E + (size_t)g * (M - alpha) + (mi < lo ? mi : mi - (hi - lo))) * N;
+        const u64x2 x = *reinterpret_cast<const u64x2 *>(op + k);
+        const u64x2 y0 = *reinterpret_cast<const u64x2 *>(key + (((size_t)g * 2 + 0) * K + pm) * N + k);
+        const u64x2 y1 = *reinterpret_cast<const u64x2 *>(key + (((size_t)g * 2 + 1) * K + pm) * N + k);
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            a0[e].mac(x[e], y0[e]);
+            a1[e].mac(x[e], y1[e]);
+        }
+    }
+    u64x2 o0, o1;
+#pragma unroll
+    for (int e = 0; e < 2; e++) o0[e] = a0[e].reduce(Md), o1[e] = a1[e].reduce(Md);
+    if (mi < ell) {
+        *reinterpret_cast<u64x2 *>(accq + (((size_t)b * 2 + 0) * ell + mi) * N + k) = o0;
+        *reinterpret_cast<u64x2 *>(accq + (((size_t)b * 2 + 1) * ell + mi) * N + k) = o1;
+    } else {
+        *reinterpret_cast<u64x2 *>(accp + (((size_t)b * 2 + 0) * ksp + (mi - ell)) * N + k) = o0;
+        *reinterpret_cast<u64x2 *>(accp + (((size_t)b * 2 + 1) * ksp + (mi - ell)) * N + k) = o1;
+    }
+}
+
+// mod-down base conversion: accp [2B][ksp][N] (coefficient domain) -> tmp [2B][l][N].  grid = (N/512, 2B)
+__global__ __launch_bounds__(kHT) void hyb_moddown_kernel(const u64 *__restrict__ accp, u64 *__restrict__ tmp, int ell, int ksp, int L, size_t N,
+                                                           const DModulus *__restrict__ mods, const u64 *__restrict__ dn)
+{
+    const int z = blockIdx.y;
+    const size_t k = ((size_t)blockIdx.x * kHT + threadIdx.x) * 2;
+    const u64 *phat_inv = dn, *half_p = dn + ksp, *half_q = dn + 2 * ksp, *w = dn + 2 * ksp + 2 * L;
+    u64x2 zz[kHybMaxAlpha];
+#pragma unroll
+    for (int j = 0; j < kHybMaxAlpha; j++) {
+        if (j < ksp) {
+            const DModulus mp = mods[L + j];
+            const u64x2 r = *reinterpret_cast<const u64x2 *>(accp + ((size_t)z * ksp + j) * N + k);
+            zz[j].x = mulmod(addmod(r.x, half_p[j], mp.q), phat_inv[j], mp);
+            zz[j].y = mulmod(addmod(r.y, half_p[j], mp.q), phat_inv[j], mp);
+        }
+    }
+    for (int i = 0; i < ell; i++) {
+        const DModulus m = mods[i];
+        Acc128 a0, a1;
+        a0.clear(), a1.clear();
+#pragma unroll
+        for (int j = 0; j < kHybMaxAlpha; j++) {
+            if (j < ksp) {
+                const u64 c = w[(size_t)j * L + i];
+                a0.mac(zz[j].x, c);
+                a1.mac(zz[j].y, c);
+            }
+        }
+        u64x2 r;
+        r.x = submod(a0.reduce(m), half_q[i], m.q), r.y = submod(a1.reduce(m), half_q[i], m.q);
+        *reinterpret_cast<u64x2 *>(tmp + ((size_t)z * ell + i) * N + k) = r;
+    }
+}
+
+// dst.c (+)= (acc_c - t_c) P^-1.  grid = (N/512, l, 2B)
+template <int MODE>
+__global__ __launch_bounds__(kHT) void hyb_final_kernel(const u64 *__restrict__ accq, const u64 *__restrict__ tmp, const void *__restrict__ items,
+                                                         HybSingle single, int ell, int ksp, int L, size_t N, const DModulus *__restrict__ mods,
+                                                         const u64 *__restrict__ dn)
+{
+    const int i = blockIdx.y, z = blockIdx.z, b = z >> 1, c = z & 1;
+    const DModulus m = mods[i];
+    const u64 pinv = dn[2 * ksp + L + i];
+    const size_t k = ((size_t)blockIdx.x * kHT + threadIdx.x) * 2;
+    const u64x2 a = *reinterpret_cast<const u64x2 *>(accq + ((size_t)z * ell + i) * N + k);
+    const u64x2 t = *reinterpret_cast<const u64x2 *>(tmp + ((size_t)z * ell + i) * N + k);
+    u64x2 v;
+    v.x = mulmod(submod(a.x, t.x, m.q), pinv, m), v.y = mulmod(submod(a.y, t.y, m.q), pinv, m);
+    u64 *dst;
+    const u64 *base;
+    if (MODE == 0) {
+        const KsItem it = static_cast<const KsItem *>(items)[b];
+        dst = it.dst.limb(c, i, N) + k, base = c == 0 ? dst : nullptr; // c0 holds the permuted source c0 (prepare), c1 starts at zero
+    } else if (MODE == 1) {
+        const MulItem it = static_cast<const MulItem *>(items)[b];
+        dst = it.dst.limb(c, i, N) + k, base = dst;                     // the tensor product's c0 / c1
+    } else {
+        dst = single.out.limb(c, i, N) + k;
+        const u64 *bp = c == 0 ? single.base0 : single.base1;
+        base = bp ? bp + (size_t)i * N + k : nullptr;
+    }
+    if (base) {
+        const u64x2 o = *reinterpret_cast<const u64x2 *>(base);
+        v.x = addmod(v.x, o.x, m.q), v.y = addmod(v.y, o.y, m.q);
+    }
+    *reinterpret_cast<u64x2 *>(dst) = v;
+}
+
+// everything after `prepare`: target [B][l][N] NTT form, digits = a copy of it (transformed in place here)
+template <int MODE>
+static void hyb_core(Context &c, const BatchWs &w, const void *items, const u64 *shared_key, HybSingle single, int B, int ell, hipStream_t s)
+{
+    const size_t N = c.N;
+    const int ksp = c.ksp, alpha = c.alpha, L = c.max_level(), K = c.K, G = c.hyb_groups(ell), M = ell + ksp, E = c.hyb_ext(ell);
+    const unsigned gx = (unsigned)(N / (2 * kHT));
+    u64 *accq = w.acc, *accp = w.acc + (size_t)B * 2 * ell * N;
+    launch_ntt(c, true, w.digits, (long)N, B * ell, nullptr, 0, ell, s);
+    hipLaunchKernelGGL(hyb_modup_kernel, dim3(gx, (unsigned)G, (unsigned)B), dim3(kHT), 0, s, w.digits, w.ext, ell, ksp, alpha, L, E, N, c.d_mods,
+                       c.hyb_up(ell));
+    launch_ntt(c, false, w.ext, (long)N, B * E, c.hyb_pidx(ell), 0, E, s);
+    hipLaunchKernelGGL(hyb_mac_kernel<MODE>, dim3(gx, (unsigned)M, (unsigned)B), dim3(kHT), 0, s, accq, accp, w.ext, w.target, items,
+                       MODE == 2 ? single.key : shared_key, ell, ksp, alpha, L, K, E, N, c.d_mods);
+    launch_ntt(c, true, accp, (long)N, 2 * B * ksp, nullptr, L, ksp, s);
+    hipLaunchKernelGGL(hyb_moddown_kernel, dim3(gx, (unsigned)(2 * B)), dim3(kHT), 0, s, accp, w.tmp, ell, ksp, L, N, c.d_mods, c.d_hyb_dn);
+    launch_ntt(c, false, w.tmp, (long)N, 2 * B * ell, nullptr, 0, ell, s);
+    hipLaunchKernelGGL(hyb_final_kernel<MODE>, dim3(gx, (unsigned)ell, (unsigned)(2 * B)), dim3(kHT), 0, s, accq, w.tmp, items, single, ell, ksp, L, N,
+                       c.d_mods, c.d_hyb_dn);
+}
+
+void hyb_rotate_hops(Context &c, const BatchWs &w, const KsItem *d_items, int B, int ell, hipStream_t s)
+{
+    hipLaunchKernelGGL(hyb_prepare_rot_kernel, dim3((unsigned)(c.N / (2 * kHT)), (unsigned)ell, (unsigned)B), dim3(kHT), 0, s, d_items, w.target,
+                       w.digits, ell, c.N, c.logN);
+    hyb_core<0>(c, w, d_items, nullptr, HybSingle{}, B, ell, s);
+}
+
+void hyb_mul_relin(Context &c, const BatchWs &w, const MulItem *d_items, const u64 *relin_key, int B, int ell, hipStream_t s)
+{
+    hipLaunchKernelGGL(hyb_prepare_mul_kernel, dim3((unsigned)(c.N / (2 * kHT)), (unsigned)ell, (unsigned)B), dim3(kHT), 0, s, d_items, w.target,
+                       w.digits, ell, c.N, c.d_mods);
+    hyb_core<1>(c, w, d_items, relin_key, HybSingle{}, B, ell, s);
+}
+
+// Evaluator::switch_key_inplace's role for one ciphertext: out = (base0, base1) + KS(target).  target [l][N] NTT form, preserved.
+void hyb_keyswitch(Context &c, const Workspace &w, CtView out, const u64 *base0, const u64 *base1, const u64 *target, const u64 *key, int ell,
+                   hipStream_t s)
+{
+    const size_t N = c.N;
+    // the batch scratch of one item: target is read in place, digits / ext / acc / tmp are the workspace's
+    BatchWs bw{ const_cast<u64 *>(target), w.ks_digits, w.ks_ext, w.ks_acc, w.ks_tmp };
+    hipLaunchKernelGGL(hyb_copy_kernel, dim3((unsigned)((size_t)ell * N / (2 * kHT))), dim3(kHT), 0, s, w.ks_digits, target);
+    hyb_core<2>(c, bw, nullptr, nullptr, HybSingle{ out, base0, base1, key }, 1, ell, s);
+}
+
+} // namespace dacapo

@@ -87,6 +87,16 @@ void b_mul_relin(Context &c, const BatchWs &w, const MulItem *d_items, const u64
 void b_rescale(Context &c, const BatchWs &w, const RsItem *d_items, int B, int ell, hipStream_t s, const SumSrc *d_srcs = nullptr,
                const Handoff &h = Handoff{});
 bool chain_fusion_supported(); // the continuation kernels exist for the default launch sequences only
+// grouped-digit hybrid key switching (hybrid_ks.hip; Context::hybrid()): b_rotate_hops / b_mul_relin / keyswitch route here
+void hyb_rotate_hops(Context &c, const BatchWs &w, const KsItem *d_items, int B, int ell, hipStream_t s);
+void hyb_mul_relin(Context &c, const BatchWs &w, const MulItem *d_items, const u64 *relin_key, int B, int ell, hipStream_t s);
+void hyb_keyswitch(Context &c, const Workspace &w, CtView out, const u64 *base0, const u64 *base1, const u64 *target, const u64 *key, int ell,
+                   hipStream_t s);
+// NTT-equivalents of one key switch at level ell: (l + 1)(l + 2) for SEAL's scheme, G (l + ksp) + 2 ksp + 2 l with grouped digits
+inline int64_t ks_ntt_count(const Context &c, int ell)
+{
+    return c.hybrid() ? (int64_t)c.hyb_groups(ell) * (ell + c.ksp) + 2 * c.ksp + 2 * ell : (int64_t)(ell + 1) * (ell + 2);
+}
 // op: Neg / Mul (ct * plain) / Copy ; b_polys as in launch_ew
 void b_ew(Context &c, EwOp op, const EwItem *d_items, int B, int polys, int b_polys, int ell, hipStream_t s);
 void b_add_plain(Context &c, const EwItem *d_items, int B, int ell, hipStream_t s);

@@ -14,7 +14,7 @@
 
 namespace dacapo {
 
-static inline int64_t ks_ntts(int ell) { return (int64_t)(ell + 1) * (ell + 2); }
+#define ks_ntts(ell) ks_ntt_count(c, (ell))
 
 template <class T>
 static T *upload(const std::vector<T> &v)
@@ -370,7 +370,7 @@ void HEVM::build_plan()
     std::vector<CtView> h_cont_other;            // filled with stream views in section 6
     std::vector<std::pair<int, int>> cont_other; // (value or -1 for a square, unused) per CONT_MUL item slot, pop order
     std::vector<int> mul_fused_src((size_t)O.size(), -1); // consumer multiply pop -> which operand (0 / 1) comes from the producer
-    if (chain_fusion && chain_fusion_supported()) {
+    if (chain_fusion && chain_fusion_supported() && !c.hybrid()) { // (the grouped-digit key switch has no continuation kernels)
         auto def_step_of = [&](int v) -> int { // step defining value v when v is a plain (non-view) pop result, else -1
             const Val &sv = V[(size_t)v];
             if (sv.root != v || sv.def_pop < 0 || O[(size_t)sv.def_pop].dead || O[(size_t)sv.def_pop].dst != v) return -1;
@@ -666,8 +666,9 @@ void HEVM::build_plan()
             break;
         }
         if (st.kind == P_ROT || st.kind == P_MULCC) {
-            need_t = std::max(need_t, B * l), need_d = std::max(need_d, B * std::max<size_t>(l, 2)), need_e = std::max(need_e, B * l * l);
-            need_a = std::max(need_a, B * 2 * (l + 1)), need_m = std::max(need_m, B * 2 * l);
+            need_t = std::max(need_t, B * l), need_d = std::max(need_d, B * std::max<size_t>(l, 2));
+            need_e = std::max(need_e, B * (c.hybrid() ? (size_t)c.hyb_ext((int)l) : l * l));
+            need_a = std::max(need_a, B * 2 * (l + (size_t)c.ksp)), need_m = std::max(need_m, B * 2 * l);
             P.launches += 8;
         } else if (st.kind == P_RESCALE) {
             need_d = std::max(need_d, B * 2), need_m = std::max(need_m, B * 2 * l);

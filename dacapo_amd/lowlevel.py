@@ -21,6 +21,10 @@ def lib():
         vp, u64p, i32, lng = C.c_void_p, C.c_void_p, C.c_int, C.c_long
         L.dc_context_create.restype = vp
         L.dc_context_create.argtypes = [i32, i32, i32, vp]
+        L.dc_context_create_hybrid.restype = vp
+        L.dc_context_create_hybrid.argtypes = [i32, i32, i32, i32]
+        L.dc_context_key_digits.argtypes = [vp]
+        L.dc_context_max_level.argtypes = [vp]
         L.dc_context_destroy.argtypes = [vp]
         L.dc_context_logn.argtypes = [vp]
         L.dc_context_num_primes.argtypes = [vp]
@@ -102,13 +106,20 @@ def read_device(ptr: int, shape, dtype=np.uint64) -> np.ndarray:
 
 
 class Context:
-    def __init__(self, logN=15, num_primes=14, bit_size=60, primes=None):
+    def __init__(self, logN=15, num_primes=14, bit_size=60, primes=None, special=1, alpha=None):
+        """special / alpha: the grouped-digit key-switching extension (dc_context_create_hybrid); 1 / 1 is SEAL's scheme"""
         L = lib()
         arr = None
         if primes is not None:
             arr = (C.c_uint64 * len(primes))(*[int(p) for p in primes])
             num_primes = len(primes)
-        self.h = L.dc_context_create(logN, num_primes, bit_size, arr)
+        alpha = special if alpha is None else alpha
+        if (special, alpha) != (1, 1):
+            assert primes is None and bit_size == 60
+            self.h = L.dc_context_create_hybrid(logN, num_primes, special, alpha)
+        else:
+            self.h = L.dc_context_create(logN, num_primes, bit_size, arr)
+        self.key_digits, self.max_level = int(L.dc_context_key_digits(self.h)), int(L.dc_context_max_level(self.h))
         self.logN, self.N, self.K = logN, 1 << logN, num_primes
         out = np.zeros(num_primes, dtype=np.uint64)
         L.dc_context_primes(self.h, out.ctypes.data)

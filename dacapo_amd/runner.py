@@ -10,6 +10,7 @@ libSEAL_HEVM.so.  Same method names, argument meaning and call sequence; the dif
 from __future__ import annotations
 
 import ctypes
+import os
 import re
 from pathlib import Path
 
@@ -96,12 +97,23 @@ def setLibnHW(argv=None):  # runner.py:123-171: only the SEAL-compatible ABI exi
 
 
 class HEVM:
-    def __init__(self, path=str((Path.home() / ".hevm" / "seal").absolute()), option="full", seed=None, logN=0, num_primes=0):
+    def __init__(self, path=str((Path.home() / ".hevm" / "seal").absolute()), option="full", seed=None, logN=0, num_primes=0,
+                 ks_special=1, ks_alpha=None):
+        """ks_special / ks_alpha (extension, seeded VMs): grouped-digit hybrid key switching -- the last ks_special primes are special, a
+        digit is ks_alpha (default ks_special) data primes.  1 / 1 = the reference's SEAL scheme."""
         reinit_lw()
         self.option = option
         self.slots = None
         if seed is not None:  # extension: keys generated in HBM, nothing on disk
-            self.vm = lw.hevm_init_seeded(logN, num_primes, seed)
+            env = {}
+            if ks_special != 1 or (ks_alpha or 1) != 1:
+                env = {"DACAPO_HEVM_KS_SPECIAL": str(ks_special), "DACAPO_HEVM_KS_ALPHA": str(ks_alpha or ks_special)}
+            os.environ.update(env)
+            try:
+                self.vm = lw.hevm_init_seeded(logN, num_primes, seed)
+            finally:
+                for k in env:
+                    os.environ.pop(k)
         else:
             if not Path(path).is_dir():  # runner.py:185-192 (the reference also waits for a key press)
                 Path(path).mkdir(parents=True)
@@ -120,6 +132,7 @@ class HEVM:
         self.ctx_handle = lw.hevm_context(self.vm)
         self.logN = L.dc_context_logn(self.ctx_handle)
         self.K = L.dc_context_num_primes(self.ctx_handle)
+        self.key_digits, self.max_level = int(L.dc_context_key_digits(self.ctx_handle)), int(L.dc_context_max_level(self.ctx_handle))
         self.N = 1 << self.logN
         self.slots = self.N >> 1
 

@@ -30,6 +30,13 @@ typedef struct dc_context dc_context;
  * CoeffModulus::Create(N, {bit_size x num_primes}) exactly as SEAL_HEVM.cpp:48-53 does (bit_size must be 60:
  * the HIP reduction is specialised to q = 2^60 - delta, delta < 2^28).  Uploads twiddle tables.  Synchronous. */
 dc_context *dc_context_create(int logN, int num_primes, int bit_size, const uint64_t *primes);
+/* EXTENSION (not SEAL's scheme; the reference's HEaaN runtime has it inside its closed library, HEAAN_HEVM.cpp:124-141): key switching
+ * with grouped digits -- the last `special` primes of the chain are special, a decomposition digit is a group of `alpha` data primes
+ * (alpha <= special), key-switch keys are [dc_context_key_digits()][2][K][N] and data levels run up to dc_context_max_level() =
+ * num_primes - special.  special = alpha = 1 is dc_context_create's (SEAL's) scheme. */
+dc_context *dc_context_create_hybrid(int logN, int num_primes, int special, int alpha);
+int dc_context_key_digits(const dc_context *ctx);
+int dc_context_max_level(const dc_context *ctx);
 void dc_context_destroy(dc_context *ctx);
 int dc_context_logn(const dc_context *ctx);
 int dc_context_num_primes(const dc_context *ctx);

@@ -10,14 +10,15 @@ def _import_keys(o: Oracle, hevm, ll):
 
     lw = runner.lw
     K, N = o.K, o.N
+    D = o.dnum if (o.ks, o.alpha) != (1, 1) else K - 1   # grouped digits: [dnum][2][K][N]
     o.sk = ll.read_device(lw.hevm_secret_key(hevm.vm), (K, N))
     o.pk = ll.read_device(lw.hevm_public_key(hevm.vm), (2, K, N))
-    o.relin = ll.read_device(lw.hevm_relin_key(hevm.vm), (K - 1, 2, K, N))
+    o.relin = ll.read_device(lw.hevm_relin_key(hevm.vm), (D, 2, K, N))
     o.galois = {}
     for elt in o.default_galois_elts():
         p = lw.hevm_galois_key(hevm.vm, elt)
         assert p, f"default Galois key {elt} missing"
-        o.galois[elt] = ll.read_device(p, (K - 1, 2, K, N))
+        o.galois[elt] = ll.read_device(p, (D, 2, K, N))
 
 
 def _get_ct(hevm, ll, reg):
