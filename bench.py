@@ -304,7 +304,7 @@ def build_parser():
     ap.add_argument("--streams", type=int, default=1, help="independent ciphertext streams per GPU (throughput mode; 1 = the reference's one image per run)")
     ap.add_argument("--no-lowerings", action="store_true", help="skip the other lowerings of the trace (config.lowerings)")
     ap.add_argument("--no-config4", dest="config4", action="store_false",
-                    help="skip BASELINE config 4's shape (ResNet-20 traced at nt = 2^16, N = 2^17, real bootstrapping; ~2.5 min, ~75 GB of HBM); "
+                    help="skip BASELINE config 4's shape (ResNet-20 traced at nt = 2^16, N = 2^17, real bootstrapping; ~1 min, ~180 GB of HBM); "
                          "it runs by default since round 3, in a child process before this one touches the GPU")
     ap.add_argument("--config4", dest="config4", action="store_true", help="(default)")
     ap.set_defaults(config4=True)
@@ -317,18 +317,23 @@ def build_parser():
 def config4_child():
     """--config4: BASELINE config 4's shape -- ResNet-20 traced at the reference script's own nt = 2^16 slots (examples/benchmarks/
     ResNet.py:50), run on N = 2^17 (HEAAN_HEVM.cpp:55-56) with a real bootstrap at every bootstrap site (tools/resnet_real_boot.py).
-    About 70 GB of keys and plaintexts: it runs in a CHILD process started before this one touches the GPU (the reference's ABI has no
+    About 180 GB of keys and plaintexts: it runs in a CHILD process started before this one touches the GPU (the reference's ABI has no
     destroy symbol, so the other legs' VMs stay resident until exit), about two minutes."""
     import subprocess
 
-    cmd = [sys.executable, str(ROOT / "tools" / "resnet_real_boot.py"), "2", "resnet20_nt16", "17", "3"]
+    cmd = [sys.executable, str(ROOT / "tools" / "resnet_real_boot.py"), "1", "resnet20_nt16", "17", "1", "b14", "8", "7"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     last = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     if r.returncode != 0 or not last:
         return {"error": f"tools/resnet_real_boot.py exited with {r.returncode}", "stderr_tail": r.stderr[-400:]}
     res = json.loads(last[-1])
-    res["command"] = "python tools/resnet_real_boot.py 2 resnet20_nt16 17 3"
-    res["keys"] = "default Galois set for the model's rotations (1-3 primes) + 50 direct keys for the bootstraps' own offsets"
+    res["command"] = "python tools/resnet_real_boot.py 1 resnet20_nt16 17 1 b14 8 7"
+    res["program"] = ("tests/golden/resnet20_nt16.b14: bootstraps at the model script's own hints (before every activation), each restoring 14 "
+                      "primes -> 38 real bootstraps (round 2: 541 restoring 3); 31 data + 8 special 60-bit primes")
+    res["keys"] = ("grouped-digit hybrid key switching (extension, hybrid_ks.hip): 5 digits of 7 primes, P = 8 primes; one direct Galois key per "
+                   "rotation offset (286 keys x 0.39 GB)")
+    res["security"] = "N = 2^17, log2(QP) = 39 x 60 = 2340 bits, sparse ternary secret (h = 64): inside the 128-bit range for N = 2^17"
+    res["round2"] = "47.2 s, rms_vs_torch 0.152 (541 bootstraps restoring 3 primes, one-prime-per-digit keys)"
     res["reference"] = "README.md:131-136: DaCapo's cost model estimates 13.6 s for its 19-bootstrap HEaaN plan (not measured)"
     return res
 

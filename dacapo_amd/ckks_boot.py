@@ -167,10 +167,10 @@ class BootstrapEmitter:
     """Emits the bootstrap of one ciphertext into `b`.  Plaintext registers of the matrices are shared by all bootstraps of a program."""
 
     def __init__(self, b: ha.Builder, logN: int, num_primes: int, target_level: int, r: int = 5, taylor_terms: int = 16, k_range: float = 16.0,
-                 msg_bits: int = 0, diag_bits: int = 55, out_bits: int = 40, groups: int = 3, cts_bits: int = 60):
+                 msg_bits: int = 0, diag_bits: int = 55, out_bits: int = 40, groups: int = 3, cts_bits: int = 60, ks: int = 1):
         self.b, self.logN, self.N, self.n = b, logN, 1 << logN, 1 << (logN - 1)
         self.primes = seal_prime_chain(logN, num_primes)
-        self.top = num_primes - 1
+        self.top = num_primes - ks  # ks special primes at the end of the chain (1 in SEAL's scheme; more with grouped-digit key switching)
         self.target, self.r, self.terms, self.k_range = target_level, r, taylor_terms, k_range
         self.msg_bits, self.diag_bits, self.out_bits, self.groups, self.cts_bits = msg_bits, diag_bits, out_bits, groups, cts_bits
         assert taylor_terms in (8, 16), "the polynomial in theta^2 is evaluated as a complete binary tree"
@@ -538,12 +538,13 @@ def simulate(hevm: bytes, cst: bytes, inputs, logN: int, primes, secret_weight: 
 
 
 # ---- a bootstrap on its own (tools/boot_demo.py, bench.py, tests) ------------------------------------------------------------------
-def single_bootstrap_program(logN: int, target: int = 3, r: int = 5, msg_bits: int = 0):
-    """(num_primes, cst, hevm, rotation offsets, emitter) of the program `one ciphertext at 1 prime, scale 2^40 -> bootstrap -> output`"""
-    K = target + boot_levels(r) + 1
+def single_bootstrap_program(logN: int, target: int = 3, r: int = 5, msg_bits: int = 0, ks: int = 1):
+    """(num_primes, cst, hevm, rotation offsets, emitter) of the program `one ciphertext at 1 prime, scale 2^40 -> bootstrap -> output`;
+    ks = number of special primes of the chain (the VM must be created with ks_special = ks)"""
+    K = target + boot_levels(r) + ks
     b = ha.Builder(slots=1 << (logN - 1), init_level=1, shadow=False)
     x = b.input(None, level=1, scale_bits=40)
-    em = BootstrapEmitter(b, logN, K, target, r=r, msg_bits=msg_bits)
+    em = BootstrapEmitter(b, logN, K, target, r=r, msg_bits=msg_bits, ks=ks)
     y, _ = em.bootstrap(x, 2.0**40)
     b.output(y)
     cst, hv, _ = b.assemble()
@@ -556,16 +557,16 @@ def rotation_offsets(hevm: bytes):
 
 
 # ---- compiled programs: opcode 10 -> real bootstrapping ------------------------------------------------------------------------------
-def lower_bootstraps(hevm: bytes, cst: bytes, logN: int, num_primes: int, msg_bits: int = 4, r: int = 5):
+def lower_bootstraps(hevm: bytes, cst: bytes, logN: int, num_primes: int, msg_bits: int = 4, r: int = 5, ks: int = 1):
     """Rewrites a program (e.g. one emitted by the reference's compiler) so that every opcode 10 -- `bootstrap`, a decrypt / re-encrypt
     stand-in in the SEAL runtime (SEAL_HEVM.cpp:324-334), the real thing in the HEaaN runtime (HEAAN_HEVM.cpp:386-399) -- becomes the
     real bootstrapping sequence of this module.  Everything else is re-emitted unchanged (same instructions, same constants, registers
     re-allocated).  All opcode 10 of the program must restore the same number of primes t, and the chain must hold num_primes =
-    t + boot_levels(r) + 1 primes.  Returns (hevm', cst')."""
+    t + boot_levels(r) + ks primes (ks special ones).  Returns (hevm', cst')."""
     h = ha.unpack_hevm(hevm)
     consts = ha.unpack_cst(cst)
     slots = 1 << (logN - 1)
-    b = ha.Builder(slots=slots, init_level=int(h["init_level"]), shadow=False, real_boot=dict(num_primes=num_primes, msg_bits=msg_bits, r=r))
+    b = ha.Builder(slots=slots, init_level=int(h["init_level"]), shadow=False, real_boot=dict(num_primes=num_primes, msg_bits=msg_bits, r=r, ks=ks))
     b.constants = [np.asarray(c, dtype=np.float64) for c in consts]
     b._const_index = {c.tobytes(): i for i, c in enumerate(b.constants)}
     cur = {}

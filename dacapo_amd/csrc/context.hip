@@ -144,7 +144,7 @@ Context::Context(int logN_, int K_, int bits, const u64 *primes_or_null, int ksp
     DC_HIP_CHECK(hipMemcpy(d_half_mod, half_mod.data(), half_mod.size() * 8, hipMemcpyHostToDevice));
 
     // ---- key-switching constants that depend on the special primes ------------------------------------------------------------
-    if (ksp < 1 || alpha < 1 || alpha > ksp || ksp >= K || alpha > 16 || (max_level() + alpha - 1) / alpha > 16) {
+    if (ksp < 1 || alpha < 1 || alpha > ksp || ksp >= K || (hybrid() && (alpha > 16 || ksp > 16 || (max_level() + alpha - 1) / alpha > 16))) {
         fprintf(stderr, "[dacapo_amd] hybrid key switching needs 1 <= alpha <= ksp < K, alpha <= 16 and at most 16 digits (K = %d, ksp = %d, alpha = %d)\n", K,
                 ksp, alpha);
         abort();

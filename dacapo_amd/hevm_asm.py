@@ -322,6 +322,8 @@ class Builder:
         t = self.init_level if target_level is None else target_level
         if self.real_boot is not None:
             return self._real_bootstrap(x, t)
+        if self.shadow and x.plain is not None:  # how large a bootstrapped value gets (sizes real_boot's msg_bits when opcode 10 is lowered later)
+            self.boot_peaks = getattr(self, "boot_peaks", []) + [float(np.max(np.abs(x.plain)))]
         out = self._new(t, x.scale_bits, x.plain)
         self._emit(OP_BOOTSTRAP, out, x, t)
         return out
@@ -333,7 +335,7 @@ class Builder:
         logN = self.slots.bit_length()  # slots = N / 2
         if self._boot_emitter is None:
             self._boot_emitter = ckks_boot.BootstrapEmitter(self, logN, rb["num_primes"], t, r=rb.get("r", 5), msg_bits=rb.get("msg_bits", 0),
-                                                            out_bits=self.waterline)
+                                                            out_bits=self.waterline, ks=rb.get("ks", 1))
             self._scale_mirror = ckks_boot.ScaleMirror(self, self._boot_emitter.primes)
         em = self._boot_emitter
         assert t == em.target, "every real bootstrap of a program restores the same number of primes"
@@ -385,6 +387,16 @@ class Builder:
             x = self._boot(x)
             assert self._fits(x.level, x.scale_bits + extra_bits), "boot_level too small for this product"
         return x
+
+    def hint(self, x: Value, need: int) -> Value:
+        """a bootstrap HINT of the traced program (the reference's model scripts call hc.bootstrap before every activation,
+        examples/benchmarks/ResNet.py:65-123): bring x to the waterline and re-encrypt it here -- where the whole layer is one ciphertext --
+        unless it still has `need` primes to spend; without hints the lazy policy bootstraps wherever a value runs out, typically inside the
+        next convolution where dozens of rotated copies are alive"""
+        if not self.lazy:
+            return x
+        x = self._prepare(x, 0)
+        return self._boot(x) if x.level - need < self.min_level else x
 
     def finish(self, x: Value) -> Value:
         """a program result: rescaled to the waterline like any other consumer would see it"""

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Real CKKS bootstrapping on the MI355X: one ciphertext at 1 prime -> `target` primes, through the extension opcodes and
-dacapo_amd/ckks_boot.py.   python tools/boot_demo.py [logN=15] [r=5] [direct_keys=1]"""
+dacapo_amd/ckks_boot.py.   python tools/boot_demo.py [logN=15] [r=5] [direct_keys=1] [target=3] [ks_special=1]
+ks_special > 1: grouped-digit hybrid key switching (hybrid_ks.hip), the chain gets that many special primes."""
 import os
 import sys
 import time
@@ -17,15 +18,17 @@ from dacapo_amd import runner  # noqa: E402
 logN = int(sys.argv[1]) if len(sys.argv) > 1 else 15
 r = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 direct = int(sys.argv[3]) if len(sys.argv) > 3 else 1
-K, cst, hv, offs_all, em = cb.single_bootstrap_program(logN, r=r)
+target = int(sys.argv[4]) if len(sys.argv) > 4 else 3
+ks = int(sys.argv[5]) if len(sys.argv) > 5 else 1
+K, cst, hv, offs_all, em = cb.single_bootstrap_program(logN, target=target, r=r, ks=ks)
 slots = 1 << (logN - 1)
 info = {'num_ops': len(ha.unpack_hevm(hv)['ops']), 'num_ptxt': ha.unpack_hevm(hv)['num_ptxt']}
-print(f"N=2^{logN}, {K} primes, r={r}: {info['num_ops']} instructions, {info['num_ptxt']} plaintexts, {len(cst)/1e6:.0f} MB of constants")
+print(f"N=2^{logN}, {K} primes ({ks} special), target {target}, r={r}: {info['num_ops']} instructions, {info['num_ptxt']} plaintexts, {len(cst)/1e6:.0f} MB of constants")
 msg = np.random.default_rng(3).uniform(-1, 1, slots)
 sim = cb.simulate(hv, cst, [msg], logN, em.primes)[0]
 print("cleartext simulation: max error", np.abs(sim - msg).max())
 t0 = time.time()
-hevm = runner.HEVM(seed=5, logN=logN, num_primes=K)
+hevm = runner.HEVM(seed=5, logN=logN, num_primes=K, ks_special=ks)
 print(f"context + keys: {time.time()-t0:.1f} s")
 if direct:
     offs = offs_all
@@ -45,5 +48,5 @@ out = hevm.getOutput()[0]
 err = np.abs(out - msg)
 st = hevm.stats()
 c = hevm.getCtxt(hevm.getResIdx(0))
-print(f"bootstrap: {dt*1e3:.2f} ms, {st['keyswitches']} key switches, result at {c.level} primes, scale 2^{np.log2(c.scale):.3f}")
+print(f"bootstrap: {dt*1e3:.2f} ms, {st['keyswitches']} key switches, {st['ntts']} NTT-equivalents, result at {c.level} primes, scale 2^{np.log2(c.scale):.3f}")
 print(f"decrypted vs message: max error {err.max():.3e}, rms {np.sqrt(np.mean(err**2)):.3e}  ({-np.log2(err.max()):.1f} bits)")

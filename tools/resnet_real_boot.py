@@ -2,7 +2,10 @@
 """The reference's ResNet-20 with REAL CKKS bootstrapping at every bootstrap site (the headline program tests/golden/resnet20.*, every
 opcode 10 rewritten by dacapo_amd/ckks_boot.lower_bootstraps): BASELINE config 4 in spirit -- the reference
 runs it on HEaaN (HEAAN_HEVM.cpp:386-399) at N = 2^17; here on SEAL-style 60-bit primes, N = 2^15, 20 primes, sparse secret.
-    python tools/resnet_real_boot.py [direct_keys=1|2] [fixture=resnet20] [logN=15] [msg_bits=4]
+    python tools/resnet_real_boot.py [direct_keys=1|2] [fixture=resnet20] [logN=15] [msg_bits=4] [lowering=""] [ks_special=1] [ks_alpha=ks_special]
+lowering: another lowering of the same trace (tests/golden/<fixture>.<lowering>.hevm.gz, same constants), e.g. b14 = bootstraps placed at the
+model script's own hints, restoring 14 primes (38 bootstraps instead of 541); ks_special > 1: grouped-digit hybrid key switching with that
+many special primes (dacapo_amd/csrc/hybrid_ks.hip), which is what makes a 31-level chain affordable at N = 2^17.
 With fixture resnet20_nt16 (the same model traced at the reference script's own nt = 2^16 slots, examples/benchmarks/ResNet.py:50) and
 logN 17 this is the HEaaN runtime's ring (HEAAN_HEVM.cpp:55-56): ~100 GB of one-prime-per-digit Galois keys, sized for one MI355X."""
 import json
@@ -24,21 +27,31 @@ direct = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 name = sys.argv[2] if len(sys.argv) > 2 else "resnet20"
 logN = int(sys.argv[3]) if len(sys.argv) > 3 else 15
 msg_bits = int(sys.argv[4]) if len(sys.argv) > 4 else 4
-KB = 3 + cb.boot_levels() + 1  # 3 primes left after a bootstrap + the special prime
+lowering = sys.argv[5] if len(sys.argv) > 5 else ""
+ks = int(sys.argv[6]) if len(sys.argv) > 6 else 1
+alpha = int(sys.argv[7]) if len(sys.argv) > 7 else ks  # primes per digit (alpha < ks: P exceeds a digit's modulus, the switching noise shrinks by the ratio)
 fx = ha.read_fixture(ROOT / "tests" / "golden" / name)
+if lowering:
+    import gzip
+
+    fx["hevm"] = gzip.open(ROOT / "tests" / "golden" / f"{name}.{lowering}.hevm.gz").read()
+boot_target = {int(r) for o, _, _, r in ha.unpack_hevm(fx["hevm"])["ops"].tolist() if o == ha.OP_BOOTSTRAP}
+assert len(boot_target) == 1, "every opcode 10 of the program must restore the same number of primes"
+boot_target = boot_target.pop()
+KB = boot_target + cb.boot_levels() + ks  # primes left after a bootstrap + the bootstrap's own levels + the special primes
 assert fx["meta"]["slots"] == 1 << (logN - 1), "the fixture was traced for another slot count"
 t0 = time.time()
-fx["hevm"], fx["cst"] = cb.lower_bootstraps(fx["hevm"], fx["cst"], logN, KB, msg_bits=msg_bits)
+fx["hevm"], fx["cst"] = cb.lower_bootstraps(fx["hevm"], fx["cst"], logN, KB, msg_bits=msg_bits, ks=ks)
 print(f"opcode 10 -> real bootstrapping: {time.time()-t0:.1f} s", flush=True)
 h = ha.unpack_hevm(fx["hevm"])
 ops = h["ops"]
 print(f"{len(ops)} instructions, {h['num_ptxt']} plaintext registers, {int((ops[:, 0] == ha.OP_MODRAISE).sum())} real bootstraps", flush=True)
 t0 = time.time()
-hevm = runner.HEVM(seed=0x4845564D, logN=logN, num_primes=KB)
+hevm = runner.HEVM(seed=0x4845564D, logN=logN, num_primes=KB, ks_special=ks, ks_alpha=alpha)
 if direct:
     offs = cb.rotation_offsets(fx["hevm"])
     if direct == 2:  # direct keys for the bootstraps' own rotations only (they run at up to 19 primes); the model's rotations run at 1-3 primes,
-        offs = cb.rotation_offsets(cb.single_bootstrap_program(logN)[2])  # where a NAF hop pair under the default keys costs little
+        offs = cb.rotation_offsets(cb.single_bootstrap_program(logN, target=boot_target, ks=ks)[2])  # where a NAF hop pair under the default keys costs little
     hevm.addRotationKeys(offs)
     print(f"{len(offs)} direct rotation keys", flush=True)
 print(f"context + keys {time.time()-t0:.1f} s", flush=True)
@@ -51,7 +64,7 @@ hevm.run()
 dt = time.perf_counter() - t0
 out = hevm.getOutput()[0]
 st = hevm.stats()
-res = {"fixture": name, "N": 1 << logN, "slots": 1 << (logN - 1), "primes": KB, "msg_bits": msg_bits, "instructions": int(len(ops)), "run_s": round(dt, 3), "key_switches": st["keyswitches"], "ntt_equivalents": st["ntts"], "ntt_per_s": round(st["ntts"] / dt),
+res = {"fixture": name + ("." + lowering if lowering else ""), "special_primes": ks, "primes_per_digit": alpha, "bootstrap_restores_primes": boot_target, "N": 1 << logN, "slots": 1 << (logN - 1), "primes": KB, "msg_bits": msg_bits, "instructions": int(len(ops)), "run_s": round(dt, 3), "key_switches": st["keyswitches"], "ntt_equivalents": st["ntts"], "ntt_per_s": round(st["ntts"] / dt),
        "real_bootstraps": int((ops[:, 0] == ha.OP_MODRAISE).sum()),
        "rms_vs_torch": float(np.sqrt(np.mean((out[:10] * 32 - fx["torch_result"]) ** 2))),
        "rms_vs_plaintext_evaluation": float(np.sqrt(np.mean((out - fx["expected"]) ** 2))),

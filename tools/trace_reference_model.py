@@ -157,7 +157,18 @@ def make_shim(builder: hevm_asm.Builder, inputs):
         # on a single Expr it inserts a bootstrap HINT.  The DaCapo pipeline decides the real placement itself, and so
         # does Builder(policy="lazy"); the hints are counted and dropped.
         state["hints"] += 1
-        return x
+        need = getattr(builder, "hint_need", None)
+        if need is None:
+            return x
+        # with --hint-need the hints are honoured: every ciphertext of the layer is re-encrypted here if it cannot pay for `need` more primes
+        if isinstance(x, np.ndarray):  # the layers hand object arrays of ciphertexts around (element-wise operators)
+            out = np.empty_like(x)
+            for idx, e in np.ndenumerate(x):
+                out[idx] = Expr(ct=builder.hint(e.ct, need)) if getattr(e, "ct", None) is not None else e
+            return out
+        if isinstance(x, Iterable):
+            return type(x)(Expr(ct=builder.hint(e.ct, need)) if getattr(e, "ct", None) is not None else e for e in x)
+        return Expr(ct=builder.hint(x.ct, need)) if x.ct is not None else x
 
     class Func:
         def __init__(self, fun, paramstr):
@@ -382,6 +393,9 @@ def main():
                     help="K > 0: every bootstrap is REAL CKKS bootstrapping (dacapo_amd/ckks_boot.py) on a chain of K primes "
                          "(K = boot-level + 17 with the default r = 5) instead of opcode 10")
     ap.add_argument("--msg-bits", type=int, default=7, help="--real-boot-primes: bound 2^msg_bits on the magnitude of a bootstrapped value")
+    ap.add_argument("--hint-need", type=int, default=None,
+                    help="honour the model script's hc.bootstrap hints: bootstrap there unless the value still has this many primes to spend "
+                         "(default: hints are dropped and the lazy policy bootstraps wherever a value runs out)")
     ap.add_argument("--suite", action="store_true", help="trace the small benchmarks (%s) into <out>/<name>.*" % ", ".join(SUITE))
     a = ap.parse_args()
     if a.suite:
@@ -405,6 +419,7 @@ def main():
     b = hevm_asm.Builder(slots=slots, waterline=a.waterline, init_level=a.init_level, policy="lazy", boot_level=a.boot_level, rotate_reserve=a.rotate_reserve, carry_scale=a.carry_scale,
                          shadow=not a.no_shadow,
                          real_boot=dict(num_primes=a.real_boot_primes, msg_bits=a.msg_bits) if a.real_boot_primes else None)
+    b.hint_need = a.hint_need
     stub_torchvision()
     sys.path.insert(0, str(REF / "python/poly"))
     os.environ.setdefault("HECATE", str(REF))
@@ -419,7 +434,7 @@ def main():
     lens = [int(len(c)) for c in b.constants]
     meta = {
         "source": f"examples/benchmarks/{a.model}.py traced through python/poly with tools/trace_reference_model.py",
-        "slots": slots, "waterline": a.waterline, "init_level": a.init_level, "boot_level": a.boot_level,
+        "slots": slots, "waterline": a.waterline, "init_level": a.init_level, "boot_level": a.boot_level, "hint_need": a.hint_need,
         "input": {"packed_len": int(len(packed)), "seed": a.seed, "kind": "smooth synthetic 3x32x32 image, CIFAR-normalised"},
         "torch_result": [float(v) for v in torch_res],
         "info": info,
@@ -429,7 +444,9 @@ def main():
         "mulcc_per_level": {str(k): v for k, v in sorted(muls.items())},
         "bootstraps": boots,
         "ntt_equivalents": ntt_equivalents(b),
-        "bootstrap_hints_dropped": sys.modules["hecate"]._state["hints"],
+        "bootstrap_hints_dropped": sys.modules["hecate"]._state["hints"] if a.hint_need is None else 0,
+        "bootstrap_hints_honoured": sys.modules["hecate"]._state["hints"] if a.hint_need is not None else 0,
+        "bootstrapped_value_peaks": sorted(round(v, 3) for v in getattr(b, "boot_peaks", []))[-8:],
         "real_boot": ({k: v for k, v in b.real_boot.items()} if b.real_boot else None),
         "hevm_sha256": hashlib.sha256(hevm).hexdigest(),
         "cst_sha256": hashlib.sha256(cst).hexdigest(),
