@@ -30,6 +30,7 @@ sys.path.insert(0, str(ROOT))
 
 import numpy as np  # noqa: E402
 
+KEY_SEED = 0x4845564D  # every replica expands the same key set from it (bench keys are reproducible, hence NOT secure: hevm_init_seeded)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
 
 
@@ -308,6 +309,9 @@ def build_parser():
                          "it runs by default since round 3, in a child process before this one touches the GPU")
     ap.add_argument("--config4", dest="config4", action="store_true", help="(default)")
     ap.set_defaults(config4=True)
+    ap.add_argument("--broadcast-keys", action="store_true",
+                    help="--gpus > 1: every rank generates its own key set, then rank 0's is shipped to the others (one flat RCCL broadcast "
+                         "per key buffer) instead of every rank expanding the same seed; either way the ranks compare key digests")
     ap.add_argument("--dry-run", action="store_true",
                     help="exercise the launch / rank / aggregation path without a GPU: no kernel runs, the step is a sleep, the process "
                          "group uses gloo (tests/test_dist_gloo.py)")
@@ -361,6 +365,16 @@ def dry_run(args, grp):
 
     fx = ha.read_fixture(ROOT / "tests" / "golden" / "resnet20")
     st = progstats.walk(fx["hevm"])
+    # the key-replication path with stand-in buffers (three "keys" of 4096 words expanded from the seed): same code as the real run's
+    import hashlib
+
+    import torch
+
+    seed = KEY_SEED + (grp.rank if args.broadcast_keys else 0)  # broadcast mode starts from DIFFERENT per-rank sets
+    fake = [torch.from_numpy(np.random.default_rng([seed, i]).integers(0, 1 << 62, 4096, dtype=np.int64)) for i in range(3)]
+    keys = grp.share_keys(lambda: int.from_bytes(hashlib.sha256(b"".join(t.numpy().tobytes() for t in fake)).digest()[:8], "little"),
+                          buffers_fn=lambda: [(i, 4096) for i in range(3)], copy_out=lambda i, w: fake[i].clone(),
+                          copy_in=lambda i, t: fake[i].copy_(t), mode="broadcast" if args.broadcast_keys else "seed")
     for _ in range(args.warmup):
         time.sleep(0.001)
     grp.barrier()
@@ -374,8 +388,8 @@ def dry_run(args, grp):
         print(json.dumps({"metric": "NTT/s (dry run: no kernel executed)", "value": round(total / elapsed, 1), "unit": "NTT/s",
                           "n_gpus": grp.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "none (dry run)",
-                          "dry_run": True,
-                          "config": {"workload": "dry run", "ntt_equivalents_per_step": st["ntt_equivalents"],
+                          "dry_run": True, "keys": keys,
+                          "config": {"workload": "dry run", "ntt_equivalents_per_step": st["ntt_equivalents"], "streams_per_gpu": args.streams,
                                      "parallelism": f"replicas x{grp.world} (no collective in the op path)"}}), flush=True)
     grp.close()
 
@@ -411,10 +425,31 @@ def main():
 
     # ---- set-up (untimed, like hc-test: context/keys, load, preprocess, encrypt) ---------------------------------
     t_setup = time.time()
-    hevm = runner.HEVM(seed=0x4845564D + rank, logN=15, num_primes=14)
+    # replicas serve ONE client: every rank holds the same key set.  Default: all ranks expand the same seed on their own
+    # GPU; --broadcast-keys: per-rank sets, then rank 0's is broadcast.  The inputs (and the encryption randomness) differ per rank.
+    hevm = runner.HEVM(seed=KEY_SEED + (rank if args.broadcast_keys else 0), logN=15, num_primes=14)
     if args.streams > 1:
         hevm.set_streams(args.streams)
-    # independent stream per rank: same program, own keys (and own encryption randomness)
+
+    def _copy_out(ptr, words):
+        import torch
+
+        t = torch.empty(words, dtype=torch.int64, device=grp.device)
+        L.dc_memcpy_d2d(t.data_ptr(), ptr, 8 * words, None)
+        L.dc_device_sync()
+        return t
+
+    def _copy_in(ptr, t):
+        import torch
+
+        torch.cuda.synchronize()
+        L.dc_memcpy_d2d(ptr, t.data_ptr(), 8 * t.numel(), None)
+        L.dc_device_sync()
+
+    key_info = grp.share_keys(hevm.keyDigest, buffers_fn=hevm.keyBuffers, copy_out=_copy_out, copy_in=_copy_in,
+                              mode="broadcast" if args.broadcast_keys else "seed")
+    if args.broadcast_keys and rank != 0:
+        hevm.keysReplaced()
     fx = None
     if args.program == "resnet20":
         fx = ha.read_fixture(ROOT / "tests" / "golden" / "resnet20")
@@ -423,7 +458,7 @@ def main():
             import gzip
             hv = gzip.open(args.hevm_gz).read()
             info = {"op_mix": "see " + args.hevm_gz}
-        image = fx["packed"]
+        image = fx["packed"] if rank == 0 else np.roll(fx["packed"], 17 * rank) * (1.0 - 0.01 * rank)  # another (meaningless) image per replica
         workload = ("ResNet-20 (SiLU) HEVM program traced from the reference's examples/benchmarks/ResNet.py with its "
                     "resnet20.silu.model weights")
     else:
@@ -550,7 +585,7 @@ def main():
                    "streams_per_gpu": args.streams,
                    "lowerings": lowerings,
                    "with_direct_rotation_keys": direct,
-                   "parallelism": f"replicas x{world} (no collective in the op path)"},
+                   "parallelism": f"replicas x{world} (no collective in the op path)", "keys": key_info},
         "hevm_wall_s": round(ms_per_step / 1e3, 4),
         "hevm_bootstrap_s_per_step": round(stats["bootstrap_s"], 4),
         "setup_s_untimed": round(t_setup, 1),

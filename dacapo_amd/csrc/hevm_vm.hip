@@ -1847,6 +1847,68 @@ void hevm_add_rotation_keys(void *vm, const int64_t *offsets, int count)
     h->plan.ready = false; // rotations by these offsets are single hops from now on: the plan of a loaded program is rebuilt
     h->drop_plan_graph();
 }
+// ---- key replication across VM replicas (evaluation keys are read-only and replicated over the GPUs) ------------------
+using namespace dacapo;
+// wrapping checksum of `words` 64-bit words: sum of x[i] * (2 i + 1)
+__global__ __launch_bounds__(256) void key_checksum_kernel(const u64 *__restrict__ x, size_t words, unsigned long long *__restrict__ out)
+{
+    __shared__ u64 part[256];
+    u64 acc = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < words; i += (size_t)gridDim.x * 256) acc += x[i] * (2 * (u64)i + 1);
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) part[threadIdx.x] += part[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) atomicAdd(out, (unsigned long long)part[0]);
+}
+// Enumerates the VM's key buffers in a canonical order (secret, public, relinearisation, Galois keys by ascending element): fills
+// ptrs[i] / words[i] for up to `cap` buffers and returns how many there are.  Replicas that hold the same key set list the same sizes.
+int hevm_key_buffers(void *vm, uint64_t **ptrs, uint64_t *words, int cap)
+{
+    auto h = V(vm);
+    const Context &c = *h->ctx;
+    std::vector<std::pair<u64 *, size_t>> v;
+    if (h->keys.sk) v.push_back({ h->keys.sk, (size_t)c.K * c.N });
+    if (h->keys.pk) v.push_back({ h->keys.pk, (size_t)2 * c.K * c.N });
+    if (h->keys.relin) v.push_back({ h->keys.relin, h->key_elems() });
+    std::vector<u32> elts;
+    for (const auto &kv : h->keys.galois) elts.push_back(kv.first);
+    std::sort(elts.begin(), elts.end());
+    for (u32 e : elts) v.push_back({ h->keys.galois.at(e), h->key_elems() });
+    for (int i = 0; i < (int)v.size() && i < cap; i++) ptrs[i] = v[(size_t)i].first, words[i] = (uint64_t)v[(size_t)i].second;
+    return (int)v.size();
+}
+// one 64-bit digest of all key material (order as above), computed on the device
+uint64_t hevm_key_digest(void *vm)
+{
+    auto h = V(vm);
+    const int n = hevm_key_buffers(vm, nullptr, nullptr, 0);
+    std::vector<uint64_t *> ptrs((size_t)n);
+    std::vector<uint64_t> words((size_t)n);
+    hevm_key_buffers(vm, ptrs.data(), words.data(), n);
+    unsigned long long *d = nullptr, out = 0;
+    DC_HIP_CHECK(hipMalloc(&d, 8));
+    u64 digest = 0x9E3779B97F4A7C15ull;
+    for (int i = 0; i < n; i++) {
+        DC_HIP_CHECK(hipMemsetAsync(d, 0, 8, h->S()));
+        hipLaunchKernelGGL(key_checksum_kernel, dim3(1024), dim3(256), 0, h->S(), ptrs[(size_t)i], (size_t)words[(size_t)i], d);
+        DC_HIP_CHECK(hipMemcpyAsync(&out, d, 8, hipMemcpyDeviceToHost, h->S()));
+        DC_HIP_CHECK(hipStreamSynchronize(h->S()));
+        digest = (digest ^ (u64)out) * 0xBF58476D1CE4E5B9ull + (u64)words[(size_t)i];
+    }
+    (void)hipFree(d);
+    return digest;
+}
+// after key buffers have been overwritten from outside (a broadcast from another replica): forget everything derived from them
+void hevm_keys_replaced(void *vm)
+{
+    auto h = V(vm);
+    DC_HIP_CHECK(hipStreamSynchronize(h->S()));
+    h->plan.ready = false;
+    h->drop_plan_graph();
+}
 void hevm_test_zero_encryption(void *vm, bool on)
 {
     if (on) fprintf(stderr, "[dacapo_amd] TEST HOOK: encryptions of zero are (0, 0) from now on -- this VM offers NO security\n");

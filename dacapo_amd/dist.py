@@ -54,6 +54,36 @@ class Group:
         self.dist.all_reduce(w, op=self.dist.ReduceOp.SUM)
         return float(t.item()), float(w.item())
 
+    # ---- key replication ------------------------------------------------------------------------------------------
+    # Replicas serve ONE client: every rank must hold the same secret / public / evaluation keys.  Two ways:
+    #   "seed"      every rank expands the same key set from the same seed on its own GPU (nothing crosses xGMI);
+    #   "broadcast" rank 0's buffers are shipped: one flat broadcast per key buffer (0.09-0.4 GB each), which RCCL runs from GPU 0 over
+    #               its seven point-to-point links at once -- not a ring, there is nothing to reduce.
+    # Either way the ranks then compare a digest of their key material and the run aborts on a mismatch.
+    def share_keys(self, digest_fn, buffers_fn=None, copy_in=None, copy_out=None, mode="seed"):
+        """digest_fn() -> int; broadcast mode also needs buffers_fn() -> [(handle, words)], copy_out(handle, words) -> 1-D int64 tensor on
+        self.device holding the buffer, copy_in(handle, tensor) writing it back.  Returns {"keys": "shared", "mode", "digest", "bytes"}"""
+        moved = 0
+        if self.dist is not None and mode == "broadcast":
+            for handle, words in buffers_fn():
+                t = copy_out(handle, words)
+                self.dist.broadcast(t, src=0)
+                if self.rank != 0:
+                    copy_in(handle, t)
+                moved += 8 * int(words)
+                del t
+        d = int(digest_fn()) & 0xFFFFFFFFFFFFFFFF
+        if self.dist is not None:
+            import torch
+
+            mine = torch.tensor([d >> 32, d & 0xFFFFFFFF], dtype=torch.int64, device=self.device)
+            every = [torch.zeros_like(mine) for _ in range(self.world)]
+            self.dist.all_gather(every, mine)
+            seen = {(int(e[0].item()) << 32) | int(e[1].item()) for e in every}
+            if len(seen) != 1:
+                raise RuntimeError(f"rank {self.rank}: the replicas hold different key sets ({sorted(hex(x) for x in seen)})")
+        return {"keys": "shared", "mode": mode, "digest": f"{d:016x}", "broadcast_bytes": moved}
+
     def close(self):
         if self.dist is not None:
             self.dist.barrier()

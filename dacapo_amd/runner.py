@@ -61,6 +61,10 @@ def reinit_lw():  # runner.py:73-117
     for f in (lw.hevm_relin_key, lw.hevm_secret_key, lw.hevm_public_key):
         f.argtypes = [ctypes.c_void_p]
         f.restype = ctypes.c_void_p
+    lw.hevm_key_buffers.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+    lw.hevm_key_digest.argtypes = [ctypes.c_void_p]
+    lw.hevm_key_digest.restype = ctypes.c_uint64
+    lw.hevm_keys_replaced.argtypes = [ctypes.c_void_p]
     lw.hevm_galois_key.argtypes = [ctypes.c_void_p, ctypes.c_uint32]
     lw.hevm_galois_key.restype = ctypes.c_void_p
     lw.hevm_plain.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_double)]
@@ -194,6 +198,19 @@ class HEVM:
             lw.decrypt_result(self.vm, i, carr)
             result[i] = data
         return result
+
+    def keyBuffers(self):
+        """[(device pointer, 64-bit words)] of the key material in canonical order (hevm_key_buffers)"""
+        n = lw.hevm_key_buffers(self.vm, None, None, 0)
+        ptrs, words = (ctypes.c_void_p * n)(), (ctypes.c_uint64 * n)()
+        lw.hevm_key_buffers(self.vm, ptrs, words, n)
+        return [(int(ptrs[i] or 0), int(words[i])) for i in range(n)]
+
+    def keyDigest(self) -> int:
+        return int(lw.hevm_key_digest(self.vm))
+
+    def keysReplaced(self):
+        lw.hevm_keys_replaced(self.vm)
 
     def close(self):
         """extension: return this VM's HBM (hevm_destroy).  The reference's runner never frees its VM; neither does this class unless asked."""

@@ -81,6 +81,13 @@ const uint64_t *hevm_relin_key(void *vm);
 const uint64_t *hevm_galois_key(void *vm, uint32_t elt);
 const uint64_t *hevm_secret_key(void *vm);
 const uint64_t *hevm_public_key(void *vm);
+/* Key replication over VM replicas (one VM per GPU): the VM's key buffers in a canonical order (secret, public,
+ * relinearisation, Galois keys by ascending element) -- device pointers and sizes in 64-bit words; returns their number (call with
+ * cap = 0 to size the arrays).  hevm_key_digest: a 64-bit digest of all of them, computed on the device.  hevm_keys_replaced: call
+ * after overwriting the buffers from outside (bench.py --broadcast-keys: one flat RCCL broadcast per buffer from GPU 0). */
+int hevm_key_buffers(void *vm, uint64_t **ptrs, uint64_t *words, int cap);
+uint64_t hevm_key_digest(void *vm);
+void hevm_keys_replaced(void *vm);
 /* device pointer + level + scale of plaintext register i after preprocess() */
 const uint64_t *hevm_plain(void *vm, int64_t i, int32_t *level, double *scale);
 /* load a program from memory images of the .cst / .hevm files */

@@ -81,6 +81,47 @@ def test_bench_gpus_flag_starts_the_ranks_itself():
     assert abs(r["value"] - 2 * per_step * r["steps"] / (r["ms_per_step"] * r["steps"] * 1e-3)) / r["value"] < 1e-3
 
 
+def test_replicas_hold_one_key_set_seeded_or_broadcast():
+    """keys are replicated over the GPUs.  Default: every rank expands the same seed -> identical digests, nothing moved.
+    --broadcast-keys: the ranks start from DIFFERENT sets, rank 0's is broadcast buffer by buffer, the digests then agree (the run would
+    abort otherwise) and the line reports the bytes shipped.  --streams S rides along on the multi-rank path (config 5 = 8 GPUs x S)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    seeded = _bench_lines(["--gpus", "2", "--steps", "1", "--warmup", "0", "--dry-run", "--streams", "3"], env)[0]
+    assert seeded["keys"]["keys"] == "shared" and seeded["keys"]["mode"] == "seed" and seeded["keys"]["broadcast_bytes"] == 0
+    assert seeded["config"]["streams_per_gpu"] == 3
+    single = _bench_lines(["--dry-run"], env)[0]
+    assert single["keys"]["digest"] == seeded["keys"]["digest"]          # the same key set at every world size
+    bc = _bench_lines(["--gpus", "2", "--steps", "1", "--warmup", "0", "--dry-run", "--broadcast-keys"], env)[0]
+    assert bc["keys"]["keys"] == "shared" and bc["keys"]["mode"] == "broadcast" and bc["keys"]["broadcast_bytes"] == 3 * 4096 * 8
+    assert bc["keys"]["digest"] == seeded["keys"]["digest"]               # rank 0's set is the seed's set
+
+
+def test_share_keys_refuses_replicas_with_different_keys(tmp_path):
+    worker = tmp_path / "w.py"
+    worker.write_text('''
+import sys
+sys.path.insert(0, %r)
+from dacapo_amd.dist import Group
+g = Group(backend="gloo")
+try:
+    g.share_keys(lambda: 1000 + g.rank)          # per-rank digests: must be refused
+    print("NOT REFUSED", flush=True)
+except RuntimeError as e:
+    print("refused:", e, flush=True)
+g.close()
+''' % str(ROOT))
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = str(sk.getsockname()[1])
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                          "--master-port", port, str(worker)], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.count("refused:") == 2 and "NOT REFUSED" not in out.stdout
+
+
 def test_bench_under_an_external_launcher_uses_its_world_size():
     """the driver's own form: torch.distributed.run ... bench.py --gpus N (RANK set => no second spawn)"""
     import json
