@@ -125,7 +125,10 @@ def real_bootstrap_leg(ll, runner, steps=3, resnet=True):
             from dacapo_amd import progstats
 
             pst = progstats.walk(hv, logN, direct_keys=True)
-            out["single"].append({"N": 1 << logN, "ms": round(dt * 1e3, 2), "instructions": int(len(ha.unpack_hevm(hv)["ops"])),
+            sec = (f"below 128-bit (N = 2^15, log2(QP) = {60 * K}, secret Hamming weight 64; the HE standard allows 881 bits at this N): "
+                   "timing / accuracy demonstration only") if logN == 15 else \
+                  f"N = 2^17, log2(QP) = {60 * K}, h = 64: inside the 128-bit range for this ring"
+            out["single"].append({"N": 1 << logN, "security": sec, "ms": round(dt * 1e3, 2), "instructions": int(len(ha.unpack_hevm(hv)["ops"])),
                                   "algorithmic_bytes": pst["algorithmic_bytes"], "achieved_gbs": round(pst["algorithmic_bytes"] / dt / 1e9, 1),
                                   "frac_of_hbm_peak": round(pst["algorithmic_bytes"] / dt / 1e9 / HBM_PEAK_GBS, 4),
                                   "key_switches": st["keyswitches"], "ntt_equivalents": st["ntts"], "ntt_per_s": round(st["ntts"] / dt),
@@ -148,6 +151,8 @@ def real_bootstrap_leg(ll, runner, steps=3, resnet=True):
             ops = ha.unpack_hevm(fx["hevm"])["ops"]
             out["resnet20_with_real_bootstraps"] = {
                 "program": "the headline program, every opcode 10 lowered to ModRaise/CoeffToSlot/EvalMod/SlotToCoeff by ckks_boot.lower_bootstraps",
+                "security": f"below 128-bit (N = 2^15, log2(QP) = {60 * KB}, h = 64): timing / accuracy demonstration only; config 4 (N = 2^17) is the "
+                            "parameter set inside the standard's range",
                 "lowering_s": round(t_lower, 1),
                 "instructions": int(len(ops)), "real_bootstraps": int((ops[:, 0] == ha.OP_MODRAISE).sum()), "run_s": round(dt, 3),
                 "key_switches": st["keyswitches"], "ntt_equivalents": st["ntts"], "ntt_per_s": round(st["ntts"] / dt),

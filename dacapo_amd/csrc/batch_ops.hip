@@ -122,7 +122,8 @@ static long fuse_mac_threshold()
 }
 
 // L2..L7 of the key-switch pipeline (fused_ks.hip) once the digits' inverse ROWS phase (L1) has been issued
-bool chain_fusion_supported() { return fuse_mac(); }
+// (with DACAPO_KS_FUSE_MAC_TILES set, a linked step could fall on the un-fused middle, whose last kernel has no continuation form)
+bool chain_fusion_supported() { return fuse_mac() && fuse_mac_threshold() == (1L << 40); }
 
 // `digits`: output of the inverse ROWS phase of the key-switch target [B][l][N] (w.digits, or the buffer a fused producer filled)
 template <int MODE>
@@ -304,19 +305,22 @@ __global__ __launch_bounds__(kBT) void b_sum_kernel(const SumItem *__restrict__ 
 }
 
 // ---- ModRaise -----------------------------------------------------------------------------------------------------------------
-// scratch[b*2 + p][k] = limb 0 of polynomial p of item b (NTT form; the caller then takes it to the coefficient domain)
-__global__ __launch_bounds__(kBT) void b_modraise_gather_kernel(u64 *__restrict__ scratch, const EwItem *__restrict__ items, size_t N)
+// scratch[b*2 + p][k] = limb 0 of polynomial p of item b (NTT form; the caller then takes it to the coefficient domain).
+// items == nullptr: one item passed by value (the one-instruction-at-a-time loop: no allocation, no copy, no synchronisation)
+__global__ __launch_bounds__(kBT) void b_modraise_gather_kernel(u64 *__restrict__ scratch, const EwItem *__restrict__ items, EwItem single, size_t N)
 {
     const int z = blockIdx.y, b = z >> 1, p = z & 1;
     const size_t k = ((size_t)blockIdx.x * kBT + threadIdx.x) * 2;
-    *reinterpret_cast<u64x2 *>(scratch + (size_t)z * N + k) = *reinterpret_cast<const u64x2 *>(items[b].a.limb(p, 0, N) + k);
+    const CtView a = items ? items[b].a : single.a;
+    *reinterpret_cast<u64x2 *>(scratch + (size_t)z * N + k) = *reinterpret_cast<const u64x2 *>(a.limb(p, 0, N) + k);
 }
 // dst[p][i][k] = centred(scratch[b*2+p][k] mod q_0) mod q_i : the integer in (-q_0/2, q_0/2] read modulo every prime of the target level
 // grid = (N/512, target, 2B)
-__global__ __launch_bounds__(kBT) void b_modraise_lift_kernel(const u64 *__restrict__ scratch, const EwItem *__restrict__ items, size_t N,
-                                                               const DModulus *__restrict__ mods)
+__global__ __launch_bounds__(kBT) void b_modraise_lift_kernel(const u64 *__restrict__ scratch, const EwItem *__restrict__ items, EwItem single,
+                                                               size_t N, const DModulus *__restrict__ mods)
 {
     const int i = blockIdx.y, z = blockIdx.z, b = z >> 1, p = z & 1;
+    const CtView dstv = items ? items[b].dst : single.dst;
     const u64 q0 = mods[0].q, qi = mods[i].q, half = q0 >> 1;
     const size_t k = ((size_t)blockIdx.x * kBT + threadIdx.x) * 2;
     const u64x2 v = *reinterpret_cast<const u64x2 *>(scratch + (size_t)z * N + k);
@@ -330,27 +334,27 @@ __global__ __launch_bounds__(kBT) void b_modraise_lift_kernel(const u64 *__restr
         } else
             r[e] = v[e] >= qi ? v[e] - qi : v[e];
     }
-    *reinterpret_cast<u64x2 *>(items[b].dst.limb(p, i, N) + k) = r;
+    *reinterpret_cast<u64x2 *>(dstv.limb(p, i, N) + k) = r;
 }
 
 void modraise(Context &c, u64 *scratch, const EwItem *h_items, int B, int target, hipStream_t s, const EwItem *d_items)
 {
     const size_t N = c.N;
-    EwItem *tmp = nullptr;
-    if (!d_items) { // eager path: one item by value
-        DC_HIP_CHECK(hipMalloc(&tmp, (size_t)B * sizeof(EwItem)));
-        DC_HIP_CHECK(hipMemcpyAsync(tmp, h_items, (size_t)B * sizeof(EwItem), hipMemcpyHostToDevice, s));
-        d_items = tmp;
+    if (!d_items && B != 1) {
+        fprintf(stderr, "[dacapo_amd] modraise: a batch needs its item table on the device\n");
+        abort();
     }
-    hipLaunchKernelGGL(b_modraise_gather_kernel, dim3((unsigned)(N / (2 * kBT)), (unsigned)(2 * B)), dim3(kBT), 0, s, scratch, d_items, N);
+    const EwItem single = d_items ? EwItem{} : h_items[0]; // eager path: the one item travels as a kernel argument
+    hipLaunchKernelGGL(b_modraise_gather_kernel, dim3((unsigned)(N / (2 * kBT)), (unsigned)(2 * B)), dim3(kBT), 0, s, scratch, d_items, single, N);
     launch_ntt(c, true, scratch, (long)N, 2 * B, nullptr, 0, 1, s);
     hipLaunchKernelGGL(b_modraise_lift_kernel, dim3((unsigned)(N / (2 * kBT)), (unsigned)target, (unsigned)(2 * B)), dim3(kBT), 0, s, scratch,
-                       d_items, N, c.d_mods);
-    for (int b = 0; b < B; b++)
-        for (int p = 0; p < 2; p++) launch_ntt(c, false, h_items[b].dst.limb(p, 0, N), (long)N, target, nullptr, 0, 0, s);
-    if (tmp) {
-        DC_HIP_CHECK(hipStreamSynchronize(s));
-        (void)hipFree(tmp);
+                       d_items, single, N, c.d_mods);
+    for (int b = 0; b < B; b++) { // one forward transform over both polynomials of an item: [2][target] limbs, the register's poly stride apart
+        const CtView d = h_items[b].dst;
+        if (d.poly_stride == (long)target * (long)N)
+            launch_ntt(c, false, d.limb(0, 0, N), (long)N, 2 * target, nullptr, 0, target, s);
+        else
+            for (int p = 0; p < 2; p++) launch_ntt(c, false, d.limb(p, 0, N), (long)N, target, nullptr, 0, 0, s);
     }
 }
 

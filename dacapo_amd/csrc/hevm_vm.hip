@@ -14,6 +14,7 @@
 #include <sys/random.h>
 
 #include <algorithm>
+#include <cmath>
 #include <chrono>
 #include <fstream>
 #include <iostream>
@@ -864,9 +865,12 @@ void HEVM::load_program(const void *data, size_t len, bool header_only)
         // may name cipher registers beyond num_ctxt_buffer (the file grows with them) but never a plaintext register that does not exist.
         for (const WireOp &op : ops) {
             if (op.opcode > 10 && (op.opcode < kOpEncodeComplex || op.opcode > kOpSetScale)) continue;
-            if (op.opcode == kOpSetScale && op.rhs >= buffer.size()) {
-                fprintf(stderr, "[dacapo_amd] .hevm: setscale reads constant %u of %zu\n", (unsigned)op.rhs, buffer.size());
-                abort();
+            if (op.opcode == kOpSetScale) { // its operand is a constant that must exist NOW (the run path indexes it unchecked), hold a value, and be a scale
+                if (op.rhs >= buffer.size() || buffer[op.rhs].empty() || !(buffer[op.rhs][0] > 0.0) || !std::isfinite(buffer[op.rhs][0])) {
+                    fprintf(stderr, "[dacapo_amd] .hevm: setscale needs constant %u of %zu to hold a finite positive scale (load the constants before the program)\n",
+                            (unsigned)op.rhs, buffer.size());
+                    abort();
+                }
             }
             if (op.opcode == 0 || op.opcode == kOpEncodeComplex) {
                 if (op.dst >= plains.size()) {
@@ -1450,7 +1454,7 @@ void HEVM::op_setscale(int dst, int src, int const_idx)
     hevm_ctxt &s = reg(src);
     hevm_ctxt &d = reg(dst);
     if (dst != src) launch_ew(*ctx, EwOp::Copy, view(d), view(s), view(s), 2, 2, s.level, S());
-    d.level = s.level, d.scale = buffer.at((size_t)const_idx).at(0);
+    d.level = s.level, d.scale = buffer[(size_t)const_idx][0]; // validated by load_program
 }
 
 // host-side constants of the device CRT for level ell (built once per level)

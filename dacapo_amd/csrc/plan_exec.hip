@@ -229,7 +229,7 @@ void HEVM::build_plan()
         case kOpSetScale: { // a relabelled view of the same buffer
             const int a = need(op.lhs, "setscale");
             const Val s = P.vals[(size_t)a];
-            const int nv = new_val(s.level, buffer.at(op.rhs).at(0));
+            const int nv = new_val(s.level, buffer[op.rhs][0]); // validated by load_program
             P.vals[(size_t)nv].root = s.root;
             P.vals[(size_t)nv].def_pop = P.vals[(size_t)s.root].def_pop;
             P.vals[(size_t)a].uses++;

@@ -241,8 +241,10 @@ Reader open_object(Reader &in, std::vector<uint8_t> &owned)
 {
     const SealHeader h = in.get<SealHeader>();
     if (h.magic != kMagic || h.header_size != 16) in.fail("not a SEAL-serialized object (bad magic / header size)");
-    if (h.version_major != 4 && !(h.version_major == 3 && h.version_minor >= 6))
-        in.fail("written by an unsupported SEAL version (need 4.x; 3.6/3.7 share the layout except for Ciphertext)");
+    // 3.6 / 3.7 headers look the same, but their Ciphertext layout has no correction_factor field and every key object here is made of
+    // ciphertexts: accepting them would misparse pub / relin / gal files with a misleading "array length" error.  The reference pins 4.0.
+    if (h.version_major != 4)
+        in.fail("written by SEAL 3.x or another unsupported version: this runtime reads SEAL 4.x serialization only (re-save the keys with SEAL 4)");
     if (h.size < 16 || h.size - 16 > in.left()) in.fail("header size field exceeds the data");
     const size_t stored = (size_t)(h.size - 16);
     const uint8_t *body = in.skip(stored);

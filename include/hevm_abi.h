@@ -26,7 +26,10 @@ void *initClientVM(char *dir);
 /* SEAL_HEVM.cpp:415 */
 void *initServerVM(char *dir);
 /* SEAL_HEVM.cpp:421  -- writes parm/pub/sec/relin/gal ".seal" files in Microsoft SEAL 4.0's binary serialization
- * (SEAL_HEVM.cpp:55-88): a key directory written here loads in the reference's runtime and vice versa.  Keys and all
+ * (SEAL_HEVM.cpp:55-88).  Format-compatible BY CONSTRUCTION, not yet verified against SEAL: the layout (16-byte header, parms_id hash,
+ * Galois key index, nested ciphertext objects) follows SEAL 4.0's published serialization and is cross-checked by an independent
+ * reader / writer (oracle/seal_format.py), but no file produced by SEAL itself has been read here and none written here has been read
+ * by SEAL (SEAL is neither vendored in the reference nor installed; tests/test_seal_diff.py runs where it is).  Keys and all
  * encryption randomness come from ChaCha20 keyed by 512 bits of getrandom(2); the call aborts if that fails.
  * DACAPO_HEVM_SEAL_COMPR = none (default) | zlib | zstd selects the compr_mode of the written files. */
 void create_context(char *dir);
