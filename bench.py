@@ -250,22 +250,19 @@ def cfg3_leg(ll, iters=5):
             "achieved_gbs": round(alg / (us * 1e-6) / 1e9, 1), "frac_of_hbm_peak": round(alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
 
 
-def cpu_baseline_leg(cst: bytes, hv: bytes, image, budget_s=15.0):
-    """oracle VM (1 thread) on a prefix of the same program; returns NTT-equivalents/s"""
+def _cpu_prefix(o, cst: bytes, hv: bytes, image, budget_s: float, threads: int):
+    """the oracle VM on a prefix of a program for `budget_s` seconds of run-time ops: (NTT-equivalents, seconds, ops, key switches)"""
     import tempfile
 
-    from oracle.oracle import Oracle, OracleVM
+    from oracle.oracle import OracleVM
 
-    t0 = time.time()
-    o = Oracle(15, 14)
-    o.keygen(seed=0x4845564D)
+    o.L.orc_set_threads(threads)
     with tempfile.TemporaryDirectory() as d:
         (Path(d) / "p.cst").write_bytes(cst)
         (Path(d) / "p.hevm").write_bytes(hv)
         vm = OracleVM(o)
         vm.load(Path(d) / "p.cst", Path(d) / "p.hevm")
     vm.encrypt(0, image)
-    setup_s = time.time() - t0
     ntts, n_ops, spent, ks = 0, 0, 0.0, 0
     for op in vm.prog.ops:
         opcode, dst, lhs, rhs = (int(x) for x in op)
@@ -290,11 +287,46 @@ def cpu_baseline_leg(cst: bytes, hv: bytes, image, budget_s=15.0):
             ntts += 2 * lvl
         if spent > budget_s:
             break
-    return {"value": round(ntts / spent, 1), "unit": "NTT/s", "cores": 1, "kind": "port",
-            "sample": f"first {n_ops} run-time ops ({ks} key switches) of the same HEVM program, "
-                      f"{spent:.1f} s of single-thread work (+{setup_s:.0f} s untimed keygen/encrypt)",
-            "seconds": round(spent, 2), "ntt_equivalents": ntts,
-            "reference_published": "README.md:176-188: 53.73 s for the DaCapo-compiled ResNet-20 on SEAL CPU (hardware unstated)"}
+    o.L.orc_set_threads(1)
+    return ntts, spent, n_ops, ks
+
+
+def cpu_baseline_leg(cst: bytes, hv: bytes, image, budget_s=15.0, hv_b13: bytes | None = None):
+    """The CPU path timed beside the GPU: the oracle VM (oracle/: a restatement of SEAL's algorithms, the reference's arithmetic being
+    unbuildable here) on a PREFIX of the same program.  `value` = 1 thread, like SEAL's evaluator and the reference's HEVM loop; beside it
+    the 8-thread OpenMP-over-limbs variant BASELINE.md names, and both again on the b13 lowering (key switches at up to 13 primes: the
+    plan shape the reference's own SEAL cost table implies, profiled_SEAL_CPU.json:5-8), where limb parallelism has something to chew on."""
+    import os as _os
+
+    from oracle.oracle import Oracle
+
+    t0 = time.time()
+    o = Oracle(15, 14)
+    o.keygen(seed=0x4845564D)
+    setup_s = time.time() - t0
+    ncpu = _os.cpu_count() or 1
+    th = min(8, ncpu)
+    ntts, spent, n_ops, ks = _cpu_prefix(o, cst, hv, image, budget_s, 1)
+    out = {"value": round(ntts / spent, 1), "unit": "NTT/s", "cores": 1, "kind": "port",
+           "sample": f"first {n_ops} run-time ops ({ks} key switches) of the same HEVM program, "
+                     f"{spent:.1f} s of single-thread work (+{setup_s:.0f} s untimed keygen)",
+           "seconds": round(spent, 2), "ntt_equivalents": ntts, "host_cpus": ncpu,
+           "reference_published": "README.md:176-188: 53.73 s for the DaCapo-compiled ResNet-20 on SEAL CPU (hardware unstated)"}
+    if o.L.orc_has_openmp() and th > 1:
+        _cpu_prefix(o, cst, hv, image, 0.5, th)  # thread-pool warm-up
+        n2, s2, ops2, ks2 = _cpu_prefix(o, cst, hv, image, budget_s / 2, th)
+        out["openmp"] = {"value": round(n2 / s2, 1), "unit": "NTT/s", "cores": th,
+                         "sample": f"first {ops2} run-time ops ({ks2} key switches), {s2:.1f} s, OpenMP over the limbs of each op",
+                         "note": "at 1-3 primes an op has 2-4 limbs to spread: little to gain on the headline lowering"}
+    if hv_b13 is not None:
+        n3, s3, ops3, ks3 = _cpu_prefix(o, cst, hv_b13, image, budget_s / 2, 1)
+        out["b13_lowering"] = {"value": round(n3 / s3, 1), "unit": "NTT/s", "cores": 1,
+                               "sample": f"first {ops3} run-time ops ({ks3} key switches at up to 13 primes) of tests/golden/resnet20.b13, {s3:.1f} s"}
+        if o.L.orc_has_openmp() and th > 1:
+            n4, s4, ops4, ks4 = _cpu_prefix(o, cst, hv_b13, image, budget_s / 2, th)
+            out["b13_lowering"]["openmp"] = {"value": round(n4 / s4, 1), "unit": "NTT/s", "cores": th,
+                                             "sample": f"first {ops4} run-time ops ({ks4} key switches), {s4:.1f} s"}
+    return out
 
 
 def build_parser():

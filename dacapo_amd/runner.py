@@ -100,6 +100,17 @@ def setLibnHW(argv=None):  # runner.py:123-171: only the SEAL-compatible ABI exi
     return
 
 
+_live_vms: dict = {}  # id(HEVM object) -> VM handle, for every VM whose device state has not been released (close / close_all)
+
+
+def close_all():
+    """extension: hevm_destroy every VM this process has created and not closed -- also those whose Python object is gone (the reference's
+    runner never frees a VM).  Test suites call it between modules: one module's VMs must not crowd the next module's out of HBM."""
+    for key, handle in list(_live_vms.items()):
+        lw.hevm_destroy(handle)
+        _live_vms.pop(key, None)
+
+
 class HEVM:
     def __init__(self, path=str((Path.home() / ".hevm" / "seal").absolute()), option="full", seed=None, logN=0, num_primes=0,
                  ks_special=1, ks_alpha=None):
@@ -132,6 +143,7 @@ class HEVM:
                 raise ValueError(option)
         from . import lowlevel
 
+        _live_vms[id(self)] = self.vm
         L = lowlevel.lib()
         self.ctx_handle = lw.hevm_context(self.vm)
         self.logN = L.dc_context_logn(self.ctx_handle)
@@ -214,9 +226,10 @@ class HEVM:
 
     def close(self):
         """extension: return this VM's HBM (hevm_destroy).  The reference's runner never frees its VM; neither does this class unless asked."""
-        if getattr(self, "vm", None):
+        if getattr(self, "vm", None) and _live_vms.get(id(self)) == self.vm:  # (not already released by close_all)
             lw.hevm_destroy(self.vm)
-            self.vm = None
+        _live_vms.pop(id(self), None)
+        self.vm = None
 
     def plaintextBytes(self) -> int:
         """extension: HBM held for the program's plaintexts (pre-encoded pool, or constants + window with DACAPO_HEVM_ONLINE_ENCODE=1)"""

@@ -37,6 +37,9 @@
  */
 #include <complex.h>
 #include <math.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -69,6 +72,27 @@ typedef struct orc_ctx {
     double complex *croot; /* croot[k] = exp(2*pi*i*bitrev(k)/(2N))    (CKKSEncoder::root_powers_) */
     uint32_t *slot_map;    /* CKKSEncoder::matrix_reps_index_map_ */
 } orc_ctx;
+
+/* SEAL's evaluator and the reference's HEVM loop are single-threaded, and so is this file by default.  For the
+ * "8-thread OpenMP over limbs" comparison of BASELINE.md the limb-parallel loops of key switching, rescale and the batched transforms
+ * carry `omp parallel for` with `if (orc_threads > 1)`: same arithmetic per limb, hence the same result bits at any thread count. */
+static int orc_threads = 1;
+void orc_set_threads(int n)
+{
+    orc_threads = n < 1 ? 1 : n;
+#ifdef _OPENMP
+    omp_set_num_threads(orc_threads);
+#endif
+}
+int orc_get_threads(void) { return orc_threads; }
+int orc_has_openmp(void)
+{
+#ifdef _OPENMP
+    return 1;
+#else
+    return 0;
+#endif
+}
 
 /* ------------------------------------------------------------------------------------------------
  * Scalar modular arithmetic
@@ -441,10 +465,12 @@ void orc_negacyclic_schoolbook(const orc_ctx *c, int p, const u64 *a, const u64 
 /* batched over an explicit prime-index list: limb b uses prime pidx[b] */
 void orc_ntt_fwd_batch(const orc_ctx *c, const int32_t *pidx, int count, u64 *data)
 {
+#pragma omp parallel for if (orc_threads > 1) schedule(dynamic)
     for (int b = 0; b < count; b++) orc_ntt_fwd(c, pidx[b], data + (size_t)b * c->N);
 }
 void orc_ntt_inv_batch(const orc_ctx *c, const int32_t *pidx, int count, u64 *data)
 {
+#pragma omp parallel for if (orc_threads > 1) schedule(dynamic)
     for (int b = 0; b < count; b++) orc_ntt_inv(c, pidx[b], data + (size_t)b * c->N);
 }
 
@@ -456,6 +482,7 @@ void orc_ntt_inv_batch(const orc_ctx *c, const int32_t *pidx, int count, u64 *da
  * ---------------------------------------------------------------------------------------------- */
 void orc_poly_add(const orc_ctx *c, int ell, const u64 *a, const u64 *b, u64 *out)
 {
+#pragma omp parallel for if (orc_threads > 1)
     for (int i = 0; i < ell; i++) {
         u64 q = c->mod[i].q;
         for (size_t j = 0; j < c->N; j++) out[i * c->N + j] = addmod(a[i * c->N + j], b[i * c->N + j], q);
@@ -463,6 +490,7 @@ void orc_poly_add(const orc_ctx *c, int ell, const u64 *a, const u64 *b, u64 *ou
 }
 void orc_poly_sub(const orc_ctx *c, int ell, const u64 *a, const u64 *b, u64 *out)
 {
+#pragma omp parallel for if (orc_threads > 1)
     for (int i = 0; i < ell; i++) {
         u64 q = c->mod[i].q;
         for (size_t j = 0; j < c->N; j++) out[i * c->N + j] = submod(a[i * c->N + j], b[i * c->N + j], q);
@@ -477,6 +505,7 @@ void orc_poly_neg(const orc_ctx *c, int ell, const u64 *a, u64 *out)
 }
 void orc_poly_mul(const orc_ctx *c, int ell, const u64 *a, const u64 *b, u64 *out)
 {
+#pragma omp parallel for if (orc_threads > 1)
     for (int i = 0; i < ell; i++) {
         const orc_mod *m = &c->mod[i];
         for (size_t j = 0; j < c->N; j++) out[i * c->N + j] = mulmod(a[i * c->N + j], b[i * c->N + j], m);
@@ -614,18 +643,21 @@ void orc_divide_round_last(const orc_ctx *c, const int32_t *pidx, int cnt, u64 *
     u64 *tmp = (u64 *)malloc(N * 8);
     orc_ntt_inv(c, pl, last);
     for (size_t j = 0; j < N; j++) last[j] = addmod(last[j], half, p);
+    free(tmp);
+#pragma omp parallel for if (orc_threads > 1) schedule(dynamic)
     for (int b = 0; b < cnt - 1; b++) {
         int pi = pidx[b];
         const orc_mod *m = &c->mod[pi];
         u64 qi = m->q;
         u64 neg_half = qi - barrett64(half, m);
         u64 inv_p = invmod_prime(p % qi, qi);
+        u64 *tmp = (u64 *)malloc(N * 8);
         for (size_t j = 0; j < N; j++) tmp[j] = addmod(barrett64(last[j], m), neg_half % qi, qi);
         orc_ntt_fwd(c, pi, tmp);
         u64 *x = poly + (size_t)b * N;
         for (size_t j = 0; j < N; j++) x[j] = mulmod(submod(x[j], tmp[j], qi), inv_p, m);
+        free(tmp);
     }
-    free(tmp);
 }
 
 /* Evaluator::rescale_to_next on one polynomial at level ell -> level ell-1 (SEAL_HEVM.cpp:283).
@@ -660,15 +692,18 @@ void orc_keyswitch(const orc_ctx *c, int ell, const u64 *target, const u64 *key,
     int K = c->K, sp = K - 1;
     size_t key_poly = (size_t)K * N, key_digit = 2 * key_poly;
     u64 *t_target = (u64 *)malloc((size_t)ell * N * 8);
-    u64 *t_ntt = (u64 *)malloc(N * 8);
     u64 *prod = (u64 *)malloc((size_t)2 * (ell + 1) * N * 8); /* [2][ell+1][N] */
-    u128 *acc = (u128 *)malloc((size_t)2 * N * sizeof(u128));
     memcpy(t_target, target, (size_t)ell * N * 8);
+#pragma omp parallel for if (orc_threads > 1) schedule(dynamic)
     for (int j = 0; j < ell; j++) orc_ntt_inv(c, j, t_target + (size_t)j * N);
 
+#pragma omp parallel for if (orc_threads > 1) schedule(dynamic)
     for (int I = 0; I <= ell; I++) {
         int ki = (I == ell) ? sp : I;
         const orc_mod *m = &c->mod[ki];
+        /* per-modulus scratch (the serial build reuses one pair; a thread needs its own) */
+        u64 *t_ntt = (u64 *)malloc(N * 8);
+        u128 *acc = (u128 *)malloc((size_t)2 * N * sizeof(u128));
         memset(acc, 0, (size_t)2 * N * sizeof(u128));
         for (int J = 0; J < ell; J++) {
             const u64 *operand;
@@ -694,6 +729,8 @@ void orc_keyswitch(const orc_ctx *c, int ell, const u64 *target, const u64 *key,
             u64 *dst = prod + ((size_t)kc * (ell + 1) + I) * N;
             for (size_t n = 0; n < N; n++) dst[n] = barrett128(acc[(size_t)kc * N + n], m);
         }
+        free(t_ntt);
+        free(acc);
     }
     /* mod-down by the special prime (the CKKS branch of switch_key_inplace) */
     u64 P = c->mod[sp].q, half = P >> 1;
@@ -703,11 +740,13 @@ void orc_keyswitch(const orc_ctx *c, int ell, const u64 *target, const u64 *key,
         u64 *out = kc ? out1 : out0;
         orc_ntt_inv(c, sp, t_last);
         for (size_t n = 0; n < N; n++) t_last[n] = addmod(t_last[n], half, P);
+#pragma omp parallel for if (orc_threads > 1) schedule(dynamic)
         for (int i = 0; i < ell; i++) {
             const orc_mod *m = &c->mod[i];
             u64 qi = m->q;
             u64 fix = qi - barrett64(half, m);
             u64 inv_p = invmod_prime(P % qi, qi);
+            u64 *t_ntt = (u64 *)malloc(N * 8);
             for (size_t n = 0; n < N; n++) t_ntt[n] = addmod(barrett64(t_last[n], m), fix % qi, qi);
             orc_ntt_fwd(c, i, t_ntt);
             u64 *x = pp + (size_t)i * N;
@@ -715,12 +754,11 @@ void orc_keyswitch(const orc_ctx *c, int ell, const u64 *target, const u64 *key,
                 u64 v = mulmod(submod(x[n], t_ntt[n], qi), inv_p, m);
                 out[(size_t)i * N + n] = addmod(out[(size_t)i * N + n], v, qi);
             }
+            free(t_ntt);
         }
     }
     free(t_target);
-    free(t_ntt);
     free(prod);
-    free(acc);
 }
 
 /* Closed form used to cross-check orc_keyswitch's digit products without lazy tricks:

@@ -13,6 +13,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="module", autouse=True)
+def _release_gpu_vms_after_each_module():
+    """The reference never frees a VM (its ABI has no destroy symbol) and neither do most tests; one module's VMs (tens of GB of direct
+    Galois keys in the bootstrapping tests) must not crowd the next module's out of HBM: hevm_destroy whatever is still alive."""
+    yield
+    mod = sys.modules.get("dacapo_amd.runner")
+    if mod is not None:
+        mod.close_all()
+
+
 @pytest.fixture(scope="session")
 def oracle_small():
     """Small ring (N=2^10, 4 x 60-bit SEAL-style primes): O(N^2) definitions stay cheap."""
