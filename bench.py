@@ -39,7 +39,7 @@ def ntt_equivalents(stats_or_counts):
 
 
 def roofline_leg(ll, ctx, limbs=4096, iters=10):
-    """forward NTT over `limbs` limbs of N = 2^15: two launches (COLS phase, ROWS phase) per transform"""
+    """forward NTT over `limbs` limbs of N = 2^15 as dc_ntt_forward launches it: the single-crossing kernel (round 3; one launch)"""
     L = ll.lib()
     N = ctx.N
     buf = ll.DeviceBuffer((limbs, N))
@@ -63,35 +63,40 @@ def roofline_leg(ll, ctx, limbs=4096, iters=10):
         L.dc_memcpy_d2d(dst.ptr, buf.ptr, buf.nbytes, None)
     L.dc_event_record(e1, None)
     copy_gbs = 2.0 * buf.nbytes / (L.dc_event_elapsed_ms(e0, e1) / iters * 1e-3) / 1e9
+    # the same launches with the round-2 transform (two launches, every limb through HBM twice), for scale
+    for _ in range(2):
+        ctx.ntt(buf, limbs, prime_base=0, prime_period=ctx.K, variant=0)
+    L.dc_event_record(e0, None)
+    for _ in range(iters):
+        ctx.ntt(buf, limbs, prime_base=0, prime_period=ctx.K, variant=0)
+    L.dc_event_record(e1, None)
+    two_ms = L.dc_event_elapsed_ms(e0, e1) / iters
     del buf, dst
-    # HBM bytes per launch pair: rocprofv3 --pmc passes cannot run inside this process (they need their own runs with the program
-    # directly after `--`, tools/ntt_only.py).  profiles/r02_ntt_hbm_traffic.json holds FETCH_SIZE (x2, the gfx950 correction) +
-    # WRITE_SIZE for the same launches; it is reported only when it was collected on exactly this build of the library.
+    # HBM bytes per launch: rocprofv3 --pmc passes cannot run inside this process (they need their own runs with the program directly
+    # after `--`, tools/ntt_variant_only.py).  profiles/r03_ntt_hbm_traffic.json holds FETCH_SIZE (x2, the gfx950 correction) + WRITE_SIZE
+    # for the same launches; it is reported only when it was collected on exactly this build of the library.
     traffic, traffic_source = None, "not collected for this build (recipe: profiles/README.md, `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE`)"
-    tf = ROOT / "profiles" / "r02_ntt_hbm_traffic.json"
+    tf = ROOT / "profiles" / "r03_ntt_hbm_traffic.json"
     if tf.exists() and limbs == 4096 and N == 32768:
         rec = json.loads(tf.read_text())
         if rec.get("lib_sha256") == lib_sha256():
-            traffic, traffic_source = rec.get("forward_ntt_hbm_bytes"), "profiles/r02_ntt_hbm_traffic.json (PMC passes on this build)"
+            traffic, traffic_source = rec.get("forward_ntt_hbm_bytes"), "profiles/r03_ntt_hbm_traffic.json (PMC passes on this build)"
         else:
-            traffic_source = "profiles/r02_ntt_hbm_traffic.json was collected on another build of the library: not reported"
-    # What bounds this launch pair (profiles/r02_experiments.txt items 8-10): every limb crosses HBM twice (one read + one write per
-    # phase), and the same kernels with the arithmetic compiled out run at the copy kernel's bandwidth, so the memory side is at the
-    # floor of the two-launch structure, 2 x (algorithmic bytes / copy bandwidth); the arithmetic (27.7 VALU instructions per forward
-    # butterfly, 7.6 of them v_mad_u64_u32; about 270 + 410 us of pure issue time) is only partly hidden behind that traffic.  A multiply
-    # with 22 % fewer instructions did not change the time: the kernels are not VALU-issue bound.
-    floor_us = 2.0 * alg_bytes / (copy_gbs * 1e9) * 1e6
+            traffic_source = "profiles/r03_ntt_hbm_traffic.json was collected on another build of the library: not reported"
+    floor_us = alg_bytes / (copy_gbs * 1e9) * 1e6
     return {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
             "traffic": traffic, "traffic_source": traffic_source,
-            "kernel": "ntt_phase_kernel<7,COLS,fwd> + ntt_phase_kernel<8,ROWS,fwd> (one forward NTT = both launches)",
+            "kernel": "ntt_full15_kernel<fwd> (one 1024-thread workgroup per limb, one HBM crossing; dacapo_amd/csrc/ntt_full.hip)",
             "launch": {"limbs": limbs, "N": N, "algorithmic_bytes": alg_bytes, "avg_us": round(ms * 1e3, 2),
                        "ntt_per_s": round(limbs / (ms * 1e-3))},
-            "limiting_resource": "two HBM crossings per limb + partly exposed integer arithmetic",
-            "two_launch_structure": {"hbm_crossings_per_limb": 2, "memory_floor_us": round(floor_us, 1),
-                                     "frac_of_memory_floor": round(floor_us / (ms * 1e3), 4),
-                                     "valu_instructions_per_butterfly": 27.7, "v_mad_u64_u32_per_butterfly": 7.6,
-                                     "source": "profiles/r02_experiments.txt items 8-10 (kernel variants without arithmetic / without "
-                                               "twiddle loads, twiddle-pair multiply, slices, software pipelining); tools/isa_mix.py"},
+            "limiting_resource": "integer-VALU time of one workgroup per CU (7 052 VALU instructions per thread, 1 792 of them v_mad_u64_u32) plus "
+                                 "its own load / exchange / store segments, which no second workgroup covers: the kernel owns the CU's register file",
+            "single_crossing": {"hbm_crossings_per_limb": 1, "copy_floor_us": round(floor_us, 1), "frac_of_copy_floor": round(floor_us / (ms * 1e3), 4),
+                                "source": "profiles/r03_ntt_full.txt (ablations: skeleton without butterflies 530 us, lane transposes 81 us, "
+                                          "LDS exchange 39 us; counters; variants that lost)"},
+            "two_launch_transform": {"avg_us": round(two_ms * 1e3, 2), "frac": round(alg_bytes / (two_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                     "note": "round 2's COLS + ROWS launch pair on the same buffer (still used below 1024 limbs, for inverse "
+                                             "transforms and for N != 2^15)"},
             "copy_kernel_gbs": round(copy_gbs, 1), "frac_of_copy": round(gbs / copy_gbs, 4)}
 
 
@@ -591,24 +596,40 @@ def main():
     roof = roofline_leg(ll, ctx)
     # the timed step's own place on the byte roofline: SURVEY.md 8(d)'s table walked over the bytecode (progstats.walk)
     step_gbs = pst["algorithmic_bytes"] / (ms_per_step * 1e-3) / 1e9
-    top = None
-    tk = ROOT / "profiles" / "r02_top_kernels.json"
+    # the timed step's own kernels: durations, PMC traffic and (where the grid encodes level and batch) algorithmic bytes per kernel,
+    # collected by tools/kernel_traffic.py on exactly this build of the library (else a note)
+    top, dominant, moved = None, None, None
+    tk = ROOT / "profiles" / "r03_step_kernels.json"
     if tk.exists():
         rec = json.loads(tk.read_text())
-        top = rec if rec.get("lib_sha256") == lib_sha256() else {"note": "profiles/r02_top_kernels.json was collected on another build"}
+        if rec.get("lib_sha256") == lib_sha256():
+            top, dominant, moved = rec.get("top_kernels"), rec.get("dominant"), rec.get("bytes_actually_moved_in_run")
+        else:
+            top = {"note": "profiles/r03_step_kernels.json was collected on another build"}
+    folded = sum(v for k, v in pst["algorithmic_bytes_by_opcode"].items() if k in ("2", "4", "6", "7", "9"))  # negate, modswitch, addcc, addcp, mulcp
+    roof["leg"] = {k: roof[k] for k in ("kernel", "achieved", "frac", "traffic", "launch")}
     roof["step"] = {"what": "one run() of the headline program", "algorithmic_bytes": pst["algorithmic_bytes"],
                     "achieved_gbs": round(step_gbs, 1), "frac": round(step_gbs / HBM_PEAK_GBS, 4),
                     "ntt_equivalents": pst["ntt_equivalents"], "bytes_by_opcode": pst["algorithmic_bytes_by_opcode"],
-                    "top_kernels": top,
-                    "note": "latency-bound: ~5 300 dependent launches of 4-30 us (tools/timeline_gaps.py over a --kernel-trace of this "
-                            "command: profiles/r02_*_timeline.txt); 62 % of these bytes belong to elementwise ops the plan folds away"}
+                    "algorithmic_bytes_of_elementwise_opcodes": folded,
+                    "bytes_actually_moved": moved,
+                    "bytes_actually_moved_gbs": (round(moved / (ms_per_step * 1e-3) / 1e9, 1) if moved else None),
+                    "dominant": dominant, "top_kernels": top,
+                    "note": "latency-bound: ~5 300 dependent launches of 4-30 us (profiles/r03_timeline.txt); most of the elementwise opcodes' "
+                            "section-8(d) bytes are never moved -- the plan folds those ops into their consumers' loaders -- which is why "
+                            "bytes_actually_moved (FETCH_SIZE x 2 + WRITE_SIZE over one run) is the honest numerator"}
     micro = ntt_micro_leg(ll)
     cfg3 = cfg3_leg(ll)
     per_op = per_op_leg(ll)
     real_boot = real_bootstrap_leg(ll, runner) if (world == 1 and not args.no_lowerings) else None
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline_leg(cst, hv, image)
+        hv13 = None
+        if fx is not None and (ROOT / "tests" / "golden" / "resnet20.b13.hevm.gz").exists():
+            import gzip
+
+            hv13 = gzip.open(ROOT / "tests" / "golden" / "resnet20.b13.hevm.gz").read()
+        cpu = cpu_baseline_leg(cst, hv, image, hv_b13=hv13)
 
     line = {
         "metric": "NTT/s (NTT-equivalents over one run() of the ResNet HEVM program, nt=2^14)",

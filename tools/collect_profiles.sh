@@ -1,15 +1,15 @@
 #!/bin/bash
 # Everything under profiles/ for one round, collected on the GPU box in one gpurun call:
-#   gpurun --timeout 1500 -- 'bash tools/collect_profiles.sh r02'
+#   gpurun --timeout 2400 -- 'bash tools/collect_profiles.sh r03'
 # Outputs go to gpurun_out/<round>/ (merged back by gpurun); copy the summaries into profiles/ afterwards.
 set -u
-R=${1:-r02}
+R=${1:-r03}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/$R
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 # A. kernel trace + stats of the bench command (program directly after `--`)
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-lowerings > $OUT/bench_under_profiler.json 2> $OUT/kt.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-lowerings --no-config4 > $OUT/bench_under_profiler.json 2> $OUT/kt.err
 KT=$(ls $OUT/kt/*/*kernel_trace.csv | head -1)
 cp $(ls $OUT/kt/*/*kernel_stats.csv | head -1) $OUT/${R}_kernel_stats.csv
 cd $ROOT
@@ -25,6 +25,20 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pw -- pyth
 cd $ROOT
 python tools/collect_traffic.py $(ls $OUT/pf/*/*counter_collection.csv | head -1) $(ls $OUT/pw/*/*counter_collection.csv | head -1) > $OUT/${R}_ntt_hbm_traffic.json
 rm -rf $OUT/pf $OUT/pw
+# B2. the timed step's own kernels: durations, FETCH_SIZE / WRITE_SIZE per kernel, algorithmic bytes where the grid encodes (level, batch)
+cd /tmp
+rocprofv3 --kernel-trace --output-format csv -d $OUT/hk -- python3 $ROOT/tools/headline_only.py 3 > /dev/null 2> $OUT/hk.err
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/hf -- python3 $ROOT/tools/headline_only.py 3 > /dev/null 2> $OUT/hf.err
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/hw -- python3 $ROOT/tools/headline_only.py 3 > /dev/null 2> $OUT/hw.err
+cd $ROOT
+python tools/kernel_traffic.py $(ls $OUT/hk/*/*kernel_trace.csv | head -1) $(ls $OUT/hf/*/*counter_collection.csv | head -1) $(ls $OUT/hw/*/*counter_collection.csv | head -1) > $OUT/${R}_step_kernels.json
+rm -rf $OUT/hk $OUT/hf $OUT/hw
+# B3. config 4 (N = 2^17, 38 real bootstraps, grouped-digit keys): kernel-time table
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c4 -- python3 $ROOT/tools/resnet_real_boot.py 1 resnet20_nt16 17 1 b14 8 7 > $OUT/${R}_config4_under_profiler.txt 2> $OUT/c4.err
+cp $(ls $OUT/c4/*/*kernel_stats.csv | head -1) $OUT/${R}_config4_kernel_stats.csv
+rm -rf $OUT/c4
+cd $ROOT
 # C. latency of dependent chains, D. several ciphertext streams on one GPU, E. the bench line itself, F. per-op table for the reference's planner
 python tools/chain_bench.py > $OUT/${R}_chain_latency.txt 2>/dev/null
 for s in 2 4 8; do python bench.py --streams $s --no-cpu-baseline --no-lowerings 2>/dev/null | python tools/bench_brief.py; done > $OUT/${R}_streams.txt
