@@ -39,6 +39,15 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c4 -- python3 $ROOT
 cp $(ls $OUT/c4/*/*kernel_stats.csv | head -1) $OUT/${R}_config4_kernel_stats.csv
 rm -rf $OUT/c4
 cd $ROOT
+# B4. one grouped-digit key switch at N = 2^17, top level: every kernel of the sequence on the byte roofline
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/hy -- python3 $ROOT/tools/hybrid_ks_bench.py 17 39 8 7 5 31 > $OUT/hy_hop.json 2> $OUT/hy.err
+cd $ROOT
+python tools/hybrid_ks_summary.py $(ls $OUT/hy/*/*kernel_stats.csv | head -1) $OUT/hy_hop.json > $OUT/${R}_hybrid_ks_kernels.txt
+python tools/hybrid_ks_bench.py >> $OUT/${R}_hybrid_ks_kernels.txt 2>/dev/null
+rm -rf $OUT/hy
+# B5. the single-crossing NTT against the two-launch tiles (HIP events)
+for n in 512 1024 4096; do python tools/ntt_full_check.py $n 20; done > $OUT/${R}_ntt_full_check.txt 2>/dev/null
 # C. latency of dependent chains, D. several ciphertext streams on one GPU, E. the bench line itself, F. per-op table for the reference's planner
 python tools/chain_bench.py > $OUT/${R}_chain_latency.txt 2>/dev/null
 for s in 2 4 8; do python bench.py --streams $s --no-cpu-baseline --no-lowerings 2>/dev/null | python tools/bench_brief.py; done > $OUT/${R}_streams.txt
