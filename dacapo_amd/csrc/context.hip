@@ -200,6 +200,68 @@ Context::Context(int logN_, int K_, int bits, const u64 *primes_or_null, int ksp
         }
         DC_HIP_CHECK(hipMalloc(&d_hyb_dn, dn.size() * 8));
         DC_HIP_CHECK(hipMemcpy(d_hyb_dn, dn.data(), dn.size() * 8, hipMemcpyHostToDevice));
+        // ---- the same two constant matrices as int8 operands of the matrix cores -------------------------------------------------
+        // A residue y < 2^60 is 8 balanced base-256 digits (y + 0x80..80 with every byte's top bit flipped: digits in [-128, 127]); a
+        // matrix entry w enters as the balanced digits of V_p = w 2^(8p) mod m for each of the operand's 8 digit positions p, so that
+        //     sum_t y_t w_t  =  sum_r 2^(8r) [ sum_{t,p} digit_p(y_t) digit_r(V_{t,p}) ]   (mod m)
+        // and the bracket is one int8 dot product of length 8 |S| <= 64 = ONE v_mfma_i32_16x16x64_i8 per (16 coefficients, 16 moduli, r).
+        // B fragment of lane l: column l & 15, k = 16 (l >> 4) + j in byte j, k = 8 t + p.
+        hyb_mfma = alpha <= 8 && ksp <= 8 && !(getenv("DACAPO_HYB_MFMA") && atoi(getenv("DACAPO_HYB_MFMA")) == 0);
+        if (hyb_mfma) {
+            auto balanced = [](u64 v, int8_t *out8) {
+                const u64 C = 0x8080808080808080ull, b = (v + C) ^ C;
+                for (int r = 0; r < 8; r++) out8[r] = (int8_t)(uint8_t)(b >> (8 * r));
+            };
+            std::vector<int8_t> bup, bdn;
+            hyb_bup_off.assign((size_t)L + 2, 0), hyb_bdn_off.assign((size_t)L + 2, 0);
+            for (int ell = 1; ell <= L; ell++) {
+                const int M = ell + ksp, nb = hyb_up_blocks(ell), G = hyb_groups(ell);
+                hyb_bup_off[(size_t)ell] = bup.size();
+                const size_t base = bup.size();
+                bup.resize(base + (size_t)G * nb * 8 * 64 * 16, 0);
+                const u64 *upl = up.data() + hyb_up_off[(size_t)ell];
+                for (int g = 0; g < G; g++) {
+                    const int lo = g * alpha, hi = std::min(lo + alpha, ell), a = hi - lo;
+                    for (int e = 0; e < M - a; e++) {
+                        const int mi = e < lo ? e : e + a, pm = mi < ell ? mi : L + (mi - ell), blk = e / 16, col = e % 16;
+                        const u64 m = primes[(size_t)pm];
+                        for (int t = 0; t < a; t++) {
+                            u64 V = upl[(size_t)ell + (size_t)(lo + t) * M + mi] % m;
+                            for (int pp = 0; pp < 8; pp++) {
+                                int8_t d8[8];
+                                balanced(V, d8);
+                                const int k = 8 * t + pp, lane = (k / 16) * 16 + col, j = k % 16;
+                                for (int r = 0; r < 8; r++)
+                                    bup[base + ((((size_t)g * nb + blk) * 8 + r) * 64 + lane) * 16 + j] = d8[r];
+                                V = h_mulmod(V, 256 % m, m);
+                            }
+                        }
+                    }
+                }
+                // mod-down: inputs z_j (j < ksp), outputs q_i (i < ell)
+                const int nd = hyb_dn_blocks(ell);
+                hyb_bdn_off[(size_t)ell] = bdn.size();
+                const size_t bd = bdn.size();
+                bdn.resize(bd + (size_t)nd * 8 * 64 * 16, 0);
+                for (int i = 0; i < ell; i++) {
+                    const u64 m = primes[(size_t)i];
+                    for (int j2 = 0; j2 < ksp; j2++) {
+                        u64 V = dn[(size_t)2 * ksp + 2 * L + (size_t)j2 * L + i] % m;
+                        for (int pp = 0; pp < 8; pp++) {
+                            int8_t d8[8];
+                            balanced(V, d8);
+                            const int k = 8 * j2 + pp, lane = (k / 16) * 16 + (i % 16), j = k % 16;
+                            for (int r = 0; r < 8; r++) bdn[bd + ((((size_t)(i / 16)) * 8 + r) * 64 + lane) * 16 + j] = d8[r];
+                            V = h_mulmod(V, 256 % m, m);
+                        }
+                    }
+                }
+            }
+            DC_HIP_CHECK(hipMalloc(&d_hyb_bup, bup.size()));
+            DC_HIP_CHECK(hipMemcpy(d_hyb_bup, bup.data(), bup.size(), hipMemcpyHostToDevice));
+            DC_HIP_CHECK(hipMalloc(&d_hyb_bdn, bdn.size()));
+            DC_HIP_CHECK(hipMemcpy(d_hyb_bdn, bdn.data(), bdn.size(), hipMemcpyHostToDevice));
+        }
     }
 }
 
@@ -236,7 +298,7 @@ void Context::ensure_scratch()
 Context::~Context()
 {
     for (void *p : { (void *)d_mods, (void *)d_tw, (void *)d_itw, (void *)d_inv_last, (void *)d_half_mod, (void *)d_ks_pidx, (void *)d_pmod,
-                     (void *)d_hyb_up, (void *)d_hyb_pidx, (void *)d_hyb_dn })
+                     (void *)d_hyb_up, (void *)d_hyb_pidx, (void *)d_hyb_dn, (void *)d_hyb_bup, (void *)d_hyb_bdn })
         if (p) (void)hipFree(p);
     for (Workspace &w : workspaces)
         for (void *p : { (void *)w.ks_digits, (void *)w.ks_ext, (void *)w.ks_acc, (void *)w.ks_tmp, (void *)w.ct_tmp })

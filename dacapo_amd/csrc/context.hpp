@@ -81,6 +81,13 @@ struct Context {
     int *d_hyb_pidx = nullptr; // per level: prime index of every raised limb, group by group
     std::vector<int> hyb_pidx_off;
     u64 *d_hyb_dn = nullptr; // phat_inv[ksp], half_p[ksp], half_q[L], pinv[L], w_dn[ksp][L]   (L = max_level())
+    // matrix-core form of the two base conversions (hybrid_ks.hip, alpha <= 8 and ksp <= 8): the constant matrices as int8 B fragments of
+    // v_mfma_i32_16x16x64_i8.  Per level: [group][block of 16 output moduli][8 digit planes][64 lanes][16 bytes]; mod-down: one "group".
+    int8_t *d_hyb_bup = nullptr, *d_hyb_bdn = nullptr;
+    std::vector<size_t> hyb_bup_off, hyb_bdn_off;
+    bool hyb_mfma = false;
+    int hyb_up_blocks(int ell) const { return (ell + ksp - 1 + 15) / 16; }  // blocks of 16 "other" moduli (the smallest digit has 1 prime)
+    int hyb_dn_blocks(int ell) const { return (ell + 15) / 16; }
     const u64 *hyb_up(int ell) const { return d_hyb_up + hyb_up_off[(size_t)ell]; }
     const int *hyb_pidx(int ell) const { return d_hyb_pidx + hyb_pidx_off[(size_t)ell]; }
     int k1 = 0, k2 = 0; // NTT split: COLS phase runs k1 stages, ROWS phase k2 = logN - k1

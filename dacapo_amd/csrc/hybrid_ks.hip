@@ -236,6 +236,119 @@ __global__ __launch_bounds__(kHT) void hyb_final_kernel(const u64 *__restrict__ 
     *reinterpret_cast<u64x2 *>(dst) = v;
 }
 
+// ---- the two base conversions on the matrix cores ------------------------------------------------------------------------------
+// out[e][n] = sum_t y_t[n] w[t][e] mod m_e for 16 coefficients x 16 output moduli per MFMA tile (see context.hip for the operand
+// encoding: balanced base-256 digits of y on the A side, of w 2^(8p) mod m on the B side; 8 accumulator planes r recombined as
+// sum_r C_r 2^(8r), a signed 80-bit integer, then reduced).  One wave = a strip of 128 coefficients (8 A fragments kept in registers),
+// one workgroup = 4 waves; the B fragments of a block of 16 moduli (8 x 16 bytes per lane) are loaded once per strip.
+// DOWN = false: mod-up of digit g = blockIdx.y of item blockIdx.z; DOWN = true: mod-down of polynomial blockIdx.z (= 2 b + c).
+typedef int v4i __attribute__((ext_vector_type(4)));
+constexpr int kConvStrip = 128; // coefficients per wave
+
+__device__ __forceinline__ u64 hyb_recombine(const v4i (&c)[8], int j, const DModulus &M)
+{
+    const int64_t slo = (int64_t)c[0][j] + ((int64_t)c[1][j] << 8) + ((int64_t)c[2][j] << 16) + ((int64_t)c[3][j] << 24);
+    const int64_t shi = (int64_t)c[4][j] + ((int64_t)c[5][j] << 8) + ((int64_t)c[6][j] << 16) + ((int64_t)c[7][j] << 24);
+    // T = slo + shi 2^32 as a 128-bit two's complement number, |T| < 2^78; T + (q << 19) is non-negative and congruent
+    const u64 lo = (u64)slo + ((u64)shi << 32);
+    const u64 hi = (u64)(slo >> 63) + (u64)(shi >> 32) + (lo < (u64)slo ? 1u : 0u);
+    const u64 lo2 = lo + (M.q << 19);
+    const u64 hi2 = hi + (M.q >> 45) + (lo2 < lo ? 1u : 0u);
+    return canon(reduce128_lazy(hi2, lo2, M.delta), M);
+}
+
+template <bool DOWN>
+__global__ __launch_bounds__(kHT) void hyb_conv_mfma_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, int ell, int ksp, int alpha, int L, int E,
+                                                             size_t N, const DModulus *__restrict__ mods, const u64 *__restrict__ cst,
+                                                             const v4i *__restrict__ btab, int nblk)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 15, kb = lane >> 4;
+    const size_t n0 = ((size_t)blockIdx.x * 4 + wave) * kConvStrip;
+    int a, lo, in_prime0, n_out;
+    const u64 *inp;
+    u64 *outp;
+    const v4i *bt;
+    if (!DOWN) {
+        const int g = blockIdx.y, b = blockIdx.z, M = ell + ksp;
+        lo = g * alpha;
+        a = min(lo + alpha, ell) - lo;
+        in_prime0 = lo;
+        n_out = M - a;
+        inp = in + ((size_t)b * ell + lo) * N;
+        outp = out + ((size_t)b * E + (size_t)g * (M - alpha)) * N;
+        bt = btab + (size_t)g * nblk * 8 * 64;
+    } else {
+        const int z = blockIdx.z;
+        lo = 0, a = ksp, in_prime0 = L, n_out = ell;
+        inp = in + (size_t)z * ksp * N;
+        outp = out + (size_t)z * ell * N;
+        bt = btab;
+    }
+    // A fragments: this lane's two inputs t = 2 kb, 2 kb + 1 of its row, times the conversion's per-input constant, as balanced bytes
+    v4i A[kConvStrip / 16];
+    const u64 C8 = 0x8080808080808080ull;
+    u64 mul[2], add[2];
+    DModulus mi[2];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const int t = 2 * kb + h, tt = t < a ? t : 0;
+        mi[h] = mods[in_prime0 + tt];
+        mul[h] = DOWN ? cst[tt] : cst[lo + tt];          // phat_inv[j] | qhat_inv[i]
+        add[h] = DOWN ? cst[ksp + tt] : 0;               // floor(P/2) mod p_j | -
+    }
+#pragma unroll
+    for (int tile = 0; tile < kConvStrip / 16; tile++) {
+        const size_t n = n0 + (size_t)tile * 16 + col;
+        u64 y[2];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int t = 2 * kb + h;
+            if (t < a) {
+                u64 x = inp[(size_t)t * N + n];
+                if (DOWN) x = addmod(x, add[h], mi[h].q);
+                y[h] = (mulmod(x, mul[h], mi[h]) + C8) ^ C8;
+            } else
+                y[h] = 0;
+        }
+        A[tile] = v4i{ (int)(u32)y[0], (int)(u32)(y[0] >> 32), (int)(u32)y[1], (int)(u32)(y[1] >> 32) };
+    }
+    for (int blk = 0; blk < nblk; blk++) {
+        if (blk * 16 >= n_out) break;
+        v4i Bf[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) Bf[r] = bt[((size_t)blk * 8 + r) * 64 + lane];
+        const int e = blk * 16 + col;
+        const bool valid = e < n_out;
+        int pm;
+        u64 post = 0;
+        if (!DOWN) {
+            const int mi2 = e < lo ? e : e + a;
+            pm = mi2 < ell ? mi2 : L + (mi2 - ell);
+        } else {
+            pm = e;
+            post = valid ? cst[2 * ksp + e] : 0; // floor(P/2) mod q_i
+        }
+        const DModulus Mo = mods[valid ? pm : 0];
+#pragma unroll
+        for (int tile = 0; tile < kConvStrip / 16; tile++) {
+            v4i c[8];
+#pragma unroll
+            for (int r = 0; r < 8; r++) c[r] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[tile], Bf[r], v4i{ 0, 0, 0, 0 }, 0, 0, 0);
+            if (valid) { // this lane: rows 4 kb .. 4 kb + 3 of the tile, column `col`
+                u64 v[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    v[j] = hyb_recombine(c, j, Mo);
+                    if (DOWN) v[j] = submod(v[j], post, Mo.q);
+                }
+                u64 *o = outp + (size_t)e * N + n0 + (size_t)tile * 16 + 4 * kb;
+                *reinterpret_cast<u64x2 *>(o) = u64x2{ v[0], v[1] };
+                *reinterpret_cast<u64x2 *>(o + 2) = u64x2{ v[2], v[3] };
+            }
+        }
+    }
+}
+
 // everything after `prepare`: target [B][l][N] NTT form, digits = a copy of it (transformed in place here)
 template <int MODE>
 static void hyb_core(Context &c, const BatchWs &w, const void *items, const u64 *shared_key, HybSingle single, int B, int ell, hipStream_t s)
@@ -245,13 +358,24 @@ static void hyb_core(Context &c, const BatchWs &w, const void *items, const u64 
     const unsigned gx = (unsigned)(N / (2 * kHT));
     u64 *accq = w.acc, *accp = w.acc + (size_t)B * 2 * ell * N;
     launch_ntt(c, true, w.digits, (long)N, B * ell, nullptr, 0, ell, s);
-    hipLaunchKernelGGL(hyb_modup_kernel, dim3(gx, (unsigned)G, (unsigned)B), dim3(kHT), 0, s, w.digits, w.ext, ell, ksp, alpha, L, E, N, c.d_mods,
-                       c.hyb_up(ell));
+    // (below 4 primes a conversion has at most a 3 x 11 matrix: the vector kernels are faster there -- 115 vs 127 us per hop at level 1, N = 2^17)
+    const bool mfma = c.hyb_mfma && N >= 4 * kConvStrip && ell >= 4;
+    const unsigned gc = (unsigned)(N / (4 * kConvStrip));
+    if (mfma)
+        hipLaunchKernelGGL(hyb_conv_mfma_kernel<false>, dim3(gc, (unsigned)G, (unsigned)B), dim3(kHT), 0, s, w.digits, w.ext, ell, ksp, alpha, L, E, N,
+                           c.d_mods, c.hyb_up(ell), reinterpret_cast<const v4i *>(c.d_hyb_bup + c.hyb_bup_off[(size_t)ell]), c.hyb_up_blocks(ell));
+    else
+        hipLaunchKernelGGL(hyb_modup_kernel, dim3(gx, (unsigned)G, (unsigned)B), dim3(kHT), 0, s, w.digits, w.ext, ell, ksp, alpha, L, E, N, c.d_mods,
+                           c.hyb_up(ell));
     launch_ntt(c, false, w.ext, (long)N, B * E, c.hyb_pidx(ell), 0, E, s);
     hipLaunchKernelGGL(hyb_mac_kernel<MODE>, dim3(gx, (unsigned)M, (unsigned)B), dim3(kHT), 0, s, accq, accp, w.ext, w.target, items,
                        MODE == 2 ? single.key : shared_key, ell, ksp, alpha, L, K, E, N, c.d_mods);
     launch_ntt(c, true, accp, (long)N, 2 * B * ksp, nullptr, L, ksp, s);
-    hipLaunchKernelGGL(hyb_moddown_kernel, dim3(gx, (unsigned)(2 * B)), dim3(kHT), 0, s, accp, w.tmp, ell, ksp, L, N, c.d_mods, c.d_hyb_dn);
+    if (mfma)
+        hipLaunchKernelGGL(hyb_conv_mfma_kernel<true>, dim3(gc, 1, (unsigned)(2 * B)), dim3(kHT), 0, s, accp, w.tmp, ell, ksp, alpha, L, E, N, c.d_mods,
+                           c.d_hyb_dn, reinterpret_cast<const v4i *>(c.d_hyb_bdn + c.hyb_bdn_off[(size_t)ell]), c.hyb_dn_blocks(ell));
+    else
+        hipLaunchKernelGGL(hyb_moddown_kernel, dim3(gx, (unsigned)(2 * B)), dim3(kHT), 0, s, accp, w.tmp, ell, ksp, L, N, c.d_mods, c.d_hyb_dn);
     launch_ntt(c, false, w.tmp, (long)N, 2 * B * ell, nullptr, 0, ell, s);
     hipLaunchKernelGGL(hyb_final_kernel<MODE>, dim3(gx, (unsigned)ell, (unsigned)(2 * B)), dim3(kHT), 0, s, accq, w.tmp, items, single, ell, ksp, L, N,
                        c.d_mods, c.d_hyb_dn);
