@@ -39,13 +39,20 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c4 -- python3 $ROOT
 cp $(ls $OUT/c4/*/*kernel_stats.csv | head -1) $OUT/${R}_config4_kernel_stats.csv
 rm -rf $OUT/c4
 cd $ROOT
-# B4. one grouped-digit key switch at N = 2^17, top level: every kernel of the sequence on the byte roofline
+# B4. one grouped-digit key switch at N = 2^17, top level: every kernel of the sequence on the byte roofline, with the two base conversions
+#     on the matrix cores (default) and on the vector units (DACAPO_HYB_MFMA=0), and the matrix-core counters of the former
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/hy -- python3 $ROOT/tools/hybrid_ks_bench.py 17 39 8 7 5 31 > $OUT/hy_hop.json 2> $OUT/hy.err
+export DACAPO_HYB_MFMA=0
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/hv -- python3 $ROOT/tools/hybrid_ks_bench.py 17 39 8 7 5 31 > $OUT/hv_hop.json 2> $OUT/hv.err
+unset DACAPO_HYB_MFMA
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_I8 SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/hm -- python3 $ROOT/tools/hybrid_ks_bench.py 17 39 8 7 5 31 > /dev/null 2> $OUT/hm.err
 cd $ROOT
-python tools/hybrid_ks_summary.py $(ls $OUT/hy/*/*kernel_stats.csv | head -1) $OUT/hy_hop.json > $OUT/${R}_hybrid_ks_kernels.txt
-python tools/hybrid_ks_bench.py >> $OUT/${R}_hybrid_ks_kernels.txt 2>/dev/null
-rm -rf $OUT/hy
+{ echo "== base conversions on the matrix cores (default)"; python tools/hybrid_ks_summary.py $(ls $OUT/hy/*/*kernel_stats.csv | head -1) $OUT/hy_hop.json;
+  echo; echo "== base conversions on the vector units (DACAPO_HYB_MFMA=0)"; python tools/hybrid_ks_summary.py $(ls $OUT/hv/*/*kernel_stats.csv | head -1) $OUT/hv_hop.json;
+  echo; echo "== counters of the matrix-core run, per launch (rocprofv3 --pmc; tools/pmc_summary.py)"; python tools/pmc_summary.py $(ls $OUT/hm/*/*counter_collection.csv | head -1) | grep -A7 "hyb_conv_mfma";
+  echo; echo "== all levels, HIP events (matrix cores / vector units)"; python tools/hybrid_ks_bench.py 2>/dev/null; DACAPO_HYB_MFMA=0 python tools/hybrid_ks_bench.py 2>/dev/null; } > $OUT/${R}_hybrid_ks_kernels.txt
+rm -rf $OUT/hy $OUT/hv $OUT/hm
 # B5. the single-crossing NTT against the two-launch tiles (HIP events)
 for n in 512 1024 4096; do python tools/ntt_full_check.py $n 20; done > $OUT/${R}_ntt_full_check.txt 2>/dev/null
 # C. latency of dependent chains, D. several ciphertext streams on one GPU, E. the bench line itself, F. per-op table for the reference's planner

@@ -16,6 +16,8 @@ G, ell, ks = row["digits"], row["level"], hop["special"]
 M = ell + ks
 limbs = dict(row["limbs_by_kernel"])
 names = {"prepare": "hyb_prepare_rot_kernel", "modup": "hyb_modup_kernel", "mac": "hyb_mac_kernel<0>", "moddown": "hyb_moddown_kernel", "final": "hyb_final_kernel<0>"}
+if any(k.startswith("hyb_conv_mfma_kernel") for k in stats):  # the matrix-core form of the two conversions
+    names["modup"], names["moddown"] = "hyb_conv_mfma_kernel<false>", "hyb_conv_mfma_kernel<true>"
 print(f"N = {hop['N']}, level {ell}, {G} digits of {hop['alpha']} primes, {ks} special primes: hop {row['hop_us']} us under HIP events, "
       f"{row['ntt_equivalents']} NTT-equivalents (SEAL's scheme at this level: {row['seal_scheme_ntt_equivalents']})")
 print(f"{'kernel':42s} {'calls':>6s} {'avg us':>9s} {'limbs':>6s} {'MB':>8s} {'GB/s':>8s} {'of 8 TB/s':>9s}")
@@ -31,7 +33,8 @@ for k, n in names.items():
 ntt_us = 0.0
 for kk, r in stats.items():
     if kk.startswith("ntt_"):
-        us = float(r["TotalDurationNs"]) / 1e3 / (int(stats[names['modup']]['Calls']) if names['modup'] in stats else 1)
+        hops = next((int(v["Calls"]) for kk2, v in stats.items() if kk2.startswith(names["prepare"])), 1)
+        us = float(r["TotalDurationNs"]) / 1e3 / hops
         ntt_us += us
         print(f"{kk[:42]:42s} {r['Calls']:>6s} {float(r['AverageNs'])/1e3:9.1f}   (transforms: {us:.1f} us per hop)")
 print(f"element-wise kernels {tot:.1f} us + transforms {ntt_us:.1f} us per hop")
