@@ -12,7 +12,9 @@ min_y = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 with open(sys.argv[1]) as f:
     for r in csv.DictReader(f):
         gy = int(r["Grid_Size_Y"])
-        if gy < min_y:
+        gx = int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"])
+        # the leg's launches: `min_y` limbs on the grid's y axis (the two-launch tiles) or as `min_y` workgroups (the single-crossing kernel)
+        if gy < min_y and not (min_y and gx >= min_y and "ntt_full" in r["Kernel_Name"]):
             continue
         name = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void dacapo::", "").replace("dacapo::", "")
         key = (name, int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"]), gy, int(r["Grid_Size_Z"]))
