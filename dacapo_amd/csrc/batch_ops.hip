@@ -321,18 +321,18 @@ __global__ __launch_bounds__(kBT) void b_modraise_lift_kernel(const u64 *__restr
 {
     const int i = blockIdx.y, z = blockIdx.z, b = z >> 1, p = z & 1;
     const CtView dstv = items ? items[b].dst : single.dst;
-    const u64 q0 = mods[0].q, qi = mods[i].q, half = q0 >> 1;
+    const DModulus Mi = mods[i];
+    const u64 q0 = mods[0].q, qi = Mi.q, half = q0 >> 1;
     const size_t k = ((size_t)blockIdx.x * kBT + threadIdx.x) * 2;
     const u64x2 v = *reinterpret_cast<const u64x2 *>(scratch + (size_t)z * N + k);
     u64x2 r;
 #pragma unroll
     for (int e = 0; e < 2; e++) {
-        if (v[e] > half) { // negative: -(q0 - v) mod q_i ; all primes lie in (2^60 - 2^28, 2^60), so one conditional subtraction reduces
-            u64 m = q0 - v[e];
-            m = m >= qi ? m - qi : m;
+        if (v[e] > half) { // negative: -(q0 - v) mod q_i (one conditional subtraction within a width class: recanon)
+            const u64 m = recanon(q0 - v[e], Mi);
             r[e] = m ? qi - m : 0;
         } else
-            r[e] = v[e] >= qi ? v[e] - qi : v[e];
+            r[e] = recanon(v[e], Mi);
     }
     *reinterpret_cast<u64x2 *>(dstv.limb(p, i, N) + k) = r;
 }

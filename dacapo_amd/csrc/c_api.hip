@@ -38,8 +38,8 @@ dc_context *dc_context_create(int logN, int num_primes, int bit_size, const uint
         fprintf(stderr, "[dacapo_amd] no HIP device: the HEVM runtime has no CPU fallback\n");
         abort();
     }
-    if (!primes && bit_size != kQBits) {
-        fprintf(stderr, "[dacapo_amd] only the 60-bit HEVM prime chain is supported (asked for %d bits)\n", bit_size);
+    if (!primes && (bit_size < kMinQBits || bit_size > kQBits)) {
+        fprintf(stderr, "[dacapo_amd] prime width %d outside %d..%d bits (the reference's chain is 60-bit, SEAL_HEVM.cpp:48-53)\n", bit_size, kMinQBits, kQBits);
         abort();
     }
     Context *c = new Context(logN, num_primes, bit_size, primes);

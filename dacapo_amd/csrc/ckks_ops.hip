@@ -20,11 +20,11 @@ __global__ __launch_bounds__(kOpThreads) void ks_lift_kernel(u64 *__restrict__ e
                                                               int sp, size_t N, const DModulus *__restrict__ mods)
 {
     const int e = blockIdx.y, j = blockIdx.z;
-    const u64 qm = mods[ks_other_prime(j, e, ell, sp)].q;
+    const DModulus Mm = mods[ks_other_prime(j, e, ell, sp)];
     const size_t k = ((size_t)blockIdx.x * kOpThreads + threadIdx.x) * 2;
     u64x2 v = *reinterpret_cast<const u64x2 *>(digits + (size_t)j * N + k);
-    v.x = v.x >= qm ? v.x - qm : v.x;
-    v.y = v.y >= qm ? v.y - qm : v.y;
+    v.x = recanon(v.x, Mm);
+    v.y = recanon(v.y, Mm);
     *reinterpret_cast<u64x2 *>(ext + ((size_t)j * ell + e) * N + k) = v;
 }
 
@@ -83,7 +83,8 @@ __global__ __launch_bounds__(kOpThreads) void dr_lift_kernel(u64 *__restrict__ t
                                                               const u64 *__restrict__ half_mod)
 {
     const int i = blockIdx.y, p = blockIdx.z;
-    const u64 ql = mods[l].q, qi = mods[i].q, half = ql >> 1;
+    const DModulus Mi = mods[i];
+    const u64 ql = mods[l].q, qi = Mi.q, half = ql >> 1;
     const u64 neg_half = qi - half_mod[(size_t)l * K + i]; // in (0, qi]
     const size_t k = ((size_t)blockIdx.x * kOpThreads + threadIdx.x) * 2;
     const u64x2 v = *reinterpret_cast<const u64x2 *>(last + p * last_poly_stride + k);
@@ -92,7 +93,7 @@ __global__ __launch_bounds__(kOpThreads) void dr_lift_kernel(u64 *__restrict__ t
     for (int e = 0; e < 2; e++) {
         u64 y = v[e] + half;
         y = y >= ql ? y - ql : y;
-        y = y >= qi ? y - qi : y;
+        y = recanon(y, Mi);
         y += neg_half;
         r[e] = y >= qi ? y - qi : y;
     }

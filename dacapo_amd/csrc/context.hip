@@ -98,11 +98,18 @@ Context::Context(int logN_, int K_, int bits, const u64 *primes_or_null, int ksp
     std::vector<u64> tw((size_t)K * N), itw((size_t)K * N);
     for (int i = 0; i < K; i++) {
         const u64 q = primes[i];
-        const u64 delta = (1ull << kQBits) - q;
-        if (q >= (1ull << kQBits) || delta >= kMaxDelta || (q - 1) % (2 * N) || !h_is_prime(q)) {
+        int qbits = 0;
+        while ((q >> qbits) != 0) qbits++;
+        const u64 delta = (qbits >= kMinQBits && qbits <= kQBits) ? (1ull << qbits) - q : kMaxDelta;
+        if (!DC_GENERIC_WIDTH && qbits != kQBits && delta < kMaxDelta) {
+            fprintf(stderr, "[dacapo_amd] prime %d is a %d-bit prime: this build (libSEAL_HEVM.so) is the reference's 60-bit chain only; other widths "
+                            "(45..60 bits) run on the generic-width build of the same sources, libSEAL_HEVM_gw.so\n", i, qbits);
+            abort();
+        }
+        if (delta >= kMaxDelta || (q - 1) % (2 * N) || !h_is_prime(q)) {
             fprintf(stderr,
-                    "[dacapo_amd] prime %d (0x%llx) is not of the HEVM form 2^60 - delta (delta < 2^28), = 1 mod 2N\n", i,
-                    (unsigned long long)q);
+                    "[dacapo_amd] prime %d (0x%llx) is not of the form 2^b - d with %d <= b <= %d, d < 2^28, = 1 mod 2N "
+                    "(the reference's chain: b = 60, SEAL_HEVM.cpp:48-53)\n", i, (unsigned long long)q, kMinQBits, kQBits);
             abort();
         }
         psi[i] = h_min_primitive_root(2 * N, q);
@@ -118,7 +125,7 @@ Context::Context(int logN_, int K_, int bits, const u64 *primes_or_null, int ksp
         }
         DModulus &m = h_mods[i];
         m.q = q;
-        m.delta = (u32)delta;
+        m.delta = fold_word(qbits, delta);
         m.pad_ = 0;
         m.inv_n = h_invmod((u64)N, q);
         m.inv_n_w = h_mulmod(m.inv_n, it[1], q);

@@ -21,7 +21,7 @@ __device__ __forceinline__ double crt_centered(const u64 *__restrict__ coef, siz
     for (int k = 0; k < ell; k++) {
         const DModulus M = mods[k];
         u64 s = 0;
-        for (int i = 0; i < k; i++) s = addmod(s, mulmod(v[i], c.mmod[i * ell + k], M), M.q);
+        for (int i = 0; i < k; i++) s = addmod(s, mulmod(recanon(v[i], M), c.mmod[i * ell + k], M), M.q); // (v_i is a residue of q_i)
         const u64 y = addmod(coef[(size_t)k * N + n], c.hmod[k], M.q);
         v[k] = mulmod(submod(y, s, M.q), c.inv[k], M);
     }
@@ -40,7 +40,7 @@ __device__ __forceinline__ double crt_centered_fixed(const u64 *__restrict__ coe
         const DModulus M = mods[k];
         u64 s = 0;
 #pragma unroll
-        for (int i = 0; i < k; i++) s = addmod(s, mulmod(v[i], c.mmod[i * ELL + k], M), M.q);
+        for (int i = 0; i < k; i++) s = addmod(s, mulmod(recanon(v[i], M), c.mmod[i * ELL + k], M), M.q);
         const u64 y = addmod(coef[(size_t)k * N + n], c.hmod[k], M.q);
         v[k] = mulmod(submod(y, s, M.q), c.inv[k], M);
     }
@@ -76,7 +76,7 @@ __device__ __forceinline__ u64 residue_of_double(double x, const DModulus &M)
         l = sh < 64 ? mant << sh : 0;
         h = sh < 64 ? mant >> (64 - sh) : mant << (sh - 64);
     }
-    const u64 r = canon(reduce128_lazy(h, l, M.delta), M);
+    const u64 r = reduce128_any(h, l, M);
     return (neg && r) ? M.q - r : r;
 }
 

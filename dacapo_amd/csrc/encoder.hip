@@ -77,7 +77,7 @@ __global__ __launch_bounds__(kEncThreads) void enc_round_lift_kernel(u64 *__rest
     u64 *o = out + (size_t)blockIdx.y * level * N + j;
     for (int k = 0; k < level; k++) {
         const DModulus M = mods[k];
-        const u64 r = canon(reduce128_lazy(h, l, M.delta), M);
+        const u64 r = reduce128_any(h, l, M);
         o[(size_t)k * N] = (neg && r) ? M.q - r : r;
     }
 }

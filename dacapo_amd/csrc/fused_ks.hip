@@ -214,7 +214,7 @@ __global__ __launch_bounds__(kTileThreads) void f_ks_icols_lift_fcols_kernel(con
     const int pm = ks_other_prime(j, e, ell, sp);
     const DModulus Mm = mods[pm];
 #pragma unroll
-    for (int r = 0; r < (1 << LOGE); r++) x[r] = x[r] >= Mm.q ? x[r] - Mm.q : x[r]; // one conditional subtraction: all primes in (2^60-2^28, 2^60)
+    for (int r = 0; r < (1 << LOGE); r++) x[r] = recanon(x[r], Mm); // one conditional subtraction within a width class (modarith.hpp)
     __syncthreads(); // the inverse tile's last LDS image has been read by everyone
     auto nold = [](int) -> u64 { return 0; };
     ntt_tile_x<K, LOGE, true, false, false, true, false>(
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(kTileThreads) void f_dr_icols_lift_fcols_kernel(con
     for (int r = 0; r < (1 << LOGE); r++) { // RNSTool::divide_and_round_q_last_ntt_inplace, coefficient-domain part
         u64 y = x[r] + half;
         y = y >= ql ? y - ql : y;
-        y = y >= qi ? y - qi : y;
+        y = recanon(y, Mi);
         y += neg_half;
         x[r] = y >= qi ? y - qi : y;
     }
@@ -274,8 +274,7 @@ __global__ __launch_bounds__(kTileThreads) void f_ks_lift_fcols_kernel(const u64
     ntt_tile<K, LOGE, true, false, false>(
         Mm, tw + ((size_t)pm << logN), logN, blockIdx.x,
         [=](int g) {
-            const u64 v = in[g];
-            return v >= Mm.q ? v - Mm.q : v;
+            return recanon(in[g], Mm);
         },
         [=](int g, u64 v) { out[g] = v; }, lds);
 }
@@ -300,7 +299,7 @@ __global__ __launch_bounds__(kTileThreads) void f_dr_lift_fcols_kernel(const u64
         [=](int g) {
             u64 y = in[g] + half;
             y = y >= ql ? y - ql : y;
-            y = y >= qi ? y - qi : y;
+            y = recanon(y, Mi);
             y += neg_half;
             return y >= qi ? y - qi : y;
         },

@@ -130,7 +130,7 @@ __global__ __launch_bounds__(kVmThreads) void lift_i128_kernel(u64 *__restrict__
         l = ~l + 1;
         h = ~h + (l == 0);
     }
-    const u64 r = canon(reduce128_lazy(h, l, M.delta), M);
+    const u64 r = reduce128_any(h, l, M);
     out[(size_t)i * N + k] = neg ? negmod(r, M.q) : r;
 }
 
@@ -716,9 +716,13 @@ void HEVM::load_keys(const std::string &dir, bool need_secret, bool need_public,
         int logN = 0;
         while (((uint64_t)1 << logN) < p.N) logN++;
         for (u64 q : p.primes)
-            if ((q >> 59) != 1 || ((1ull << kQBits) - q) >= kMaxDelta)
-                m.fail("coefficient modulus outside this backend's range: every prime must be 2^60 - delta with delta < 2^28 "
-                       "(what CoeffModulus::Create(N, {60, ...}) of SEAL_HEVM.cpp:48-53 yields)");
+            {
+                int qb = 0;
+                while ((q >> qb) != 0) qb++;
+                if (qb < kMinQBits || qb > kQBits || ((1ull << qb) - q) >= kMaxDelta)
+                    m.fail("coefficient modulus outside this backend's range: every prime must be 2^b - d with 45 <= b <= 60 and d < 2^28 "
+                           "(CoeffModulus::Create(N, {60, ...}) of SEAL_HEVM.cpp:48-53 yields b = 60)");
+            }
         init_context(logN, (int)p.primes.size(), p.primes.data());
     }
     const Context &c = *ctx;

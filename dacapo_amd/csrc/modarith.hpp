@@ -19,14 +19,18 @@ namespace dacapo {
 typedef uint64_t u64;
 typedef uint32_t u32;
 
-constexpr int kQBits = 60;
-constexpr u64 kQMask = (1ull << kQBits) - 1;
+constexpr int kQBits = 60;   // the reference's chain; the widest supported prime
+constexpr int kMinQBits = 45; // round 3: any prime q = 2^b - d with 45 <= b <= 60 and d < 2^(b-32) (HEaaN-style 51-bit rescale primes included)
 constexpr u32 kMaxDelta = 1u << 28;
 
 // Per-prime constants, one entry per prime of the key-level chain, resident in HBM (and L2).
+// `delta` is the WIDTH-TAGGED fold word every reduction below takes: bits 0..27 = d = 2^b - q, bits 28..31 = 60 - b.  For the
+// reference's 60-bit chain the tag is 0 and the word is d itself.  The word is wave-uniform wherever a kernel handles one limb per
+// workgroup, so the shift amount b - 32, the mask and d are scalar-unit values: the generic width costs the 60-bit path no vector
+// instruction (the constant shifts of round 2 became register operands of the same v_alignbit / v_lshrrev).
 struct DModulus {
     u64 q;
-    u32 delta;   // 2^60 - q
+    u32 delta;   // width-tagged fold word (see above)
     u32 pad_;
     u64 inv_n;   // N^{-1} mod q
     u64 inv_n_w; // N^{-1} * (psi^{bitrev(1)})^{-1} mod q : last inverse-NTT stage twiddle with the scaling merged
@@ -58,10 +62,30 @@ __device__ __forceinline__ void mul_wide(u64 a, u64 b, u64 &hi, u64 &lo)
     hi = p11;
 }
 
-// x (any 64-bit value) -> congruent value < 2^60 + 15*delta < 2q.   1 mad
-__device__ __forceinline__ u64 fold60(u64 x, u32 delta)
+// Two builds of the same sources (csrc/Makefile): libSEAL_HEVM.so with DC_GENERIC_WIDTH = 0 -- the reference's 60-bit chain only, every
+// shift an immediate, exactly round 2's instruction streams -- and libSEAL_HEVM_gw.so with DC_GENERIC_WIDTH = 1, where the width travels
+// in the fold word.  Measured with one build for both (run-time shifts and a uniform branch for the third fold inside every modular
+// multiply): the 60-bit headline 46.2 -> 48.9 ms, the NTT leg 870 -> 1 030 us, config 3 458 -> 508 us; hence two builds.
+#ifndef DC_GENERIC_WIDTH
+#define DC_GENERIC_WIDTH 0
+#endif
+__host__ __device__ __forceinline__ u32 fold_word(int bits, u64 d) { return (u32)d | ((u32)(kQBits - bits) << 28); }
+#if DC_GENERIC_WIDTH
+__device__ __forceinline__ u32 fw_d(u32 fw) { return fw & 0x0FFFFFFFu; }          // 2^b - q
+__device__ __forceinline__ u32 fw_sh(u32 fw) { return 28u - (fw >> 28); }         // b - 32
+__device__ __forceinline__ u32 fw_mask(u32 fw) { return (1u << fw_sh(fw)) - 1u; } // low b - 32 bits of a high word
+__device__ __forceinline__ bool fw_narrow(u32 fw) { return (fw >> 28) != 0; }
+#else // the 60-bit chain: the tag is 0 (checked when the context is built), the word is d itself
+__device__ __forceinline__ u32 fw_d(u32 fw) { return fw; }
+__device__ __forceinline__ constexpr u32 fw_sh(u32) { return 28u; }
+__device__ __forceinline__ constexpr u32 fw_mask(u32) { return 0x0FFFFFFFu; }
+__device__ __forceinline__ constexpr bool fw_narrow(u32) { return false; }
+#endif
+
+// x (any 64-bit value) -> congruent value < 2^b + 2^(64-b) d < 2q.   1 mad   (named for the 60-bit chain it was written for)
+__device__ __forceinline__ u64 fold60(u64 x, u32 fw)
 {
-    return mad32(hi32(x) >> 28, delta, pack64(lo32(x), hi32(x) & 0x0FFFFFFFu));
+    return mad32(hi32(x) >> fw_sh(fw), fw_d(fw), pack64(lo32(x), hi32(x) & fw_mask(fw)));
 }
 
 // any 64-bit value -> canonical residue
@@ -71,16 +95,20 @@ __device__ __forceinline__ u64 canon(u64 x, const DModulus &m)
     return r >= m.q ? r - m.q : r;
 }
 
-// T = hi*2^64 + w1*2^32 + w0 < 2^124  ->  congruent value < 2^62.   3 mads, 5 other VALU ops
-__device__ __forceinline__ u64 reduce_words(u64 hi, u32 w1, u32 w0, u32 delta)
+// T = hi*2^64 + w1*2^32 + w0 < 2^(2b+4) (products of lazy b-bit values; b = 60: < 2^124)  ->  congruent value < 4q.   3 mads, 5 other VALU ops
+__device__ __forceinline__ u64 reduce_words(u64 hi, u32 w1, u32 w0, u32 fw)
 {
-    const u32 H0 = shr_pair(lo32(hi), w1, 28);       // floor(T / 2^60), low word
-    const u32 H1 = shr_pair(hi32(hi), lo32(hi), 28);  //                   high word (hi < 2^60)
-    const u64 A = opaque(mad32(H0, delta, pack64(w0, w1 & 0x0FFFFFFFu))); // < 2^60 + 2^60
-    const u64 Bv = opaque((u64)H1 * delta);           // weight 2^32, < 2^60
-    // Bv * 2^32 = (Bv >> 28) * 2^60 + (Bv & (2^28-1)) * 2^32
-    const u64 C = opaque(mad32(shr_pair(hi32(Bv), lo32(Bv), 28), delta, A)); // < 2^61 + 2^60
-    return pack64(lo32(C), hi32(C) + (lo32(Bv) & 0x0FFFFFFFu));       // < 2^62
+    const u32 sh = fw_sh(fw), delta = fw_d(fw), mask = fw_mask(fw);
+    const u32 H0 = shr_pair(lo32(hi), w1, sh);        // floor(T / 2^b), low word
+    const u32 H1 = shr_pair(hi32(hi), lo32(hi), sh);   //                  high word (hi < 2^b)
+    const u64 A = opaque(mad32(H0, delta, pack64(w0, w1 & mask))); // < 2^b + 2^b
+    const u64 Bv = opaque((u64)H1 * delta);            // weight 2^32, < 2^b
+    // Bv * 2^32 = (Bv >> (b-32)) * 2^b + (Bv & (2^(b-32) - 1)) * 2^32
+    const u64 C = opaque(mad32(shr_pair(hi32(Bv), lo32(Bv), sh), delta, A)); // < 2^61 + 2^60
+    const u64 R = pack64(lo32(C), hi32(C) + (lo32(Bv) & mask));     // < 2^62: below 4q for the 60-bit chain (d ~ 2^25)
+    // A narrower prime needs a third fold: each one divides by 2^b / d, and with b = 51, d ~ 2^26 two of them leave ~2^58.  The tag is
+    // wave-uniform: the reference's chain skips this on the scalar unit.  Result then < 2^b + 2^(62-b) d < 2q.
+    return fw_narrow(fw) ? fold60(R, fw) : R;
 }
 __device__ __forceinline__ u64 reduce128_lazy(u64 hi, u64 lo, u32 delta) { return reduce_words(hi, hi32(lo), lo32(lo), delta); }
 
@@ -98,6 +126,15 @@ __device__ __forceinline__ u64 mulmod_lazy(u64 a, u64 b, u32 delta)
 
 __device__ __forceinline__ u64 mulmod(u64 a, u64 b, const DModulus &m) { return canon(mulmod_lazy(a, b, m.delta), m); }
 
+// A canonical residue of ANOTHER prime of the chain (or the sum of two values below 2^60) -> canonical residue mod M.  Within one
+// width class all primes lie within 2^28 of each other and one conditional subtraction is the whole reduction (SEAL: modulo_poly_coeffs
+// only when q_j > q_m); a narrower target prime (mixed chains) needs the fold.  The width tag is wave-uniform.
+__device__ __forceinline__ u64 recanon(u64 x, const DModulus &m)
+{
+    if (fw_narrow(m.delta)) return canon(x, m);
+    return x >= m.q ? x - m.q : x;
+}
+
 // canonical operands
 __device__ __forceinline__ u64 addmod(u64 a, u64 b, u64 q)
 {
@@ -106,6 +143,18 @@ __device__ __forceinline__ u64 addmod(u64 a, u64 b, u64 q)
 }
 __device__ __forceinline__ u64 submod(u64 a, u64 b, u64 q) { return a >= b ? a - b : a + q - b; }
 __device__ __forceinline__ u64 negmod(u64 a, u64 q) { return a ? q - a : 0; }
+
+// any T = hi 2^64 + lo < 2^124 -> canonical residue (encoder, opcode 10: integers far beyond a product of two residues).  The 60-bit chain
+// reduces directly; a narrower prime goes through (hi mod q) (2^64 mod q) + (lo mod q).
+__device__ __forceinline__ u64 reduce128_any(u64 hi, u64 lo, const DModulus &m)
+{
+    if (fw_narrow(m.delta)) {
+        const u64 r63 = canon(1ull << 63, m), r64 = r63 + r63 >= m.q ? r63 + r63 - m.q : r63 + r63;
+        const u64 a = canon(mulmod_lazy(r64, canon(hi, m), m.delta), m), b = canon(lo, m);
+        return a + b >= m.q ? a + b - m.q : a + b;
+    }
+    return canon(reduce128_lazy(hi, lo, m.delta), m);
+}
 
 // 128-bit accumulator for sums of products of canonical residues (each < 2^120): up to 16 terms keep
 // hi < 2^60, the precondition of reduce128_lazy.

@@ -6,18 +6,35 @@ import ctypes as C
 
 import numpy as np
 
-from . import LIB_PATH
+from . import LIB_PATH, LIB_PATH_GW
 
 _lib = None
+_libs: dict = {}
 
 
-def lib():
+def lib_gw():
+    """the generic-width build of the same sources (libSEAL_HEVM_gw.so: primes of 45..60 bits, mixed chains; csrc/modarith.hpp).  Device
+    memory is the process's HIP runtime's either way, so DeviceBuffer pointers go to both libraries."""
+    return lib(LIB_PATH_GW)
+
+
+def lib(path=None):
     global _lib
+    if path is not None and str(path) != str(LIB_PATH):
+        if str(path) not in _libs:
+            _libs[str(path)] = _bind(path)
+        return _libs[str(path)]
     if _lib is None:
-        if not LIB_PATH.exists():
-            raise RuntimeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+        _lib = _bind(LIB_PATH)
+    return _lib
+
+
+def _bind(path):
+    if True:  # (one indentation level kept from the single-library version)
+        if not path.exists():
+            raise RuntimeError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                                "(there is no CPU fallback for the HEVM hot path)")
-        L = C.CDLL(str(LIB_PATH))
+        L = C.CDLL(str(path))
         vp, u64p, i32, lng = C.c_void_p, C.c_void_p, C.c_int, C.c_long
         L.dc_context_create.restype = vp
         L.dc_context_create.argtypes = [i32, i32, i32, vp]
@@ -61,8 +78,7 @@ def lib():
         L.dc_poly_add.argtypes = [vp, u64p, u64p, u64p, i32, vp]
         L.dc_galois_elt_from_step.restype = C.c_uint32
         L.dc_galois_elt_from_step.argtypes = [vp, i32]
-        _lib = L
-    return _lib
+    return L
 
 
 class DeviceBuffer:
@@ -108,7 +124,9 @@ def read_device(ptr: int, shape, dtype=np.uint64) -> np.ndarray:
 class Context:
     def __init__(self, logN=15, num_primes=14, bit_size=60, primes=None, special=1, alpha=None):
         """special / alpha: the grouped-digit key-switching extension (dc_context_create_hybrid); 1 / 1 is SEAL's scheme"""
-        L = lib()
+        narrow = bit_size != 60 or (primes is not None and any(int(p).bit_length() != 60 for p in primes))
+        L = lib_gw() if narrow else lib()   # other prime widths: the generic-width build
+        self.L = L
         arr = None
         if primes is not None:
             arr = (C.c_uint64 * len(primes))(*[int(p) for p in primes])
@@ -129,7 +147,7 @@ class Context:
 
     def __del__(self):
         try:
-            lib().dc_context_destroy(self.h)
+            self.L.dc_context_destroy(self.h)
         except Exception:
             pass
 
@@ -142,9 +160,9 @@ class Context:
         args = (buf.at(offset), self.N if limb_stride is None else limb_stride, count,
                 prime_idx.ptr if prime_idx is not None else None, prime_base, prime_period, stream)
         if variant is None:
-            (lib().dc_ntt_inverse if inverse else lib().dc_ntt_forward)(self.h, *args)
+            (self.L.dc_ntt_inverse if inverse else self.L.dc_ntt_forward)(self.h, *args)
         else:
-            lib().dc_ntt_variant(self.h, variant, int(inverse), *args)
+            self.L.dc_ntt_variant(self.h, variant, int(inverse), *args)
 
     def elt_from_step(self, step: int) -> int:
-        return int(lib().dc_galois_elt_from_step(self.h, step))
+        return int(self.L.dc_galois_elt_from_step(self.h, step))

@@ -1,0 +1,86 @@
+"""GPU: the modular arithmetic is no longer tied to 60-bit primes (round 3; modarith.hpp's width-tagged fold word, built as libSEAL_HEVM_gw.so beside the 60-bit-only default library): any chain of primes
+q = 2^b - d, 45 <= b <= 60, d < 2^28 -- uniform 51-bit chains like the rescale primes of the reference's HEaaN configuration
+(profiled_HEAAN_GPU.json: rescalingFactor 51), and MIXED chains (60-bit base and special primes around 51-bit rescale primes).  Against
+the oracle (generic Barrett arithmetic on whatever primes it is given), limb for limb: NTT / inverse NTT, rotation hop, ct x ct +
+relinearise, rescale -- at every level."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle.oracle import Ciphertext, Oracle, splitmix_fill  # noqa: E402
+
+
+def _chain(logN, widths):
+    """one prime per entry of `widths`, CoeffModulus::Create style per width class (scan down from 2^b in steps of 2N), no repeats"""
+    from dacapo_amd import ckks_boot as cb
+
+    out, used = [], set()
+    for b in widths:
+        v = (1 << b) + 1
+        while True:
+            v -= 2 << logN
+            if v not in used and cb._is_prime(v):
+                used.add(v)
+                out.append(v)
+                break
+    return out
+
+
+@pytest.mark.parametrize("logN,widths", [(12, [51] * 5), (13, [48, 48, 48, 48]), (12, [60, 51, 51, 51, 60]), (12, [55, 60, 45, 51, 58, 60])])
+def test_ntt_and_evaluator_ops_on_other_prime_widths(logN, widths):
+    from dacapo_amd import lowlevel as ll
+
+    primes = _chain(logN, widths)
+    K, N = len(primes), 1 << logN
+    o = Oracle(logN, K, primes=primes)
+    ctx = ll.Context(logN, primes=primes)
+    assert ctx.primes == o.primes == primes and ctx.roots == [o.psi(p) for p in range(K)]
+    L = ctx.L   # libSEAL_HEVM_gw.so: the generic-width build of the same sources
+    assert L is ll.lib_gw()
+    # NTT round trip and == oracle, every prime
+    a = np.stack([splitmix_fill(17 + i, N) % np.uint64(primes[i]) for i in range(K)])
+    a[0, : N // 2] = 0
+    a[1, :] = np.uint64(primes[1] - 1)
+    d = ll.DeviceBuffer.from_host(a)
+    ctx.ntt(d, K)
+    assert (d.to_host() == o.ntt_fwd(a, list(range(K)))).all()
+    ctx.ntt(d, K, inverse=True)
+    assert (d.to_host() == a).all()
+    elt = o.elt_from_step(3)
+    o.keygen(seed=5, galois_elts=[elt])
+    dk, dr = ll.DeviceBuffer.from_host(o.galois[elt]), ll.DeviceBuffer.from_host(o.relin)
+    for ell in range(1, K):
+        q = np.array(primes[:ell], dtype=np.uint64)[:, None]
+        x = np.stack([np.stack([splitmix_fill(1 + 7 * p + i + 100 * ell, N) for i in range(ell)]) % q for p in range(2)])
+        y = np.stack([np.stack([splitmix_fill(99 + 7 * p + i + 100 * ell, N) for i in range(ell)]) % q for p in range(2)])
+        dx, dy, dd = ll.DeviceBuffer.from_host(x), ll.DeviceBuffer.from_host(y), ll.DeviceBuffer((2, ell, N))
+        st = ell * N
+        X, Y = Ciphertext(x, 2.0**40), Ciphertext(y, 2.0**40)
+        L.dc_ct_rotate_hop(ctx.h, dd.ptr, st, dx.ptr, st, elt, dk.ptr, ell, None)
+        assert (dd.to_host() == o.apply_galois(X, elt).data).all(), ("rotate", ell)
+        L.dc_ct_mul_relin(ctx.h, dd.ptr, st, dx.ptr, st, dy.ptr, st, dr.ptr, ell, None)
+        want = o.mul_relin(X, Y)
+        assert (dd.to_host() == want.data).all(), ("mul_relin", ell)
+        if ell >= 2:
+            L.dc_ct_rescale(ctx.h, dd.ptr, st, dd.ptr, st, ell, None)
+            assert (dd.to_host()[:, : ell - 1] == o.rescale(want).data).all(), ("rescale", ell)
+
+
+def test_both_builds_agree_on_the_reference_chain():
+    """the generic-width build computes the 60-bit chain too (tag 0): same limbs as the default build, which keeps round 2's instruction
+    streams (immediate shifts, no third fold)"""
+    from dacapo_amd import lowlevel as ll
+
+    ctx = ll.Context(13, 5)
+    assert ctx.L is ll.lib() and all(p >> 59 == 1 for p in ctx.primes)
+    gw = ll.lib_gw()
+    arr = (__import__("ctypes").c_uint64 * 5)(*ctx.primes)
+    h = gw.dc_context_create(13, 5, 60, arr)
+    N = 1 << 13
+    a = np.stack([splitmix_fill(3 + i, N) % np.uint64(ctx.primes[i]) for i in range(5)])
+    d0, d1 = ll.DeviceBuffer.from_host(a), ll.DeviceBuffer.from_host(a)
+    ctx.ntt(d0, 5)
+    gw.dc_ntt_forward(h, d1.ptr, N, 5, None, 0, 0, None)
+    assert (d0.to_host() == d1.to_host()).all()
+    gw.dc_context_destroy(h)

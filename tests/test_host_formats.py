@@ -50,11 +50,13 @@ def test_resnet_shaped_program_has_the_traced_op_mix():
     assert 50 <= mix["bootstrap"] <= 200 and info["num_ctxt"] < 32  # SEAL-VM "bootstrap" = cheap re-encryption, used often
 
 
-def test_library_exports_every_declared_symbol():
-    """the C-ABI library loads without a GPU and exports everything include/*.h declares"""
-    from dacapo_amd import LIB_PATH
+@pytest.mark.parametrize("which", ["default", "generic_width"])
+def test_library_exports_every_declared_symbol(which):
+    """the C-ABI library loads without a GPU and exports everything include/*.h declares -- the default build (the reference's 60-bit chain)
+    and the generic-width build of the same sources (libSEAL_HEVM_gw.so: 45..60-bit primes)"""
+    from dacapo_amd import LIB_PATH, LIB_PATH_GW
 
-    lib = ctypes.CDLL(str(LIB_PATH))
+    lib = ctypes.CDLL(str(LIB_PATH if which == "default" else LIB_PATH_GW))
     names = set()
     for h in ("hevm_abi.h", "dacapo_ckks.h"):
         text = (ROOT / "include" / h).read_text()
