@@ -454,7 +454,11 @@ void HEVM::init_context(int logN, int K, const u64 *primes)
     int ksp = 1, alpha = 1;
     if (const char *e = getenv("DACAPO_HEVM_KS_SPECIAL")) ksp = alpha = std::max(1, atoi(e));
     if (const char *e = getenv("DACAPO_HEVM_KS_ALPHA")) alpha = std::max(1, atoi(e));
-    ctx.reset(new Context(logN, K, kQBits, primes, ksp, alpha));
+    // DACAPO_HEVM_PRIME_BITS = b (45..60; the generic-width build only): the chain CoeffModulus::Create(N, {b, b, ...}) instead of the
+    // reference's 60-bit one (SEAL_HEVM.cpp:48-53) -- e.g. 51 for rescale primes of the HEaaN configuration's width
+    int bits = kQBits;
+    if (const char *e = getenv("DACAPO_HEVM_PRIME_BITS")) bits = atoi(e);
+    ctx.reset(new Context(logN, K, bits, primes, ksp, alpha));
     ctx->ensure_scratch();
     encoder.reset(new HostEncoder(logN));
     if (const char *e = getenv("DACAPO_HEVM_PLAN")) use_plan = atoi(e) != 0;

@@ -84,3 +84,23 @@ def test_both_builds_agree_on_the_reference_chain():
     gw.dc_ntt_forward(h, d1.ptr, N, 5, None, 0, 0, None)
     assert (d0.to_host() == d1.to_host()).all()
     gw.dc_context_destroy(h)
+
+
+def test_vm_program_on_a_51_bit_chain_matches_the_oracle_vm():
+    """the whole boundary on 51-bit primes: key generation, encode, encrypt, a program with rotations (incl. multi-hop NAF offsets), ct x ct,
+    ct x pt, rescales by 51-bit primes, decrypt / decode -- GPU VM (generic-width build) == oracle VM limb for limb.  A child process: the
+    VM binding picks its library at import time."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    env = dict(os.environ, DACAPO_AMD_LIB=str(root / "dacapo_amd" / "lib" / "libSEAL_HEVM_gw.so"), DACAPO_HEVM_PRIME_BITS="51")
+    out = subprocess.run([sys.executable, str(root / "tools" / "narrow_chain_demo.py"), "12", "7"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-1500:]
+    res = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert res["prime_bits"] == 51 and res["limbs_identical"] and res["scale_identical"]
+    assert res["max_error_vs_cleartext"] < 1e-5
+    assert res["op_mix"]["rescale"] >= 2 and res["op_mix"]["mulcc"] == 2
