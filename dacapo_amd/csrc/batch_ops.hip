@@ -159,10 +159,10 @@ static void b_ks_tail(Context &c, const BatchWs &w, u64 *digits, const KsItem *i
     f_frows_final(c, (MODE == 1 && fused_mac) ? 4 : MODE, w.tmp, final_items, w.acc, 2 * B, ell, sp, s, RsItem{}, nullptr, nullptr, h);
 }
 
-void b_rotate_hops(Context &c, const BatchWs &w, const KsItem *d_items, int B, int ell, hipStream_t s, const Handoff &h)
+void b_rotate_hops(Context &c, const BatchWs &w, const KsItem *d_items, int B, int ell, hipStream_t s, const Handoff &h, int unique)
 {
     if (c.hybrid()) { // (the plan links no steps in this mode: h is empty)
-        hyb_rotate_hops(c, w, d_items, B, ell, s);
+        hyb_rotate_hops(c, w, d_items, B, ell, s, unique);
         return;
     }
     f_irows_rot_c1(c, d_items, ell, w.digits, B, s);

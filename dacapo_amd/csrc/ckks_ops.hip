@@ -188,6 +188,15 @@ void mul_relin(Context &c, const Workspace &w, CtView dst, CtView a, CtView b, c
 void rotate_hop(Context &c, const Workspace &w, CtView dst, CtView src, u32 galois_elt, const u64 *galois_key, int ell,
                 hipStream_t s)
 {
+    if (c.hybrid()) { // grouped-digit mode decomposes before the automorphism (hybrid_ks.hip): its own single-hop sequence, source kept apart from dst
+        CtView from = src;
+        if (src.p == dst.p) {
+            from = CtView{ w.ct_tmp, (long)ell * (long)c.N };
+            launch_ew(c, EwOp::Copy, from, src, src, 2, 2, ell, s);
+        }
+        hyb_rotate_hop_single(c, w, dst, from, galois_elt, galois_key, ell, s);
+        return;
+    }
     // permuted (c0, c1) -> scratch [2][ell][N]; c1' is the key-switch target, c0' the base of output poly 0
     CtView tmp{ w.ct_tmp, (long)ell * (long)c.N };
     launch_galois(c, tmp, src, galois_elt, 2, ell, s);

@@ -186,6 +186,7 @@ class HEVM {
         int wave = 0, lane = 0;             // steps of one wave are independent: lane 1 runs on the auxiliary stream
         Handoff h;                          // link to a fused producer (h.in) / consumer (h.cont, h.out) step, plan.hpp
         int fused_consumer = -1;            // index of the step whose first phase this step's last kernel computes
+        int unique = 0;                     // P_ROT, grouped-digit mode: distinct source ciphertexts among the items (shared decompositions)
     };
     struct Plan {
         bool ready = false;

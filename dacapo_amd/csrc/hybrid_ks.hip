@@ -6,7 +6,9 @@
 // with ksp = alpha = 1 it is SEAL's switch_key_inplace and the fused launch sequences of fused_ks.hip stay in charge.
 //
 // Launch sequence of a batch of B key switches at level l (G = ceil(l / alpha) digits, M = l + ksp moduli, E = G M - l raised limbs):
-//   prepare   rotation: dst.c0 = galois(src.c0), target = digits = galois(src.c1)   |   ct x ct: tensor product, target = digits = c2
+//   prepare   rotation: dst.c0 = galois(src.c0), digits[slot] = src.c1 -- taken BEFORE the automorphism, so hops of one source share a
+//             decomposition ("hoisting"), the Galois permutation is applied to the raised limbs in the NTT domain by `mac`'s loads
+//             |   ct x ct: tensor product, target = digits = c2
 //   iNTT      digits [B][l]                                   (batched transforms of ntt_kernels.hip / ntt_full.hip)
 //   mod-up    ext[b][g][e] = sum_{i in S_g} [x_i qhat_i^-1]_{q_i} (Q_g / q_i)  mod m_e   -- the base conversion, a [|S_g| x (M - |S_g|)]
 //             constant matrix applied to every coefficient: 128-bit lazy accumulators, one reduction per output
@@ -37,21 +39,20 @@ struct HybSingle { // one key switch by value (the one-instruction-at-a-time loo
     const u64 *base0 = nullptr, *base1 = nullptr, *key = nullptr;
 };
 
-// rotation items: dst.c0 = galois(src.c0); target[b] = digits[b] = galois(src.c1).  grid = (N/512, l, B)
-__global__ __launch_bounds__(kHT) void hyb_prepare_rot_kernel(const KsItem *__restrict__ items, u64 *__restrict__ target, u64 *__restrict__ digits,
-                                                               int ell, size_t N, int logN)
+// rotation items: dst.c0 = galois(src.c0); digits[slot] = src.c1 AS IT IS -- the digits are taken before the automorphism (see the header and
+// oracle orc_rotate_ks_hybrid), so hops of one source ciphertext share one decomposition: every item of a slot writes the same limbs.
+// `single` (items == nullptr): one hop by value.  grid = (N/512, l, B)
+__global__ __launch_bounds__(kHT) void hyb_prepare_rot_kernel(const KsItem *__restrict__ items, KsItem single, u64 *__restrict__ digits, int ell,
+                                                               size_t N, int logN, int use_slots)
 {
     const int i = blockIdx.y, b = blockIdx.z;
-    const KsItem it = items[b];
+    const KsItem it = items ? items[b] : single;
     const size_t k = ((size_t)blockIdx.x * kHT + threadIdx.x) * 2;
     const u32 g = hyb_galois_src((u32)k, it.elt, logN); // an aligned pair of outputs reads an aligned pair of inputs, possibly swapped
     const u64x2 v0 = *reinterpret_cast<const u64x2 *>(it.src.limb(0, i, N) + (g & ~1u));
-    const u64x2 v1 = *reinterpret_cast<const u64x2 *>(it.src.limb(1, i, N) + (g & ~1u));
-    const u64x2 c0 = (g & 1u) ? u64x2{ v0.y, v0.x } : v0, c1 = (g & 1u) ? u64x2{ v1.y, v1.x } : v1;
-    *reinterpret_cast<u64x2 *>(it.dst.limb(0, i, N) + k) = c0;
-    const size_t o = ((size_t)b * ell + i) * N + k;
-    *reinterpret_cast<u64x2 *>(target + o) = c1;
-    *reinterpret_cast<u64x2 *>(digits + o) = c1;
+    *reinterpret_cast<u64x2 *>(it.dst.limb(0, i, N) + k) = (g & 1u) ? u64x2{ v0.y, v0.x } : v0;
+    const size_t slot = use_slots ? it.slot : (size_t)b;
+    *reinterpret_cast<u64x2 *>(digits + (slot * ell + i) * N + k) = *reinterpret_cast<const u64x2 *>(it.src.limb(1, i, N) + k);
 }
 
 // ct x ct items: dst.c0 = a0 b0, dst.c1 = a0 b1 + a1 b0, target[b] = digits[b] = a1 b1.  grid = (N/512, l, B)
@@ -127,26 +128,39 @@ __global__ __launch_bounds__(kHT) void hyb_modup_kernel(const u64 *__restrict__ 
     }
 }
 
-// inner products with the key.  grid = (N/512, M, B).  MODE 0 rotation items (per-item key), 1 ct x ct items (shared key), 2 single
+// inner products with the key.  grid = (N/512, M, B).  MODE 0 rotation items (per-item key; every operand -- a raised limb of the item's
+// slot, or the NTT-form limb of src.c1 itself where the modulus belongs to the digit -- is read THROUGH the item's Galois permutation),
+// 1 ct x ct items (shared key), 2 one key switch by value
 template <int MODE>
 __global__ __launch_bounds__(kHT) void hyb_mac_kernel(u64 *__restrict__ accq, u64 *__restrict__ accp, const u64 *__restrict__ ext,
-                                                       const u64 *__restrict__ target, const void *__restrict__ items,
+                                                       const u64 *__restrict__ target, const void *__restrict__ items, KsItem single,
                                                        const u64 *__restrict__ shared_key, int ell, int ksp, int alpha, int L, int K, int E, size_t N,
-                                                       const DModulus *__restrict__ mods)
+                                                       int logN, int use_slots, const DModulus *__restrict__ mods)
 {
     const int mi = blockIdx.y, b = blockIdx.z, M = ell + ksp, pm = mi < ell ? mi : L + (mi - ell);
     const DModulus Md = mods[pm];
-    const u64 *key = MODE == 0 ? static_cast<const KsItem *>(items)[b].key : shared_key;
+    KsItem it{};
+    if (MODE == 0) it = items ? static_cast<const KsItem *>(items)[b] : single;
+    const u64 *key = MODE == 0 ? it.key : shared_key;
     const size_t k = ((size_t)blockIdx.x * kHT + threadIdx.x) * 2;
+    const size_t slot = MODE == 0 ? (use_slots ? it.slot : (size_t)b) : (size_t)b;
+    u32 gsrc = (u32)k;
+    if (MODE == 0) gsrc = hyb_galois_src((u32)k, it.elt, logN);
     const int G = (ell + alpha - 1) / alpha;
     Acc128 a0[2], a1[2];
 #pragma unroll
     for (int e = 0; e < 2; e++) a0[e].clear(), a1[e].clear();
     for (int g = 0; g < G; g++) { // G <= 16: the 128-bit sums stay below 2^124
         const int lo = g * alpha, hi = min(lo + alpha, ell);
-        const u64 *op = (mi >= lo && mi < hi) ? target + ((size_t)b * ell + mi) * N
-                                              : ext + ((size_t)b * E + (size_t)g * (M - alpha) + (mi < lo ? mi : mi - (hi - lo))) * N;
-        const u64x2 x = *reinterpret_cast<const u64x2 *>(op + k);
+        const bool own = mi >= lo && mi < hi;
+        const u64 *op = own ? (MODE == 0 ? it.src.limb(1, mi, N) : target + ((size_t)b * ell + mi) * N)
+                            : ext + (slot * E + (size_t)g * (M - alpha) + (mi < lo ? mi : mi - (hi - lo))) * N;
+        u64x2 x;
+        if (MODE == 0) {
+            const u64x2 v = *reinterpret_cast<const u64x2 *>(op + (gsrc & ~1u));
+            x = (gsrc & 1u) ? u64x2{ v.y, v.x } : v;
+        } else
+            x = *reinterpret_cast<const u64x2 *>(op + k);
         const u64x2 y0 = *reinterpret_cast<const u64x2 *>(key + (((size_t)g * 2 + 0) * K + pm) * N + k);
         const u64x2 y1 = *reinterpret_cast<const u64x2 *>(key + (((size_t)g * 2 + 1) * K + pm) * N + k);
 #pragma unroll
@@ -205,8 +219,8 @@ __global__ __launch_bounds__(kHT) void hyb_moddown_kernel(const u64 *__restrict_
 // dst.c (+)= (acc_c - t_c) P^-1.  grid = (N/512, l, 2B)
 template <int MODE>
 __global__ __launch_bounds__(kHT) void hyb_final_kernel(const u64 *__restrict__ accq, const u64 *__restrict__ tmp, const void *__restrict__ items,
-                                                         HybSingle single, int ell, int ksp, int L, size_t N, const DModulus *__restrict__ mods,
-                                                         const u64 *__restrict__ dn)
+                                                         HybSingle single, KsItem rot_single, int ell, int ksp, int L, size_t N,
+                                                         const DModulus *__restrict__ mods, const u64 *__restrict__ dn)
 {
     const int i = blockIdx.y, z = blockIdx.z, b = z >> 1, c = z & 1;
     const DModulus m = mods[i];
@@ -219,7 +233,7 @@ __global__ __launch_bounds__(kHT) void hyb_final_kernel(const u64 *__restrict__ 
     u64 *dst;
     const u64 *base;
     if (MODE == 0) {
-        const KsItem it = static_cast<const KsItem *>(items)[b];
+        const KsItem it = items ? static_cast<const KsItem *>(items)[b] : rot_single;
         dst = it.dst.limb(c, i, N) + k, base = c == 0 ? dst : nullptr; // c0 holds the permuted source c0 (prepare), c1 starts at zero
     } else if (MODE == 1) {
         const MulItem it = static_cast<const MulItem *>(items)[b];
@@ -349,27 +363,29 @@ __global__ __launch_bounds__(kHT) void hyb_conv_mfma_kernel(const u64 *__restric
     }
 }
 
-// everything after `prepare`: target [B][l][N] NTT form, digits = a copy of it (transformed in place here)
+// everything after `prepare`.  U = decompositions to compute (digits [U][l][N] in NTT form on entry, transformed in place here): U = B
+// except for rotation batches whose items share sources (use_slots); MODE 1 / 2: target [B][l][N] NTT form.
 template <int MODE>
-static void hyb_core(Context &c, const BatchWs &w, const void *items, const u64 *shared_key, HybSingle single, int B, int ell, hipStream_t s)
+static void hyb_core(Context &c, const BatchWs &w, const void *items, const u64 *shared_key, HybSingle single, KsItem rot_single, int B, int U,
+                     int use_slots, int ell, hipStream_t s)
 {
     const size_t N = c.N;
     const int ksp = c.ksp, alpha = c.alpha, L = c.max_level(), K = c.K, G = c.hyb_groups(ell), M = ell + ksp, E = c.hyb_ext(ell);
     const unsigned gx = (unsigned)(N / (2 * kHT));
     u64 *accq = w.acc, *accp = w.acc + (size_t)B * 2 * ell * N;
-    launch_ntt(c, true, w.digits, (long)N, B * ell, nullptr, 0, ell, s);
+    launch_ntt(c, true, w.digits, (long)N, U * ell, nullptr, 0, ell, s);
     // (below 4 primes a conversion has at most a 3 x 11 matrix: the vector kernels are faster there -- 115 vs 127 us per hop at level 1, N = 2^17)
     const bool mfma = c.hyb_mfma && N >= 4 * kConvStrip && ell >= 4;
     const unsigned gc = (unsigned)(N / (4 * kConvStrip));
     if (mfma)
-        hipLaunchKernelGGL(hyb_conv_mfma_kernel<false>, dim3(gc, (unsigned)G, (unsigned)B), dim3(kHT), 0, s, w.digits, w.ext, ell, ksp, alpha, L, E, N,
+        hipLaunchKernelGGL(hyb_conv_mfma_kernel<false>, dim3(gc, (unsigned)G, (unsigned)U), dim3(kHT), 0, s, w.digits, w.ext, ell, ksp, alpha, L, E, N,
                            c.d_mods, c.hyb_up(ell), reinterpret_cast<const v4i *>(c.d_hyb_bup + c.hyb_bup_off[(size_t)ell]), c.hyb_up_blocks(ell));
     else
-        hipLaunchKernelGGL(hyb_modup_kernel, dim3(gx, (unsigned)G, (unsigned)B), dim3(kHT), 0, s, w.digits, w.ext, ell, ksp, alpha, L, E, N, c.d_mods,
+        hipLaunchKernelGGL(hyb_modup_kernel, dim3(gx, (unsigned)G, (unsigned)U), dim3(kHT), 0, s, w.digits, w.ext, ell, ksp, alpha, L, E, N, c.d_mods,
                            c.hyb_up(ell));
-    launch_ntt(c, false, w.ext, (long)N, B * E, c.hyb_pidx(ell), 0, E, s);
-    hipLaunchKernelGGL(hyb_mac_kernel<MODE>, dim3(gx, (unsigned)M, (unsigned)B), dim3(kHT), 0, s, accq, accp, w.ext, w.target, items,
-                       MODE == 2 ? single.key : shared_key, ell, ksp, alpha, L, K, E, N, c.d_mods);
+    launch_ntt(c, false, w.ext, (long)N, U * E, c.hyb_pidx(ell), 0, E, s);
+    hipLaunchKernelGGL(hyb_mac_kernel<MODE>, dim3(gx, (unsigned)M, (unsigned)B), dim3(kHT), 0, s, accq, accp, w.ext, w.target, items, rot_single,
+                       MODE == 2 ? single.key : shared_key, ell, ksp, alpha, L, K, E, N, c.logN, use_slots, c.d_mods);
     launch_ntt(c, true, accp, (long)N, 2 * B * ksp, nullptr, L, ksp, s);
     if (mfma)
         hipLaunchKernelGGL(hyb_conv_mfma_kernel<true>, dim3(gc, 1, (unsigned)(2 * B)), dim3(kHT), 0, s, accp, w.tmp, ell, ksp, alpha, L, E, N, c.d_mods,
@@ -377,22 +393,32 @@ static void hyb_core(Context &c, const BatchWs &w, const void *items, const u64 
     else
         hipLaunchKernelGGL(hyb_moddown_kernel, dim3(gx, (unsigned)(2 * B)), dim3(kHT), 0, s, accp, w.tmp, ell, ksp, L, N, c.d_mods, c.d_hyb_dn);
     launch_ntt(c, false, w.tmp, (long)N, 2 * B * ell, nullptr, 0, ell, s);
-    hipLaunchKernelGGL(hyb_final_kernel<MODE>, dim3(gx, (unsigned)ell, (unsigned)(2 * B)), dim3(kHT), 0, s, accq, w.tmp, items, single, ell, ksp, L, N,
-                       c.d_mods, c.d_hyb_dn);
+    hipLaunchKernelGGL(hyb_final_kernel<MODE>, dim3(gx, (unsigned)ell, (unsigned)(2 * B)), dim3(kHT), 0, s, accq, w.tmp, items, single, rot_single, ell,
+                       ksp, L, N, c.d_mods, c.d_hyb_dn);
 }
 
-void hyb_rotate_hops(Context &c, const BatchWs &w, const KsItem *d_items, int B, int ell, hipStream_t s)
+void hyb_rotate_hops(Context &c, const BatchWs &w, const KsItem *d_items, int B, int ell, hipStream_t s, int unique)
 {
-    hipLaunchKernelGGL(hyb_prepare_rot_kernel, dim3((unsigned)(c.N / (2 * kHT)), (unsigned)ell, (unsigned)B), dim3(kHT), 0, s, d_items, w.target,
-                       w.digits, ell, c.N, c.logN);
-    hyb_core<0>(c, w, d_items, nullptr, HybSingle{}, B, ell, s);
+    const int use_slots = unique > 0 ? 1 : 0, U = use_slots ? unique : B;
+    hipLaunchKernelGGL(hyb_prepare_rot_kernel, dim3((unsigned)(c.N / (2 * kHT)), (unsigned)ell, (unsigned)B), dim3(kHT), 0, s, d_items, KsItem{},
+                       w.digits, ell, c.N, c.logN, use_slots);
+    hyb_core<0>(c, w, d_items, nullptr, HybSingle{}, KsItem{}, B, U, use_slots, ell, s);
+}
+
+void hyb_rotate_hop_single(Context &c, const Workspace &w, CtView dst, CtView src, u32 galois_elt, const u64 *galois_key, int ell, hipStream_t s)
+{
+    const KsItem it{ src, dst, galois_key, galois_elt, 0 };
+    BatchWs bw{ nullptr, w.ks_digits, w.ks_ext, w.ks_acc, w.ks_tmp };
+    hipLaunchKernelGGL(hyb_prepare_rot_kernel, dim3((unsigned)(c.N / (2 * kHT)), (unsigned)ell, 1), dim3(kHT), 0, s, (const KsItem *)nullptr, it,
+                       w.ks_digits, ell, c.N, c.logN, 0);
+    hyb_core<0>(c, bw, nullptr, nullptr, HybSingle{}, it, 1, 1, 0, ell, s);
 }
 
 void hyb_mul_relin(Context &c, const BatchWs &w, const MulItem *d_items, const u64 *relin_key, int B, int ell, hipStream_t s)
 {
     hipLaunchKernelGGL(hyb_prepare_mul_kernel, dim3((unsigned)(c.N / (2 * kHT)), (unsigned)ell, (unsigned)B), dim3(kHT), 0, s, d_items, w.target,
                        w.digits, ell, c.N, c.d_mods);
-    hyb_core<1>(c, w, d_items, relin_key, HybSingle{}, B, ell, s);
+    hyb_core<1>(c, w, d_items, relin_key, HybSingle{}, KsItem{}, B, B, 0, ell, s);
 }
 
 // Evaluator::switch_key_inplace's role for one ciphertext: out = (base0, base1) + KS(target).  target [l][N] NTT form, preserved.
@@ -403,7 +429,7 @@ void hyb_keyswitch(Context &c, const Workspace &w, CtView out, const u64 *base0,
     // the batch scratch of one item: target is read in place, digits / ext / acc / tmp are the workspace's
     BatchWs bw{ const_cast<u64 *>(target), w.ks_digits, w.ks_ext, w.ks_acc, w.ks_tmp };
     hipLaunchKernelGGL(hyb_copy_kernel, dim3((unsigned)((size_t)ell * N / (2 * kHT))), dim3(kHT), 0, s, w.ks_digits, target);
-    hyb_core<2>(c, bw, nullptr, nullptr, HybSingle{ out, base0, base1, key }, 1, ell, s);
+    hyb_core<2>(c, bw, nullptr, nullptr, HybSingle{ out, base0, base1, key }, KsItem{}, 1, 1, 0, ell, s);
 }
 
 } // namespace dacapo

@@ -20,7 +20,8 @@ namespace dacapo {
 struct KsItem {   // one key-switch hop of a rotation: dst = apply_galois(src)
     CtView src, dst;
     const u64 *key;
-    u32 elt, pad;
+    u32 elt;
+    u32 slot;     // grouped-digit mode: which decomposition of the batch this hop reads (hops of one source ciphertext share one); else 0
 };
 struct MulItem {  // dst = relinearize(a * b)
     CtView a, b, dst;
@@ -81,14 +82,17 @@ struct BatchWs {
     u64 *tmp = nullptr;    // [B][2][l][N]
 };
 
-void b_rotate_hops(Context &c, const BatchWs &w, const KsItem *d_items, int B, int ell, hipStream_t s, const Handoff &h = Handoff{});
+// `unique`: grouped-digit mode only -- the number of distinct decompositions the items' `slot` fields name (0: every item its own)
+void b_rotate_hops(Context &c, const BatchWs &w, const KsItem *d_items, int B, int ell, hipStream_t s, const Handoff &h = Handoff{}, int unique = 0);
 void b_mul_relin(Context &c, const BatchWs &w, const MulItem *d_items, const u64 *relin_key, int B, int ell, hipStream_t s,
                  const Handoff &h = Handoff{});
 void b_rescale(Context &c, const BatchWs &w, const RsItem *d_items, int B, int ell, hipStream_t s, const SumSrc *d_srcs = nullptr,
                const Handoff &h = Handoff{});
 bool chain_fusion_supported(); // the continuation kernels exist for the default launch sequences only
 // grouped-digit hybrid key switching (hybrid_ks.hip; Context::hybrid()): b_rotate_hops / b_mul_relin / keyswitch route here
-void hyb_rotate_hops(Context &c, const BatchWs &w, const KsItem *d_items, int B, int ell, hipStream_t s);
+void hyb_rotate_hops(Context &c, const BatchWs &w, const KsItem *d_items, int B, int ell, hipStream_t s, int unique = 0);
+// one rotation hop by value (the one-instruction-at-a-time loop): src must not alias dst
+void hyb_rotate_hop_single(Context &c, const Workspace &w, CtView dst, CtView src, u32 galois_elt, const u64 *galois_key, int ell, hipStream_t s);
 void hyb_mul_relin(Context &c, const BatchWs &w, const MulItem *d_items, const u64 *relin_key, int B, int ell, hipStream_t s);
 void hyb_keyswitch(Context &c, const Workspace &w, CtView out, const u64 *base0, const u64 *base1, const u64 *target, const u64 *key, int ell,
                    hipStream_t s);

@@ -600,9 +600,18 @@ void HEVM::build_plan()
         switch (st.kind) {
         case P_ROT:
             st.first = (int)h_ks.size();
-            for (int pi : step_pops[s])
-                for (int q = 0; q < S; q++)
-                    h_ks.push_back(KsItem{ view(O[(size_t)pi].srcs[0], q), view(O[(size_t)pi].dst, q), O[(size_t)pi].key, O[(size_t)pi].elt, 0 });
+            {
+                // grouped-digit mode: hops of one source ciphertext share its decomposition (inverse NTT, mod-up, NTT of the raised limbs):
+                // bootstrapping's baby steps, a convolution's taps.  slot = index of the source among the step's distinct sources.
+                std::map<const u64 *, u32> slot_of;
+                for (int pi : step_pops[s])
+                    for (int q = 0; q < S; q++) {
+                        const CtView sv = view(O[(size_t)pi].srcs[0], q);
+                        const u32 slot = c.hybrid() ? slot_of.emplace(sv.p, (u32)slot_of.size()).first->second : 0u;
+                        h_ks.push_back(KsItem{ sv, view(O[(size_t)pi].dst, q), O[(size_t)pi].key, O[(size_t)pi].elt, slot });
+                    }
+                st.unique = (int)slot_of.size();
+            }
             break;
         case P_MULCC:
             st.first = (int)h_mul.size();
@@ -877,7 +886,7 @@ void HEVM::issue_plan(hipStream_t s)
             hipStream_t q = st.lane ? aux_stream : s;
             const BatchWs &w = P.ws[st.lane];
             switch (st.kind) {
-            case P_ROT: b_rotate_hops(c, w, P.d_ks + st.first, st.count, st.level, q, st.h); break;
+            case P_ROT: b_rotate_hops(c, w, P.d_ks + st.first, st.count, st.level, q, st.h, st.unique); break;
             case P_MULCC: b_mul_relin(c, w, P.d_mul + st.first, keys.relin, st.count, st.level, q, st.h); break;
             case P_RESCALE: b_rescale(c, w, P.d_rs + st.first, st.count, st.level, q, P.d_sum_srcs, st.h); break;
             case P_SUM: b_sum(c, P.d_sum + st.first, P.d_sum_srcs, st.count, st.level, q); break;

@@ -821,7 +821,25 @@ static u64 prod_mod_except(const orc_ctx *c, int lo, int hi, int skip, u64 m)
     return r;
 }
 
+static void keyswitch_hybrid_perm(const orc_ctx *c, int ell, const u64 *target, const u64 *key, u64 *out0, u64 *out1, const uint32_t *perm);
 void orc_keyswitch_hybrid(const orc_ctx *c, int ell, const u64 *target, const u64 *key, u64 *out0, u64 *out1)
+{
+    keyswitch_hybrid_perm(c, ell, target, key, out0, out1, NULL);
+}
+/* The key-switch half of a ROTATION in grouped-digit mode: (out0, out1) += KS(galois(c1)) with the digits taken BEFORE the automorphism --
+ * decompose c1 (inverse NTT, mod-up, NTT), then apply the Galois permutation to every raised limb in the NTT domain (a ring automorphism
+ * maps a valid decomposition of c1 to a valid decomposition of galois(c1)).  That order is what lets rotations of ONE ciphertext share the
+ * decomposition ("hoisting": bootstrapping's baby steps, a convolution's taps); it is this runtime's definition of a grouped-digit rotation
+ * whether or not anything is shared, so hoisted and un-hoisted executions agree bit for bit.  (SEAL's scheme rotates first; this mode is
+ * not SEAL's.) */
+void orc_rotate_ks_hybrid(const orc_ctx *c, int ell, const u64 *c1, uint32_t elt, const u64 *key, u64 *out0, u64 *out1)
+{
+    uint32_t *perm = (uint32_t *)malloc(c->N * sizeof(uint32_t));
+    orc_galois_table(c, elt, perm);
+    keyswitch_hybrid_perm(c, ell, c1, key, out0, out1, perm);
+    free(perm);
+}
+static void keyswitch_hybrid_perm(const orc_ctx *c, int ell, const u64 *target, const u64 *key, u64 *out0, u64 *out1, const uint32_t *perm)
 {
     size_t N = c->N;
     int K = c->K, ks = c->ks, al = c->alpha, L = K - ks, M = ell + ks;
@@ -860,7 +878,10 @@ void orc_keyswitch_hybrid(const orc_ctx *c, int ell, const u64 *target, const u6
             for (int kc = 0; kc < 2; kc++) {
                 const u64 *kk = key + (size_t)g * key_digit + (size_t)kc * key_poly + (size_t)pm * N;
                 u64 *o = prod + ((size_t)kc * M + I) * N;
-                for (size_t n = 0; n < N; n++) o[n] = addmod(o[n], mulmod(operand[n], kk[n], m), m->q);
+                if (perm)
+                    for (size_t n = 0; n < N; n++) o[n] = addmod(o[n], mulmod(operand[perm[n]], kk[n], m), m->q);
+                else
+                    for (size_t n = 0; n < N; n++) o[n] = addmod(o[n], mulmod(operand[n], kk[n], m), m->q);
             }
         }
     }

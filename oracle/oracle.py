@@ -412,7 +412,16 @@ class Oracle:
         return Ciphertext(np.stack([c0, c1]), a.scale * b.scale)
 
     def apply_galois(self, a: Ciphertext, elt: int) -> Ciphertext:
-        """Evaluator::apply_galois_inplace, CKKS branch."""
+        """Evaluator::apply_galois_inplace, CKKS branch.  Grouped-digit mode (extension): the digits are taken before the automorphism
+        (orc_rotate_ks_hybrid), so that rotations of one ciphertext can share their decomposition."""
+        if (self.ks, self.alpha) != (1, 1):
+            c0 = self.galois_ntt(a.data[0], elt)
+            c1 = np.zeros_like(c0)
+            src1 = np.ascontiguousarray(a.data[1])
+            key = self.galois[elt]
+            assert key.shape == (self.dnum, 2, self.K, self.N)
+            self.L.orc_rotate_ks_hybrid(self.ctx, a.ell, _p(src1), C.c_uint32(elt), _p(key), _p(c0), _p(c1))
+            return Ciphertext(np.stack([c0, c1]), a.scale)
         c0 = self.galois_ntt(a.data[0], elt)
         temp = self.galois_ntt(a.data[1], elt)
         c1 = np.zeros_like(c0)
