@@ -403,6 +403,8 @@ def config4_child():
                    "rotation offset (286 keys x 0.39 GB)")
     res["security"] = "N = 2^17, log2(QP) = 39 x 60 = 2340 bits, sparse ternary secret (h = 64): inside the 128-bit range for N = 2^17"
     res["round2"] = "47.2 s, rms_vs_torch 0.152 (541 bootstraps restoring 3 primes, one-prime-per-digit keys)"
+    res["ntt_equivalents_note"] = ("counted per key switch as G (l + k) + 2 k + 2 l; rotations of one ciphertext in a wave share their decomposition "
+                                   "(hoisting), so fewer transforms than that are executed")
     res["reference"] = "README.md:131-136: DaCapo's cost model estimates 13.6 s for its 19-bootstrap HEaaN plan (not measured)"
     return res
 
