@@ -36,7 +36,7 @@ for ell in ([only] if only else sorted({1, alpha, 12, 14, Lmax} & set(range(1, L
     us = L.dc_event_elapsed_ms(e0, e1) / iters * 1e3
     G, M = -(-ell // alpha), ell + ks
     E = G * M - ell
-    alg = {"prepare": 5 * ell, "modup": ell + E, "mac": E + ell + 2 * G * M + 2 * M, "moddown": 2 * ks + 2 * ell, "final": 2 * ell + 2 * ell + ell + 2 * ell}
+    alg = {"prepare": 4 * ell, "modup": ell + E, "mac": E + ell + 2 * G * M + 2 * M, "moddown": 2 * ks + 2 * ell, "final": 2 * ell + 2 * ell + ell + 2 * ell}
     ntts = G * M + 2 * ks + 2 * ell
     total = (2 * ell + 2 * G * M + 2 * ell) + sum(alg.values())  # + transforms: 2 limbs each (in place), the key counted once (mac)
     rows.append({"level": ell, "digits": G, "hop_us": round(us, 1), "ntt_equivalents": ntts, "ntt_per_s": round(ntts / (us * 1e-6)),
