@@ -84,21 +84,39 @@ def roofline_leg(ll, ctx, limbs=4096, iters=10):
         else:
             traffic_source = "profiles/r03_ntt_hbm_traffic.json was collected on another build of the library: not reported"
     floor_us = alg_bytes / (copy_gbs * 1e9) * 1e6
+    # what actually bounds the kernel: the vector ALUs' issue rate (profiles/r03_ntt_full.txt).  The counters come from their own rocprofv3
+    # --pmc run (tools/ntt_valu.py) and are reported only for exactly this build of the library.
+    valu = {"source": "not collected for this build (recipe: tools/collect_profiles.sh B4b, tools/ntt_valu.py)"}
+    vf = ROOT / "profiles" / "r03_ntt_valu.json"
+    if vf.exists() and limbs == 4096 and N == 32768:
+        rec = json.loads(vf.read_text())
+        if rec.get("lib_sha256") == lib_sha256():
+            k = next((v for n, v in rec.get("kernels", {}).items() if n.startswith("ntt_full15_kernel<false>")), None)
+            if k:
+                valu = {"source": "profiles/r03_ntt_valu.json (rocprofv3 --pmc on this build)",
+                        "valu_instructions_per_wave_per_limb": k.get("valu_instructions_per_wave_per_limb"),
+                        "simd_valu_busy_frac": k.get("simd_valu_busy_frac"),
+                        "clock_ghz_if_counter_sums_8_xcds": k.get("clock_ghz_if_counter_sums_8_xcds")}
+        else:
+            valu = {"source": "profiles/r03_ntt_valu.json was collected on another build of the library: not reported"}
     return {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
             "traffic": traffic, "traffic_source": traffic_source,
-            "kernel": "ntt_full15_kernel<fwd> (one 1024-thread workgroup per limb, one HBM crossing; dacapo_amd/csrc/ntt_full.hip)",
+            "kernel": "ntt_full15_kernel<fwd> (a 1024-thread workgroup owns a limb, one HBM crossing; persistent grid of one workgroup per CU; "
+                      "dacapo_amd/csrc/ntt_full.hip)",
             "launch": {"limbs": limbs, "N": N, "algorithmic_bytes": alg_bytes, "avg_us": round(ms * 1e3, 2),
                        "ntt_per_s": round(limbs / (ms * 1e-3)),
                        "timing": "HIP events around 10 back-to-back launches; 20 warm-up launches, then best of three alternating rounds",
                        "rounds_us": [[round(a * 1e3, 1), round(b * 1e3, 1)] for a, b in rounds]},
-            "limiting_resource": "integer-VALU time of one workgroup per CU (7 052 VALU instructions per thread, 1 792 of them v_mad_u64_u32) plus "
-                                 "its own load / exchange / store segments, which no second workgroup covers: the kernel owns the CU's register file",
+            "limiting_resource": "VALU issue: with the loads and the stores removed the kernel keeps 91 % of its time, and the SIMDs' vector ALUs "
+                                 "are busy 84-91 % of it (60-bit modular butterflies on 32-bit ALUs: ~19 VALU instructions each, 7 of them "
+                                 "v_mad_u64_u32); the HBM fraction is what that arithmetic leaves",
+            "valu": valu,
             "single_crossing": {"hbm_crossings_per_limb": 1, "copy_floor_us": round(floor_us, 1), "frac_of_copy_floor": round(floor_us / (ms * 1e3), 4),
-                                "source": "profiles/r03_ntt_full.txt (ablations: skeleton without butterflies 530 us, lane transposes 81 us, "
-                                          "LDS exchange 39 us; counters; variants that lost)"},
+                                "source": "profiles/r03_ntt_full.txt (ablations: no loads / no stores / neither 813 / 844 / 796 of 874 us; exchanges "
+                                          "2 and 3 through LDS; the modular multiply's carries; persistent grid; variants that lost)"},
             "two_launch_transform": {"avg_us": round(two_ms * 1e3, 2), "frac": round(alg_bytes / (two_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                     "note": "round 2's COLS + ROWS launch pair on the same buffer (still used below 1024 limbs, for inverse "
-                                             "transforms and for N != 2^15)"},
+                                     "note": "round 2's COLS + ROWS launch pair on the same buffer (still used below 1024 limbs forward / 2048 "
+                                             "inverse, and for N != 2^15)"},
             "copy_kernel_gbs": round(copy_gbs, 1), "frac_of_copy": round(gbs / copy_gbs, 4)}
 
 

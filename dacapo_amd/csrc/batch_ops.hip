@@ -358,8 +358,67 @@ void modraise(Context &c, u64 *scratch, const EwItem *h_items, int B, int target
     }
 }
 
+// The same sum with both polynomials of an item in one thread: a plaintext limb is read once instead of twice (3 instead of 4 loads per
+// product term).  grid = (N/512, l, B); taken for launches large enough to fill the chip with half the workgroups.
+__global__ __launch_bounds__(kBT) void b_sum_pair_kernel(const SumItem *__restrict__ items, const SumSrc *__restrict__ srcs, size_t N,
+                                                          const DModulus *__restrict__ mods)
+{
+    const int i = blockIdx.y, b = blockIdx.z;
+    const SumItem it = items[b];
+    const DModulus M = mods[i];
+    const size_t k = ((size_t)blockIdx.x * kBT + threadIdx.x) * 2;
+    u64 s[2][2] = { { 0, 0 }, { 0, 0 } }; // [poly][element], lazy exactly as in b_sum_kernel
+    Acc128 a[2][2];
+#pragma unroll
+    for (int p = 0; p < 2; p++) a[p][0].clear(), a[p][1].clear();
+    int n_plain = 0, n_prod = 0;
+    for (int t = 0; t < it.count; t++) {
+        const SumSrc src = srcs[it.first + t];
+        const u64x2 v0 = *reinterpret_cast<const u64x2 *>(src.v.limb(0, i, N) + k);
+        const u64x2 v1 = *reinterpret_cast<const u64x2 *>(src.v.limb(1, i, N) + k);
+        if (src.plain) {
+            const u64x2 w = *reinterpret_cast<const u64x2 *>(src.plain + (size_t)i * N + k);
+            a[0][0].mac(v0.x, w.x), a[0][1].mac(v0.y, w.y);
+            a[1][0].mac(v1.x, w.x), a[1][1].mac(v1.y, w.y);
+            if ((++n_prod & 15) == 0) {
+#pragma unroll
+                for (int p = 0; p < 2; p++)
+#pragma unroll
+                    for (int e = 0; e < 2; e++) {
+                        s[p][e] = fold60(s[p][e], M.delta) + a[p][e].reduce(M);
+                        a[p][e].clear();
+                    }
+            }
+        } else {
+            s[0][0] += v0.x, s[0][1] += v0.y, s[1][0] += v1.x, s[1][1] += v1.y;
+            if ((++n_plain & 7) == 0) {
+#pragma unroll
+                for (int p = 0; p < 2; p++) s[p][0] = fold60(s[p][0], M.delta), s[p][1] = fold60(s[p][1], M.delta);
+            }
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+        u64x2 r;
+        r.x = addmod(canon(s[p][0], M), a[p][0].reduce(M), M.q);
+        r.y = addmod(canon(s[p][1], M), a[p][1].reduce(M), M.q);
+        *reinterpret_cast<u64x2 *>(it.dst.limb(p, i, N) + k) = r;
+    }
+}
+
+static long sum_pair_min_workgroups()
+{ // DACAPO_SUM_PAIR_MIN_WGS: workgroups the paired form must still have (default 4 per CU); 0 = always, a huge value = never
+    static const long v = getenv("DACAPO_SUM_PAIR_MIN_WGS") ? atol(getenv("DACAPO_SUM_PAIR_MIN_WGS")) : 1024;
+    return v;
+}
+
 void b_sum(Context &c, const SumItem *d_items, const SumSrc *d_srcs, int B, int ell, hipStream_t s)
 {
+    if ((long)(c.N / (2 * kBT)) * ell * B >= sum_pair_min_workgroups()) {
+        hipLaunchKernelGGL(b_sum_pair_kernel, dim3((unsigned)(c.N / (2 * kBT)), (unsigned)ell, (unsigned)B), dim3(kBT), 0, s, d_items, d_srcs, c.N,
+                           c.d_mods);
+        return;
+    }
     hipLaunchKernelGGL(b_sum_kernel, dim3((unsigned)(c.N / (2 * kBT)), (unsigned)ell, (unsigned)(2 * B)), dim3(kBT), 0, s, d_items, d_srcs,
                        c.N, c.d_mods);
 }

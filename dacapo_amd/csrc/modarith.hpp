@@ -50,6 +50,12 @@ __device__ __forceinline__ u64 opaque(u64 x)
     return x;
 }
 
+__device__ __forceinline__ u32 opaque32(u32 x)
+{
+    asm("" : "+v"(x));
+    return x;
+}
+
 // full 64x64 -> 128 product, 4 x v_mad_u64_u32 (any operands)
 __device__ __forceinline__ void mul_wide(u64 a, u64 b, u64 &hi, u64 &lo)
 {
@@ -105,7 +111,8 @@ __device__ __forceinline__ u64 reduce_words(u64 hi, u32 w1, u32 w0, u32 fw)
     const u64 Bv = opaque((u64)H1 * delta);            // weight 2^32, < 2^b
     // Bv * 2^32 = (Bv >> (b-32)) * 2^b + (Bv & (2^(b-32) - 1)) * 2^32
     const u64 C = opaque(mad32(shr_pair(hi32(Bv), lo32(Bv), sh), delta, A)); // < 2^61 + 2^60
-    const u64 R = pack64(lo32(C), hi32(C) + (lo32(Bv) & mask));     // < 2^62: below 4q for the 60-bit chain (d ~ 2^25)
+    // (fenced so that the sum stays a 32-bit add on the high word: hipcc otherwise turns it into v_and + v_mov 0 + a 64-bit add)
+    const u64 R = pack64(lo32(C), opaque32(hi32(C) + (lo32(Bv) & mask))); // < 2^62: below 4q for the 60-bit chain (d ~ 2^25)
     // A narrower prime needs a third fold: each one divides by 2^b / d, and with b = 51, d ~ 2^26 two of them leave ~2^58.  The tag is
     // wave-uniform: the reference's chain skips this on the scalar unit.  Result then < 2^b + 2^(62-b) d < 2q.
     return fw_narrow(fw) ? fold60(R, fw) : R;
@@ -118,9 +125,11 @@ __device__ __forceinline__ u64 reduce128_lazy(u64 hi, u64 lo, u32 delta) { retur
 __device__ __forceinline__ u64 mulmod_lazy(u64 a, u64 b, u32 delta)
 {
     const u32 a0 = lo32(a), a1 = hi32(a), b0 = lo32(b), b1 = hi32(b);
+    // (the two 32-bit carries are fenced BEFORE their zero extension: a fence on the extended 64-bit value makes hipcc copy the pair it
+    // builds, v_mov_b32 + v_mov_b64 per carry -- 6 036 -> 5 686 VALU instructions per thread in the single-crossing NTT)
     const u64 p00 = opaque((u64)a0 * b0);
-    const u64 mid = opaque(mad32(a1, b0, opaque(mad32(a0, b1, opaque((u64)hi32(p00))))));
-    const u64 hi = opaque(mad32(a1, b1, opaque((u64)hi32(mid))));
+    const u64 mid = opaque(mad32(a1, b0, opaque(mad32(a0, b1, (u64)opaque32(hi32(p00))))));
+    const u64 hi = opaque(mad32(a1, b1, (u64)opaque32(hi32(mid))));
     return reduce_words(hi, lo32(mid), lo32(p00), delta);
 }
 

@@ -10,7 +10,7 @@
 //     forward   pass A: stages 0..4   regs = a   thread = (b, c)   twiddles tw[2^s + (a >> ..)]: wave-uniform -> scalar loads
 //               -- exchange 1 (through LDS, across waves): regs a <-> thread bits b
 //               pass B: stages 5..9   regs = b   thread = (a, c)   twiddles depend on a: two addresses per wave instruction
-//               -- exchange 2 (inside the wavefront, lane_swap: v_permlane16_swap / DPP): regs b <-> lane bits c
+//               -- exchange 2 (inside the wavefront): regs b <-> lane bits c
 //               pass C: stages 10..14 regs = c   thread = (a, b)   twiddles per thread, contiguous over the lanes
 //               -- exchange 3 (inside the wavefront): regs c <-> lane bits b, so that the store is lane-contiguous
 //     inverse   the mirror image (Gentleman-Sande stages 14..0, N^-1 merged into the last one).
@@ -19,6 +19,11 @@
 // Exchange 1 moves the whole limb (256 KiB) through the 160 KiB LDS in two rounds: registers whose destination is one of the first
 // ten waves (20 of the 32 register indices: exactly 160 KiB) first, the other twelve after those waves have read.  A thread then
 // holds at most 12 old + 32 new coefficients (88 VGPRs); the kernel is built for 128 VGPRs = 16 waves per CU = one workgroup.
+//
+// What bounds it (profiles/r03_ntt_full.txt): VALU issue, not HBM -- with the loads AND the stores removed the forward kernel still
+// takes 796 of 874 us, and SQ_ACTIVE_INST_VALU is 88-96 % of the SIMDs' cycles at the 2.14 GHz the chip holds under this load.  Hence
+// exchanges 2 and 3 go through wave-private LDS regions instead of 416 DPP / permlane instructions each (full_transpose_lds), and the
+// modular multiply's two carries are fenced before their zero extension (modarith.hpp): 7 052 -> 5 457 VALU instructions per thread.
 #include "kernels.hpp"
 #include "lane_xchg.hpp"
 #include "ntt_tile.hpp"
@@ -202,20 +207,76 @@ __device__ __forceinline__ void full_transpose(u64 (&x)[32])
         if (!(j & 1)) lane_swap<1>(x[j], x[j | 1]);
 }
 
+// The same transpose with four of its five bit swaps through LDS: the kernel is bound by VALU issue (7 052 VALU instructions per thread at
+// ~87 % of the SIMDs' issue rate; profiles/r03_ntt_full.txt), and the in-register form spends 416 of them per transpose.  Register bit 4
+// <-> lane bit 4 stays in registers (v_permlane16_swap, one instruction per dword); that leaves, for each half of the registers, a 16 x 16
+// transpose inside every 16-lane row: 16 ds_write_b64 + 16 ds_read_b64 with all lanes active, in a wave-private region of 16 rows of 65
+// words (the odd row stride spreads a read's 16 rows x 2 lane rows over all banks).  No barrier: a wave's LDS operations execute in order.
+constexpr int kFullTrStride = 65, kFullTrElems = 16 * kFullTrStride; // per wave: 8 320 B, 16 waves: 133 120 B of the 160 KiB
+__device__ __forceinline__ void full_transpose_lds(u64 (&x)[32], u64 *__restrict__ lds, int tid)
+{
+#if defined(DC_FULL_NO_TRANSPOSE) // timing experiment only (wrong results)
+    return;
+#endif
+    const int wave = tid >> 6, lane = tid & 63;
+    u64 *__restrict__ wl = lds + wave * kFullTrElems;
+    u64 *__restrict__ wr = wl + lane, *__restrict__ rd = wl + (lane & 15) * kFullTrStride + (lane & 48);
+#pragma unroll
+    for (int j = 0; j < 16; j++) lane_swap<16>(x[j], x[j | 16]);
+#pragma unroll
+    for (int g = 0; g < 2; g++) {
+#pragma unroll
+        for (int j = 0; j < 16; j++) wr[j * kFullTrStride] = x[g * 16 + j];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int j = 0; j < 16; j++) x[g * 16 + j] = rd[j];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
+#ifndef DC_FULL_LDS_TRANSPOSE
+#define DC_FULL_LDS_TRANSPOSE 1
+#endif
+// exchanges 2 and 3.  With the LDS form, a __syncthreads() must separate them from exchange 1 (which uses the whole LDS) on either side.
+__device__ __forceinline__ void full_tr(u64 (&x)[32], u64 *__restrict__ lds, int tid)
+{
+#if DC_FULL_LDS_TRANSPOSE
+    full_transpose_lds(x, lds, tid);
+#else
+    full_transpose(x);
+#endif
+}
+__device__ __forceinline__ void full_tr_sync()
+{
+#if DC_FULL_LDS_TRANSPOSE
+    __syncthreads();
+#endif
+}
+
 // Exchange 1.  Before: thread (f = wave * 2 + (lane >> 5), c = lane & 31) holds the element whose register field is r in x[r].
 // After: thread (f', c) holds in y[r'] the element that thread (r', c) had in x[f'].  (forward: f = b, r = a; inverse: f = a, r = b)
-__device__ __forceinline__ void full_exchange(u64 (&y)[32], const u64 (&x)[32], u64 *__restrict__ lds)
+template <bool IN_LOOP = false>
+__device__ __forceinline__ void full_exchange(u64 (&y)[32], const u64 (&x)[32], u64 *__restrict__ lds, int tid)
 {
 #if defined(DC_FULL_NO_XCHG) // timing experiment only (wrong results)
 #pragma unroll
     for (int j = 0; j < 32; j++) y[j] = x[j];
     return;
 #endif
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 31, f = (wave << 1) | (lane >> 5);
+    const int wave = tid >> 6, lane = tid & 63, c = lane & 31, f = (wave << 1) | (lane >> 5);
     // image "for the reader": [r' = f of the writer][reader thread] ; round 1 holds the readers of waves 0..9 (r < 20)
 #pragma unroll
     for (int r = 0; r < 20; r++) lds[f * 640 + r * 32 + c] = x[r];
     __syncthreads();
+    if constexpr (IN_LOOP) { // y is assigned under a branch in either round: without a definition that dominates both, its live range wraps
+                             // around the caller's loop and 40-70 VGPRs are spilled at the loop header
+#pragma unroll
+        for (int j = 0; j < 32; j++) asm volatile("" : "=v"(y[j]));
+    }
     if (wave < 10) {
 #pragma unroll
         for (int j = 0; j < 32; j++) y[j] = lds[j * 640 + wave * 64 + lane];
@@ -230,70 +291,108 @@ __device__ __forceinline__ void full_exchange(u64 (&y)[32], const u64 (&x)[32], 
     }
 }
 
-template <bool INV>
-__global__ __launch_bounds__(kFullThreads) void ntt_full15_kernel(u64 *__restrict__ data, long limb_stride, const int *__restrict__ prime_idx,
-                                                                   int prime_base, int prime_period, const DModulus *__restrict__ mods,
-                                                                   const u64 *__restrict__ tw_all)
+// One limb, forward or inverse.  IN_LOOP: called from the persistent kernel's loop (see there).
+template <bool INV, bool IN_LOOP>
+__device__ __forceinline__ void full_limb(u64 *__restrict__ d, const u64 *__restrict__ tw, const DModulus &M, u64 *__restrict__ lds, int tid)
 {
-    // One limb per workgroup, no loop: a persistent form (grid = 256 or 512 workgroups walking over the limbs, so that one limb's stores
-    // overlap the next one's loads) was measured slower, 1057-1128 us against 894 on 4096 limbs -- the loop makes the compiler keep its
-    // invariants in registers and spill 71-94 VGPRs (profiles/r03_experiments.txt).
-    __shared__ __attribute__((aligned(16))) u64 lds[kFullLdsElems];
-    const int limb = blockIdx.x;
-    const int p = prime_idx ? prime_idx[limb % prime_period] : prime_base + (limb % prime_period);
-    u64 *__restrict__ d = data + (long)limb * limb_stride;
-    const DModulus M = mods[p];
-    const u64 *__restrict__ tw = tw_all + ((size_t)p << kFullLogN);
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lo = lane & 31;
+    const int wave = tid >> 6, lane = tid & 63, lo = lane & 31;
     const u32 f = (u32)((wave << 1) | (lane >> 5)); // the 5-bit field this thread carries in exchange 1 / passes B and C
     u64 x[32], y[32];
     FullTw t;
     const u64 im = tw[1]; // psi^(N/2) (forward table) or its inverse (inverse table): wave-uniform
     if (!INV) {
+#if defined(DC_FULL_NO_LOAD) // timing experiment only (wrong results)
+#pragma unroll
+        for (int j = 0; j < 32; j++) x[j] = (u64)(tid * 33 + j) + M.q;
+#else
 #pragma unroll
         for (int j = 0; j < 32; j++) x[j] = d[j * 1024 + tid]; // regs = a, thread = (b, c)
+#endif
         full_pass_a<false>(x, tw, M);
-        full_exchange(y, x, lds);                              // regs = b, thread = (a = f, c)
+        full_exchange<IN_LOOP>(y, x, lds, tid);                // regs = b, thread = (a = f, c)
+        full_tr_sync();
 #if defined(DC_FULL_FWD_PIPELINED)
         full_tw_small<5>(t, f, tw);
         full_pass_bc<5, false>(y, t, f, tw, im, M);
-        full_transpose(y);                                     // regs = c, lane bits 0..4 = b
+        full_tr(y, lds, tid);                                  // regs = c, lane bits 0..4 = b
         const u32 hc = (f << 5) | (u32)lo;
         full_tw_small<10>(t, hc, tw);
         full_pass_bc<10, false>(y, t, hc, tw, im, M);
 #else
         full_fwd_pass_simple<5>(y, f, tw, M);
-        full_transpose(y);                                     // regs = c, lane bits 0..4 = b
+        full_tr(y, lds, tid);                                  // regs = c, lane bits 0..4 = b
         full_fwd_pass_simple<10>(y, (f << 5) | (u32)lo, tw, M);
 #endif
-        full_transpose(y);                                     // regs = b, lane bits 0..4 = c
+        full_tr(y, lds, tid);                                  // regs = b, lane bits 0..4 = c
+#if defined(DC_FULL_NO_STORE) // timing experiment only (wrong results): one store per thread instead of 32
+        u64 acc = 0;
+#pragma unroll
+        for (int j = 0; j < 32; j++) acc ^= canon(y[j], M);
+        d[tid] = acc;
+#else
 #pragma unroll
         for (int j = 0; j < 32; j++) d[(int)f * 1024 + j * 32 + lo] = canon(y[j], M);
+#endif
     } else {
         const u32 hc = (f << 5) | (u32)lo;
         full_tw_u4<10>(t, hc, tw);
 #pragma unroll
         for (int j = 0; j < 32; j++) x[j] = d[(int)f * 1024 + j * 32 + lo]; // regs = b, thread = (a = f, c)
-        full_transpose(x);                                     // regs = c, lane bits 0..4 = b
+        full_tr(x, lds, tid);                                  // regs = c, lane bits 0..4 = b
         full_pass_bc<10, true>(x, t, hc, tw, im, M);
         full_tw_u4<5>(t, f, tw);
-        full_transpose(x);                                     // regs = b, lane bits 0..4 = c
+        full_tr(x, lds, tid);                                  // regs = b, lane bits 0..4 = c
         full_pass_bc<5, true>(x, t, f, tw, im, M);
-        full_exchange(y, x, lds);                              // regs = a, thread = (b = f, c)
+        full_tr_sync();
+        full_exchange<IN_LOOP>(y, x, lds, tid);                // regs = a, thread = (b = f, c)
         full_pass_a<true>(y, tw, M);
 #pragma unroll
         for (int j = 0; j < 32; j++) d[j * 1024 + tid] = canon(y[j], M);
     }
 }
 
+// grid = count (one limb per workgroup) or fewer: a PERSISTENT grid of one workgroup per CU, each walking over the limbs
+// (limb = blockIdx.x + k * gridDim.x), so that a limb's stores drain under the next limb's loads and no workgroup is relaunched in
+// between.  Two things keep hipcc from spilling in the loop form (round 3's first attempt spilled 71-94 VGPRs and ran at 1057-1128 us
+// against 894): the thread index is laundered per iteration (otherwise the 62 twiddle offsets of passes B and C are hoisted out of the
+// loop as invariants), and full_exchange<true> defines y[] before the two rounds' branches assign it.
+template <bool INV>
+__global__ __launch_bounds__(kFullThreads) void ntt_full15_kernel(u64 *__restrict__ data, long limb_stride, const int *__restrict__ prime_idx,
+                                                                   int prime_base, int prime_period, const DModulus *__restrict__ mods,
+                                                                   const u64 *__restrict__ tw_all, int count)
+{
+    __shared__ __attribute__((aligned(16))) u64 lds[kFullLdsElems];
+    for (int limb = blockIdx.x; limb < count; limb += gridDim.x) {
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid)); // a per-iteration value as far as the optimiser can tell
+        const int p = prime_idx ? prime_idx[limb % prime_period] : prime_base + (limb % prime_period);
+        const DModulus M = mods[p];
+        full_limb<INV, true>(data + (long)limb * limb_stride, tw_all + ((size_t)p << kFullLogN), M, lds, tid);
+        __syncthreads(); // the next limb's exchange / transposes write what the slowest waves may still be reading
+    }
+}
+
 bool ntt_full_supported(const Context &c) { return c.logN == kFullLogN; }
 long ntt_full_min_limbs(bool inverse)
-{ // Below this many limbs the two-launch tiles (16 workgroups per limb, several per CU) are faster: measured forward 148 vs 121 us at
-  // 512 limbs, 250-259 vs 270-278 at 1024, 894 vs 1180 at 4096; inverse 280 vs 249-253 at 1024, 1080 vs 1069 at 4096 -- the inverse
-  // only ties, so it keeps the two-launch form unless asked (profiles/r03_ntt_full.txt).  0 = never.
+{ // Below this many limbs the two-launch tiles (16 workgroups per limb, several per CU) are faster.  Measured after the LDS transposes
+  // (profiles/r03_ntt_full.txt), single-crossing vs two-launch: forward 229 vs 256 us at 1024 limbs, 425 vs 577 at 2048, 777 vs 1106 at
+  // 4096 (144 vs 129 at 512); inverse 240 vs 241 at 1024, 477 vs 505 at 2048, 919 vs 981 at 4096.  0 = never.
     static const long f = getenv("DACAPO_NTT_FULL_MIN_LIMBS") ? atol(getenv("DACAPO_NTT_FULL_MIN_LIMBS")) : 1024;
-    static const long i = getenv("DACAPO_NTT_FULL_INV_MIN_LIMBS") ? atol(getenv("DACAPO_NTT_FULL_INV_MIN_LIMBS")) : 0;
+    static const long i = getenv("DACAPO_NTT_FULL_INV_MIN_LIMBS") ? atol(getenv("DACAPO_NTT_FULL_INV_MIN_LIMBS")) : 2048;
     return inverse ? i : f;
+}
+
+static int full_persist_grid(bool inverse)
+{ // DACAPO_NTT_FULL_PERSIST / DACAPO_NTT_FULL_INV_PERSIST: workgroups of the persistent grid (default: one per CU); 0 = one workgroup
+  // per limb.  Measured on 4096 limbs: forward 788 -> 782 us, inverse 896 -> 901 (a tie: both directions take the same form).
+    static const int g[2] = { [] {
+                                 if (const char *e = getenv("DACAPO_NTT_FULL_PERSIST")) return atoi(e);
+                                 int dev = 0, cus = 256;
+                                 if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+                                 return cus;
+                             }(),
+                             [] { return getenv("DACAPO_NTT_FULL_INV_PERSIST") ? atoi(getenv("DACAPO_NTT_FULL_INV_PERSIST")) : -1; }() };
+    return inverse && g[1] >= 0 ? g[1] : g[0];
 }
 
 void launch_ntt_full(const Context &c, bool inverse, u64 *data, long limb_stride, int count, const int *d_prime_idx, int prime_base,
@@ -301,13 +400,14 @@ void launch_ntt_full(const Context &c, bool inverse, u64 *data, long limb_stride
 {
     if (count <= 0) return;
     if (prime_period <= 0) prime_period = 1 << 30;
-    const unsigned grid = (unsigned)count;
+    const int pg = full_persist_grid(inverse);
+    const unsigned grid = (unsigned)(pg > 0 && count > pg ? pg : count);
     if (!inverse)
         hipLaunchKernelGGL(ntt_full15_kernel<false>, dim3(grid), dim3(kFullThreads), 0, s, data, limb_stride, d_prime_idx, prime_base,
-                           prime_period, c.d_mods, c.d_tw);
+                           prime_period, c.d_mods, c.d_tw, count);
     else
         hipLaunchKernelGGL(ntt_full15_kernel<true>, dim3(grid), dim3(kFullThreads), 0, s, data, limb_stride, d_prime_idx, prime_base,
-                           prime_period, c.d_mods, c.d_itw);
+                           prime_period, c.d_mods, c.d_itw, count);
 }
 
 } // namespace dacapo

@@ -136,7 +136,8 @@ def test_single_crossing_kernel_matches_oracle_and_the_two_launch_tiles():
     got = ds.to_host()
     assert (got[:, 1] == np.uint64(0xDEADBEEF)).all()
     assert (got[:, 0] == o.ntt_fwd(s[:, 0], [2 + b % 4 for b in range(6)])).all()
-    # a batch at which the library's own choice is the single-crossing kernel (forward) / the two-launch tiles (inverse)
+    # a batch at which the library's own choice is the single-crossing kernel forward (>= 1024 limbs; the inverse switches at 2048, and
+    # variant=1 runs it here): more limbs than CUs, not a multiple of them, so the persistent grid's workgroups walk 4 or 5 limbs each
     limbs = 1040
     big = np.stack([splitmix_fill(0x4845564D + b, N) % np.uint64(o.primes[b % K]) for b in range(limbs)])
     outs = []

@@ -53,8 +53,14 @@ cd $ROOT
   echo; echo "== counters of the matrix-core run, per launch (rocprofv3 --pmc; tools/pmc_summary.py)"; python tools/pmc_summary.py $(ls $OUT/hm/*/*counter_collection.csv | head -1) | grep -A7 "hyb_conv_mfma";
   echo; echo "== all levels, HIP events (matrix cores / vector units)"; python tools/hybrid_ks_bench.py 2>/dev/null; DACAPO_HYB_MFMA=0 python tools/hybrid_ks_bench.py 2>/dev/null; } > $OUT/${R}_hybrid_ks_kernels.txt
 rm -rf $OUT/hy $OUT/hv $OUT/hm
+# B4b. VALU occupancy of the single-crossing NTT (what bounds it: profiles/r03_ntt_full.txt)
+cd /tmp
+rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/nv -- python3 $ROOT/tools/ntt_variant_only.py 1 4096 2 > /dev/null 2> $OUT/nv.err
+cd $ROOT
+python tools/ntt_valu.py $(ls $OUT/nv/*/*counter_collection.csv | head -1) $(ls $OUT/nv/*/*kernel_trace.csv | head -1) > $OUT/${R}_ntt_valu.json
+rm -rf $OUT/nv
 # B5. the single-crossing NTT against the two-launch tiles (HIP events)
-for n in 512 1024 4096; do python tools/ntt_full_check.py $n 20; done > $OUT/${R}_ntt_full_check.txt 2>/dev/null
+for n in 512 1024 2048 4096; do python tools/ntt_full_check.py $n 20; done > $OUT/${R}_ntt_full_check.txt 2>/dev/null
 # C. latency of dependent chains, D. several ciphertext streams on one GPU, E. the bench line itself, F. per-op table for the reference's planner
 python tools/chain_bench.py > $OUT/${R}_chain_latency.txt 2>/dev/null
 for s in 2 4 8; do python bench.py --streams $s --no-cpu-baseline --no-lowerings 2>/dev/null | python tools/bench_brief.py; done > $OUT/${R}_streams.txt

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Headline program only (ResNet-20 fixture): ms per run() and the decrypted error; for kernel-tuning sweeps.
-    [DACAPO_AMD_LIB=...] python tools/quick_headline.py [steps]"""
+    [DACAPO_AMD_LIB=...] python tools/quick_headline.py [steps] [fixture = resnet20 | resnet20.b6 | resnet20.b13]"""
 import json
 import sys
 import time
@@ -15,6 +15,9 @@ from dacapo_amd import runner  # noqa: E402
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 fx = ha.read_fixture(ROOT / "tests" / "golden" / "resnet20")
+if len(sys.argv) > 2 and sys.argv[2] != "resnet20":  # another lowering of the same trace: same constants, other bytecode
+    import gzip
+    fx["hevm"] = gzip.open(ROOT / "tests" / "golden" / (sys.argv[2] + ".hevm.gz")).read()
 vm = runner.HEVM(seed=0x4845564D, logN=15, num_primes=14)
 vm.load_mem(fx["cst"], fx["hevm"])
 vm.setInput(0, fx["packed"])
