@@ -740,3 +740,23 @@ def test_destroy_returns_the_vms_memory():
     free1 = free_bytes()
     one_vm = 6 * 2 * 6 * (1 << 14) * 8 * 5  # a lower bound on one VM's keys alone (~35 MB)
     assert free0 - free1 < one_vm, f"{(free0 - free1) / 1e6:.1f} MB still held after four create/destroy cycles"
+
+
+@pytest.mark.parametrize("min_wgs", ["0", "1000000000000"])
+def test_n_ary_sum_kernels_match_the_oracle_vm(min_wgs):
+    """batch_ops.hip b_sum: a convolution-shaped sum (19 ciphertext x plaintext products + 9 bare ciphertexts: more than one 16-term and one
+    8-term reduction window) in both forms of the kernel -- both polynomials of an item in one thread (large launches) and one polynomial
+    per workgroup -- equals the oracle VM's multiply_plain / add sequence limb for limb.  A child process: the threshold is read once."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    env = dict(os.environ, DACAPO_SUM_PAIR_MIN_WGS=min_wgs)
+    out = subprocess.run([sys.executable, str(root / "tools" / "sum_pair_check.py"), "13", "5"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-1500:]
+    res = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert res["limbs_identical"] and res["scale_identical"] and res["max_error_vs_cleartext"] < 1e-4
+    assert res["op_mix"]["mulcp"] >= 20 and res["op_mix"]["addcc"] >= 27
