@@ -136,6 +136,16 @@ Context::Context(int logN_, int K_, int bits, const u64 *primes_or_null, int ksp
     DC_HIP_CHECK(hipMalloc(&d_itw, itw.size() * 8));
     DC_HIP_CHECK(hipMemcpy(d_tw, tw.data(), tw.size() * 8, hipMemcpyHostToDevice));
     DC_HIP_CHECK(hipMemcpy(d_itw, itw.data(), itw.size() * 8, hipMemcpyHostToDevice));
+    if (!DC_GENERIC_WIDTH && logN == 15) { // (the only ring the single-crossing kernel exists for; only its forward passes use pairs)
+        std::vector<u64> pr(tw.size() * 2);
+        for (int i = 0; i < K; i++)
+            for (size_t k = 0; k < N; k++) {
+                const u64 w = tw[(size_t)i * N + k];
+                pr[2 * ((size_t)i * N + k)] = w, pr[2 * ((size_t)i * N + k) + 1] = h_mulmod(w, 1ull << 31, primes[(size_t)i]);
+            }
+        DC_HIP_CHECK(hipMalloc(&d_tw2, pr.size() * 8));
+        DC_HIP_CHECK(hipMemcpy(d_tw2, pr.data(), pr.size() * 8, hipMemcpyHostToDevice));
+    }
 
     // divide-and-round constants for every (dropped prime l, remaining prime i) pair
     std::vector<u64> inv_last((size_t)K * K, 0), half_mod((size_t)K * K, 0);
@@ -304,7 +314,7 @@ void Context::ensure_scratch()
 
 Context::~Context()
 {
-    for (void *p : { (void *)d_mods, (void *)d_tw, (void *)d_itw, (void *)d_inv_last, (void *)d_half_mod, (void *)d_ks_pidx, (void *)d_pmod,
+    for (void *p : { (void *)d_mods, (void *)d_tw, (void *)d_itw, (void *)d_tw2, (void *)d_inv_last, (void *)d_half_mod, (void *)d_ks_pidx, (void *)d_pmod,
                      (void *)d_hyb_up, (void *)d_hyb_pidx, (void *)d_hyb_dn, (void *)d_hyb_bup, (void *)d_hyb_bdn })
         if (p) (void)hipFree(p);
     for (Workspace &w : workspaces)

@@ -96,6 +96,9 @@ struct Context {
     DModulus *d_mods = nullptr;
     u64 *d_tw = nullptr;  // [K][N] psi^bitrev(k)
     u64 *d_itw = nullptr; // [K][N] inverse of the above, same index
+    // N = 2^15, 60-bit build: the forward table as pairs (w, w 2^31 mod q), 16 bytes per entry, for the single-crossing kernel's twiddle-pair
+    // multiply (ntt_full.hip, modarith.hpp mulmod_pair); nullptr otherwise
+    u64 *d_tw2 = nullptr;
     Workspace ws0;                     // default workspace (kernel-level C ABI, set-up work)
     std::vector<Workspace> workspaces; // everything ever handed out, for the destructor
     u64 *d_inv_last = nullptr;  // [K][K] : inv_last[l*K + i] = q_l^{-1} mod q_i (i != l)

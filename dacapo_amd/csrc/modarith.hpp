@@ -135,6 +135,20 @@ __device__ __forceinline__ u64 mulmod_lazy(u64 a, u64 b, u32 delta)
 
 __device__ __forceinline__ u64 mulmod(u64 a, u64 b, const DModulus &m) { return canon(mulmod_lazy(a, b, m.delta), m); }
 
+#if !DC_GENERIC_WIDTH
+// Multiplication by a CONSTANT stored as the pair (w, W = w 2^31 mod q), both canonical: y < 2^62 -> congruent to w y, < 2q.   5 mads.
+// With y = y0 + y1 2^31 (y0, y1 < 2^31): w y = w y0 + W y1 (mod q).  Column 0 = w.lo y0 + W.lo y1 < 2^63 + 2^63 and column 1 (weight 2^32) =
+// w.hi y0 + W.hi y1 + carry < 2^59 + 2^59 (w.hi, W.hi < 2^28) cannot overflow, the sum T = col1 2^32 + lo32(col0) is below 2^92, so the
+// part above 2^60 fits one word and ONE fold finishes: T mod 2^60 + (T >> 60) d <= 2^60 - 1 + (2^32 - 1) d < 2q for every d < 2^28.
+__device__ __forceinline__ u64 mulmod_pair(u64 w, u64 W, u64 y, u32 delta)
+{
+    const u32 y0 = lo32(y) & 0x7FFFFFFFu, y1 = shr_pair(hi32(y), lo32(y), 31);
+    const u64 c0 = opaque(mad32(lo32(W), y1, opaque((u64)lo32(w) * y0)));
+    const u64 c1 = opaque(mad32(hi32(W), y1, opaque(mad32(hi32(w), y0, (u64)opaque32(hi32(c0))))));
+    return opaque(mad32(shr_pair(hi32(c1), lo32(c1), 28), delta, pack64(lo32(c0), lo32(c1) & 0x0FFFFFFFu)));
+}
+#endif
+
 // A canonical residue of ANOTHER prime of the chain (or the sum of two values below 2^60) -> canonical residue mod M.  Within one
 // width class all primes lie within 2^28 of each other and one conditional subtraction is the whole reduction (SEAL: modulo_poly_coeffs
 // only when q_j > q_m); a narrower target prime (mixed chains) needs the fold.  The width tag is wave-uniform.

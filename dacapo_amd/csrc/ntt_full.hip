@@ -184,6 +184,66 @@ __device__ __forceinline__ void full_pass_bc(u64 (&x)[32], FullTw &t, u32 hi, co
     }
 }
 
+// ---- forward passes A and B with twiddle PAIRS (w, w 2^31 mod q) and modarith.hpp's mulmod_pair: 5 mads and one fold per multiply instead
+// of 7 and two.  The product comes out below 2q, so with x folded in every butterfly -- xf = fold(x) < 2q, t = w y < 2q, (x, y) <- (xf + t,
+// xf + 2q - t) -- every value stays below 4q < 2^62, mulmod_pair's operand range; the first stage's x is canonical and needs no fold.  Pass
+// C then runs on words: its inputs (< 4q) are inside every range its fold schedule assumes.  Same residues as the word butterflies, hence
+// the same canonical outputs, bit for bit.  Tables: Context::d_tw2 (60-bit build, N = 2^15).  Measured on 4096 limbs (profiles/
+// r03_ntt_full.txt): pairs in A 784 us (words: 781), A + B 742, A + B + C 784 (pass C's 31 per-thread pairs are 16-byte loads: twice the
+// twiddle bytes, what round 2 found on the tiles), B's pairs through scalar loads + select 781-796; the inverse with pairs in any prefix
+// of its passes 1068-1138 against 910 on words (its first stage needs 16 pairs at once) -- so: forward A + B, inverse words.
+#ifndef DC_FULL_PAIRS
+#define DC_FULL_PAIRS (!DC_GENERIC_WIDTH)
+#endif
+#if DC_FULL_PAIRS
+template <bool FOLD>
+__device__ __forceinline__ void ct_bfly_p(u64 &x, u64 &y, u64 w, u64 W, const DModulus &M)
+{
+    const u64 xf = FOLD ? fold60(x, M.delta) : x;
+    const u64 t = mulmod_pair(w, W, y, M.delta);
+    x = xf + t;
+    y = xf + (M.q << 1) - t;
+}
+template <int U>
+__device__ __forceinline__ void full_stage_a_p(u64 (&x)[32], const u64 *__restrict__ tw2, const DModulus &M)
+{
+#pragma unroll
+    for (int g = 0; g < (1 << U); g++) {
+        const u64 w = tw2[2 * ((1u << U) + (u32)g)], W = tw2[2 * ((1u << U) + (u32)g) + 1]; // wave-uniform: scalar loads
+#pragma unroll
+        for (int e = 0; e < (16 >> U); e++) {
+            const int j0 = (g << (5 - U)) | e;
+            ct_bfly_p<(U != 0)>(x[j0], x[j0 | (16 >> U)], w, W, M);
+        }
+    }
+}
+__device__ __forceinline__ void full_fwd_pass_a_p(u64 (&x)[32], const u64 *__restrict__ tw2, const DModulus &M)
+{
+    full_stage_a_p<0>(x, tw2, M);
+    full_stage_a_p<1>(x, tw2, M);
+    full_stage_a_p<2>(x, tw2, M);
+    full_stage_a_p<3>(x, tw2, M);
+    full_stage_a_p<4>(x, tw2, M);
+}
+// pass B, each pair loaded (16 bytes per lane, two addresses per wave instruction) where it is used
+__device__ __forceinline__ void full_fwd_pass_b_p(u64 (&x)[32], u32 hi, const u64 *__restrict__ tw2, const DModulus &M)
+{
+#pragma unroll
+    for (int u = 0; u < 5; u++) {
+#pragma unroll
+        for (int g = 0; g < (1 << u); g++) {
+            const ulonglong2 tp = *reinterpret_cast<const ulonglong2 *>(tw2 + 2 * ((size_t)(1u << (5 + u)) + (hi << u) + (u32)g));
+            const int half = 16 >> u;
+#pragma unroll
+            for (int e = 0; e < half; e++) {
+                const int j0 = (g << (5 - u)) | e;
+                ct_bfly_p<true>(x[j0], x[j0 | half], tp.x, tp.y, M);
+            }
+        }
+    }
+}
+#endif
+
 // 32 x 32 transpose between the register index and lane bits 0..4, inside the wavefront: register bit k <-> lane bit k
 __device__ __forceinline__ void full_transpose(u64 (&x)[32])
 {
@@ -292,12 +352,29 @@ __device__ __forceinline__ void full_exchange(u64 (&y)[32], const u64 (&x)[32], 
 }
 
 // One limb, forward or inverse.  IN_LOOP: called from the persistent kernel's loop (see there).
-template <bool INV, bool IN_LOOP>
-__device__ __forceinline__ void full_limb(u64 *__restrict__ d, const u64 *__restrict__ tw, const DModulus &M, u64 *__restrict__ lds, int tid)
+template <bool INV, bool IN_LOOP, bool PAIRS>
+__device__ __forceinline__ void full_limb(u64 *__restrict__ d, const u64 *__restrict__ tw, const u64 *__restrict__ tw2, const DModulus &M,
+                                          u64 *__restrict__ lds, int tid)
 {
     const int wave = tid >> 6, lane = tid & 63, lo = lane & 31;
     const u32 f = (u32)((wave << 1) | (lane >> 5)); // the 5-bit field this thread carries in exchange 1 / passes B and C
     u64 x[32], y[32];
+#if DC_FULL_PAIRS
+    if constexpr (PAIRS && !INV) {
+#pragma unroll
+        for (int j = 0; j < 32; j++) x[j] = d[j * 1024 + tid]; // regs = a, thread = (b, c)
+        full_fwd_pass_a_p(x, tw2, M);
+        full_exchange<IN_LOOP>(y, x, lds, tid);                // regs = b, thread = (a = f, c)
+        full_tr_sync();
+        full_fwd_pass_b_p(y, f, tw2, M);
+        full_tr(y, lds, tid);                                  // regs = c, lane bits 0..4 = b
+        full_fwd_pass_simple<10>(y, (f << 5) | (u32)lo, tw, M);
+        full_tr(y, lds, tid);                                  // regs = b, lane bits 0..4 = c
+#pragma unroll
+        for (int j = 0; j < 32; j++) d[(int)f * 1024 + j * 32 + lo] = canon(y[j], M);
+        return;
+    }
+#endif
     FullTw t;
     const u64 im = tw[1]; // psi^(N/2) (forward table) or its inverse (inverse table): wave-uniform
     if (!INV) {
@@ -356,18 +433,32 @@ __device__ __forceinline__ void full_limb(u64 *__restrict__ d, const u64 *__rest
 // between.  Two things keep hipcc from spilling in the loop form (round 3's first attempt spilled 71-94 VGPRs and ran at 1057-1128 us
 // against 894): the thread index is laundered per iteration (otherwise the 62 twiddle offsets of passes B and C are hoisted out of the
 // loop as invariants), and full_exchange<true> defines y[] before the two rounds' branches assign it.
-template <bool INV>
+template <bool INV, bool PAIRS>
 __global__ __launch_bounds__(kFullThreads) void ntt_full15_kernel(u64 *__restrict__ data, long limb_stride, const int *__restrict__ prime_idx,
                                                                    int prime_base, int prime_period, const DModulus *__restrict__ mods,
-                                                                   const u64 *__restrict__ tw_all, int count)
+                                                                   const u64 *__restrict__ tw_all, const u64 *__restrict__ tw2_all, int count)
 {
     __shared__ __attribute__((aligned(16))) u64 lds[kFullLdsElems];
-    for (int limb = blockIdx.x; limb < count; limb += gridDim.x) {
+    // The grid walks over the limbs PRIME BY PRIME (all limbs of residue 0 mod the period, then residue 1, ...): the workgroups of an XCD
+    // then read one or two primes' twiddle tables at a time (0.25 MB each) out of its 4 MB L2 instead of all of them.
+    const int period = prime_period < count ? prime_period : count; // residues that occur
+    const int big = count % period, ns = count / period, nb = ns + 1; // the first `big` residues have nb limbs, the others ns
+    for (int pos = blockIdx.x; pos < count; pos += gridDim.x) {
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid)); // a per-iteration value as far as the optimiser can tell
-        const int p = prime_idx ? prime_idx[limb % prime_period] : prime_base + (limb % prime_period);
+        int r, k;
+        if (pos < big * nb)
+            r = pos / nb, k = pos - r * nb;
+        else {
+            const int q = pos - big * nb;
+            r = big + q / ns, k = q - (q / ns) * ns;
+        }
+        r = __builtin_amdgcn_readfirstlane(r), k = __builtin_amdgcn_readfirstlane(k); // (the divisions run on the vector unit: back to scalars)
+        const int limb = k * period + r;
+        const int p = prime_idx ? prime_idx[r] : prime_base + r;
         const DModulus M = mods[p];
-        full_limb<INV, true>(data + (long)limb * limb_stride, tw_all + ((size_t)p << kFullLogN), M, lds, tid);
+        full_limb<INV, true, PAIRS>(data + (long)limb * limb_stride, tw_all + ((size_t)p << kFullLogN),
+                                    PAIRS ? tw2_all + ((size_t)p << (kFullLogN + 1)) : nullptr, M, lds, tid);
         __syncthreads(); // the next limb's exchange / transposes write what the slowest waves may still be reading
     }
 }
@@ -395,6 +486,12 @@ static int full_persist_grid(bool inverse)
     return inverse && g[1] >= 0 ? g[1] : g[0];
 }
 
+static bool full_pairs()
+{ // DACAPO_NTT_FULL_PAIRS=0: word butterflies in every forward pass (A/B measurements; the pair tables exist either way)
+    static const bool v = !(getenv("DACAPO_NTT_FULL_PAIRS") && atoi(getenv("DACAPO_NTT_FULL_PAIRS")) == 0);
+    return v;
+}
+
 void launch_ntt_full(const Context &c, bool inverse, u64 *data, long limb_stride, int count, const int *d_prime_idx, int prime_base,
                      int prime_period, hipStream_t s)
 {
@@ -402,12 +499,19 @@ void launch_ntt_full(const Context &c, bool inverse, u64 *data, long limb_stride
     if (prime_period <= 0) prime_period = 1 << 30;
     const int pg = full_persist_grid(inverse);
     const unsigned grid = (unsigned)(pg > 0 && count > pg ? pg : count);
+#if DC_FULL_PAIRS
+    if (!inverse && full_pairs() && c.d_tw2) {
+        hipLaunchKernelGGL((ntt_full15_kernel<false, true>), dim3(grid), dim3(kFullThreads), 0, s, data, limb_stride, d_prime_idx, prime_base,
+                           prime_period, c.d_mods, c.d_tw, c.d_tw2, count);
+        return;
+    }
+#endif
     if (!inverse)
-        hipLaunchKernelGGL(ntt_full15_kernel<false>, dim3(grid), dim3(kFullThreads), 0, s, data, limb_stride, d_prime_idx, prime_base,
-                           prime_period, c.d_mods, c.d_tw, count);
+        hipLaunchKernelGGL((ntt_full15_kernel<false, false>), dim3(grid), dim3(kFullThreads), 0, s, data, limb_stride, d_prime_idx, prime_base,
+                           prime_period, c.d_mods, c.d_tw, (const u64 *)nullptr, count);
     else
-        hipLaunchKernelGGL(ntt_full15_kernel<true>, dim3(grid), dim3(kFullThreads), 0, s, data, limb_stride, d_prime_idx, prime_base,
-                           prime_period, c.d_mods, c.d_itw, count);
+        hipLaunchKernelGGL((ntt_full15_kernel<true, false>), dim3(grid), dim3(kFullThreads), 0, s, data, limb_stride, d_prime_idx, prime_base,
+                           prime_period, c.d_mods, c.d_itw, (const u64 *)nullptr, count);
 }
 
 } // namespace dacapo
