@@ -91,7 +91,7 @@ def roofline_leg(ll, ctx, limbs=4096, iters=10):
     if vf.exists() and limbs == 4096 and N == 32768:
         rec = json.loads(vf.read_text())
         if rec.get("lib_sha256") == lib_sha256():
-            k = next((v for n, v in rec.get("kernels", {}).items() if n.startswith("ntt_full15_kernel<false>")), None)
+            k = next((v for n, v in rec.get("kernels", {}).items() if n.startswith("ntt_full15_kernel<false")), None)
             if k:
                 valu = {"source": "profiles/r03_ntt_valu.json (rocprofv3 --pmc on this build)",
                         "valu_instructions_per_wave_per_limb": k.get("valu_instructions_per_wave_per_limb"),
@@ -107,13 +107,14 @@ def roofline_leg(ll, ctx, limbs=4096, iters=10):
                        "ntt_per_s": round(limbs / (ms * 1e-3)),
                        "timing": "HIP events around 10 back-to-back launches; 20 warm-up launches, then best of three alternating rounds",
                        "rounds_us": [[round(a * 1e3, 1), round(b * 1e3, 1)] for a, b in rounds]},
-            "limiting_resource": "VALU issue: with the loads and the stores removed the kernel keeps 91 % of its time, and the SIMDs' vector ALUs "
-                                 "are busy 84-91 % of it (60-bit modular butterflies on 32-bit ALUs: ~19 VALU instructions each, 7 of them "
-                                 "v_mad_u64_u32); the HBM fraction is what that arithmetic leaves",
+            "limiting_resource": "VALU issue and the twiddles' vector-memory path: with the loads and the stores removed the kernel keeps 91 % of its "
+                                 "time, and the SIMDs' vector ALUs are busy 82-91 % of it (60-bit modular butterflies on 32-bit ALUs: 15-19 VALU "
+                                 "instructions each, 5-7 of them v_mad_u64_u32); the HBM fraction is what that arithmetic leaves",
             "valu": valu,
             "single_crossing": {"hbm_crossings_per_limb": 1, "copy_floor_us": round(floor_us, 1), "frac_of_copy_floor": round(floor_us / (ms * 1e3), 4),
                                 "source": "profiles/r03_ntt_full.txt (ablations: no loads / no stores / neither 813 / 844 / 796 of 874 us; exchanges "
-                                          "2 and 3 through LDS; the modular multiply's carries; persistent grid; variants that lost)"},
+                                          "2 and 3 through LDS; the modular multiply's carries; persistent grid walking prime by prime; "
+                                          "twiddle pairs in passes A and B; variants that lost)"},
             "two_launch_transform": {"avg_us": round(two_ms * 1e3, 2), "frac": round(alg_bytes / (two_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                      "note": "round 2's COLS + ROWS launch pair on the same buffer (still used below 1024 limbs forward / 2048 "
                                              "inverse, and for N != 2^15)"},

@@ -35,9 +35,9 @@ def per_launch(path, counter):
 
 fetch, write = per_launch(sys.argv[1], "FETCH_SIZE"), per_launch(sys.argv[2], "WRITE_SIZE")
 hbm = {k: (2.0 * fetch[k] + write.get(k, 0.0)) * 1024.0 for k in fetch}
-# forward transform: the single-crossing kernel ntt_full15_kernel<false> (round 3: what dc_ntt_forward launches on 4096 limbs of N = 2^15),
+# forward transform: the single-crossing kernel ntt_full15_kernel<false, ...> (round 3: what dc_ntt_forward launches on 4096 limbs of N = 2^15),
 # else the two phase kernels with INV = false
-fwd = [k for k in hbm if k.startswith("ntt_full15_kernel<false>")] or [k for k in hbm if re.search(r"<\d, \d, (true|false), false, ", k)]
+fwd = [k for k in hbm if k.startswith("ntt_full15_kernel<false")] or [k for k in hbm if re.search(r"<\d, \d, (true|false), false, ", k)]
 out = {"command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (separate passes) --kernel-trace -- python3 tools/ntt_only.py 15 4096 2   (dc_ntt_forward / "
                   "dc_ntt_inverse: forward = the single-crossing kernel, inverse = the two-launch tiles)",
        "lib_sha256": hashlib.sha256((ROOT / "dacapo_amd" / "lib" / "libSEAL_HEVM.so").read_bytes()).hexdigest(),
