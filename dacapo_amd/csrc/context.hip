@@ -106,9 +106,9 @@ Context::Context(int logN_, int K_, int bits, const u64 *primes_or_null, int ksp
                             "(45..60 bits) run on the generic-width build of the same sources, libSEAL_HEVM_gw.so\n", i, qbits);
             abort();
         }
-        if (delta >= kMaxDelta || (q - 1) % (2 * N) || !h_is_prime(q)) {
+        if (delta >= kMaxDelta || !prime_shape_ok(q, qbits) || (q - 1) % (2 * N) || !h_is_prime(q)) {
             fprintf(stderr,
-                    "[dacapo_amd] prime %d (0x%llx) is not of the form 2^b - d with %d <= b <= %d, d < 2^28, = 1 mod 2N "
+                    "[dacapo_amd] prime %d (0x%llx) is not of the form 2^b - d with %d <= b <= %d, d < 2^28, d 2^(64-b) < q, = 1 mod 2N "
                     "(the reference's chain: b = 60, SEAL_HEVM.cpp:48-53)\n", i, (unsigned long long)q, kMinQBits, kQBits);
             abort();
         }

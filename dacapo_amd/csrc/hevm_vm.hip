@@ -723,8 +723,8 @@ void HEVM::load_keys(const std::string &dir, bool need_secret, bool need_public,
             {
                 int qb = 0;
                 while ((q >> qb) != 0) qb++;
-                if (qb < kMinQBits || qb > kQBits || ((1ull << qb) - q) >= kMaxDelta)
-                    m.fail("coefficient modulus outside this backend's range: every prime must be 2^b - d with 45 <= b <= 60 and d < 2^28 "
+                if (!prime_shape_ok(q, qb))
+                    m.fail("coefficient modulus outside this backend's range: every prime must be 2^b - d with 45 <= b <= 60, d < 2^28 and d 2^(64-b) < q "
                            "(CoeffModulus::Create(N, {60, ...}) of SEAL_HEVM.cpp:48-53 yields b = 60)");
             }
         init_context(logN, (int)p.primes.size(), p.primes.data());

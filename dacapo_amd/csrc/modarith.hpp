@@ -20,8 +20,16 @@ typedef uint64_t u64;
 typedef uint32_t u32;
 
 constexpr int kQBits = 60;   // the reference's chain; the widest supported prime
-constexpr int kMinQBits = 45; // round 3: any prime q = 2^b - d with 45 <= b <= 60 and d < 2^(b-32) (HEaaN-style 51-bit rescale primes included)
+constexpr int kMinQBits = 45; // round 3: any prime q = 2^b - d with 45 <= b <= 60, d < 2^28 and d 2^(64-b) < q (HEaaN-style 51-bit rescale primes included)
 constexpr u32 kMaxDelta = 1u << 28;
+// the second condition is what lets ONE fold take any 64-bit value below 2q (fold60 / canon): (x >> b) d + (x mod 2^b) < 2^(64-b) d + 2^b.
+// It only bites at b = 45 (d < 2^26); tests/test_modarith_model.py executes the range arguments of this file on integers.
+__host__ __device__ inline bool prime_shape_ok(u64 q, int bits)
+{
+    if (bits < kMinQBits || bits > kQBits) return false;
+    const u64 d = (1ull << bits) - q;
+    return d < kMaxDelta && (bits == kQBits || (d << (64 - bits)) < q); // (d < 2^28, 64 - b <= 19: no overflow)
+}
 
 // Per-prime constants, one entry per prime of the key-level chain, resident in HBM (and L2).
 // `delta` is the WIDTH-TAGGED fold word every reduction below takes: bits 0..27 = d = 2^b - q, bits 28..31 = 60 - b.  For the
