@@ -116,7 +116,7 @@ def roofline_leg(ll, ctx, limbs=4096, iters=10):
                                           "2 and 3 through LDS; the modular multiply's carries; persistent grid walking prime by prime; "
                                           "twiddle pairs in passes A and B; variants that lost)"},
             "two_launch_transform": {"avg_us": round(two_ms * 1e3, 2), "frac": round(alg_bytes / (two_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                     "note": "round 2's COLS + ROWS launch pair on the same buffer (still used below 1024 limbs forward / 2048 "
+                                     "note": "round 2's COLS + ROWS launch pair on the same buffer (still used below 640 limbs forward / 2048 "
                                              "inverse, and for N != 2^15)"},
             "copy_kernel_gbs": round(copy_gbs, 1), "frac_of_copy": round(gbs / copy_gbs, 4)}
 

@@ -465,10 +465,11 @@ __global__ __launch_bounds__(kFullThreads) void ntt_full15_kernel(u64 *__restric
 
 bool ntt_full_supported(const Context &c) { return c.logN == kFullLogN; }
 long ntt_full_min_limbs(bool inverse)
-{ // Below this many limbs the two-launch tiles (16 workgroups per limb, several per CU) are faster.  Measured after the LDS transposes
-  // (profiles/r03_ntt_full.txt), single-crossing vs two-launch: forward 229 vs 256 us at 1024 limbs, 425 vs 577 at 2048, 777 vs 1106 at
-  // 4096 (144 vs 129 at 512); inverse 240 vs 241 at 1024, 477 vs 505 at 2048, 919 vs 981 at 4096.  0 = never.
-    static const long f = getenv("DACAPO_NTT_FULL_MIN_LIMBS") ? atol(getenv("DACAPO_NTT_FULL_MIN_LIMBS")) : 1024;
+{ // Below this many limbs the two-launch tiles (16 workgroups per limb, several per CU) are faster.  Measured on the final kernels
+  // (profiles/r03_ntt_full_check.txt and r03_ntt_full.txt), single-crossing vs two-launch: forward 127 vs 119 us at 512 limbs, 150 vs 157
+  // at 640, 159 vs 193 at 768, 216 vs 266 at 1024, 415 vs 587 at 2048, 753 vs 1123 at 4096; inverse 172 vs 149 at 640, 230 vs 204 at 896,
+  // 236 vs 244 at 1024, 480 vs 512 at 2048, 919 vs 997 at 4096.  0 = never.
+    static const long f = getenv("DACAPO_NTT_FULL_MIN_LIMBS") ? atol(getenv("DACAPO_NTT_FULL_MIN_LIMBS")) : 640;
     static const long i = getenv("DACAPO_NTT_FULL_INV_MIN_LIMBS") ? atol(getenv("DACAPO_NTT_FULL_INV_MIN_LIMBS")) : 2048;
     return inverse ? i : f;
 }

@@ -84,7 +84,7 @@ def test_linearity_and_convolution_at_full_size():
 @pytest.mark.parametrize("logN,K,limbs", [(15, 14, 520), (17, 3, 136)])
 def test_large_batch_uses_the_throughput_tiles_and_matches_oracle(logN, K, limbs):
     """>= 5000 workgroups per launch: the radix-8 (2048-coefficient) tile geometry (round 3: at N = 2^15 the roofline leg's forward
-    transform takes the single-crossing kernel from 1024 limbs on; this batch of 520 stays on the tiles, and N = 2^17 always does).
+    transform takes the single-crossing kernel from 640 limbs on; this batch of 520 stays on the tiles, and N = 2^17 always does).
     Forward == oracle on a spread of limbs, repeated launches agree, forward/inverse round trips are exact."""
     ll, ctx = _ctx(logN, K)
     o = Oracle(logN, K)
@@ -109,7 +109,7 @@ def test_large_batch_uses_the_throughput_tiles_and_matches_oracle(logN, K, limbs
 def test_single_crossing_kernel_matches_oracle_and_the_two_launch_tiles():
     """ntt_full.hip (one 1024-thread workgroup per limb of N = 2^15, one HBM crossing) through dc_ntt_variant: forward and inverse ==
     oracle bit for bit on an irregular prime pattern and on the edge limbs (zeros, q - 1), with a limb stride, and == the two-launch
-    transform on a batch large enough that dc_ntt_forward itself takes the single-crossing kernel (>= 1024 limbs)."""
+    transform on a batch large enough that dc_ntt_forward itself takes the single-crossing kernel (>= 640 limbs)."""
     ll, ctx = _ctx(15, 14)
     o = Oracle(15, 14)
     N, K = 1 << 15, 14
@@ -136,7 +136,7 @@ def test_single_crossing_kernel_matches_oracle_and_the_two_launch_tiles():
     got = ds.to_host()
     assert (got[:, 1] == np.uint64(0xDEADBEEF)).all()
     assert (got[:, 0] == o.ntt_fwd(s[:, 0], [2 + b % 4 for b in range(6)])).all()
-    # a batch at which the library's own choice is the single-crossing kernel forward (>= 1024 limbs; the inverse switches at 2048, and
+    # a batch at which the library's own choice is the single-crossing kernel forward (>= 640 limbs; the inverse switches at 2048, and
     # variant=1 runs it here): more limbs than CUs, not a multiple of them, so the persistent grid's workgroups walk 4 or 5 limbs each
     limbs = 1040
     big = np.stack([splitmix_fill(0x4845564D + b, N) % np.uint64(o.primes[b % K]) for b in range(limbs)])
