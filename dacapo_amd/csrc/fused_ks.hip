@@ -12,7 +12,8 @@
 //   L5 irows   : special-prime limb of both accumulators
 //   L6 icols+round+fcols : finish its iNTT, add floor(P/2), reduce into q_i, subtract, first NTT phase
 //   L7 frows+final : second NTT phase, (acc - t) * P^-1 + base, written straight into the destination
-// 7 launches instead of 13; rescale is L5'-L7' = 3 instead of 7.  L2/L6 recompute the inverse COLS phase once per
+// 7 launches instead of 13; rescale is L5'-L7' = 3 instead of 7.  (Round 3: throughput-bound launches take MERGE instantiations of L2 / L6
+// / L3-L5 that do not repeat work per target modulus / per accumulator; see the kernels.)  L2/L6 recompute the inverse COLS phase once per
 // target modulus (it is 1/(l+1) of that kernel's work) to keep every workgroup at two phases.
 #include "ntt_tile.hpp"
 #include "plan.hpp"
@@ -196,33 +197,40 @@ __global__ __launch_bounds__(kTileThreads) void f_irows_kernel(Src src, u64 *__r
 }
 
 // L2: z = (b*l + j)*l + e
-template <int K, int LOGE>
+// MERGE (throughput-bound launches, grid.y = B*l): one workgroup finishes the iNTT of digit (b, j) ONCE and runs the base change + first
+// NTT phase for each of its l target moduli in turn, instead of l workgroups each recomputing the inverse phase (a quarter of the
+// launch's work at l = 2, a third at l = 3) -- what the large-batch path gets from two launches and a round trip through HBM.
+template <int K, int LOGE, bool MERGE>
 __global__ __launch_bounds__(kTileThreads) void f_ks_icols_lift_fcols_kernel(const u64 *__restrict__ digits, u64 *__restrict__ ext,
                                                                               int ell, int sp, const DModulus *__restrict__ mods,
                                                                               const u64 *__restrict__ tw, const u64 *__restrict__ itw,
                                                                               int logN)
 {
     __shared__ __attribute__((aligned(16))) u64 lds[TileGeo<LOGE>::LDS_ELEMS];
-    const int z = blockIdx.y, e = z % ell, dj = z / ell, j = dj % ell;
+    const int z = blockIdx.y, dj = MERGE ? z : z / ell, j = dj % ell;
     const size_t N = (size_t)1 << logN;
     const u64 *in = digits + (size_t)dj * N;
-    u64 *out = ext + (size_t)z * N;
     u64 x[1 << LOGE];
     auto nost = [](int, u64) {};
     ntt_tile_x<K, LOGE, true, true, true, false, true>(
         x, mods[j], itw + ((size_t)j << logN), logN, blockIdx.x, [=](int g) { return in[g]; }, nost, lds);
-    const int pm = ks_other_prime(j, e, ell, sp);
-    const DModulus Mm = mods[pm];
-#pragma unroll
-    for (int r = 0; r < (1 << LOGE); r++) x[r] = recanon(x[r], Mm); // one conditional subtraction within a width class (modarith.hpp)
-    __syncthreads(); // the inverse tile's last LDS image has been read by everyone
     auto nold = [](int) -> u64 { return 0; };
-    ntt_tile_x<K, LOGE, true, false, false, true, false>(
-        x, Mm, tw + ((size_t)pm << logN), logN, blockIdx.x, nold, [=](int g, u64 v) { out[g] = v; }, lds);
+    for (int e = MERGE ? 0 : z % ell; e < (MERGE ? ell : z % ell + 1); e++) {
+        u64 *out = ext + ((size_t)dj * ell + e) * N;
+        const int pm = ks_other_prime(j, e, ell, sp);
+        const DModulus Mm = mods[pm];
+        u64 y[1 << LOGE];
+#pragma unroll
+        for (int r = 0; r < (1 << LOGE); r++) y[r] = recanon(x[r], Mm); // one conditional subtraction within a width class (modarith.hpp)
+        __syncthreads(); // the previous tile's last LDS image has been read by everyone
+        ntt_tile_x<K, LOGE, true, false, false, true, false>(
+            y, Mm, tw + ((size_t)pm << logN), logN, blockIdx.x, nold, [=](int g, u64 v) { out[g] = v; }, lds);
+    }
 }
 
 // L6 / R2: z = bp*cnt + i : finish the iNTT of the dropped limb bp (prime l), round, change base to prime i, first NTT phase
-template <int K, int LOGE>
+// MERGE (grid.y = polys): the same sharing as in L2 -- the dropped limb's inverse phase once, then every target modulus in turn
+template <int K, int LOGE, bool MERGE>
 __global__ __launch_bounds__(kTileThreads) void f_dr_icols_lift_fcols_kernel(const u64 *__restrict__ last, long last_stride,
                                                                               u64 *__restrict__ tmp, int cnt, int l, int Kp,
                                                                               const DModulus *__restrict__ mods,
@@ -231,29 +239,34 @@ __global__ __launch_bounds__(kTileThreads) void f_dr_icols_lift_fcols_kernel(con
                                                                               int logN)
 {
     __shared__ __attribute__((aligned(16))) u64 lds[TileGeo<LOGE>::LDS_ELEMS];
-    const int z = blockIdx.y, i = z % cnt, bp = z / cnt;
+    const int z = blockIdx.y, bp = MERGE ? z : z / cnt;
     const size_t N = (size_t)1 << logN;
     const u64 *in = last + (long)bp * last_stride;
-    u64 *out = tmp + (size_t)z * N;
     u64 x[1 << LOGE];
     auto nost = [](int, u64) {};
     ntt_tile_x<K, LOGE, true, true, true, false, true>(
         x, mods[l], itw + ((size_t)l << logN), logN, blockIdx.x, [=](int g) { return in[g]; }, nost, lds);
-    const DModulus Mi = mods[i];
-    const u64 ql = mods[l].q, qi = Mi.q, half = ql >> 1;
-    const u64 neg_half = qi - half_mod[(size_t)l * Kp + i];
+    const u64 ql = mods[l].q, half = ql >> 1;
 #pragma unroll
-    for (int r = 0; r < (1 << LOGE); r++) { // RNSTool::divide_and_round_q_last_ntt_inplace, coefficient-domain part
-        u64 y = x[r] + half;
-        y = y >= ql ? y - ql : y;
-        y = recanon(y, Mi);
-        y += neg_half;
-        x[r] = y >= qi ? y - qi : y;
+    for (int r = 0; r < (1 << LOGE); r++) { // RNSTool::divide_and_round_q_last_ntt_inplace, coefficient-domain part: + floor(q_l / 2) mod q_l
+        const u64 y = x[r] + half;
+        x[r] = y >= ql ? y - ql : y;
     }
-    __syncthreads();
     auto nold = [](int) -> u64 { return 0; };
-    ntt_tile_x<K, LOGE, true, false, false, true, false>(
-        x, Mi, tw + ((size_t)i << logN), logN, blockIdx.x, nold, [=](int g, u64 v) { out[g] = v; }, lds);
+    for (int i = MERGE ? 0 : z % cnt; i < (MERGE ? cnt : z % cnt + 1); i++) {
+        u64 *out = tmp + ((size_t)bp * cnt + i) * N;
+        const DModulus Mi = mods[i];
+        const u64 qi = Mi.q, neg_half = qi - half_mod[(size_t)l * Kp + i];
+        u64 y[1 << LOGE];
+#pragma unroll
+        for (int r = 0; r < (1 << LOGE); r++) { // ... reduced into q_i, - floor(q_l / 2) mod q_i
+            const u64 v = recanon(x[r], Mi) + neg_half;
+            y[r] = v >= qi ? v - qi : v;
+        }
+        __syncthreads();
+        ntt_tile_x<K, LOGE, true, false, false, true, false>(
+            y, Mi, tw + ((size_t)i << logN), logN, blockIdx.x, nold, [=](int g, u64 v) { out[g] = v; }, lds);
+    }
 }
 
 // Throughput variants of L2 / L6 for large batches: the inverse COLS phase has already been run once per source limb
@@ -531,7 +544,7 @@ __global__ __launch_bounds__(kTileThreads) void f_frows_final_cont_kernel(const 
 // operand itself, which is already in NTT form -- and multiplies by the key limb at the same coefficients.  The special-prime
 // accumulators continue in registers into the inverse ROWS phase that the mod-down starts with.
 // MODE 0: rotation (operand = c1 of the item through its Galois permutation, key per item); MODE 1: relinearisation.
-template <int K, int LOGE, int MODE>
+template <int K, int LOGE, int MODE, bool MERGE>
 __global__ __launch_bounds__(kTileThreads) void f_ks_frows_mac_kernel(const u64 *__restrict__ ext, const u64 *__restrict__ target,
                                                                        const KsItem *__restrict__ items,
                                                                        const u64 *__restrict__ shared_key, u64 *__restrict__ acc, int ell,
@@ -541,7 +554,10 @@ __global__ __launch_bounds__(kTileThreads) void f_ks_frows_mac_kernel(const u64 
     __shared__ __attribute__((aligned(16))) u64 lds[TileGeo<LOGE>::LDS_ELEMS];
     constexpr int E = 1 << LOGE, NP = num_passes<LOGE>(K);
     const int y = blockIdx.y, b = blockIdx.z, sp = Kp - 1;
-    const int m = y < ell ? y : ell, psel = y - ell; // psel < 0: both accumulators
+    // psel < 0: both accumulators.  MERGE (grid.y = l + 1, throughput-bound launches): ONE workgroup row does the special prime for both
+    // accumulators -- the l transforms of the lifted digits once instead of twice, then the two inverse ROWS phases one after the other
+    // (its own instantiation: both accumulators live through the epilogue cost 16-20 VGPRs, a wave per SIMD)
+    const int m = y < ell ? y : ell, psel = (MERGE && y == ell) ? -1 : y - ell;
     const int pm = m == ell ? sp : m;
     const size_t N = (size_t)1 << logN;
     const DModulus M = mods[pm];
@@ -603,14 +619,18 @@ __global__ __launch_bounds__(kTileThreads) void f_ks_frows_mac_kernel(const u64 
 #pragma unroll
         for (int e = 0; e < E; e++) o0[g[e]] = a0[e].reduce(M), o1[g[e]] = a1[e].reduce(M);
     } else {
-        u64 r[E];
+        const int p_lo = MERGE ? 0 : psel, p_hi = MERGE ? 1 : psel;
+        for (int p = p_lo; p <= p_hi; p++) {
+            u64 r[E];
 #pragma unroll
-        for (int e = 0; e < E; e++) r[e] = psel == 0 ? a0[e].reduce(M) : a1[e].reduce(M);
-        u64 *o = acc + (((size_t)b * 2 + psel) * (ell + 1) + ell) * N;
-        if (lds_used) __syncthreads();
-        auto nold = [](int) -> u64 { return 0; };
-        ntt_tile_x<K, LOGE, false, true, false, true, false>(r, M, itw + ((size_t)sp << logN), logN, blockIdx.x, nold,
-                                                             [=](int gi, u64 v) { o[gi] = v; }, lds);
+            for (int e = 0; e < E; e++) r[e] = p == 0 ? a0[e].reduce(M) : a1[e].reduce(M);
+            u64 *o = acc + (((size_t)b * 2 + p) * (ell + 1) + ell) * N;
+            if (lds_used) __syncthreads();
+            auto nold = [](int) -> u64 { return 0; };
+            ntt_tile_x<K, LOGE, false, true, false, true, false>(r, M, itw + ((size_t)sp << logN), logN, blockIdx.x, nold,
+                                                                 [=](int gi, u64 v) { o[gi] = v; }, lds);
+            lds_used = true;
+        }
     }
 }
 
@@ -742,15 +762,29 @@ void f_frows_boot_final(const Context &c, const u64 *ptx, const BootItem *items,
                                                   c.d_mods, c.d_tw, c.logN));
 }
 
+static long ks_merge_special_min_wgs()
+{ // DACAPO_KS_MERGE_SPECIAL_MIN_WGS: launches of at least this many workgroups (more than the chip holds at once: throughput, not one
+  // workgroup's latency, is what counts) let one row of workgroups serve both special-prime accumulators; a huge value = never
+    static const long v = getenv("DACAPO_KS_MERGE_SPECIAL_MIN_WGS") ? atol(getenv("DACAPO_KS_MERGE_SPECIAL_MIN_WGS")) : 2048;
+    return v;
+}
+
 void f_ks_frows_mac(const Context &c, int mode, const u64 *ext, const u64 *target, const KsItem *items, const u64 *shared_key, u64 *acc,
                     int B, int ell, hipStream_t s)
 {
 #define DC_FMAC(LEV, MD)                                                                                                                  \
     {                                                                                                                                     \
         constexpr int LE = LEV;                                                                                                           \
-        const dim3 grid((unsigned)(c.N >> TileGeo<LE>::LOG), (unsigned)(ell + 2), (unsigned)B);                                          \
-        DC_K_SWITCH(c.k2, hipLaunchKernelGGL((f_ks_frows_mac_kernel<KK, LE, MD>), grid, dim3(kTileThreads), 0, s, ext, target, items, shared_key, \
-                                             acc, ell, c.K, c.d_mods, c.d_tw, c.d_itw, c.logN));                                          \
+        const long wgs = (long)(c.N >> TileGeo<LE>::LOG) * (ell + 2) * B;                                                                \
+        const int merge = wgs >= ks_merge_special_min_wgs() ? 1 : 0;                                                                      \
+        const dim3 grid((unsigned)(c.N >> TileGeo<LE>::LOG), (unsigned)(ell + 2 - merge), (unsigned)B);                                  \
+        if (merge) {                                                                                                                      \
+            DC_K_SWITCH(c.k2, hipLaunchKernelGGL((f_ks_frows_mac_kernel<KK, LE, MD, true>), grid, dim3(kTileThreads), 0, s, ext, target, items,   \
+                                                 shared_key, acc, ell, c.K, c.d_mods, c.d_tw, c.d_itw, c.logN));                         \
+        } else {                                                                                                                          \
+            DC_K_SWITCH(c.k2, hipLaunchKernelGGL((f_ks_frows_mac_kernel<KK, LE, MD, false>), grid, dim3(kTileThreads), 0, s, ext, target, items,  \
+                                                 shared_key, acc, ell, c.K, c.d_mods, c.d_tw, c.d_itw, c.logN));                         \
+        }                                                                                                                                 \
     }
     // (the radix-8 geometry was measured for this kernel too: 8 coefficients x two 128-bit accumulators per thread cost more in
     // occupancy than the saved LDS exchange returns -- config 3: 520 us against 455 us; profiles/r02_experiments.txt)
@@ -762,17 +796,46 @@ void f_ks_frows_mac(const Context &c, int mode, const u64 *ext, const u64 *targe
 #undef DC_FMAC
 }
 
+static long ks_merge_lift_min_wgs()
+{ // DACAPO_KS_MERGE_LIFT_MIN_WGS: launches of L2 / L6 with at least this many workgroups (in the unmerged geometry) share the inverse
+  // COLS phase among a source limb's target moduli; a huge value = never
+    static const long v = getenv("DACAPO_KS_MERGE_LIFT_MIN_WGS") ? atol(getenv("DACAPO_KS_MERGE_LIFT_MIN_WGS")) : 1024;
+    return v;
+}
+// (the tile geometry is chosen from the unmerged limb count either way: the merged form is a throughput form of the same launch)
+#define DC_MERGED_LAUNCH(limbs, sources, per_source, KERNEL, ...)                                                                          \
+    {                                                                                                                                     \
+        const bool tiny = use_tiny_tiles(c.N, (limbs)), small = !tiny && use_small_tiles(c.N, (limbs));                                  \
+        const int le = tiny ? 1 : small ? 2 : 3;                                                                                          \
+        const bool merge = (per_source) > 1 && (long)(c.N >> (le == 1 ? TileGeo<1>::LOG : le == 2 ? TileGeo<2>::LOG : TileGeo<3>::LOG)) * (limbs) >= ks_merge_lift_min_wgs(); \
+        if (!merge) {                                                                                                                     \
+            DC_GEO_SWITCH(c.k1, (limbs), hipLaunchKernelGGL((KERNEL<KK, LE, false>), grid, dim3(kTileThreads), 0, s, __VA_ARGS__));      \
+        } else if (le == 1) {                                                                                                             \
+            constexpr int LE = 1;                                                                                                         \
+            const dim3 grid((unsigned)(c.N >> TileGeo<LE>::LOG), (unsigned)(sources));                                                    \
+            DC_K_SWITCH(c.k1, hipLaunchKernelGGL((KERNEL<KK, LE, true>), grid, dim3(kTileThreads), 0, s, __VA_ARGS__))                    \
+        } else if (le == 2) {                                                                                                             \
+            constexpr int LE = 2;                                                                                                         \
+            const dim3 grid((unsigned)(c.N >> TileGeo<LE>::LOG), (unsigned)(sources));                                                    \
+            DC_K_SWITCH(c.k1, hipLaunchKernelGGL((KERNEL<KK, LE, true>), grid, dim3(kTileThreads), 0, s, __VA_ARGS__))                    \
+        } else {                                                                                                                          \
+            constexpr int LE = 3;                                                                                                         \
+            const dim3 grid((unsigned)(c.N >> TileGeo<LE>::LOG), (unsigned)(sources));                                                    \
+            DC_K_SWITCH(c.k1, hipLaunchKernelGGL((KERNEL<KK, LE, true>), grid, dim3(kTileThreads), 0, s, __VA_ARGS__))                    \
+        }                                                                                                                                 \
+    }
+
 void f_ks_icols_lift_fcols(const Context &c, const u64 *digits, u64 *ext, int B, int ell, hipStream_t s)
 {
-    DC_GEO_SWITCH(c.k1, B * ell * ell, hipLaunchKernelGGL((f_ks_icols_lift_fcols_kernel<KK, LE>), grid, dim3(kTileThreads), 0, s, digits, ext,
-                                                          ell, c.K - 1, c.d_mods, c.d_tw, c.d_itw, c.logN));
+    DC_MERGED_LAUNCH(B * ell * ell, B * ell, ell, f_ks_icols_lift_fcols_kernel, digits, ext, ell, c.K - 1, c.d_mods, c.d_tw, c.d_itw, c.logN)
 }
 
 void f_dr_icols_lift_fcols(const Context &c, const u64 *last, long last_stride, u64 *tmp, int polys, int cnt, int l, hipStream_t s)
 {
-    DC_GEO_SWITCH(c.k1, polys * cnt, hipLaunchKernelGGL((f_dr_icols_lift_fcols_kernel<KK, LE>), grid, dim3(kTileThreads), 0, s, last,
-                                                        last_stride, tmp, cnt, l, c.K, c.d_mods, c.d_half_mod, c.d_tw, c.d_itw, c.logN));
+    DC_MERGED_LAUNCH(polys * cnt, polys, cnt, f_dr_icols_lift_fcols_kernel, last, last_stride, tmp, cnt, l, c.K, c.d_mods, c.d_half_mod, c.d_tw,
+                     c.d_itw, c.logN)
 }
+#undef DC_MERGED_LAUNCH
 
 void f_ks_lift_fcols(const Context &c, const u64 *digits, u64 *ext, int B, int ell, hipStream_t s)
 {
