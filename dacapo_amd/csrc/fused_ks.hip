@@ -797,8 +797,9 @@ void f_ks_frows_mac(const Context &c, int mode, const u64 *ext, const u64 *targe
 }
 
 static long ks_merge_lift_min_wgs()
-{ // DACAPO_KS_MERGE_LIFT_MIN_WGS: launches of L2 / L6 with at least this many workgroups (in the unmerged geometry) share the inverse
-  // COLS phase among a source limb's target moduli; a huge value = never
+{ // DACAPO_KS_MERGE_LIFT_MIN_WGS: launches of L2 / L6 that still have at least this many workgroups AFTER merging share the inverse COLS
+  // phase among a source limb's target moduli (a single key switch at 13 primes has 5408 fine workgroups or 416 merged ones: merged it
+  // leaves CUs idle, 115 us against 93); a huge value = never
     static const long v = getenv("DACAPO_KS_MERGE_LIFT_MIN_WGS") ? atol(getenv("DACAPO_KS_MERGE_LIFT_MIN_WGS")) : 1024;
     return v;
 }
@@ -807,7 +808,7 @@ static long ks_merge_lift_min_wgs()
     {                                                                                                                                     \
         const bool tiny = use_tiny_tiles(c.N, (limbs)), small = !tiny && use_small_tiles(c.N, (limbs));                                  \
         const int le = tiny ? 1 : small ? 2 : 3;                                                                                          \
-        const bool merge = (per_source) > 1 && (long)(c.N >> (le == 1 ? TileGeo<1>::LOG : le == 2 ? TileGeo<2>::LOG : TileGeo<3>::LOG)) * (limbs) >= ks_merge_lift_min_wgs(); \
+        const bool merge = (per_source) > 1 && (long)(c.N >> (le == 1 ? TileGeo<1>::LOG : le == 2 ? TileGeo<2>::LOG : TileGeo<3>::LOG)) * (sources) >= ks_merge_lift_min_wgs(); \
         if (!merge) {                                                                                                                     \
             DC_GEO_SWITCH(c.k1, (limbs), hipLaunchKernelGGL((KERNEL<KK, LE, false>), grid, dim3(kTileThreads), 0, s, __VA_ARGS__));      \
         } else if (le == 1) {                                                                                                             \
