@@ -760,3 +760,25 @@ def test_n_ary_sum_kernels_match_the_oracle_vm(min_wgs):
     res = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
     assert res["limbs_identical"] and res["scale_identical"] and res["max_error_vs_cleartext"] < 1e-4
     assert res["op_mix"]["mulcp"] >= 20 and res["op_mix"]["addcc"] >= 27
+
+
+@pytest.mark.parametrize("min_wgs", ["0", "1000000000000"])
+def test_merged_and_fine_launch_shapes_of_the_key_switch_match_the_oracle_vm(min_wgs):
+    """fused_ks.hip: the MERGE instantiations of L2 / L6 (one inverse COLS phase per source limb for all its target moduli) and of the fused
+    L3-L5 kernel (both special-prime accumulators in one workgroup row) against the fine-grained ones, each forced for every launch of a
+    program with 29 rotations (multi-hop), a ct x ct product and rescales at several levels: both equal the oracle VM limb for limb.  A
+    child process: the thresholds are read once."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    env = dict(os.environ, DACAPO_KS_MERGE_LIFT_MIN_WGS=min_wgs, DACAPO_KS_MERGE_SPECIAL_MIN_WGS=min_wgs)
+    for logN, K in (("13", "5"), ("12", "7")):
+        out = subprocess.run([sys.executable, str(root / "tools" / "sum_pair_check.py"), logN, K], env=env, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stderr[-1500:]
+        res = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+        assert res["limbs_identical"] and res["scale_identical"] and res["max_error_vs_cleartext"] < 1e-4
+        assert res["stats"]["keyswitches"] >= 40
