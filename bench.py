@@ -129,64 +129,61 @@ def real_bootstrap_leg(ll, runner, steps=3, resnet=True):
     from dacapo_amd import ckks_boot as cb
     from dacapo_amd import hevm_asm as ha
 
-    os.environ["DACAPO_HEVM_SECRET_HW"] = "64"
+    sparse = {"secret_hw": 64}
     KB = 3 + cb.boot_levels() + 1
     out = {"parameters": f"{KB} x 60-bit primes ({KB - 1} data + 1 special), secret Hamming weight 64, r = 5 double angles, 4 + 10 + 3 levels",
            "reference": "profiled_HEAAN_GPU.json earth.bootstrap_single: 0.29-0.46 s at N = 2^17 on HEaaN (its GPU unstated)", "single": []}
-    try:
-        for logN in (15, 17):
-            K, cst, hv, offs, _ = cb.single_bootstrap_program(logN)
-            hevm = runner.HEVM(seed=5, logN=logN, num_primes=K)
-            hevm.addRotationKeys(offs)
-            hevm.load_mem(cst, hv)
-            msg = np.random.default_rng(3).uniform(-1, 1, hevm.slots)
-            hevm.setInput(0, msg)
+    for logN in (15, 17):
+        K, cst, hv, offs, _ = cb.single_bootstrap_program(logN)
+        hevm = runner.HEVM(seed=5, logN=logN, num_primes=K, vm_options=sparse)
+        hevm.addRotationKeys(offs)
+        hevm.load_mem(cst, hv)
+        msg = np.random.default_rng(3).uniform(-1, 1, hevm.slots)
+        hevm.setInput(0, msg)
+        hevm.run()
+        t0 = time.perf_counter()
+        for _ in range(steps):
             hevm.run()
-            t0 = time.perf_counter()
-            for _ in range(steps):
-                hevm.run()
-            dt = (time.perf_counter() - t0) / steps
-            err = np.abs(hevm.getOutput()[0] - msg)
-            st = hevm.stats()
-            from dacapo_amd import progstats
+        dt = (time.perf_counter() - t0) / steps
+        err = np.abs(hevm.getOutput()[0] - msg)
+        st = hevm.stats()
+        from dacapo_amd import progstats
 
-            pst = progstats.walk(hv, logN, direct_keys=True)
-            sec = (f"below 128-bit (N = 2^15, log2(QP) = {60 * K}, secret Hamming weight 64; the HE standard allows 881 bits at this N): "
-                   "timing / accuracy demonstration only") if logN == 15 else \
-                  f"N = 2^17, log2(QP) = {60 * K}, h = 64: inside the 128-bit range for this ring"
-            out["single"].append({"N": 1 << logN, "security": sec, "ms": round(dt * 1e3, 2), "instructions": int(len(ha.unpack_hevm(hv)["ops"])),
-                                  "algorithmic_bytes": pst["algorithmic_bytes"], "achieved_gbs": round(pst["algorithmic_bytes"] / dt / 1e9, 1),
-                                  "frac_of_hbm_peak": round(pst["algorithmic_bytes"] / dt / 1e9 / HBM_PEAK_GBS, 4),
-                                  "key_switches": st["keyswitches"], "ntt_equivalents": st["ntts"], "ntt_per_s": round(st["ntts"] / dt),
-                                  "max_error": float(err.max()), "rms_error": float(np.sqrt(np.mean(err**2))),
-                                  "precision_bits": round(float(-np.log2(err.max())), 1)})
-            hevm.close()  # hevm_destroy: the next VM gets this one's HBM back
-        if resnet:
-            fx = ha.read_fixture(ROOT / "tests" / "golden" / "resnet20")
-            t0 = time.time()
-            fx["hevm"], fx["cst"] = cb.lower_bootstraps(fx["hevm"], fx["cst"], 15, KB, msg_bits=4)  # every opcode 10 -> real bootstrapping
-            t_lower = time.time() - t0
-            hevm = runner.HEVM(seed=0x4845564D, logN=15, num_primes=KB)
-            hevm.addRotationKeys(cb.rotation_offsets(fx["hevm"]))
-            hevm.load_mem(fx["cst"], fx["hevm"])
-            hevm.setInput(0, fx["packed"])
-            t0 = time.perf_counter()
-            hevm.run()
-            dt = time.perf_counter() - t0
-            o, st = hevm.getOutput()[0], hevm.stats()
-            ops = ha.unpack_hevm(fx["hevm"])["ops"]
-            out["resnet20_with_real_bootstraps"] = {
-                "program": "the headline program, every opcode 10 lowered to ModRaise/CoeffToSlot/EvalMod/SlotToCoeff by ckks_boot.lower_bootstraps",
-                "security": f"below 128-bit (N = 2^15, log2(QP) = {60 * KB}, h = 64): timing / accuracy demonstration only; config 4 (N = 2^17) is the "
-                            "parameter set inside the standard's range",
-                "lowering_s": round(t_lower, 1),
-                "instructions": int(len(ops)), "real_bootstraps": int((ops[:, 0] == ha.OP_MODRAISE).sum()), "run_s": round(dt, 3),
-                "key_switches": st["keyswitches"], "ntt_equivalents": st["ntts"], "ntt_per_s": round(st["ntts"] / dt),
-                "rms_vs_torch": float(np.sqrt(np.mean((o[:10] * 32 - fx["torch_result"]) ** 2))),
-                "rms_vs_plaintext_evaluation": float(np.sqrt(np.mean((o - fx["expected"]) ** 2)))}
-            hevm.close()
-    finally:
-        os.environ.pop("DACAPO_HEVM_SECRET_HW", None)
+        pst = progstats.walk(hv, logN, direct_keys=True)
+        sec = (f"below 128-bit (N = 2^15, log2(QP) = {60 * K}, secret Hamming weight 64; the HE standard allows 881 bits at this N): "
+               "timing / accuracy demonstration only") if logN == 15 else \
+              f"N = 2^17, log2(QP) = {60 * K}, h = 64: inside the 128-bit range for this ring"
+        out["single"].append({"N": 1 << logN, "security": sec, "ms": round(dt * 1e3, 2), "instructions": int(len(ha.unpack_hevm(hv)["ops"])),
+                              "algorithmic_bytes": pst["algorithmic_bytes"], "achieved_gbs": round(pst["algorithmic_bytes"] / dt / 1e9, 1),
+                              "frac_of_hbm_peak": round(pst["algorithmic_bytes"] / dt / 1e9 / HBM_PEAK_GBS, 4),
+                              "key_switches": st["keyswitches"], "ntt_equivalents": st["ntts"], "ntt_per_s": round(st["ntts"] / dt),
+                              "max_error": float(err.max()), "rms_error": float(np.sqrt(np.mean(err**2))),
+                              "precision_bits": round(float(-np.log2(err.max())), 1)})
+        hevm.close()  # hevm_destroy: the next VM gets this one's HBM back
+    if resnet:
+        fx = ha.read_fixture(ROOT / "tests" / "golden" / "resnet20")
+        t0 = time.time()
+        fx["hevm"], fx["cst"] = cb.lower_bootstraps(fx["hevm"], fx["cst"], 15, KB, msg_bits=4)  # every opcode 10 -> real bootstrapping
+        t_lower = time.time() - t0
+        hevm = runner.HEVM(seed=0x4845564D, logN=15, num_primes=KB, vm_options=sparse)
+        hevm.addRotationKeys(cb.rotation_offsets(fx["hevm"]))
+        hevm.load_mem(fx["cst"], fx["hevm"])
+        hevm.setInput(0, fx["packed"])
+        t0 = time.perf_counter()
+        hevm.run()
+        dt = time.perf_counter() - t0
+        o, st = hevm.getOutput()[0], hevm.stats()
+        ops = ha.unpack_hevm(fx["hevm"])["ops"]
+        out["resnet20_with_real_bootstraps"] = {
+            "program": "the headline program, every opcode 10 lowered to ModRaise/CoeffToSlot/EvalMod/SlotToCoeff by ckks_boot.lower_bootstraps",
+            "security": f"below 128-bit (N = 2^15, log2(QP) = {60 * KB}, h = 64): timing / accuracy demonstration only; config 4 (N = 2^17) is the "
+                        "parameter set inside the standard's range",
+            "lowering_s": round(t_lower, 1),
+            "instructions": int(len(ops)), "real_bootstraps": int((ops[:, 0] == ha.OP_MODRAISE).sum()), "run_s": round(dt, 3),
+            "key_switches": st["keyswitches"], "ntt_equivalents": st["ntts"], "ntt_per_s": round(st["ntts"] / dt),
+            "rms_vs_torch": float(np.sqrt(np.mean((o[:10] * 32 - fx["torch_result"]) ** 2))),
+            "rms_vs_plaintext_evaluation": float(np.sqrt(np.mean((o - fx["expected"]) ** 2)))}
+        hevm.close()
     return out
 
 

@@ -13,7 +13,7 @@ a GPU, fails loudly.
 import os
 from pathlib import Path
 
-# DACAPO_AMD_LIB: another build of the same library (kernel-tuning sweeps: tools/sweep_lds_pad.sh); never a different backend
+# DACAPO_AMD_LIB: another build of the same library (kernel-tuning sweeps: tools/experiments/sweep_lds_pad.sh); never a different backend
 LIB_PATH = Path(os.environ.get("DACAPO_AMD_LIB") or Path(__file__).resolve().parent / "lib" / "libSEAL_HEVM.so")
 # the generic-width build of the same sources (csrc/modarith.hpp DC_GENERIC_WIDTH = 1): primes of 45..60 bits, mixed chains
 LIB_PATH_GW = Path(__file__).resolve().parent / "lib" / "libSEAL_HEVM_gw.so"

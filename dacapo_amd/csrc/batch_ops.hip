@@ -102,27 +102,15 @@ __global__ __launch_bounds__(kBT) void b_ks_mac_kernel(u64 *__restrict__ acc, co
     *reinterpret_cast<u64x2 *>(ac + ((size_t)1 * (ell + 1) + m) * N + k) = o1;
 }
 
-static bool fuse_mac()
-{
-    static const bool v = !(getenv("DACAPO_KS_FUSE_MAC") && atoi(getenv("DACAPO_KS_FUSE_MAC")) == 0);
-    return v;
-}
+static bool fuse_mac() { return option(OPT_KS_FUSE_MAC) != 0; }
 // work (in 1024-coefficient tiles of lifted digits) from which a key switch takes the large-batch launch sequence
-static long big_threshold()
-{
-    static const long v = getenv("DACAPO_KS_BIG_TILES") ? atol(getenv("DACAPO_KS_BIG_TILES")) : 4096;
-    return v;
-}
+static long big_threshold() { return (long)option(OPT_KS_BIG_TILES); }
 // ... and up to which the second NTT phase, the inner products and the special prime's first inverse phase stay one launch
 // (always, by default: at N = 2^16 / 24 primes the fused launch is 17 % faster than three, at the HEVM sizes it is even)
-static long fuse_mac_threshold()
-{
-    static const long v = getenv("DACAPO_KS_FUSE_MAC_TILES") ? atol(getenv("DACAPO_KS_FUSE_MAC_TILES")) : (1L << 40);
-    return v;
-}
+static long fuse_mac_threshold() { return (long)option(OPT_KS_FUSE_MAC_TILES); }
 
 // L2..L7 of the key-switch pipeline (fused_ks.hip) once the digits' inverse ROWS phase (L1) has been issued
-// (with DACAPO_KS_FUSE_MAC_TILES set, a linked step could fall on the un-fused middle, whose last kernel has no continuation form)
+// (with option ks_fuse_mac_tiles set, a linked step could fall on the un-fused middle, whose last kernel has no continuation form)
 bool chain_fusion_supported() { return fuse_mac() && fuse_mac_threshold() == (1L << 40); }
 
 // `digits`: output of the inverse ROWS phase of the key-switch target [B][l][N] (w.digits, or the buffer a fused producer filled)
@@ -407,9 +395,8 @@ __global__ __launch_bounds__(kBT) void b_sum_pair_kernel(const SumItem *__restri
 }
 
 static long sum_pair_min_workgroups()
-{ // DACAPO_SUM_PAIR_MIN_WGS: workgroups the paired form must still have (default 4 per CU); 0 = always, a huge value = never
-    static const long v = getenv("DACAPO_SUM_PAIR_MIN_WGS") ? atol(getenv("DACAPO_SUM_PAIR_MIN_WGS")) : 1024;
-    return v;
+{ // option sum_pair_min_wgs: workgroups the paired form must still have (default 4 per CU); 0 = always, a huge value = never
+    return (long)option(OPT_SUM_PAIR_MIN_WGS);
 }
 
 void b_sum(Context &c, const SumItem *d_items, const SumSrc *d_srcs, int B, int ell, hipStream_t s)

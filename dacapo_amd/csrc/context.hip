@@ -223,7 +223,7 @@ Context::Context(int logN_, int K_, int bits, const u64 *primes_or_null, int ksp
         //     sum_t y_t w_t  =  sum_r 2^(8r) [ sum_{t,p} digit_p(y_t) digit_r(V_{t,p}) ]   (mod m)
         // and the bracket is one int8 dot product of length 8 |S| <= 64 = ONE v_mfma_i32_16x16x64_i8 per (16 coefficients, 16 moduli, r).
         // B fragment of lane l: column l & 15, k = 16 (l >> 4) + j in byte j, k = 8 t + p.
-        hyb_mfma = alpha <= 8 && ksp <= 8 && !(getenv("DACAPO_HYB_MFMA") && atoi(getenv("DACAPO_HYB_MFMA")) == 0);
+        hyb_mfma = alpha <= 8 && ksp <= 8 && option(OPT_HYB_MFMA) != 0;
         if (hyb_mfma) {
             auto balanced = [](u64 v, int8_t *out8) {
                 const u64 C = 0x8080808080808080ull, b = (v + C) ^ C;

@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "modarith.hpp"
+#include "options.hpp"
 
 namespace dacapo {
 

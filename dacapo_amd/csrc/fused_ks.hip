@@ -763,10 +763,9 @@ void f_frows_boot_final(const Context &c, const u64 *ptx, const BootItem *items,
 }
 
 static long ks_merge_special_min_wgs()
-{ // DACAPO_KS_MERGE_SPECIAL_MIN_WGS: launches of at least this many workgroups (more than the chip holds at once: throughput, not one
+{ // option ks_merge_special_min_wgs: launches of at least this many workgroups (more than the chip holds at once: throughput, not one
   // workgroup's latency, is what counts) let one row of workgroups serve both special-prime accumulators; a huge value = never
-    static const long v = getenv("DACAPO_KS_MERGE_SPECIAL_MIN_WGS") ? atol(getenv("DACAPO_KS_MERGE_SPECIAL_MIN_WGS")) : 2048;
-    return v;
+    return (long)option(OPT_KS_MERGE_SPECIAL_MIN_WGS);
 }
 
 void f_ks_frows_mac(const Context &c, int mode, const u64 *ext, const u64 *target, const KsItem *items, const u64 *shared_key, u64 *acc,
@@ -797,11 +796,10 @@ void f_ks_frows_mac(const Context &c, int mode, const u64 *ext, const u64 *targe
 }
 
 static long ks_merge_lift_min_wgs()
-{ // DACAPO_KS_MERGE_LIFT_MIN_WGS: launches of L2 / L6 that still have at least this many workgroups AFTER merging share the inverse COLS
+{ // option ks_merge_lift_min_wgs: launches of L2 / L6 that still have at least this many workgroups AFTER merging share the inverse COLS
   // phase among a source limb's target moduli (a single key switch at 13 primes has 5408 fine workgroups or 416 merged ones: merged it
   // leaves CUs idle, 115 us against 93); a huge value = never
-    static const long v = getenv("DACAPO_KS_MERGE_LIFT_MIN_WGS") ? atol(getenv("DACAPO_KS_MERGE_LIFT_MIN_WGS")) : 1024;
-    return v;
+    return (long)option(OPT_KS_MERGE_LIFT_MIN_WGS);
 }
 // (the tile geometry is chosen from the unmerged limb count either way: the merged form is a throughput form of the same launch)
 #define DC_MERGED_LAUNCH(limbs, sources, per_source, KERNEL, ...)                                                                          \

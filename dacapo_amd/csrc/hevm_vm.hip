@@ -441,35 +441,42 @@ static u64 *dalloc(size_t elems)
     return p;
 }
 
-void HEVM::init_context(int logN, int K, const u64 *primes)
+void HEVM::init_context(int logN, int K, const u64 *primes, int dir_ksp, int dir_alpha)
 {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
         fprintf(stderr, "[dacapo_amd] no HIP device: the HEVM runtime has no CPU fallback\n");
         abort();
     }
-    // EXTENSION: DACAPO_HEVM_KS_SPECIAL = k > 1 switches key switching to grouped digits (hybrid_ks.hip): the last k primes of the chain
-    // are special, a digit is DACAPO_HEVM_KS_ALPHA (default k) data primes.  Not SEAL's key format: a key directory written in this
-    // mode loads only into a VM created with the same two values.
-    int ksp = 1, alpha = 1;
-    if (const char *e = getenv("DACAPO_HEVM_KS_SPECIAL")) ksp = alpha = std::max(1, atoi(e));
-    if (const char *e = getenv("DACAPO_HEVM_KS_ALPHA")) alpha = std::max(1, atoi(e));
-    // DACAPO_HEVM_PRIME_BITS = b (45..60; the generic-width build only): the chain CoeffModulus::Create(N, {b, b, ...}) instead of the
-    // reference's 60-bit one (SEAL_HEVM.cpp:48-53) -- e.g. 51 for rescale primes of the HEaaN configuration's width
-    int bits = kQBits;
-    if (const char *e = getenv("DACAPO_HEVM_PRIME_BITS")) bits = atoi(e);
+    // VM options (options.hpp), read once here: this VM keeps what it was created with.
+    // EXTENSION: ks_special = k > 1 switches key switching to grouped digits (hybrid_ks.hip): the last k primes of the chain are special,
+    // a digit is ks_alpha (default k) data primes.  Not SEAL's key format: a key directory written in this mode records (k, alpha) in
+    // hybrid.txt and loads only into a VM created with the same two values.
+    int ksp = std::max(1, (int)option(OPT_KS_SPECIAL));
+    int alpha = option(OPT_KS_ALPHA) > 0 ? (int)option(OPT_KS_ALPHA) : ksp;
+    if (dir_ksp > 0) { // a key directory written in grouped-digit mode says so itself (hybrid.txt): it sets the mode unless the options ask for another
+        if ((ksp != 1 || alpha != 1) && (ksp != dir_ksp || alpha != dir_alpha)) {
+            fprintf(stderr, "[dacapo_amd] the key directory was written with ks_special = %d, ks_alpha = %d; options ask for %d / %d\n", dir_ksp,
+                    dir_alpha, ksp, alpha);
+            abort();
+        }
+        ksp = dir_ksp, alpha = dir_alpha;
+    }
+    // prime_bits = b (45..60; the generic-width build only): the chain CoeffModulus::Create(N, {b, b, ...}) instead of the reference's
+    // 60-bit one (SEAL_HEVM.cpp:48-53) -- e.g. 51 for rescale primes of the HEaaN configuration's width
+    const int bits = (int)option(OPT_PRIME_BITS);
     ctx.reset(new Context(logN, K, bits, primes, ksp, alpha));
     ctx->ensure_scratch();
     encoder.reset(new HostEncoder(logN));
-    if (const char *e = getenv("DACAPO_HEVM_PLAN")) use_plan = atoi(e) != 0;
-    if (const char *e = getenv("DACAPO_HEVM_PLAN_GRAPH")) plan_graph = atoi(e) != 0;
-    if (const char *e = getenv("DACAPO_HEVM_PLAN_LANES")) plan_lanes = atoi(e) >= 2 ? 2 : 1;
-    if (const char *e = getenv("DACAPO_HEVM_HOST_ENCODER")) host_encoder = atoi(e) != 0;
-    if (const char *e = getenv("DACAPO_HEVM_FOLD_RESCALE_BOOT")) fold_rescale_into_boot = atoi(e) != 0;
-    if (const char *e = getenv("DACAPO_HEVM_MAX_BATCH")) max_batch = std::max(1, atoi(e));
-    if (const char *e = getenv("DACAPO_HEVM_CHAIN_FUSION")) chain_fusion = atoi(e) != 0;
-    if (const char *e = getenv("DACAPO_HEVM_SECRET_HW")) secret_weight = atoi(e);
-    if (const char *e = getenv("DACAPO_HEVM_ONLINE_ENCODE")) online_encode = atoi(e) != 0 && use_plan && !host_encoder;
+    use_plan = option(OPT_PLAN) != 0;
+    plan_graph = option(OPT_PLAN_GRAPH) != 0;
+    plan_lanes = option(OPT_PLAN_LANES) >= 2 ? 2 : 1;
+    host_encoder = option(OPT_HOST_ENCODER) != 0;
+    fold_rescale_into_boot = option(OPT_FOLD_RESCALE_BOOT) != 0;
+    max_batch = std::max(1, (int)option(OPT_MAX_BATCH));
+    chain_fusion = option(OPT_CHAIN_FUSION) != 0;
+    secret_weight = (int)option(OPT_SECRET_HW);
+    online_encode = option(OPT_ONLINE_ENCODE) != 0 && use_plan && !host_encoder;
     lanes.resize(1);
     DC_HIP_CHECK(hipStreamCreateWithFlags(&lanes[0].stream, hipStreamNonBlocking));
     lanes[0].ws = ctx->ws0;
@@ -526,7 +533,7 @@ void HEVM::generate_keys(const RngKeys &rng_, bool secret, bool pub, bool eval)
         // Sparse ternary secret with exactly `secret_weight` non-zero coefficients (what bootstrappable parameter sets use: the ModRaise
         // overflow I of ckks_boot.py is ~ sqrt(h / 12) wide).  Positions and signs from the secret ChaCha20 key, drawn on the host.
         if ((size_t)secret_weight > N / 2) {
-            fprintf(stderr, "[dacapo_amd] DACAPO_HEVM_SECRET_HW=%d is not sparse for N = %zu\n", secret_weight, N);
+            fprintf(stderr, "[dacapo_amd] option secret_hw=%d is not sparse for N = %zu\n", secret_weight, N);
             abort();
         }
         std::vector<int8_t> coef(N, 0);
@@ -669,6 +676,19 @@ void HEVM::save_keys(const std::string &dir)
         put_kswitch_keys(w, c, key_id, c.N, present);
         write_object_file(join(dir, "gal.seal"), w.buf, mode);
     }
+    // Grouped-digit keys (extension) use SEAL's container with another digit count and are NOT SEAL-loadable; parm.seal cannot say so, and two
+    // settings with the same digit count (K = 30: 6 / 6 and 8 / 7 both give 4 digits) would load into each other's VM and compute garbage.
+    // The directory therefore carries the two numbers in a sidecar that load_keys checks.
+    const std::string side = join(dir, "hybrid.txt");
+    if (c.hybrid()) {
+        FILE *f = fopen(side.c_str(), "w");
+        if (!f || fprintf(f, "ks_special=%d ks_alpha=%d\n# grouped-digit key-switching keys (dacapo_amd extension): not loadable by SEAL\n", c.ksp, c.alpha) < 0) {
+            fprintf(stderr, "[dacapo_amd] cannot write %s\n", side.c_str());
+            abort();
+        }
+        fclose(f);
+    } else
+        remove(side.c_str()); // (a directory rewritten in SEAL mode must not keep an older sidecar)
 }
 
 // one PublicKey of a key-switch key, or pub.seal: checks it against the context and returns its [2][K][N] limbs
@@ -727,7 +747,20 @@ void HEVM::load_keys(const std::string &dir, bool need_secret, bool need_public,
                     m.fail("coefficient modulus outside this backend's range: every prime must be 2^b - d with 45 <= b <= 60, d < 2^28 and d 2^(64-b) < q "
                            "(CoeffModulus::Create(N, {60, ...}) of SEAL_HEVM.cpp:48-53 yields b = 60)");
             }
-        init_context(logN, (int)p.primes.size(), p.primes.data());
+        int dir_ksp = 0, dir_alpha = 0;
+        if (FILE *f = fopen(join(dir, "hybrid.txt").c_str(), "r")) {
+            if (fscanf(f, "ks_special=%d ks_alpha=%d", &dir_ksp, &dir_alpha) != 2 || dir_ksp < 1 || dir_alpha < 1 || dir_alpha > dir_ksp) {
+                fprintf(stderr, "[dacapo_amd] %s/hybrid.txt is malformed\n", dir.c_str());
+                abort();
+            }
+            fclose(f);
+        }
+        init_context(logN, (int)p.primes.size(), p.primes.data(), dir_ksp, dir_alpha);
+        if (ctx->hybrid() && dir_ksp == 0) {
+            fprintf(stderr, "[dacapo_amd] options ask for grouped-digit key switching (ks_special = %d, ks_alpha = %d) but %s holds SEAL-format keys "
+                            "(no hybrid.txt)\n", ctx->ksp, ctx->alpha, dir.c_str());
+            abort();
+        }
     }
     const Context &c = *ctx;
     const sealio::ParmsId key_id = parms_id_at(c.K);
@@ -1183,12 +1216,16 @@ void HEVM::decrypt(int64_t i, double *out)
     Context &c = *ctx;
     const size_t N = c.N;
     hevm_ctxt &ct = reg((size_t)i);
-    const int ell = ct.level;
-    if (!keys.sk || ell < 1) {
+    if (!keys.sk || ct.level < 1) {
         fprintf(stderr, "[dacapo_amd] decrypt: no secret key or empty register %lld\n", (long long)i);
         abort();
     }
     u64 *pt = W().ks_tmp;
+    // Above 16 primes the modulus leaves a double's range (2^960) and the device CRT takes the first 16 limbs only: the plaintext polynomial
+    // m = c0 + c1 s mod Q has |coefficients| < Q_16 / 2 for anything that decodes to finite doubles at all (an integer beyond 2^959 divided by
+    // any admissible scale is not a CKKS message but overflowed noise), and then its centred representative mod Q_16 is the one mod Q_ell.
+    // Limbs are independent, so decrypting and inverse-transforming only those 16 changes nothing about them.
+    const int ell = !host_encoder && ct.level > 16 ? 16 : ct.level;
     hipLaunchKernelGGL(decrypt_kernel, dim3((unsigned)(N / (2 * kVmThreads)), (unsigned)ell), dim3(kVmThreads), 0, S(), pt,
                        view(ct), keys.sk, N, c.d_mods);
     launch_ntt(c, true, pt, (long)N, ell, nullptr, 0, 0, S());
@@ -1664,7 +1701,7 @@ void HEVM::run()
         return;
     }
     if (streams != 1) {
-        fprintf(stderr, "[dacapo_amd] several ciphertext streams need the batched plan (DACAPO_HEVM_PLAN=1, no debug)\n");
+        fprintf(stderr, "[dacapo_amd] several ciphertext streams need the batched plan (option plan = 1, no debug)\n");
         abort();
     }
     execute();
@@ -1717,10 +1754,8 @@ static std::vector<char> slurp(const char *path)
 }
 
 static void env_params(int &logN, int &K)
-{ // the reference hard-codes N = 15, L = 14 (SEAL_HEVM.cpp:39-40); tests shrink the ring through the environment
-    logN = 15, K = 14;
-    if (const char *e = getenv("DACAPO_HEVM_LOGN")) logN = atoi(e);
-    if (const char *e = getenv("DACAPO_HEVM_PRIMES")) K = atoi(e);
+{ // the reference hard-codes N = 15, L = 14 (SEAL_HEVM.cpp:39-40) -- the defaults of options logn / primes; tests shrink the ring
+    logN = (int)dacapo::option(dacapo::OPT_LOGN), K = (int)dacapo::option(dacapo::OPT_PRIMES);
 }
 
 extern "C" {
@@ -1798,6 +1833,13 @@ void *hevm_init_seeded(int logN, int num_primes, uint64_t seed)
     auto vm = new HEVM();
     vm->init_context(logN > 0 ? logN : dl, num_primes > 0 ? num_primes : dk, nullptr);
     vm->generate_keys(dacapo::rng_keys_from_test_seed(seed), true, true, true); // reproducible and therefore insecure: tests / bench only
+    return vm;
+}
+void *hevm_init_seeded_primes(int logN, const uint64_t *primes, int num_primes, uint64_t seed)
+{ // the same on an explicit chain (each prime = 1 mod 2N, 45..60 bits; other than 60: the generic-width build), e.g. a HEaaN-style mixed one
+    auto vm = new HEVM();
+    vm->init_context(logN, num_primes, primes);
+    vm->generate_keys(dacapo::rng_keys_from_test_seed(seed), true, true, true);
     return vm;
 }
 void *hevm_context(void *vm)

@@ -106,7 +106,7 @@ class HEVM {
     u64 *d_epoch = nullptr; // run() counter in HBM, mixed into the encryption randomness (graph replays stay fresh)
 
     // The VM's HIP stream and the scratch of one in-flight composite op.  run() executes the batched plan (plan.hpp); with
-    // DACAPO_HEVM_PLAN=0 or setDebug(true) it is the reference's loop instead: one instruction at a time, in program order.
+    // option plan = 0 or setDebug(true) it is the reference's loop instead: one instruction at a time, in program order.
     struct Lane {
         hipStream_t stream = nullptr;
         Workspace ws;
@@ -124,14 +124,14 @@ class HEVM {
     // batched device encoder (encoder.hip): tables, and the arenas the plaintext registers of the loaded program live in
     EncTables enc_tables;
     std::vector<u64 *> plain_arenas;
-    // DACAPO_HEVM_ONLINE_ENCODE=1: plaintexts are encoded at use from the resident constants instead of being kept pre-encoded
+    // option online_encode = 1: plaintexts are encoded at use from the resident constants instead of being kept pre-encoded
     bool online_encode = false;
     struct OnlineEncode {
         double *d_consts = nullptr;
         size_t const_bytes = 0;
         std::map<int, EncItem> items; // plaintext register -> what to encode
     } online;
-    bool host_encoder = false; // DACAPO_HEVM_HOST_ENCODER=1: encode on the host (HostEncoder), one plaintext at a time
+    bool host_encoder = false; // option host_encoder = 1: encode on the host (HostEncoder), one plaintext at a time
     void ensure_enc_tables();
     void preprocess_device();
     void free_plains();
@@ -227,13 +227,13 @@ class HEVM {
         hipGraph_t graph = nullptr;
         hipGraphExec_t graph_exec = nullptr;
     } plan;
-    bool plan_graph = true; // replay the plan's launch sequence as one HIP graph (DACAPO_HEVM_PLAN_GRAPH=0: issue it launch by launch)
+    bool plan_graph = true; // replay the plan's launch sequence as one HIP graph (option plan_graph = 0: issue it launch by launch)
     void capture_plan();
     void drop_plan_graph();
     void issue_plan(hipStream_t s);
     bool use_plan = true;
     bool test_zero_enc = false; // hevm_test_zero_encryption: encryptions of zero are (0, 0) -- INSECURE, parity tests of opcode 10 only
-    int max_batch = 64; // items per heavy step (DACAPO_HEVM_MAX_BATCH): 64 measured best on the ResNet-20 program (16 ... 256 tried)
+    int max_batch = 64; // items per heavy step (option max_batch): 64 measured best on the ResNet-20 program (16 ... 256 tried)
     std::vector<u64 *> home; // permanent buffer block of every architectural register (program inputs live here)
     // Throughput mode: `streams` independent ciphertext streams share the program, keys and plaintexts; every buffer is a
     // block of `streams` slices and encrypt/decrypt/getCtxt address the slice selected by hevm_select_stream().
@@ -246,11 +246,11 @@ class HEVM {
     void boot_item(CtView src, int src_level, double src_scale, hevm_ctxt &dst, int target_level);
     void plan_zero_encrypt(int first, int B, int t, hipStream_t s);
     void plan_boot_step(int first, int B, int ell, int t, int lane, hipStream_t s, const Handoff &h);
-    int secret_weight = 0; // DACAPO_HEVM_SECRET_HW=h: key generation draws a ternary secret with exactly h non-zero coefficients (0: uniform ternary, SEAL's)
-    bool chain_fusion = true; // DACAPO_HEVM_CHAIN_FUSION=0: every step runs all of its own launches
+    int secret_weight = 0; // option secret_hw = h: key generation draws a ternary secret with exactly h non-zero coefficients (0: uniform ternary, SEAL's)
+    bool chain_fusion = true; // option chain_fusion = 0: every step runs all of its own launches
     hipStream_t aux_stream = nullptr;
-    bool fold_rescale_into_boot = false; // DACAPO_HEVM_FOLD_RESCALE_BOOT=1: do a rescale that only feeds an opcode 10 inside its re-encoder
-    int plan_lanes = 2; // independent steps of a wave also use an auxiliary stream (pays off only inside the graph; DACAPO_HEVM_PLAN_LANES=1: one stream)
+    bool fold_rescale_into_boot = false; // option fold_rescale_boot = 1: do a rescale that only feeds an opcode 10 inside its re-encoder
+    int plan_lanes = 2; // independent steps of a wave also use an auxiliary stream (pays off only inside the graph; option plan_lanes = 1: one stream)
     void bump_epoch(hipStream_t s);
 
     // statistics of the last run()
@@ -262,7 +262,7 @@ class HEVM {
     HEVM() { g_vm_allocs = &allocs; }
     void destroy_device_state(); // streams, events, graph, every tracked allocation; the object is unusable afterwards
     size_t key_elems() const { return (size_t)ctx->key_digits() * 2 * ctx->K * ctx->N; }
-    void init_context(int logN, int K, const u64 *primes);
+    void init_context(int logN, int K, const u64 *primes, int dir_ksp = 0, int dir_alpha = 0);
     void generate_keys(const RngKeys &rng, bool secret, bool pub, bool eval);
     void gen_kswitch_key(u64 *key, const u64 *new_key, u64 key_id);
     void add_galois_key(u32 elt);

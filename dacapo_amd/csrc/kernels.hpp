@@ -25,7 +25,7 @@ void launch_ntt(const Context &c, bool inverse, u64 *data, long limb_stride, int
 void launch_ntt_two_phase(const Context &c, bool inverse, u64 *data, long limb_stride, int count, const int *d_prime_idx,
                           int prime_base, int prime_period, hipStream_t s);
 // single-crossing transform (ntt_full.hip): one 1024-thread workgroup per limb, N = 2^15 only.  launch_ntt takes it for launches of
-// at least ntt_full_min_limbs() limbs (DACAPO_NTT_FULL_MIN_LIMBS / DACAPO_NTT_FULL_INV_MIN_LIMBS; 0 = never)
+// at least ntt_full_min_limbs() limbs (option ntt_full_min_limbs / option ntt_full_inv_min_limbs; 0 = never)
 bool ntt_full_supported(const Context &c);
 long ntt_full_min_limbs(bool inverse);
 void launch_ntt_full(const Context &c, bool inverse, u64 *data, long limb_stride, int count, const int *d_prime_idx, int prime_base,

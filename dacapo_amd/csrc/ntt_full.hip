@@ -469,28 +469,25 @@ long ntt_full_min_limbs(bool inverse)
   // (profiles/r03_ntt_full_check.txt and r03_ntt_full.txt), single-crossing vs two-launch: forward 127 vs 119 us at 512 limbs, 150 vs 157
   // at 640, 159 vs 193 at 768, 216 vs 266 at 1024, 415 vs 587 at 2048, 753 vs 1123 at 4096; inverse 172 vs 149 at 640, 230 vs 204 at 896,
   // 236 vs 244 at 1024, 480 vs 512 at 2048, 919 vs 997 at 4096.  0 = never.
-    static const long f = getenv("DACAPO_NTT_FULL_MIN_LIMBS") ? atol(getenv("DACAPO_NTT_FULL_MIN_LIMBS")) : 640;
-    static const long i = getenv("DACAPO_NTT_FULL_INV_MIN_LIMBS") ? atol(getenv("DACAPO_NTT_FULL_INV_MIN_LIMBS")) : 2048;
-    return inverse ? i : f;
+    return (long)option(inverse ? OPT_NTT_FULL_INV_MIN_LIMBS : OPT_NTT_FULL_MIN_LIMBS);
 }
 
 static int full_persist_grid(bool inverse)
-{ // DACAPO_NTT_FULL_PERSIST / DACAPO_NTT_FULL_INV_PERSIST: workgroups of the persistent grid (default: one per CU); 0 = one workgroup
+{ // options ntt_full_persist / ntt_full_inv_persist: workgroups of the persistent grid (-1, the default: one per CU); 0 = one workgroup
   // per limb.  Measured on 4096 limbs: forward 788 -> 782 us, inverse 896 -> 901 (a tie: both directions take the same form).
-    static const int g[2] = { [] {
-                                 if (const char *e = getenv("DACAPO_NTT_FULL_PERSIST")) return atoi(e);
-                                 int dev = 0, cus = 256;
-                                 if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-                                 return cus;
-                             }(),
-                             [] { return getenv("DACAPO_NTT_FULL_INV_PERSIST") ? atoi(getenv("DACAPO_NTT_FULL_INV_PERSIST")) : -1; }() };
-    return inverse && g[1] >= 0 ? g[1] : g[0];
+    static const int cus = [] {
+        int dev = 0, n = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        return n;
+    }();
+    const int f = (int)option(OPT_NTT_FULL_PERSIST), i = (int)option(OPT_NTT_FULL_INV_PERSIST);
+    const int g = inverse && i >= 0 ? i : f;
+    return g < 0 ? cus : g;
 }
 
 static bool full_pairs()
-{ // DACAPO_NTT_FULL_PAIRS=0: word butterflies in every forward pass (A/B measurements; the pair tables exist either way)
-    static const bool v = !(getenv("DACAPO_NTT_FULL_PAIRS") && atoi(getenv("DACAPO_NTT_FULL_PAIRS")) == 0);
-    return v;
+{ // option ntt_full_pairs = 0: word butterflies in every forward pass (A/B measurements; the pair tables exist either way)
+    return option(OPT_NTT_FULL_PAIRS) != 0;
 }
 
 void launch_ntt_full(const Context &c, bool inverse, u64 *data, long limb_stride, int count, const int *d_prime_idx, int prime_base,

@@ -29,6 +29,7 @@
 
 #include "lane_xchg.hpp"
 #include "modarith.hpp"
+#include "options.hpp"
 
 namespace dacapo {
 
@@ -295,17 +296,10 @@ __device__ __forceinline__ void ntt_tile(const DModulus M, const u64 *__restrict
 
 // geometry choice for a launch of `limbs` limb-phases: the latency geometry while the throughput one would leave most
 // of the 256 CUs without a workgroup, the one-butterfly geometry while even that leaves SIMDs without a wave
-inline long small_tile_threshold()
-{
-    static const long v = getenv("DACAPO_SMALL_TILE_WGS") ? atol(getenv("DACAPO_SMALL_TILE_WGS")) : 5000;
-    return v;
-}
+inline long small_tile_threshold() { return (long)option(OPT_SMALL_TILE_WGS); }
 inline bool use_small_tiles(size_t N, long limbs) { return (long)(N >> kTileLog) * limbs < small_tile_threshold(); }
-inline long tiny_tile_threshold()
-{ // in 512-coefficient workgroups (4 waves each): 256 = one wave on each of the 1024 SIMDs
-    static const long v = getenv("DACAPO_TINY_TILE_WGS") ? atol(getenv("DACAPO_TINY_TILE_WGS")) : 512;
-    return v;
-}
+// in 512-coefficient workgroups (4 waves each): 256 = one wave on each of the 1024 SIMDs
+inline long tiny_tile_threshold() { return (long)option(OPT_TINY_TILE_WGS); }
 inline bool use_tiny_tiles(size_t N, long limbs) { return (long)(N >> TileGeo<1>::LOG) * limbs <= tiny_tile_threshold(); }
 
 } // namespace dacapo

@@ -1,0 +1,125 @@
+// The option table of options.hpp: names, defaults, the one environment variable, and the C entry points hevm_set_option /
+// hevm_get_option / hevm_reset_options (include/hevm_abi.h).  Host-only C++.
+#include "options.hpp"
+
+#include "../../include/hevm_abi.h"
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+namespace dacapo {
+
+struct OptDef {
+    const char *name;
+    long long def;
+};
+// same order as enum Opt.  Launch-shape defaults are measured (profiles/r02_experiments.txt, r03_ntt_full_check.txt, r03_experiments.txt).
+static const OptDef kDefs[OPT_COUNT] = {
+    { "logn", 15 },
+    { "primes", 14 },
+    { "prime_bits", 60 },
+    { "ks_special", 1 },
+    { "ks_alpha", 0 },
+    { "secret_hw", 0 },
+    { "plan", 1 },
+    { "plan_graph", 1 },
+    { "plan_lanes", 2 },
+    { "max_batch", 64 },
+    { "chain_fusion", 1 },
+    { "host_encoder", 0 },
+    { "online_encode", 0 },
+    { "fold_rescale_boot", 0 },
+    { "hyb_mfma", 1 },
+    { "hyb_fuse", 1 },
+    { "seal_compr", 0 },
+    { "trace", 0 },
+    { "step_profile", 0 },
+    { "small_tile_wgs", 5000 },
+    { "tiny_tile_wgs", 512 },
+    { "ntt_full_min_limbs", 640 },
+    { "ntt_full_inv_min_limbs", 2048 },
+    { "ntt_full_persist", -1 },
+    { "ntt_full_inv_persist", -1 },
+    { "ntt_full_pairs", 1 },
+    { "ks_merge_special_min_wgs", 2048 },
+    { "ks_merge_lift_min_wgs", 1024 },
+    { "ks_fuse_mac", 1 },
+    { "ks_big_tiles", 4096 },
+    { "ks_fuse_mac_tiles", 1LL << 40 },
+    { "sum_pair_min_wgs", 1024 },
+};
+
+static long long g_val[OPT_COUNT];
+static bool g_init = false;
+
+static int find(const char *name, size_t len)
+{
+    for (int i = 0; i < OPT_COUNT; i++)
+        if (strlen(kDefs[i].name) == len && !strncmp(kDefs[i].name, name, len)) return i;
+    return -1;
+}
+
+static void unknown(const char *what, const char *name, size_t len)
+{
+    fprintf(stderr, "[dacapo_amd] %s: unknown option \"%.*s\"; known:", what, (int)len, name);
+    for (int i = 0; i < OPT_COUNT; i++) fprintf(stderr, " %s", kDefs[i].name);
+    fprintf(stderr, "\n");
+    abort();
+}
+
+static void init()
+{
+    if (g_init) return;
+    g_init = true;
+    for (int i = 0; i < OPT_COUNT; i++) g_val[i] = kDefs[i].def;
+    const char *e = getenv("DACAPO_HEVM_OPTIONS"); // the only environment variable the library reads
+    while (e && *e) {
+        const char *end = strchr(e, ',');
+        const size_t len = end ? (size_t)(end - e) : strlen(e);
+        const char *eq = (const char *)memchr(e, '=', len);
+        if (len) {
+            if (!eq) unknown("DACAPO_HEVM_OPTIONS (expected name=value)", e, len);
+            const int i = find(e, (size_t)(eq - e));
+            if (i < 0) unknown("DACAPO_HEVM_OPTIONS", e, (size_t)(eq - e));
+            g_val[i] = strtoll(eq + 1, nullptr, 0);
+        }
+        e = end ? end + 1 : nullptr;
+    }
+}
+
+long long option(Opt o)
+{
+    init();
+    return g_val[o];
+}
+
+} // namespace dacapo
+
+extern "C" {
+
+// 0 on success; an unknown name aborts with the list of names (a mistyped option must not silently run the default)
+int hevm_set_option(const char *name, long long value)
+{
+    dacapo::init();
+    const int i = dacapo::find(name, strlen(name));
+    if (i < 0) dacapo::unknown("hevm_set_option", name, strlen(name));
+    dacapo::g_val[i] = value;
+    return 0;
+}
+
+long long hevm_get_option(const char *name)
+{
+    dacapo::init();
+    const int i = dacapo::find(name, strlen(name));
+    if (i < 0) dacapo::unknown("hevm_get_option", name, strlen(name));
+    return dacapo::g_val[i];
+}
+
+// every option back to its default (DACAPO_HEVM_OPTIONS is not re-read)
+void hevm_reset_options(void)
+{
+    dacapo::init();
+    for (int i = 0; i < dacapo::OPT_COUNT; i++) dacapo::g_val[i] = dacapo::kDefs[i].def;
+}
+}

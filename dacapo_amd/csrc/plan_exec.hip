@@ -805,7 +805,7 @@ void HEVM::build_plan()
     P.n_keyswitch *= S, P.n_ntt *= S;
     P.ready = true;
     if (plan_graph) capture_plan(); // part of the (untimed) preparation, like the plan itself
-    if (getenv("DACAPO_HEVM_TRACE")) {
+    if (option(OPT_TRACE)) {
         static const char *kn[] = { "rot", "mulcc", "rescale", "sum", "neg", "mulp", "addp", "copy", "boot", "modraise" };
         size_t nsteps[10] = { 0 }, nitems[10] = { 0 };
         std::map<std::pair<int, int>, std::pair<size_t, size_t>> ks; // (kind, level) -> steps, items
@@ -816,7 +816,7 @@ void HEVM::build_plan()
                 e.first++, e.second += (size_t)st.count;
             }
         }
-        if (atoi(getenv("DACAPO_HEVM_TRACE")) >= 2) { // the first 400 steps, one line per wave
+        if (option(OPT_TRACE) >= 2) { // the first 400 steps, one line per wave
             int lastw = -1;
             for (size_t i = 0; i < P.steps.size() && i < 400; i++) {
                 const Step &st = P.steps[i];
@@ -849,7 +849,7 @@ void HEVM::build_plan()
             fprintf(stderr, "[dacapo_amd] plan:   %-8s level %2d: %5zu steps %6zu items\n", kn[kv.first.first], kv.first.second,
                     kv.second.first, kv.second.second);
     }
-    if (getenv("DACAPO_HEVM_TRACE"))
+    if (option(OPT_TRACE))
         fprintf(stderr, "[dacapo_amd] plan: %zu ops -> %zu pseudo-ops -> %zu steps (%zu on the auxiliary stream, %zu fused into their producer's last kernel) in %d waves, ~%zu launches, %zu live buffers (%.1f GB pool)\n",
                 ops.size(), O.size(), P.steps.size(), (size_t)std::count_if(P.steps.begin(), P.steps.end(), [](const Step &st) { return st.lane == 1; }), P.n_fused,
                 max_wave, P.launches, P.max_live, (double)P.pool.size() * buf_elems * 8 / 1e9);
@@ -863,9 +863,9 @@ void HEVM::issue_plan(hipStream_t s)
         if (P.zenc) DC_HIP_CHECK(hipMemsetAsync(P.zenc, 0, P.zenc_bytes, s));
     } else
         for (const Plan::BootChunk &bc : P.boot_chunks) plan_zero_encrypt(bc.first, bc.count, bc.target, s);
-    // DACAPO_HEVM_STEP_PROFILE=1: synchronise after every step and attribute wall time to (kind, level, batch size) -- a
+    // option step_profile = 1: synchronise after every step and attribute wall time to (kind, level, batch size) -- a
     // diagnosis mode (every step then pays a full launch round trip, as the steps of a dependent chain do anyway)
-    static const bool step_profile = getenv("DACAPO_HEVM_STEP_PROFILE") && atoi(getenv("DACAPO_HEVM_STEP_PROFILE")) && !plan_graph;
+    const bool step_profile = option(OPT_STEP_PROFILE) != 0 && !plan_graph;
     std::map<std::tuple<int, int, int>, std::pair<int, double>> prof;
     size_t ev = 0, eg = 0;
     for (size_t a = 0; a < P.steps.size();) {

@@ -1,6 +1,8 @@
 // SEAL 4.0 serialization (see seal_serial.hpp for the format and the reference call sites it serves).  Host code only.
 #include "seal_serial.hpp"
 
+#include "options.hpp"
+
 #include <dlfcn.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -282,11 +284,11 @@ void Writer::put_dynarray(const uint64_t *data, uint64_t count)
 
 Compr compr_from_env()
 {
-    const char *e = getenv("DACAPO_HEVM_SEAL_COMPR");
-    if (!e || !strcmp(e, "none")) return COMPR_NONE;
-    if (!strcmp(e, "zlib")) return COMPR_ZLIB;
-    if (!strcmp(e, "zstd")) return COMPR_ZSTD;
-    fprintf(stderr, "[dacapo_amd] DACAPO_HEVM_SEAL_COMPR=%s: expected none, zlib or zstd\n", e);
+    const long long v = dacapo::option(dacapo::OPT_SEAL_COMPR);
+    if (v == 0) return COMPR_NONE;
+    if (v == 1) return COMPR_ZLIB;
+    if (v == 2) return COMPR_ZSTD;
+    fprintf(stderr, "[dacapo_amd] option seal_compr = %lld: expected 0 (none), 1 (zlib) or 2 (zstd)\n", v);
     abort();
 }
 

@@ -87,7 +87,7 @@ class Writer {
 // header + (compressed) members -> file
 void write_object_file(const std::string &path, const std::vector<uint8_t> &members, Compr mode);
 std::vector<uint8_t> read_file(const std::string &path);
-Compr compr_from_env(); // DACAPO_HEVM_SEAL_COMPR = none (default) | zlib | zstd
+Compr compr_from_env(); // option seal_compr (options.hpp) = 0 none (default) | 1 zlib | 2 zstd
 bool zstd_available();
 
 struct Params {

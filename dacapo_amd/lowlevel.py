@@ -29,6 +29,11 @@ def lib(path=None):
     return _lib
 
 
+def loaded_libs():
+    """the bound builds of the library, for runner.set_option (each build has its own option table)"""
+    return ([_lib] if _lib is not None else []) + list(_libs.values())
+
+
 def _bind(path):
     if True:  # (one indentation level kept from the single-library version)
         if not path.exists():
@@ -78,6 +83,9 @@ def _bind(path):
         L.dc_poly_add.argtypes = [vp, u64p, u64p, u64p, i32, vp]
         L.dc_galois_elt_from_step.restype = C.c_uint32
         L.dc_galois_elt_from_step.argtypes = [vp, i32]
+        from .runner import bind_options
+
+        bind_options(L)
     return L
 
 

@@ -23,6 +23,9 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+#if defined(__GNUC__)
+#pragma GCC visibility push(default) /* the library is built with -fvisibility=hidden: what this header declares is what it exports */
+#endif
 
 typedef struct dc_context dc_context;
 
@@ -115,6 +118,9 @@ void dc_poly_add(dc_context *ctx, uint64_t *dst, const uint64_t *a, const uint64
 /* GaloisTool::get_elt_from_step (host): step > 0 rotates left; 0 = conjugation; returns 0 if |step| >= N/2 */
 uint32_t dc_galois_elt_from_step(const dc_context *ctx, int step);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -18,6 +18,9 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+#if defined(__GNUC__)
+#pragma GCC visibility push(default) /* the library is built with -fvisibility=hidden: what this header declares is what it exports */
+#endif
 
 /* SEAL_HEVM.cpp:405  -- runner.py:35 declares and passes (char*, bool); the 2nd argument is accepted and ignored */
 void *initFullVM(char *dir, bool device);
@@ -31,7 +34,7 @@ void *initServerVM(char *dir);
  * reader / writer (oracle/seal_format.py), but no file produced by SEAL itself has been read here and none written here has been read
  * by SEAL (SEAL is neither vendored in the reference nor installed; tests/test_seal_diff.py runs where it is).  Keys and all
  * encryption randomness come from ChaCha20 keyed by 512 bits of getrandom(2); the call aborts if that fails.
- * DACAPO_HEVM_SEAL_COMPR = none (default) | zlib | zstd selects the compr_mode of the written files. */
+ * option seal_compr = none (default) | zlib | zstd selects the compr_mode of the written files. */
 void create_context(char *dir);
 /* SEAL_HEVM.cpp:424 */
 void load(void *vm, char *constant, char *vmfile);
@@ -77,6 +80,10 @@ struct hevm_ctxt {
  * reference's hard-coded N = 2^15, 14 primes (SEAL_HEVM.cpp:39-40).  TEST / BENCH ONLY: all randomness is expanded from
  * the 64-bit `seed` so that runs are reproducible -- such keys are NOT secure.  create_context() is the secure path. */
 void *hevm_init_seeded(int logN, int num_primes, uint64_t seed);
+/* ... on an explicit prime chain (every prime = 1 mod 2N, 45..60 bits, the last `ks_special` of them special): e.g. a HEaaN-style mixed
+ * chain, 60-bit base and special primes around 51-bit rescale primes (HEAAN_HEVM.cpp:55-56, profiled_HEAAN_GPU.json).  Primes narrower
+ * than 60 bits need the generic-width build of the library (libSEAL_HEVM_gw.so); the default build aborts with a message. */
+void *hevm_init_seeded_primes(int logN, const uint64_t *primes, int num_primes, uint64_t seed);
 /* the kernel-level context (dc_context*, include/dacapo_ckks.h) behind a VM */
 void *hevm_context(void *vm);
 /* device pointers to key material: relin key, galois key for `elt` (NULL if absent), secret/public key */
@@ -105,7 +112,7 @@ void hevm_select_stream(void *vm, int s);
 /* wall seconds the last run() spent inside opcode 10 (decrypt / re-encode / encrypt) */
 double hevm_last_run_bootstrap_seconds(void *vm);
 /* HBM bytes held for the loaded program's plaintexts (pre-encoded pool, or constants + encode window with
- * DACAPO_HEVM_ONLINE_ENCODE=1: plaintexts encoded at use, HEAAN_HEVM.cpp:266-281) */
+ * option online_encode = 1: plaintexts encoded at use, HEAAN_HEVM.cpp:266-281) */
 uint64_t hevm_plaintext_bytes(void *vm);
 /* Frees a VM: its keys, registers, plaintext pool, plan, streams and graph.  The reference's ABI has no such symbol (its VM handles are
  * allocated with `new` and never freed, SEAL_HEVM.cpp:404-419): a host that creates VMs repeatedly can call this; the handle (and the
@@ -126,6 +133,16 @@ void hevm_test_zero_encryption(void *vm, bool on);
 void hevm_save_ctxt(void *vm, int64_t reg, const char *path);
 void hevm_load_ctxt(void *vm, int64_t reg, const char *path);
 
+/* Run-time options (dacapo_amd/csrc/options.hpp holds the ONE table: names, defaults, meaning).  VM options -- "logn", "primes",
+ * "prime_bits", "ks_special", "ks_alpha", "secret_hw", "plan", "plan_graph", "plan_lanes", "max_batch", "chain_fusion", "host_encoder",
+ * "online_encode", "fold_rescale_boot", "hyb_mfma", "hyb_fuse", "seal_compr", "trace", "step_profile" -- are read when a VM (or kernel-level
+ * context) is created; launch-shape thresholds -- "small_tile_wgs", "tiny_tile_wgs", "ntt_full_min_limbs", ... -- at every launch.
+ * Process-wide, not thread-safe (like the rest of this ABI).  An unknown name aborts with the list of names.  A caller that only knows
+ * the reference's 18 symbols sets the same names through the single environment variable DACAPO_HEVM_OPTIONS="name=value,...". */
+int hevm_set_option(const char *name, long long value);
+long long hevm_get_option(const char *name);
+void hevm_reset_options(void);
+
 /* ---- host-only helpers: SEAL 4.0 serialization and the PRNG's block function, no GPU touched --------------- */
 /* EncryptionParameters::parms_id of CKKS parameters (poly_modulus_degree, primes[0..count)): BLAKE2b-256 */
 void hevm_seal_parms_id(uint64_t poly_modulus_degree, const uint64_t *primes, int count, uint64_t out[4]);
@@ -144,6 +161,9 @@ int hevm_seal_zstd_available(void);
 void hevm_chacha20_block(const uint32_t key[8], uint64_t counter, uint64_t nonce, uint32_t out[16]);
 void hevm_chacha20_blocks_device(const uint32_t key[8], uint64_t counter, uint64_t nonce, int blocks, uint32_t *out_host);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

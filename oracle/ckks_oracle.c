@@ -640,10 +640,8 @@ void orc_divide_round_last(const orc_ctx *c, const int32_t *pidx, int cnt, u64 *
     int pl = pidx[cnt - 1];
     u64 p = c->mod[pl].q, half = p >> 1;
     u64 *last = poly + (size_t)(cnt - 1) * N;
-    u64 *tmp = (u64 *)malloc(N * 8);
     orc_ntt_inv(c, pl, last);
     for (size_t j = 0; j < N; j++) last[j] = addmod(last[j], half, p);
-    free(tmp);
 #pragma omp parallel for if (orc_threads > 1) schedule(dynamic)
     for (int b = 0; b < cnt - 1; b++) {
         int pi = pidx[b];

@@ -4,8 +4,9 @@ import numpy as np
 from oracle.oracle import Ciphertext, Oracle, OracleVM, Plaintext
 
 
-def _import_keys(o: Oracle, hevm, ll):
-    """pull the GPU VM's key material into the oracle so both interpret the program on identical limbs"""
+def _import_keys(o: Oracle, hevm, ll, elts=None, relin=True):
+    """pull the GPU VM's key material into the oracle so both interpret the program on identical limbs.  `elts`: the Galois elements to
+    import (default: SEAL's default set); at N = 2^17 / 39 primes a key is 0.4 GB, so the big-geometry tests name the ones they use."""
     from dacapo_amd import runner
 
     lw = runner.lw
@@ -13,12 +14,54 @@ def _import_keys(o: Oracle, hevm, ll):
     D = o.dnum if (o.ks, o.alpha) != (1, 1) else K - 1   # grouped digits: [dnum][2][K][N]
     o.sk = ll.read_device(lw.hevm_secret_key(hevm.vm), (K, N))
     o.pk = ll.read_device(lw.hevm_public_key(hevm.vm), (2, K, N))
-    o.relin = ll.read_device(lw.hevm_relin_key(hevm.vm), (D, 2, K, N))
+    o.relin = ll.read_device(lw.hevm_relin_key(hevm.vm), (D, 2, K, N)) if relin else None
     o.galois = {}
-    for elt in o.default_galois_elts():
+    for elt in (o.default_galois_elts() if elts is None else elts):
         p = lw.hevm_galois_key(hevm.vm, elt)
-        assert p, f"default Galois key {elt} missing"
+        assert p, f"Galois key {elt} missing"
         o.galois[elt] = ll.read_device(p, (D, 2, K, N))
+
+
+def run_conv_shaped_program(logN, K, tmp_path, seed=31):
+    """a convolution-shaped program -- 19 rotated ct x pt products + 9 bare rotated ciphertexts summed (more than one 16-term and one 8-term
+    reduction window of the n-ary sum), a second reader that is a rotation (the sum is materialised), a ct x ct product and rescales at
+    several levels, 29 rotations incl. multi-hop ones -- on the GPU VM and on the oracle VM: returns what a test asserts on.  Launch-shape
+    options in force around the call select the kernel forms (the plan's graph is recorded by load_mem)."""
+    from dacapo_amd import hevm_asm as ha
+    from dacapo_amd import lowlevel as ll
+    from dacapo_amd import runner
+
+    slots = 1 << (logN - 1)
+    rng = np.random.default_rng(9)
+    b = ha.Builder(slots=slots, init_level=K - 1, policy="lazy", boot_level=K - 1, shadow=True)
+    x, y = b.input(rng.uniform(-1, 1, slots)), b.input(rng.uniform(-1, 1, slots))
+    acc = None
+    for k in range(19):
+        t = b.mul_plain(b.rotate(x if k % 3 else y, 1 << (k % 7)), rng.uniform(-1, 1, slots))
+        acc = t if acc is None else b.add(acc, t)
+    z = b.mul_plain(y, rng.uniform(-1, 1, slots))
+    for k in range(9):
+        acc = b.add(acc, b.rotate(z, 3 + 2 * k))
+    u = b.add(acc, b.rotate(acc, 5))
+    b.output(b.finish(b.mul(u, u)))
+    cst, hv, info = b.assemble()
+    hevm = runner.HEVM(seed=seed, logN=logN, num_primes=K)
+    o = Oracle(logN, K)
+    _import_keys(o, hevm, ll)
+    hevm.load_mem(cst, hv)
+    ovm = _mirror_vm(hevm, ll, o, cst, hv, tmp_path)
+    for i, a in enumerate(b.args):
+        hevm.setInput(i, a.plain)
+        ovm.ciphers[i] = _get_ct(hevm, ll, i)
+    hevm.run()
+    ovm.run()
+    r = ovm.prog.res_dst[0]
+    got, want = _get_ct(hevm, ll, r), ovm.ciphers[r]
+    out = hevm.getOutput()[0]
+    res = {"limbs_identical": bool(got.ell == want.ell and (got.data == want.data).all()), "scale_identical": bool(got.scale == want.scale),
+           "max_error_vs_cleartext": float(np.abs(out - b.expected()[0]).max()), "op_mix": info["op_mix"], "stats": hevm.stats()}
+    hevm.close()
+    return res
 
 
 def _get_ct(hevm, ll, reg):

@@ -29,16 +29,10 @@ def _program(logN, target=3, r=5):
     return K, cst, hv, offs
 
 
-def _vm(logN, K, weight, offs, env=None):
+def _vm(logN, K, weight, offs, opts=None):
     from dacapo_amd import runner
 
-    env = dict(env or {}, DACAPO_HEVM_SECRET_HW=str(weight))
-    os.environ.update(env)
-    try:
-        hevm = runner.HEVM(seed=21, logN=logN, num_primes=K)
-    finally:
-        for k in env:
-            os.environ.pop(k)
+    hevm = runner.HEVM(seed=21, logN=logN, num_primes=K, vm_options=dict(opts or {}, secret_hw=weight))
     if offs:
         hevm.addRotationKeys(offs)
     return hevm
@@ -89,13 +83,13 @@ def test_sparse_secret_and_extension_opcodes_against_the_oracle(tmp_path):
     assert (o.ntt_inv(o.decrypt(ovm.ciphers[1]).data[:1], [0])[0] == m1).all()
 
 
-@pytest.mark.parametrize("plan", ["1", "0"])
+@pytest.mark.parametrize("plan", [1, 0])
 def test_bootstrap_limbs_bit_identical_to_the_oracle(tmp_path, plan):
     from dacapo_amd import lowlevel as ll
 
     logN = 12
     K, cst, hv, offs = _program(logN)
-    hevm = _vm(logN, K, 32, offs, {"DACAPO_HEVM_PLAN": plan})
+    hevm = _vm(logN, K, 32, offs, {"plan": plan})
     o = Oracle(logN, K)
     _import_keys(o, hevm, ll)
     from dacapo_amd import runner

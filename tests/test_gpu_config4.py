@@ -35,11 +35,7 @@ def fixture_nt16():
 def _sparse_vm(logN, K, offs):
     from dacapo_amd import runner
 
-    os.environ["DACAPO_HEVM_SECRET_HW"] = "64"
-    try:
-        hevm = runner.HEVM(seed=0x4845564D, logN=logN, num_primes=K)
-    finally:
-        os.environ.pop("DACAPO_HEVM_SECRET_HW")
+    hevm = runner.HEVM(seed=0x4845564D, logN=logN, num_primes=K, vm_options={"secret_hw": 64})
     if offs:
         hevm.addRotationKeys(offs)
     return hevm
@@ -108,11 +104,7 @@ def test_config4_resnet20_nt16_with_real_bootstraps_decrypts_to_the_torch_logits
     hv, cst = cb.lower_bootstraps(hv0, fx["cst"], 17, K, msg_bits=1, ks=ks)    # bootstrapped values are the activations' inputs: |x| <= 1
     ops = ha.unpack_hevm(hv)["ops"]
     assert int((ops[:, 0] == ha.OP_BOOTSTRAP).sum()) == 0 and int((ops[:, 0] == ha.OP_MODRAISE).sum()) == 38
-    os.environ["DACAPO_HEVM_SECRET_HW"] = "64"
-    try:
-        hevm = runner.HEVM(seed=0x4845564D, logN=17, num_primes=K, ks_special=ks, ks_alpha=alpha)
-    finally:
-        os.environ.pop("DACAPO_HEVM_SECRET_HW")
+    hevm = runner.HEVM(seed=0x4845564D, logN=17, num_primes=K, ks_special=ks, ks_alpha=alpha, vm_options={"secret_hw": 64})
     assert hevm.max_level == 31 and hevm.key_digits == 5
     hevm.addRotationKeys(cb.rotation_offsets(hv))
     hevm.load_mem(cst, hv)

@@ -1,0 +1,156 @@
+"""GPU: the grouped-digit key switch AT BASELINE CONFIG 4's GEOMETRY -- N = 2^17, 31 data + 8 special primes, digits of 7 primes, the base
+conversions on the matrix cores (64 byte planes: the full width of the MFMA operand layout) -- against the oracle, limb for limb.  This is
+the code that carries the config-4 run (dacapo_amd/csrc/hybrid_ks.hip; what it serves in the reference: HEAAN_HEVM.cpp:300-303 rotate,
+:386-399 bootstrap), and tests/test_gpu_hybrid.py only reaches N <= 2^13, alpha <= 3:
+  * kernel level (include/dacapo_ckks.h): one rotation hop and one ct x ct multiply + relinearise at levels 1, 3 (below the matrix-core
+    threshold), 4 (at it), 7 (exactly one digit), 8 (a one-prime last digit), 14 (two digits: where the model runs), 31 (top: 5 digits,
+    partial last one) == orc_rotate_ks_hybrid / orc_keyswitch_hybrid;
+  * a hoisted batch through the VM's plan: five rotations of one ciphertext and two of another in one wave (shared decompositions), at the
+    top level and again at 12 primes, direct keys and a two-hop offset mixed == the oracle VM, which rotates one instruction at a time;
+  * the prefix of the nt = 2^16 ResNet trace on grouped-digit keys (ks = 8, alpha = 7): bit-identical to the oracle VM."""
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from gpu_helpers import _get_ct, _import_keys, _mirror_vm  # noqa: E402
+from oracle.oracle import Ciphertext, Oracle, lib as orc_lib, splitmix_fill  # noqa: E402
+
+LOGN, KS, ALPHA = 17, 8, 7
+K4 = 31 + KS
+GOLDEN = Path(__file__).resolve().parent / "golden" / "resnet20_nt16"
+
+
+def _threads():
+    import os
+
+    orc_lib().orc_set_threads(min(8, os.cpu_count() or 1))   # OpenMP over limbs: same arithmetic per limb (tests/test_oracle_hybrid.py)
+
+
+def test_rotate_hop_and_mul_relin_at_config4_geometry_match_the_oracle():
+    from dacapo_amd import lowlevel as ll
+
+    _threads()
+    N = 1 << LOGN
+    o = Oracle(LOGN, K4)
+    o.set_hybrid(KS, ALPHA)
+    ctx = ll.Context(LOGN, K4, special=KS, alpha=ALPHA)
+    assert ctx.primes == o.primes and ctx.key_digits == o.dnum == 5 and ctx.max_level == o.max_level == 31
+    pr = np.array(o.primes, dtype=np.uint64)
+    # a key is a constant of the key switch: uniform limbs exercise every residue path (a real key's limbs ARE uniform)
+    keys = []
+    for s in (7, 1007):
+        k = np.stack([splitmix_fill(s + i, N) for i in range(o.dnum * 2 * K4)]).reshape(o.dnum, 2, K4, N)
+        k %= pr[None, None, :, None]
+        keys.append(k)
+    elt = o.elt_from_step(5)
+    o.galois[elt], o.relin = keys
+    dk, dr = ll.DeviceBuffer.from_host(keys[0]), ll.DeviceBuffer.from_host(keys[1])
+    L = ll.lib()
+    for ell in (1, 3, 4, 7, 8, 14, 31):
+        q = pr[:ell, None]
+        a = np.stack([np.stack([splitmix_fill(1 + 7 * p + i + 100 * ell, N) for i in range(ell)]) % q for p in range(2)])
+        b = np.stack([np.stack([splitmix_fill(99 + 7 * p + i + 100 * ell, N) for i in range(ell)]) % q for p in range(2)])
+        da, db, dd = ll.DeviceBuffer.from_host(a), ll.DeviceBuffer.from_host(b), ll.DeviceBuffer((2, ell, N))
+        st = ell * N
+        A, B = Ciphertext(a, 2.0**40), Ciphertext(b, 2.0**40)
+        L.dc_ct_rotate_hop(ctx.h, dd.ptr, st, da.ptr, st, elt, dk.ptr, ell, None)
+        assert (dd.to_host() == o.apply_galois(A, elt).data).all(), ("rotate", ell)
+        L.dc_ct_mul_relin(ctx.h, dd.ptr, st, da.ptr, st, db.ptr, st, dr.ptr, ell, None)
+        assert (dd.to_host() == o.mul_relin(A, B).data).all(), ("mul_relin", ell)
+
+
+@pytest.mark.parametrize("plan", [1, 0])
+def test_hoisted_rotation_batch_at_config4_geometry_matches_the_oracle_vm(tmp_path, plan):
+    from dacapo_amd import hevm_asm as ha
+    from dacapo_amd import lowlevel as ll
+    from dacapo_amd import runner
+
+    _threads()
+    slots = 1 << (LOGN - 1)
+    rng = np.random.default_rng(17)
+    b = ha.Builder(slots=slots, init_level=31, policy="lazy", boot_level=31, shadow=True)
+    x, y = b.input(rng.uniform(-1, 1, slots)), b.input(rng.uniform(-1, 1, slots))
+    offs_x, offs_y = (1, 2, 3, 5, 8), (7, 6)                           # 6 = 8 - 2 under the default keys: two hops; the others get direct keys
+    direct = [1, 2, 3, 5, 8, 7]
+
+    def taps(u, v):
+        acc = None
+        for k, w in zip(offs_x, rng.uniform(-1, 1, len(offs_x))):
+            t = b.mul_plain(b.rotate(u, k), [float(w)])
+            acc = t if acc is None else b.add(acc, t)
+        for k in offs_y:
+            acc = b.add(acc, b.mul_plain(b.rotate(v, k), [0.5]))
+        return acc
+
+    top = taps(x, y)                                                   # seven rotations in one wave at 31 primes
+    xl, yl = b.modswitch(x, 19), b.modswitch(y, 19)                    # ... and at 12 primes, where config 4's convolutions run
+    low = taps(xl, yl)
+    b.output(b.finish(top))
+    b.output(b.finish(low))
+    cst, hv, _ = b.assemble()
+    hevm = runner.HEVM(seed=5, logN=LOGN, num_primes=K4, ks_special=KS, ks_alpha=ALPHA, vm_options={"plan": plan})
+    assert hevm.max_level == 31 and hevm.key_digits == 5
+    hevm.addRotationKeys(direct)
+    o = Oracle(LOGN, K4)
+    o.set_hybrid(KS, ALPHA)
+    elts = sorted({o.elt_from_step(s) for s in direct + [8, -2]})
+    _import_keys(o, hevm, ll, elts=elts, relin=False)
+    hevm.load_mem(cst, hv)
+    ovm = _mirror_vm(hevm, ll, o, cst, hv, tmp_path)
+    for i, a in enumerate(b.args):
+        hevm.setInput(i, a.plain)
+        ovm.ciphers[i] = _get_ct(hevm, ll, i)
+    hevm.run()
+    ovm.run()
+    for i in range(2):
+        r = ovm.prog.res_dst[i]
+        got, want = _get_ct(hevm, ll, r), ovm.ciphers[r]
+        assert got.ell == want.ell and got.scale == want.scale
+        assert (got.data == want.data).all(), (plan, i)
+    out = hevm.getOutput()
+    for i in range(2):
+        assert np.abs(out[i] - b.expected()[i]).max() < 1e-5
+    hevm.close()
+
+
+def test_nt16_prefix_bit_exact_at_n17_on_grouped_digit_keys(tmp_path):
+    """tests/test_gpu_config4.py::test_nt16_prefix_bit_exact_at_n17 with ks_special = 8, ks_alpha = 7: the stem convolution of the nt = 2^16
+    trace as config 4 runs it (the .b14 lowering: 27 rotations at 14 primes as NAF hops of the default Galois keys, 25 ct x pt, 2 rescales) through the grouped-digit sequence, rotations of one
+    source sharing their decomposition"""
+    from dacapo_amd import hevm_asm as ha
+    from dacapo_amd import lowlevel as ll
+    from dacapo_amd import runner
+
+    _threads()
+    import gzip
+
+    fx = ha.read_fixture(GOLDEN)
+    hv0 = gzip.open(str(GOLDEN) + ".b14.hevm.gz").read()               # the lowering config 4 runs: inputs at 14 primes -> two digits
+    prog = ha.unpack_hevm(hv0)
+    ops, init_level = prog["ops"], int(prog["init_level"])
+    first_boot = int(np.nonzero(ops[:, 0] == ha.OP_BOOTSTRAP)[0][0])
+    hv, lvl, _ = ha.truncate_hevm(hv0, first_boot)
+    K = init_level + KS
+    hevm = runner.HEVM(seed=0x4845564D, logN=LOGN, num_primes=K, ks_special=KS, ks_alpha=ALPHA)
+    assert hevm.max_level == init_level == 14 and hevm.key_digits == 2
+    hevm.load_mem(fx["cst"], hv)
+    o = Oracle(LOGN, K)
+    o.set_hybrid(KS, ALPHA)
+    rot = {int(np.array(r, dtype=np.uint16).astype(np.int16)) for op, _, _, r in ops[:first_boot].tolist() if op == ha.OP_ROTATE}
+    o.galois = dict.fromkeys(o.default_galois_elts())                   # the default-set hops this prefix takes (Evaluator::rotate_internal's NAF)
+    elts = {e for s in rot for e in o.rotate_hops(s)}
+    _import_keys(o, hevm, ll, elts=sorted(elts), relin=False)
+    ovm = _mirror_vm(hevm, ll, o, fx["cst"], hv, tmp_path)
+    hevm.setInput(0, fx["packed"])
+    ovm.ciphers[0] = _get_ct(hevm, ll, 0)
+    hevm.run()
+    ovm.run()
+    reg = ovm.prog.res_dst[0]
+    got, want = _get_ct(hevm, ll, reg), ovm.ciphers[reg]
+    assert got.ell == want.ell == lvl and got.scale == want.scale
+    assert (got.data == want.data).all()
+    assert hevm.stats()["keyswitches"] >= 27
+    hevm.close()

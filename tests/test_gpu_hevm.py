@@ -16,22 +16,14 @@ from gpu_helpers import _get_ct, _import_keys, _mirror_vm  # noqa: E402
 def vm13(request):
     """plan   = default: the batched execution plan (SSA-renamed registers, one batched launch sequence per wave; independent
              steps of a wave on an auxiliary stream; the whole sequence replayed as one HIP graph);
-    eager  = the reference's dispatch loop, one instruction at a time on one stream (DACAPO_HEVM_PLAN=0);
+    eager  = the reference's dispatch loop, one instruction at a time on one stream (option plan = 0);
     plan1  = the plan issued launch by launch on one stream (no graph, no auxiliary stream)."""
-    import os
-
     from dacapo_amd import lowlevel as ll
     from dacapo_amd import runner
 
-    env = {"plan": {}, "eager": {"DACAPO_HEVM_PLAN": "0"},
-           "plan1": {"DACAPO_HEVM_PLAN_LANES": "1", "DACAPO_HEVM_PLAN_GRAPH": "0"}}[request.param]
-    os.environ.update(env)
-    try:
-        hevm = runner.HEVM(seed=0x4845564D, logN=13, num_primes=7)
-        hevm.mode = request.param
-    finally:
-        for k in env:
-            os.environ.pop(k)
+    opts = {"plan": {}, "eager": {"plan": 0}, "plan1": {"plan_lanes": 1, "plan_graph": 0}}[request.param]
+    hevm = runner.HEVM(seed=0x4845564D, logN=13, num_primes=7, vm_options=opts)
+    hevm.mode = request.param
     o = Oracle(13, 7)
     _import_keys(o, hevm, ll)
     return hevm, o, ll
@@ -158,15 +150,13 @@ def read_hevm_bytes(hv):
         return read_hevm(f.name)
 
 
-def test_file_based_runner_sequence(tmp_path, monkeypatch):
+def test_file_based_runner_sequence(tmp_path):
     """the reference's call sequence through files: create_context -> initFullVM -> load -> encrypt -> run -> decrypt"""
     from dacapo_amd import hevm_asm as ha
     from dacapo_amd import runner
 
-    monkeypatch.setenv("DACAPO_HEVM_LOGN", "12")
-    monkeypatch.setenv("DACAPO_HEVM_PRIMES", "4")
     keydir = tmp_path / "keys"
-    hevm = runner.HEVM(path=str(keydir))
+    hevm = runner.HEVM(path=str(keydir), vm_options={"logn": 12, "primes": 4})
     assert sorted(p.name for p in keydir.iterdir()) == ["gal.seal", "parm.seal", "pub.seal", "relin.seal", "sec.seal"]
     assert hevm.logN == 12 and hevm.K == 4
     rng = np.random.default_rng(3)
@@ -344,7 +334,7 @@ def test_large_batch_path_bit_exact(tmp_path):
 
 def test_device_encoder_is_bit_identical_to_host_encoder():
     """preprocess() encodes every plaintext register in batched device kernels (encoder.hip) and decrypt() decodes on the
-    device; DACAPO_HEVM_HOST_ENCODER=1 keeps the one-at-a-time host FFTs.  Encoder: same algorithm, same operation order,
+    device; option host_encoder = 1 keeps the one-at-a-time host FFTs.  Encoder: same algorithm, same operation order,
     no FMA contraction: identical limbs.  Decoder: same values to 1e-10."""
     import ctypes
     import os
@@ -367,12 +357,7 @@ def test_device_encoder_is_bit_identical_to_host_encoder():
     assert info["num_ptxt"] == 17
     plains, decoded = [], []
     for host in (False, True):
-        if host:
-            os.environ["DACAPO_HEVM_HOST_ENCODER"] = "1"
-        try:
-            hevm = runner.HEVM(seed=5, logN=13, num_primes=7)
-        finally:
-            os.environ.pop("DACAPO_HEVM_HOST_ENCODER", None)
+        hevm = runner.HEVM(seed=5, logN=13, num_primes=7, vm_options={"host_encoder": int(host)})
         hevm.load_mem(cst, hv)
         got = []
         for i in range(info["num_ptxt"]):
@@ -554,15 +539,14 @@ def test_random_lazy_programs_with_bootstraps(vm13, seed):
         assert np.sqrt(np.mean((res[k] - ref) ** 2)) < 2e-5 * max(1.0, float(np.abs(ref).max())), (seed, k, info["op_mix"])
 
 
-@pytest.mark.parametrize("plan", ["1", "0"])
-def test_zero_hop_rotate_is_a_copy_not_an_alias(monkeypatch, plan):
+@pytest.mark.parametrize("plan", [1, 0])
+def test_zero_hop_rotate_is_a_copy_not_an_alias(plan):
     """rotate by 0 into ANOTHER register copies (rotate_vector, SEAL_HEVM.cpp:273).  The reference's addcp then overwrites the
     scale of its lhs register only (:308): the copy must keep the old scale, in the plan (SSA values) as in the eager loop."""
     from dacapo_amd import hevm_asm as ha
     from dacapo_amd import runner
 
-    monkeypatch.setenv("DACAPO_HEVM_PLAN", plan)
-    hevm = runner.HEVM(seed=7, logN=12, num_primes=4)
+    hevm = runner.HEVM(seed=7, logN=12, num_primes=4, vm_options={"plan": plan})
     E, ROT, ADDCP = ha.OP_ENCODE, ha.OP_ROTATE, ha.OP_ADDCP
     ops = [(E, 0, 0, (3 << 10) + 20),   # plaintext at scale 2^20
            (ROT, 1, 0, 0),              # r1 = copy of r0 (scale 2^30)
@@ -659,8 +643,8 @@ def test_direct_rotation_keys_make_rotations_single_hops(tmp_path):
     assert np.sqrt(np.mean((res - b.expected()[0]) ** 2)) < 1e-5 and np.abs(res - base).max() < 1e-4
 
 
-def test_online_encode_is_bit_identical_to_the_pre_encoded_pool(monkeypatch):
-    """DACAPO_HEVM_ONLINE_ENCODE=1 (the HEaaN runtime's way, HEAAN_HEVM.cpp:266-281,353-363): constants stay resident as doubles
+def test_online_encode_is_bit_identical_to_the_pre_encoded_pool():
+    """option online_encode = 1 (the HEaaN runtime's way, HEAAN_HEVM.cpp:266-281,353-363): constants stay resident as doubles
     and every plaintext register is encoded right before the wave that first reads it, into a window recycled wave by wave.  Same
     seed, same program, same input: the result limbs equal the pre-encoded run's bit for bit, and the plaintext footprint shrinks."""
     from dacapo_amd import hevm_asm as ha
@@ -681,8 +665,7 @@ def test_online_encode_is_bit_identical_to_the_pre_encoded_pool(monkeypatch):
     cst, hv, info = b.assemble()
     res = {}
     for mode in ("0", "1"):
-        monkeypatch.setenv("DACAPO_HEVM_ONLINE_ENCODE", mode)
-        hevm = runner.HEVM(seed=77, logN=13, num_primes=7)
+        hevm = runner.HEVM(seed=77, logN=13, num_primes=7, vm_options={"online_encode": int(mode)})
         hevm.load_mem(cst, hv)
         hevm.setInput(0, x.plain)
         hevm.run()
@@ -742,43 +725,45 @@ def test_destroy_returns_the_vms_memory():
     assert free0 - free1 < one_vm, f"{(free0 - free1) / 1e6:.1f} MB still held after four create/destroy cycles"
 
 
-@pytest.mark.parametrize("min_wgs", ["0", "1000000000000"])
-def test_n_ary_sum_kernels_match_the_oracle_vm(min_wgs):
+@pytest.mark.parametrize("min_wgs", [0, 10**12])
+def test_n_ary_sum_kernels_match_the_oracle_vm(tmp_path, min_wgs):
     """batch_ops.hip b_sum: a convolution-shaped sum (19 ciphertext x plaintext products + 9 bare ciphertexts: more than one 16-term and one
     8-term reduction window) in both forms of the kernel -- both polynomials of an item in one thread (large launches) and one polynomial
-    per workgroup -- equals the oracle VM's multiply_plain / add sequence limb for limb.  A child process: the threshold is read once."""
-    import json
-    import os
-    import subprocess
-    import sys
-    from pathlib import Path
+    per workgroup -- equals the oracle VM's multiply_plain / add sequence limb for limb.  The launch-shape option is flipped in-process
+    (hevm_set_option; round 3 had to fork a child per setting because the threshold was latched from the environment)."""
+    from dacapo_amd import runner
+    from gpu_helpers import run_conv_shaped_program
 
-    root = Path(__file__).resolve().parent.parent
-    env = dict(os.environ, DACAPO_SUM_PAIR_MIN_WGS=min_wgs)
-    out = subprocess.run([sys.executable, str(root / "tools" / "sum_pair_check.py"), "13", "5"], env=env, capture_output=True, text=True, timeout=900)
-    assert out.returncode == 0, out.stderr[-1500:]
-    res = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    with runner.options(sum_pair_min_wgs=min_wgs):
+        res = run_conv_shaped_program(13, 5, tmp_path)
     assert res["limbs_identical"] and res["scale_identical"] and res["max_error_vs_cleartext"] < 1e-4
     assert res["op_mix"]["mulcp"] >= 20 and res["op_mix"]["addcc"] >= 27
 
 
-@pytest.mark.parametrize("min_wgs", ["0", "1000000000000"])
-def test_merged_and_fine_launch_shapes_of_the_key_switch_match_the_oracle_vm(min_wgs):
+@pytest.mark.parametrize("min_wgs", [0, 10**12])
+def test_merged_and_fine_launch_shapes_of_the_key_switch_match_the_oracle_vm(tmp_path, min_wgs):
     """fused_ks.hip: the MERGE instantiations of L2 / L6 (one inverse COLS phase per source limb for all its target moduli) and of the fused
     L3-L5 kernel (both special-prime accumulators in one workgroup row) against the fine-grained ones, each forced for every launch of a
-    program with 29 rotations (multi-hop), a ct x ct product and rescales at several levels: both equal the oracle VM limb for limb.  A
-    child process: the thresholds are read once."""
-    import json
-    import os
-    import subprocess
-    import sys
-    from pathlib import Path
+    program with 29 rotations (multi-hop), a ct x ct product and rescales at several levels: both equal the oracle VM limb for limb."""
+    from dacapo_amd import runner
+    from gpu_helpers import run_conv_shaped_program
 
-    root = Path(__file__).resolve().parent.parent
-    env = dict(os.environ, DACAPO_KS_MERGE_LIFT_MIN_WGS=min_wgs, DACAPO_KS_MERGE_SPECIAL_MIN_WGS=min_wgs)
-    for logN, K in (("13", "5"), ("12", "7")):
-        out = subprocess.run([sys.executable, str(root / "tools" / "sum_pair_check.py"), logN, K], env=env, capture_output=True, text=True, timeout=900)
-        assert out.returncode == 0, out.stderr[-1500:]
-        res = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
-        assert res["limbs_identical"] and res["scale_identical"] and res["max_error_vs_cleartext"] < 1e-4
-        assert res["stats"]["keyswitches"] >= 40
+    with runner.options(ks_merge_lift_min_wgs=min_wgs, ks_merge_special_min_wgs=min_wgs):
+        for logN, K in ((13, 5), (12, 7)):
+            res = run_conv_shaped_program(logN, K, tmp_path)
+            assert res["limbs_identical"] and res["scale_identical"] and res["max_error_vs_cleartext"] < 1e-4
+            assert res["stats"]["keyswitches"] >= 40
+
+
+def test_options_table_round_trips_and_rejects_nothing_silently():
+    """hevm_set_option / hevm_get_option / hevm_reset_options (include/hevm_abi.h): a value set is the value read, a with-block restores,
+    reset returns to the documented defaults -- the reference's ring among them (SEAL_HEVM.cpp:39-40: N = 2^15, 14 primes)"""
+    from dacapo_amd import runner
+
+    assert runner.get_option("logn") == 15 and runner.get_option("primes") == 14 and runner.get_option("plan") == 1
+    with runner.options(sum_pair_min_wgs=7, plan=0):
+        assert runner.get_option("sum_pair_min_wgs") == 7 and runner.get_option("plan") == 0
+    assert runner.get_option("sum_pair_min_wgs") == 1024 and runner.get_option("plan") == 1
+    runner.set_option("max_batch", 16)
+    runner.lw.hevm_reset_options()
+    assert runner.get_option("max_batch") == 64

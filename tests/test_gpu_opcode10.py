@@ -25,14 +25,13 @@ def _centered_diff(o, a, b, ell):
     return np.where(d > int(q) // 2, d - np.int64(int(q)), d)
 
 
-@pytest.mark.parametrize("plan", ["1", "0"])
-def test_reencoded_plaintext_matches_decode_then_encode(monkeypatch, plan):
+@pytest.mark.parametrize("plan", [1, 0])
+def test_reencoded_plaintext_matches_decode_then_encode(plan):
     from dacapo_amd import hevm_asm as ha
     from dacapo_amd import lowlevel as ll
     from dacapo_amd import runner
 
-    monkeypatch.setenv("DACAPO_HEVM_PLAN", plan)
-    hevm = runner.HEVM(seed=0x4845564D, logN=13, num_primes=7)
+    hevm = runner.HEVM(seed=0x4845564D, logN=13, num_primes=7, vm_options={"plan": plan})
     o = Oracle(13, 7)
     _import_keys(o, hevm, ll)
     runner.lw.hevm_test_zero_encryption(hevm.vm, True)

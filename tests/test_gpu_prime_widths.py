@@ -86,21 +86,46 @@ def test_both_builds_agree_on_the_reference_chain():
     gw.dc_context_destroy(h)
 
 
-def test_vm_program_on_a_51_bit_chain_matches_the_oracle_vm():
-    """the whole boundary on 51-bit primes: key generation, encode, encrypt, a program with rotations (incl. multi-hop NAF offsets), ct x ct,
-    ct x pt, rescales by 51-bit primes, decrypt / decode -- GPU VM (generic-width build) == oracle VM limb for limb.  A child process: the
-    VM binding picks its library at import time."""
-    import json
-    import os
-    import subprocess
-    import sys
-    from pathlib import Path
+def _vm_program(slots, levels, bits):
+    from dacapo_amd import hevm_asm as ha
 
-    root = Path(__file__).resolve().parent.parent
-    env = dict(os.environ, DACAPO_AMD_LIB=str(root / "dacapo_amd" / "lib" / "libSEAL_HEVM_gw.so"), DACAPO_HEVM_PRIME_BITS="51")
-    out = subprocess.run([sys.executable, str(root / "tools" / "narrow_chain_demo.py"), "12", "7"], env=env, capture_output=True, text=True, timeout=900)
-    assert out.returncode == 0, out.stderr[-1500:]
-    res = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
-    assert res["prime_bits"] == 51 and res["limbs_identical"] and res["scale_identical"]
-    assert res["max_error_vs_cleartext"] < 1e-5
-    assert res["op_mix"]["rescale"] >= 2 and res["op_mix"]["mulcc"] == 2
+    rng = np.random.default_rng(6)
+    # ciphertexts at 2^40, plaintexts at one prime's worth of scale (2^bits), one rescale per product: the lazy policy with `bits`-bit primes
+    b = ha.Builder(slots=slots, init_level=levels, policy="lazy", boot_level=levels, rescale_bits=bits, shadow=True)
+    x, y = b.input(rng.uniform(-1, 1, slots)), b.input(rng.uniform(-1, 1, slots))
+    t = b.add(b.mul(x, y), b.rotate(x, 3))
+    t = b.add(b.mul_plain(t, rng.uniform(-1, 1, slots)), b.rotate(y, -5))
+    u = b.mul(t, t)
+    u = b.add(u, b.rotate(b.mul_plain(x, [0.25]), 33))
+    b.output(b.finish(u))
+    return b
+
+
+def test_vm_program_on_a_51_bit_chain_matches_the_oracle_vm(tmp_path):
+    """the whole boundary on 51-bit primes: key generation, encode, encrypt, a program with rotations (incl. multi-hop NAF offsets), ct x ct,
+    ct x pt, rescales by 51-bit primes, decrypt / decode -- GPU VM (generic-width build, picked by runner.HEVM from option prime_bits) ==
+    oracle VM limb for limb, in the same process as the 60-bit VMs of the other tests (round 3 needed a child: the binding was per process)"""
+    from dacapo_amd import lowlevel as ll
+    from dacapo_amd import runner
+    from gpu_helpers import _get_ct, _import_keys, _mirror_vm
+
+    logN, K, bits = 12, 7, 51
+    b = _vm_program(1 << (logN - 1), K - 1, bits)
+    cst, hv, info = b.assemble()
+    hevm = runner.HEVM(seed=77, logN=logN, num_primes=K, vm_options={"prime_bits": bits})
+    o = Oracle(logN, K, bit_size=bits)
+    assert [int(p).bit_length() for p in o.primes] == [bits] * K
+    _import_keys(o, hevm, ll)
+    hevm.load_mem(cst, hv)
+    ovm = _mirror_vm(hevm, ll, o, cst, hv, tmp_path)
+    for i, a in enumerate(b.args):
+        hevm.setInput(i, a.plain)
+        ovm.ciphers[i] = _get_ct(hevm, ll, i)
+    hevm.run()
+    ovm.run()
+    r = ovm.prog.res_dst[0]
+    got, want = _get_ct(hevm, ll, r), ovm.ciphers[r]
+    assert got.ell == want.ell and got.scale == want.scale and (got.data == want.data).all()
+    assert np.abs(hevm.getOutput()[0] - b.expected()[0]).max() < 1e-5
+    assert info["op_mix"]["rescale"] >= 2 and info["op_mix"]["mulcc"] == 2
+    hevm.close()

@@ -57,17 +57,9 @@ def test_resnet20_first_layer_bit_exact(vm15, fixture20, tmp_path):
 
 def test_resnet20_single_stream_no_graph(fixture20):
     """the plan issued launch by launch on one stream (the default replays it as one HIP graph with an auxiliary stream)"""
-    import os
-
     from dacapo_amd import runner
 
-    env = {"DACAPO_HEVM_PLAN_LANES": "1", "DACAPO_HEVM_PLAN_GRAPH": "0"}
-    os.environ.update(env)
-    try:
-        hevm = runner.HEVM(seed=0x4845564D + 1, logN=15, num_primes=14)
-    finally:
-        for k in env:
-            os.environ.pop(k)
+    hevm = runner.HEVM(seed=0x4845564D + 1, logN=15, num_primes=14, vm_options={"plan_lanes": 1, "plan_graph": 0})
     hevm.load_mem(fixture20["cst"], fixture20["hevm"])
     hevm.setInput(0, fixture20["packed"])
     for _ in range(2):
@@ -78,15 +70,9 @@ def test_resnet20_single_stream_no_graph(fixture20):
 
 def test_resnet20_rescale_folded_into_opcode10(fixture20):
     """opt-in: a rescale that only feeds an opcode 10 is done inside its re-encoder; same logits"""
-    import os
-
     from dacapo_amd import runner
 
-    os.environ["DACAPO_HEVM_FOLD_RESCALE_BOOT"] = "1"
-    try:
-        hevm = runner.HEVM(seed=0x4845564D + 4, logN=15, num_primes=14)
-    finally:
-        os.environ.pop("DACAPO_HEVM_FOLD_RESCALE_BOOT")
+    hevm = runner.HEVM(seed=0x4845564D + 4, logN=15, num_primes=14, vm_options={"fold_rescale_boot": 1})
     hevm.load_mem(fixture20["cst"], fixture20["hevm"])
     hevm.setInput(0, fixture20["packed"])
     hevm.run()
@@ -164,17 +150,11 @@ def test_resnet20_other_lowerings_decrypt_to_the_same_logits(fixture20, tag):
 
 
 def test_resnet20_online_encode_shrinks_the_plaintext_footprint(fixture20):
-    """DACAPO_HEVM_ONLINE_ENCODE=1: the 5 894 plaintext registers are encoded at use from the resident constants (0.5 GB of doubles)
+    """option online_encode = 1: the 5 894 plaintext registers are encoded at use from the resident constants (0.5 GB of doubles)
     into a recycled window instead of living pre-encoded in HBM (6 GB); same logits"""
-    import os
-
     from dacapo_amd import runner
 
-    os.environ["DACAPO_HEVM_ONLINE_ENCODE"] = "1"
-    try:
-        hevm = runner.HEVM(seed=0x4845564D + 6, logN=15, num_primes=14)
-    finally:
-        os.environ.pop("DACAPO_HEVM_ONLINE_ENCODE")
+    hevm = runner.HEVM(seed=0x4845564D + 6, logN=15, num_primes=14, vm_options={"online_encode": 1})
     hevm.load_mem(fixture20["cst"], fixture20["hevm"])
     hevm.setInput(0, fixture20["packed"])
     hevm.run()

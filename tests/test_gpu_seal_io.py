@@ -26,18 +26,12 @@ def _dev(ll, ptr, shape):
 
 @pytest.fixture(scope="module")
 def keydir(tmp_path_factory):
-    """create_context at N = 2^12, 4 primes (the reference hard-codes 2^15 / 14; the environment shrinks it for tests)"""
-    import os
-
+    """create_context at N = 2^12, 4 primes (the reference hard-codes 2^15 / 14; options logn / primes shrink it for tests)"""
     from dacapo_amd import runner
 
     d = tmp_path_factory.mktemp("seal_keys")
-    os.environ["DACAPO_HEVM_LOGN"], os.environ["DACAPO_HEVM_PRIMES"] = "12", "4"
-    try:
-        runner.reinit_lw()
+    with runner.options(logn=12, primes=4):
         runner.lw.create_context(str(d).encode())
-    finally:
-        os.environ.pop("DACAPO_HEVM_LOGN"), os.environ.pop("DACAPO_HEVM_PRIMES")
     return d
 
 
@@ -90,15 +84,10 @@ def test_created_key_directory_is_seal_format(keydir):
 
 def test_two_contexts_never_share_randomness(keydir, tmp_path):
     """create_context draws from getrandom(): two directories made by the same binary have unrelated keys"""
-    import os
-
     from dacapo_amd import runner
 
-    os.environ["DACAPO_HEVM_LOGN"], os.environ["DACAPO_HEVM_PRIMES"] = "12", "4"
-    try:
+    with runner.options(logn=12, primes=4):
         runner.lw.create_context(str(tmp_path).encode())
-    finally:
-        os.environ.pop("DACAPO_HEVM_LOGN"), os.environ.pop("DACAPO_HEVM_PRIMES")
     a, b = sf.read_key_dir(keydir), sf.read_key_dir(tmp_path)
     assert (a["sk"]["data"] != b["sk"]["data"]).mean() > 0.4 and (a["pk"]["data"][1] != b["pk"]["data"][1]).mean() > 0.99
 
@@ -155,14 +144,9 @@ def test_ciphertext_files_round_trip_and_carry_the_level_id(keydir, tmp_path):
     hevm.load_mem(cst, hv)
     hevm.setInput(0, x)
     o = Oracle(12, 4)
-    for compr in ("none", "zlib"):
-        import os
-
-        os.environ["DACAPO_HEVM_SEAL_COMPR"] = compr
-        try:
+    for compr in (0, 1):                                                 # option seal_compr: none, zlib
+        with runner.options(seal_compr=compr):
             hevm.saveCtxt(0, tmp_path / "in.ct")
-        finally:
-            os.environ.pop("DACAPO_HEVM_SEAL_COMPR")
         ct, _ = sf.read_ciphertext_members(sf.unwrap((tmp_path / "in.ct").read_bytes())[0])
         dev = _get_ct(hevm, ll, 0)
         assert ct["limbs"] == 3 and ct["parms_id"] == sf.parms_id(o.N, o.primes[:3]) and ct["scale"] == 2.0**40

@@ -62,6 +62,7 @@ def test_library_exports_every_declared_symbol(which):
     for h in ("hevm_abi.h", "dacapo_ckks.h"):
         text = (ROOT / "include" / h).read_text()
         text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        text = re.sub(r"^\s*#.*$", "", text, flags=re.M)          # preprocessor lines (#pragma GCC visibility push(default))
         names |= set(re.findall(r"\b(\w+)\s*\([^;{]*\)\s*;", text))
     names -= {"defined"}
     reference_18 = {"initFullVM", "initClientVM", "initServerVM", "create_context", "load", "loadClient", "encrypt", "decrypt",
@@ -70,6 +71,34 @@ def test_library_exports_every_declared_symbol(which):
     assert reference_18 <= names and len(names) >= 18 + 25
     for n in sorted(names):
         assert hasattr(lib, n), n
+    # ... and NOTHING else: -fvisibility=hidden + csrc/exports.map (round 3's library exported ~250 dacapo:: C++ symbols next to these)
+    import subprocess
+
+    path = LIB_PATH if which == "default" else LIB_PATH_GW
+    nm = subprocess.run(["nm", "-D", "--defined-only", str(path)], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in nm.splitlines() if ln.strip()}
+    assert exported == names, (sorted(exported - names), sorted(names - exported))
+    listed = set(re.findall(r"^\s+(\w+);", (ROOT / "dacapo_amd" / "csrc" / "exports.map").read_text(), flags=re.M))
+    assert listed == names
+
+
+def test_options_come_from_one_environment_variable(tmp_path):
+    """a caller that only knows the reference's 18 symbols configures the library through ONE environment variable,
+    DACAPO_HEVM_OPTIONS="name=value,..." (csrc/options.hpp), parsed the first time an option is read; a mistyped name aborts with the list
+    of names instead of silently running the default.  Host-only: no GPU call."""
+    import subprocess
+    import sys
+
+    code = ("import ctypes, sys; sys.path.insert(0, %r); from dacapo_amd import runner; L = runner.reinit_lw();"
+            "print(L.hevm_get_option(b'logn'), L.hevm_get_option(b'primes'), L.hevm_get_option(b'plan'), L.hevm_get_option(b'sum_pair_min_wgs'))" % str(ROOT))
+    import os
+
+    env = dict(os.environ, DACAPO_HEVM_OPTIONS="logn=12,primes=4,sum_pair_min_wgs=0")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.split() == ["12", "4", "1", "0"], out.stderr[-500:]
+    env = dict(os.environ, DACAPO_HEVM_OPTIONS="logn=12,primse=4")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode != 0 and "unknown option" in out.stderr and "primes" in out.stderr
 
 
 def test_outputs_keep_their_registers_when_used_afterwards():

@@ -10,7 +10,6 @@ from pathlib import Path
 import numpy as np
 
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
-os.environ.setdefault("DACAPO_HEVM_SECRET_HW", "64")
 from dacapo_amd import ckks_boot as cb  # noqa: E402
 from dacapo_amd import hevm_asm as ha  # noqa: E402
 from dacapo_amd import runner  # noqa: E402
@@ -28,7 +27,7 @@ msg = np.random.default_rng(3).uniform(-1, 1, slots)
 sim = cb.simulate(hv, cst, [msg], logN, em.primes)[0]
 print("cleartext simulation: max error", np.abs(sim - msg).max())
 t0 = time.time()
-hevm = runner.HEVM(seed=5, logN=logN, num_primes=K, ks_special=ks)
+hevm = runner.HEVM(seed=5, logN=logN, num_primes=K, ks_special=ks, vm_options={"secret_hw": 64})
 print(f"context + keys: {time.time()-t0:.1f} s")
 if direct:
     offs = offs_all

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Where the GPU idles inside the last run() of a rocprofv3 --kernel-trace CSV: idle time before a kernel = its start minus the latest
-end of everything that started earlier, grouped by (previous kernel -> this kernel).  usage: python tools/gap_pairs.py <csv> [run_index]"""
+end of everything that started earlier, grouped by (previous kernel -> this kernel).  usage: python tools/experiments/gap_pairs.py <csv> [run_index]"""
 import collections
 import csv
 import re

@@ -1,6 +1,6 @@
 // Cost of a grid-wide barrier on gfx950 (cooperative launch, all workgroups resident) against the ~2.8 us a dependent kernel
 // launch costs: decides whether a persistent "phase interpreter" kernel could beat launch chains for single-ciphertext steps.
-//   hipcc --offload-arch=gfx950 -O3 tools/gridsync_bench.hip -o /tmp/gridsync && timeout 60 /tmp/gridsync
+//   hipcc --offload-arch=gfx950 -O3 tools/experiments/gridsync_bench.hip -o /tmp/gridsync && timeout 60 /tmp/gridsync
 #include <hip/hip_cooperative_groups.h>
 #include <hip/hip_runtime.h>
 #include <stdio.h>

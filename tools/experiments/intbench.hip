@@ -1,5 +1,5 @@
 // Microbenchmark: integer-multiply issue rates on gfx950 (grounds the VALU ceiling of the NTT butterfly).
-// hipcc --offload-arch=gfx950 -O3 tools/intbench.hip -o /tmp/intbench && /tmp/intbench
+// hipcc --offload-arch=gfx950 -O3 tools/experiments/intbench.hip -o /tmp/intbench && /tmp/intbench
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Instruction mix per kernel from a hipcc -S listing (development aid): python tools/isa_mix.py file.s [filter]"""
+"""Instruction mix per kernel from a hipcc -S listing (development aid): python tools/experiments/isa_mix.py file.s [filter]"""
 import collections
 import re
 import sys

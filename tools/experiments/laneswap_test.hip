@@ -1,6 +1,6 @@
 // Self-check of dacapo_amd/csrc/lane_xchg.hpp on the device: for every distance D, lane_swap<D> must exchange x1 of lane L
 // with x0 of lane L ^ D (bit D of L clear) and leave everything else in place.
-//   hipcc --offload-arch=gfx950 -O3 -I dacapo_amd/csrc tools/laneswap_test.hip -o /tmp/laneswap_test && /tmp/laneswap_test
+//   hipcc --offload-arch=gfx950 -O3 -I dacapo_amd/csrc tools/experiments/laneswap_test.hip -o /tmp/laneswap_test && /tmp/laneswap_test
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 

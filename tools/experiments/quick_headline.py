@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Headline program only (ResNet-20 fixture): ms per run() and the decrypted error; for kernel-tuning sweeps.
-    [DACAPO_AMD_LIB=...] python tools/quick_headline.py [steps] [fixture = resnet20 | resnet20.b6 | resnet20.b13]"""
+    [DACAPO_AMD_LIB=...] python tools/experiments/quick_headline.py [steps] [fixture = resnet20 | resnet20.b6 | resnet20.b13]"""
 import json
 import sys
 import time
@@ -8,7 +8,7 @@ from pathlib import Path
 
 import numpy as np
 
-ROOT = Path(__file__).resolve().parent.parent
+ROOT = Path(__file__).resolve().parent.parent.parent
 sys.path.insert(0, str(ROOT))
 from dacapo_amd import hevm_asm as ha  # noqa: E402
 from dacapo_amd import runner  # noqa: E402

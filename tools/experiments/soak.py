@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Soak: the headline program run() `n` times in one VM -- time per run, decrypted error and free HBM must not drift.
-    python tools/soak.py [n=300]"""
+    python tools/experiments/soak.py [n=300]"""
 import ctypes
 import json
 import sys
@@ -9,7 +9,7 @@ from pathlib import Path
 
 import numpy as np
 
-ROOT = Path(__file__).resolve().parent.parent
+ROOT = Path(__file__).resolve().parent.parent.parent
 sys.path.insert(0, str(ROOT))
 from dacapo_amd import hevm_asm as ha  # noqa: E402
 from dacapo_amd import lowlevel as ll  # noqa: E402

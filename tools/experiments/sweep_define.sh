@@ -1,8 +1,8 @@
 #!/bin/bash
 # Kernel-tuning sweeps over compile-time constants of the NTT tiles: builds one variant of the library per argument into
 # dacapo_amd/lib/variants/ (git-ignored like every .so).  Each argument is NAME:FLAGS, e.g.
-#   tools/sweep_define.sh "t0l0:-DDC_TW_WORD_STAGES_T=0 -DDC_TW_WORD_STAGES_L=0" "t2l0:-DDC_TW_WORD_STAGES_T=2"
-# and is timed on the GPU box with  DACAPO_AMD_LIB=dacapo_amd/lib/variants/libSEAL_HEVM.<NAME>.so python tools/ntt_leg.py
+#   tools/experiments/sweep_define.sh "t0l0:-DDC_TW_WORD_STAGES_T=0 -DDC_TW_WORD_STAGES_L=0" "t2l0:-DDC_TW_WORD_STAGES_T=2"
+# and is timed on the GPU box with  DACAPO_AMD_LIB=dacapo_amd/lib/variants/libSEAL_HEVM.<NAME>.so python tools/experiments/ntt_leg.py
 set -e
 cd "$(dirname "$0")/../dacapo_amd/csrc"
 mkdir -p ../lib/variants

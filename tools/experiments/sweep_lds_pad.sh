@@ -1,7 +1,7 @@
 #!/bin/bash
 # LDS row padding sweep for the NTT tiles (ntt_tile.hpp kLdsPad): builds one variant of the library per value into
 # dacapo_amd/lib/variants/ (git-ignored like every .so), to be timed on the GPU box with
-#   for p in 1 2 3 4 5 8 9; do DACAPO_AMD_LIB=dacapo_amd/lib/variants/libSEAL_HEVM.pad$p.so python tools/ntt_leg.py; done
+#   for p in 1 2 3 4 5 8 9; do DACAPO_AMD_LIB=dacapo_amd/lib/variants/libSEAL_HEVM.pad$p.so python tools/experiments/ntt_leg.py; done
 set -e
 cd "$(dirname "$0")/../dacapo_amd/csrc"
 mkdir -p ../lib/variants

@@ -18,7 +18,6 @@ import numpy as np
 
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
-os.environ.setdefault("DACAPO_HEVM_SECRET_HW", "64")
 from dacapo_amd import hevm_asm as ha  # noqa: E402
 from dacapo_amd import ckks_boot as cb  # noqa: E402
 from dacapo_amd import runner  # noqa: E402
@@ -47,7 +46,7 @@ h = ha.unpack_hevm(fx["hevm"])
 ops = h["ops"]
 print(f"{len(ops)} instructions, {h['num_ptxt']} plaintext registers, {int((ops[:, 0] == ha.OP_MODRAISE).sum())} real bootstraps", flush=True)
 t0 = time.time()
-hevm = runner.HEVM(seed=0x4845564D, logN=logN, num_primes=KB, ks_special=ks, ks_alpha=alpha)
+hevm = runner.HEVM(seed=0x4845564D, logN=logN, num_primes=KB, ks_special=ks, ks_alpha=alpha, vm_options={"secret_hw": 64})
 if direct:
     offs = cb.rotation_offsets(fx["hevm"])
     if direct == 2:  # direct keys for the bootstraps' own rotations only (they run at up to 19 primes); the model's rotations run at 1-3 primes,
