@@ -379,8 +379,10 @@ def build_parser():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--program", default="resnet20", choices=["resnet20", "shaped"],
-                    help="resnet20 = the reference model's traced op stream + real weights (tests/golden); shaped = synthetic op mix")
+    ap.add_argument("--program", default="resnet20", choices=["resnet20", "shaped", "config4"],
+                    help="resnet20 = the reference model's traced op stream + real weights (tests/golden); shaped = synthetic op mix; "
+                         "config4 = BASELINE config 4's stream (nt = 2^16 trace, N = 2^17, real bootstraps, grouped-digit keys) as the timed "
+                         "step: with --gpus N this is BASELINE config 5, one such stream per GPU")
     ap.add_argument("--hevm-gz", default=None, help="--program resnet20: another lowering of the same trace (same constants)")
     ap.add_argument("--layers", type=int, default=20, help="--program shaped: depth (20 = the traced op mix)")
     ap.add_argument("--streams", type=int, default=1, help="independent ciphertext streams per GPU (throughput mode; 1 = the reference's one image per run)")
@@ -425,6 +427,121 @@ def config4_child():
     return res
 
 
+CONFIG4 = {"fixture": "resnet20_nt16", "lowering": "b14", "logN": 17, "ks_special": 8, "ks_alpha": 7, "msg_bits": 1, "secret_hw": 64}
+
+
+def config4_program():
+    """BASELINE config 4's program: the nt = 2^16 trace whose 38 bootstrap sites (the model script's own hints, each restoring 14 primes) are
+    lowered to real CKKS bootstrapping (dacapo_amd/ckks_boot.py).  Returns (fixture, constants, bytecode, primes in the chain, rotation offsets)."""
+    import gzip
+
+    from dacapo_amd import ckks_boot as cb
+    from dacapo_amd import hevm_asm as ha
+
+    g = ROOT / "tests" / "golden"
+    fx = ha.read_fixture(g / CONFIG4["fixture"])
+    hv0 = gzip.open(g / f"{CONFIG4['fixture']}.{CONFIG4['lowering']}.hevm.gz").read()
+    target = {int(r) for o, _, _, r in ha.unpack_hevm(hv0)["ops"].tolist() if o == ha.OP_BOOTSTRAP}
+    assert len(target) == 1
+    K = target.pop() + cb.boot_levels() + CONFIG4["ks_special"]
+    hv, cst = cb.lower_bootstraps(hv0, fx["cst"], CONFIG4["logN"], K, msg_bits=CONFIG4["msg_bits"], ks=CONFIG4["ks_special"])
+    return fx, cst, hv, K, cb.rotation_offsets(hv)
+
+
+def config4_ntt_equivalents(hv, K):
+    """NTT-equivalents of one run of the program, counted per key switch as the grouped-digit sequence executes it without sharing:
+    G (l + k) + 2 k + 2 l per hop, 2 l per rescale (what hevm_last_run_stats reports on the device)"""
+    from dacapo_amd import hevm_asm as ha
+    from dacapo_amd import progstats
+
+    st = progstats.walk(hv, CONFIG4["logN"], direct_keys=True)
+    k, a = CONFIG4["ks_special"], CONFIG4["ks_alpha"]
+    ks = sum(n * (-(-int(l) // a) * (int(l) + k) + 2 * k + 2 * int(l)) for l, n in st["key_switch_level_histogram"].items())
+    rs = sum(n * 2 * int(l) for l, n in st.get("rescale_level_histogram", {}).items())
+    return int(ks + rs), st
+
+
+def main_config4(args, grp):
+    """--program config4 [--gpus N]: every rank runs BASELINE config 4's stream on its own GPU -- own VM, the SAME key set (same seed, or
+    --broadcast-keys; digests compared), its own input -- no collective in the op path: with N = 8 this is BASELINE config 5.  The timed step
+    is one run() (38 real bootstraps, ~10 k key switches, seconds): keep --steps small."""
+    from dacapo_amd import lowlevel as ll
+    from dacapo_amd import runner
+
+    rank, local_rank, world = grp.rank, grp.local_rank, grp.world
+    fx, cst, hv, K, offs = config4_program()
+    L = ll.lib()
+    L.dc_set_device(local_rank)
+
+    def barrier_sync():
+        grp.barrier()
+        L.dc_device_sync()
+
+    t_setup = time.time()
+    hevm = runner.HEVM(seed=KEY_SEED + (rank if args.broadcast_keys else 0), logN=CONFIG4["logN"], num_primes=K, ks_special=CONFIG4["ks_special"],
+                       ks_alpha=CONFIG4["ks_alpha"], vm_options={"secret_hw": CONFIG4["secret_hw"]})
+    hevm.addRotationKeys(offs)  # (before the digest: the direct keys are part of the replicated key set)
+
+    def _copy_out(ptr, words):
+        import torch
+
+        t = torch.empty(words, dtype=torch.int64, device=grp.device)
+        L.dc_memcpy_d2d(t.data_ptr(), ptr, 8 * words, None)
+        L.dc_device_sync()
+        return t
+
+    def _copy_in(ptr, t):
+        import torch
+
+        torch.cuda.synchronize()
+        L.dc_memcpy_d2d(ptr, t.data_ptr(), 8 * t.numel(), None)
+        L.dc_device_sync()
+
+    key_info = grp.share_keys(hevm.keyDigest, buffers_fn=hevm.keyBuffers, copy_out=_copy_out, copy_in=_copy_in,
+                              mode="broadcast" if args.broadcast_keys else "seed")
+    if args.broadcast_keys and rank != 0:
+        hevm.keysReplaced()
+    image = fx["packed"] if rank == 0 else np.roll(fx["packed"], 17 * rank) * (1.0 - 0.01 * rank)
+    hevm.load_mem(cst, hv)
+    hevm.setInput(0, image)
+    t_setup = time.time() - t_setup
+    for _ in range(args.warmup):
+        hevm.run()
+    barrier_sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        hevm.run()
+    barrier_sync()
+    elapsed = time.perf_counter() - t0
+    stats = hevm.stats()
+    out = hevm.getOutput()[0]
+    elapsed, total = grp.job_totals(elapsed, float(stats["ntts"]) * args.steps)
+    if rank == 0:
+        rms = float(np.sqrt(np.mean((out[:10] * 32 - fx["torch_result"]) ** 2)))
+        print(json.dumps(config4_line(args, world, elapsed, total, stats["ntts"], stats["keyswitches"], key_info, t_setup, rms, len(offs), K)), flush=True)
+    hevm.close()
+    grp.close()
+
+
+def config4_line(args, world, elapsed, total, ntts_per_step, ks_per_step, key_info, t_setup, rms, n_keys, K, dry=False):
+    N = 1 << CONFIG4["logN"]
+    key_bytes = n_keys * (-(-(K - CONFIG4["ks_special"]) // CONFIG4["ks_alpha"])) * 2 * K * N * 8
+    return {"metric": "NTT/s (NTT-equivalents of N = 2^17 over one run() of the ResNet HEVM program traced at nt = 2^16: BASELINE config 4's stream"
+                      + (", dry run: no kernel executed)" if dry else ")"),
+            "value": round(total / elapsed, 1), "unit": "NTT/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64",
+            "data": "none (dry run)" if dry else "synthetic image; weights = the reference's resnet20.silu.model", "dry_run": dry,
+            "measured_on_hardware": not dry,
+            "config": {"workload": f"BASELINE config {5 if world > 1 else 4}: ResNet-20 (SiLU) traced at nt = 2^16 slots, N = 2^17, {K} x 60-bit primes "
+                                   f"({K - CONFIG4['ks_special']} data + {CONFIG4['ks_special']} special), 38 real bootstraps each restoring 14 primes, "
+                                   "grouped-digit hybrid key switching, one independent ciphertext stream per GPU",
+                       "ntt_equivalents_per_step": ntts_per_step, "key_switches_per_step": ks_per_step, "rotation_keys": n_keys,
+                       "key_bytes_per_gpu": key_bytes, "streams_per_gpu": 1,
+                       "parallelism": f"replicas x{world} (no collective in the op path)", "keys": key_info},
+            "hevm_wall_s": round(elapsed / args.steps, 3), "setup_s_untimed": round(t_setup, 1),
+            "decrypted_error": None if rms is None else {"rms_vs_torch": rms, "reference_published_rms": 9.5e-4}}
+
+
 def spawn_ranks(args, argv) -> int:
     """`python bench.py --gpus N` outside a launcher: start N ranks as a CHILD torch.distributed.run (this parent has not touched the
     GPU and never does -- a process that has initialised HIP must not exec another program on this pool) and hand its exit code back."""
@@ -446,8 +563,14 @@ def dry_run(args, grp):
     from dacapo_amd import hevm_asm as ha
     from dacapo_amd import progstats
 
-    fx = ha.read_fixture(ROOT / "tests" / "golden" / "resnet20")
-    st = progstats.walk(fx["hevm"])
+    cfg4 = args.program == "config4"
+    if cfg4:  # config 5's launch path: the same lowering and work count as the real run, the device work replaced by a sleep
+        _, _, hv4, K4, offs4 = config4_program()
+        ntts4, st4 = config4_ntt_equivalents(hv4, K4)
+        st = {"ntt_equivalents": ntts4}
+    else:
+        fx = ha.read_fixture(ROOT / "tests" / "golden" / "resnet20")
+        st = progstats.walk(fx["hevm"])
     # the key-replication path with stand-in buffers (three "keys" of 4096 words expanded from the seed): same code as the real run's
     import hashlib
 
@@ -467,7 +590,10 @@ def dry_run(args, grp):
     grp.barrier()
     elapsed = time.perf_counter() - t0
     elapsed, total = grp.job_totals(elapsed, float(st["ntt_equivalents"]) * args.steps)
-    if grp.rank == 0:
+    if grp.rank == 0 and cfg4:
+        print(json.dumps(config4_line(args, grp.world, elapsed, total, st["ntt_equivalents"], int(sum(st4["key_switch_level_histogram"].values())), keys, 0.0,
+                                      None, len(offs4), K4, dry=True)), flush=True)
+    elif grp.rank == 0:
         print(json.dumps({"metric": "NTT/s (dry run: no kernel executed)", "value": round(total / elapsed, 1), "unit": "NTT/s",
                           "n_gpus": grp.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "none (dry run)",
@@ -484,7 +610,8 @@ def main():
         sys.exit(spawn_ranks(args, argv))
 
     # rank 0 of a 1-GPU run only: the other legs of the line are N = 1 figures as well
-    config4 = config4_child() if (args.config4 and args.gpus == 1 and not args.dry_run and "RANK" not in os.environ) else None
+    config4 = config4_child() if (args.config4 and args.gpus == 1 and not args.dry_run and "RANK" not in os.environ
+                                  and args.program != "config4") else None
 
     from dacapo_amd.dist import Group
 
@@ -494,6 +621,8 @@ def main():
         print(f"[bench] --gpus {args.gpus} but the launcher started {world} rank(s): reporting n_gpus = {world}", file=sys.stderr)
     if args.dry_run:
         return dry_run(args, grp)
+    if args.program == "config4":
+        return main_config4(args, grp)
 
     from dacapo_amd import hevm_asm as ha
     from dacapo_amd import lowlevel as ll

@@ -217,6 +217,32 @@ Context::Context(int logN_, int K_, int bits, const u64 *primes_or_null, int ksp
         }
         DC_HIP_CHECK(hipMalloc(&d_hyb_dn, dn.size() * 8));
         DC_HIP_CHECK(hipMemcpy(d_hyb_dn, dn.data(), dn.size() * 8, hipMemcpyHostToDevice));
+        { // the conversions' per-input constants folded into the inverse transforms' N^-1 words (hybrid_fused.hip)
+            std::vector<DModulus> um;
+            hyb_upmods_off.assign((size_t)L + 2, 0);
+            for (int ell = 1; ell <= L; ell++) {
+                hyb_upmods_off[(size_t)ell] = um.size();
+                const u64 *upl = up.data() + hyb_up_off[(size_t)ell];
+                for (int i = 0; i < ell; i++) {
+                    DModulus m = h_mods[(size_t)i];
+                    m.inv_n = h_mulmod(m.inv_n, upl[i], m.q), m.inv_n_w = h_mulmod(m.inv_n_w, upl[i], m.q);
+                    um.push_back(m);
+                }
+            }
+            DC_HIP_CHECK(hipMalloc(&d_hyb_upmods, um.size() * sizeof(DModulus)));
+            DC_HIP_CHECK(hipMemcpy(d_hyb_upmods, um.data(), um.size() * sizeof(DModulus), hipMemcpyHostToDevice));
+            std::vector<DModulus> dm(h_mods.begin(), h_mods.end());
+            std::vector<u64> hp((size_t)ksp);
+            for (int j = 0; j < ksp; j++) {
+                DModulus &m = dm[(size_t)(L + j)];
+                m.inv_n = h_mulmod(m.inv_n, dn[(size_t)j], m.q), m.inv_n_w = h_mulmod(m.inv_n_w, dn[(size_t)j], m.q);
+                hp[(size_t)j] = h_mulmod(dn[(size_t)(ksp + j)], dn[(size_t)j], m.q);
+            }
+            DC_HIP_CHECK(hipMalloc(&d_hyb_dnmods, dm.size() * sizeof(DModulus)));
+            DC_HIP_CHECK(hipMemcpy(d_hyb_dnmods, dm.data(), dm.size() * sizeof(DModulus), hipMemcpyHostToDevice));
+            DC_HIP_CHECK(hipMalloc(&d_hyb_hp, hp.size() * 8));
+            DC_HIP_CHECK(hipMemcpy(d_hyb_hp, hp.data(), hp.size() * 8, hipMemcpyHostToDevice));
+        }
         // ---- the same two constant matrices as int8 operands of the matrix cores -------------------------------------------------
         // A residue y < 2^60 is 8 balanced base-256 digits (y + 0x80..80 with every byte's top bit flipped: digits in [-128, 127]); a
         // matrix entry w enters as the balanced digits of V_p = w 2^(8p) mod m for each of the operand's 8 digit positions p, so that
@@ -315,7 +341,8 @@ void Context::ensure_scratch()
 Context::~Context()
 {
     for (void *p : { (void *)d_mods, (void *)d_tw, (void *)d_itw, (void *)d_tw2, (void *)d_inv_last, (void *)d_half_mod, (void *)d_ks_pidx, (void *)d_pmod,
-                     (void *)d_hyb_up, (void *)d_hyb_pidx, (void *)d_hyb_dn, (void *)d_hyb_bup, (void *)d_hyb_bdn })
+                     (void *)d_hyb_up, (void *)d_hyb_pidx, (void *)d_hyb_dn, (void *)d_hyb_bup, (void *)d_hyb_bdn, (void *)d_hyb_upmods, (void *)d_hyb_dnmods,
+                     (void *)d_hyb_hp })
         if (p) (void)hipFree(p);
     for (Workspace &w : workspaces)
         for (void *p : { (void *)w.ks_digits, (void *)w.ks_ext, (void *)w.ks_acc, (void *)w.ks_tmp, (void *)w.ct_tmp })

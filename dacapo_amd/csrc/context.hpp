@@ -89,6 +89,13 @@ struct Context {
     bool hyb_mfma = false;
     int hyb_up_blocks(int ell) const { return (ell + ksp - 1 + 15) / 16; }  // blocks of 16 "other" moduli (the smallest digit has 1 prime)
     int hyb_dn_blocks(int ell) const { return (ell + 15) / 16; }
+    // fused sequence (hybrid_fused.hip): the per-input constants of the two conversions ride on the inverse transforms' last stage -- copies
+    // of the per-prime constants whose N^-1 words carry qhat_inv_i (per level: the last digit's composition depends on it) resp. phat_inv_j
+    DModulus *d_hyb_upmods = nullptr; // per level ell: [ell]
+    std::vector<size_t> hyb_upmods_off;
+    DModulus *d_hyb_dnmods = nullptr; // [K]: the special primes' entries modified
+    u64 *d_hyb_hp = nullptr;          // [ksp]: floor(P/2) phat_inv_j mod p_j (added after the scaled inverse transform)
+    const DModulus *hyb_upmods(int ell) const { return d_hyb_upmods + hyb_upmods_off[(size_t)ell]; }
     const u64 *hyb_up(int ell) const { return d_hyb_up + hyb_up_off[(size_t)ell]; }
     const int *hyb_pidx(int ell) const { return d_hyb_pidx + hyb_pidx_off[(size_t)ell]; }
     int k1 = 0, k2 = 0; // NTT split: COLS phase runs k1 stages, ROWS phase k2 = logN - k1

@@ -17,6 +17,7 @@
 // target modulus (it is 1/(l+1) of that kernel's work) to keep every workgroup at two phases.
 #include "ntt_tile.hpp"
 #include "plan.hpp"
+#include "tile_dispatch.hpp"
 
 namespace dacapo {
 
@@ -680,31 +681,7 @@ __global__ __launch_bounds__(kTileThreads) void f_frows_boot_final_kernel(const 
         lds);
 }
 
-// ---- launchers (K and geometry dispatch) ---------------------------------------------------------------------------------
-#define DC_K_SWITCH(Kval, ...)                                                                            \
-    switch (Kval) {                                                                                       \
-    case 6: { constexpr int KK = 6; __VA_ARGS__; } break;                                                        \
-    case 7: { constexpr int KK = 7; __VA_ARGS__; } break;                                                        \
-    case 8: { constexpr int KK = 8; __VA_ARGS__; } break;                                                        \
-    case 9: { constexpr int KK = 9; __VA_ARGS__; } break;                                                        \
-    default: fprintf(stderr, "[dacapo_amd] unsupported NTT phase size 2^%d\n", Kval); abort();             \
-    }
-// CALL sees KK (phase size) and LE (log2 coefficients per thread); grid.x = tiles of that geometry
-#define DC_GEO_SWITCH(Kval, limbs, ...)                                                                   \
-    if (use_tiny_tiles(c.N, (limbs))) {                                                                   \
-        constexpr int LE = 1;                                                                             \
-        const dim3 grid((unsigned)(c.N >> TileGeo<LE>::LOG), (unsigned)(limbs));                          \
-        DC_K_SWITCH(Kval, __VA_ARGS__)                                                                         \
-    } else if (use_small_tiles(c.N, (limbs))) {                                                           \
-        constexpr int LE = 2;                                                                             \
-        const dim3 grid((unsigned)(c.N >> TileGeo<LE>::LOG), (unsigned)(limbs));                          \
-        DC_K_SWITCH(Kval, __VA_ARGS__)                                                                         \
-    } else {                                                                                              \
-        constexpr int LE = 3;                                                                             \
-        const dim3 grid((unsigned)(c.N >> TileGeo<LE>::LOG), (unsigned)(limbs));                          \
-        DC_K_SWITCH(Kval, __VA_ARGS__)                                                                         \
-    }
-
+// ---- launchers (K and geometry dispatch: tile_dispatch.hpp) ---------------------------------------------------------------
 template <class Src>
 static void launch_irows(const Context &c, Src src, u64 *out, long out_stride, int count, hipStream_t s)
 {

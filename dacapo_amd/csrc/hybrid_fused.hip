@@ -1,0 +1,325 @@
+// EXTENSION (see hybrid_ks.hip): the FUSED launch sequence of grouped-digit hybrid key switching -- round 4.  Same arithmetic as
+// hybrid_ks.hip's nine-kernel-plus-four-transforms sequence (which stays selectable, option hyb_fuse = 0, as a second implementation) and as
+// oracle/ckks_oracle.c orc_keyswitch_hybrid: every value written is the canonical residue of the same integer, so limbs are bit-identical.
+// What it serves in the reference: HEAAN_HEVM.cpp:300-303 (rotate), :386-399 (bootstrap).
+//
+//   round 3                                  | here
+//   prepare: c0' = galois(c0), digits = c1   | --   (F1 reads c1 in place; F9 gathers c0 through the Galois map in its epilogue)
+//   iNTT digits            (2 launches)      | F1   inverse ROWS phase, out of place, once per decomposition (first item of a slot)
+//                                            | F2   inverse COLS phase whose last stage multiplies by N^-1 qhat_inv_i (Context::hyb_upmods):
+//                                            |      the conversion's per-input constant costs nothing
+//   mod-up                 (1)               | F3   forward COLS phase of every raised limb with the conversion as its LOADER: sum_t y_t w[t][e]
+//   NTT ext                (2)               |      in three 64-bit columns of 30-bit limb products (4 mads per term, no carries)
+//                                            | F4   forward ROWS phase
+//   mac                    (1)               | F5   inner products with the key (hyb_mac_kernel, unchanged: key-bound)
+//   iNTT acc_P             (2)               | F6   inverse ROWS;  F7  inverse COLS with N^-1 phat_inv_j folded (Context::d_hyb_dnmods)
+//   mod-down               (1)               | F8   forward COLS phase of the 2 l correction limbs with the conversion as its loader
+//   NTT tmp                (2)               | F9   forward ROWS phase with (acc - t) P^-1 + base as its store epilogue
+//   final                  (1)               |
+//   13 launches; a raised limb crosses HBM 6 times (written by mod-up, read + written by either NTT phase, read by mac)
+//                                            | 9 launches; 4 crossings (F3 w, F4 r + w, F5 r); prepare's 4 l, mod-down's and final's limbs gone
+// option hyb_fuse = 2 keeps the two conversions as separate matrix-core launches (hyb_conv_mfma_kernel on pre-scaled inputs) inside this
+// sequence: F3 / F8 become conversion + two-phase transform.  Which of 1 / 2 is the default is decided by measurement.
+#include "plan.hpp"
+#include "tile_dispatch.hpp"
+
+namespace dacapo {
+
+__device__ __forceinline__ u32 hf_galois_idx(u32 k, u32 elt, int logN)
+{ // GaloisTool::apply_galois_ntt index map (poly_kernels.hip)
+    const u32 r = (__brev(k) >> (32 - logN)) * 2u + 1u;
+    const u32 idx = ((elt * r) >> 1) & ((1u << logN) - 1u);
+    return __brev(idx) >> (32 - logN);
+}
+
+// sum of up to 8 products y w with y, w < 2^60, kept as three 64-bit columns of 30-bit limb products: y = y0 + y1 2^30, w = w0 + w1 2^30,
+// every product < 2^60, so c0 < 8 2^60, c1 < 16 2^60 <= 2^64 - 16 2^31, c2 < 8 2^60 never overflow and a term is 4 v_mad_u64_u32 with no
+// carry handling (a 128-bit accumulator: 4 mads + 6 adds with carries).  w is wave-uniform in every use (a conversion constant): scalar operands.
+struct Acc3 {
+    u64 c0, c1, c2;
+    __device__ __forceinline__ void clear() { c0 = c1 = c2 = 0; }
+    __device__ __forceinline__ void mac(u64 y, u32 w0, u32 w1)
+    {
+        const u32 y0 = lo32(y) & 0x3FFFFFFFu, y1 = (u32)(y >> 30);
+        c0 = mad32(y0, w0, c0);
+        c1 = mad32(y0, w1, c1);
+        c1 = mad32(y1, w0, c1);
+        c2 = mad32(y1, w1, c2);
+    }
+    // T = c0 + c1 2^30 + c2 2^60 < 2^124 -> canonical residue
+    __device__ __forceinline__ u64 reduce(const DModulus &M) const
+    {
+        u64 lo = c0 + (c1 << 30);
+        u64 hi = (c1 >> 34) + (lo < c0 ? 1u : 0u);
+        const u64 l2 = lo + (c2 << 60);
+        hi += (c2 >> 4) + (l2 < lo ? 1u : 0u);
+        return reduce128_any(hi, l2, M);
+    }
+};
+__device__ __forceinline__ u32 w_lo30(u64 w) { return (u32)w & 0x3FFFFFFFu; }
+__device__ __forceinline__ u32 w_hi30(u64 w) { return (u32)(w >> 30); }
+
+// true for the first item of the batch that names this item's decomposition slot (wave-uniform; every wave of the workgroup agrees)
+__device__ __forceinline__ bool hf_first_of_slot(const KsItem *__restrict__ items, int b)
+{
+    const u32 mine = items[b].slot;
+    const int lane = threadIdx.x & 63;
+    for (int base = 0; base < b; base += 64) {
+        const int j = base + lane;
+        const bool hit = j < b && items[j].slot == mine;
+        if (__ballot(hit)) return false;
+    }
+    return true;
+}
+
+// ---- F1: inverse ROWS phase of the decomposition's source limbs, out of place.  z = b * ell + i.
+// MODE 0: rotation items -- src.c1 as it is (the digits are taken BEFORE the automorphism), once per slot; MODE 1: strided source
+// (target [B][ell][N]: ct x ct's c2, or one key switch by value)
+template <int K, int LOGE, int MODE>
+__global__ __launch_bounds__(kTileThreads) void hybf_irows_kernel(const KsItem *__restrict__ items, KsItem single, const u64 *__restrict__ target,
+                                                                   u64 *__restrict__ digits, int ell, int use_slots,
+                                                                   const DModulus *__restrict__ mods, const u64 *__restrict__ itw, int logN)
+{
+    __shared__ __attribute__((aligned(16))) u64 lds[TileGeo<LOGE>::LDS_ELEMS];
+    const int z = blockIdx.y, i = z % ell, b = z / ell;
+    const size_t N = (size_t)1 << logN;
+    const u64 *in;
+    size_t slot = (size_t)b;
+    if (MODE == 0) {
+        if (items && use_slots) {
+            if (!hf_first_of_slot(items, b)) return;
+            slot = items[b].slot;
+        }
+        const KsItem it = items ? items[b] : single;
+        in = it.src.limb(1, i, N);
+    } else
+        in = target + (size_t)z * N;
+    u64 *out = digits + (slot * ell + i) * N;
+    ntt_tile<K, LOGE, false, true, false>(
+        mods[i], itw + ((size_t)i << logN), logN, blockIdx.x, [=](int g) { return in[g]; }, [=](int g, u64 v) { out[g] = v; }, lds);
+}
+
+// ---- F3: mod-up as the loader of the raised limbs' first forward phase.  y = blockIdx.y = u * E + r (decomposition u, raised limb r in
+// the order of Context::hyb_pidx: digit by digit, the other moduli ascending).  digits [U][ell][N]: y_t = [x_t qhat_t^-1]_{q_t} (F2).
+template <int K, int LOGE>
+__global__ __launch_bounds__(kTileThreads) void hybf_modup_fcols_kernel(const u64 *__restrict__ digits, u64 *__restrict__ ext, int ell, int ksp,
+                                                                         int alpha, int L, int E, const DModulus *__restrict__ mods,
+                                                                         const u64 *__restrict__ up, const u64 *__restrict__ tw, int logN)
+{
+    __shared__ __attribute__((aligned(16))) u64 lds[TileGeo<LOGE>::LDS_ELEMS];
+    constexpr int EC = 1 << LOGE;
+    const size_t N = (size_t)1 << logN;
+    const int r = blockIdx.y % E, u = blockIdx.y / E, M = ell + ksp, full = M - alpha, G = (ell + alpha - 1) / alpha;
+    int g = r / full;
+    g = g < G ? g : G - 1; // (the last digit may be partial: it has more than `full` other moduli)
+    const int idx = r - g * full, lo = g * alpha, hi = min(lo + alpha, ell), a = hi - lo;
+    const int mi = idx < lo ? idx : idx + a, pm = mi < ell ? mi : L + (mi - ell);
+    const DModulus Mo = mods[pm];
+    const u64 *w = up + ell + (size_t)lo * M + mi; // w[t * M] = (Q_g / q_{lo+t}) mod m
+    const u64 *src = digits + ((size_t)u * ell + lo) * N;
+    int gi[EC];
+#pragma unroll
+    for (int j = 0; j < EC; j++) gi[j] = tile_gidx<K, LOGE, true>(0, logN, blockIdx.x, j);
+    Acc3 acc[EC];
+#pragma unroll
+    for (int j = 0; j < EC; j++) acc[j].clear();
+    u64 x[EC];
+#pragma unroll
+    for (int j = 0; j < EC; j++) x[j] = 0;
+    for (int t = 0; t < a; t++) {
+        const u64 c = w[(size_t)t * M];
+        const u32 c0 = w_lo30(c), c1 = w_hi30(c);
+        u64 y[EC];
+#pragma unroll
+        for (int j = 0; j < EC; j++) y[j] = src[(size_t)t * N + gi[j]];
+#pragma unroll
+        for (int j = 0; j < EC; j++) acc[j].mac(y[j], c0, c1);
+        if ((t & 7) == 7 && t + 1 < a) { // more than 8 inputs (alpha up to 16): bank the columns
+#pragma unroll
+            for (int j = 0; j < EC; j++) x[j] = addmod(x[j], acc[j].reduce(Mo), Mo.q), acc[j].clear();
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < EC; j++) x[j] = addmod(x[j], acc[j].reduce(Mo), Mo.q);
+    u64 *out = ext + (size_t)blockIdx.y * N;
+    auto nold = [](int) -> u64 { return 0; };
+    ntt_tile_x<K, LOGE, true, false, false, true, false>(x, Mo, tw + ((size_t)pm << logN), logN, blockIdx.x, nold, [=](int gg, u64 v) { out[gg] = v; }, lds);
+}
+
+// ---- F8: mod-down as the loader of the correction limbs' first forward phase.  y = z * ell + i (polynomial z = 2 b + c, data prime i).
+// accp [2B][ksp][N]: r_j phat_j^-1 mod p_j (F7); t_i = sum_j [(r_j + floor(P/2)) phat_j^-1]_{p_j} (P / p_j) - floor(P/2)  mod q_i
+template <int K, int LOGE>
+__global__ __launch_bounds__(kTileThreads) void hybf_moddown_fcols_kernel(const u64 *__restrict__ accp, u64 *__restrict__ tmp, int ell, int ksp,
+                                                                           int L, const DModulus *__restrict__ mods, const u64 *__restrict__ dn,
+                                                                           const u64 *__restrict__ hp, const u64 *__restrict__ tw, int logN)
+{
+    __shared__ __attribute__((aligned(16))) u64 lds[TileGeo<LOGE>::LDS_ELEMS];
+    constexpr int EC = 1 << LOGE;
+    const size_t N = (size_t)1 << logN;
+    const int i = blockIdx.y % ell, z = blockIdx.y / ell;
+    const DModulus Mo = mods[i];
+    const u64 half_q = dn[2 * ksp + i];
+    const u64 *w = dn + 2 * ksp + 2 * L + i; // w[j * L] = (P / p_j) mod q_i
+    const u64 *src = accp + (size_t)z * ksp * N;
+    int gi[EC];
+#pragma unroll
+    for (int j = 0; j < EC; j++) gi[j] = tile_gidx<K, LOGE, true>(0, logN, blockIdx.x, j);
+    Acc3 acc[EC];
+    u64 x[EC];
+#pragma unroll
+    for (int j = 0; j < EC; j++) acc[j].clear(), x[j] = 0;
+    for (int t = 0; t < ksp; t++) {
+        const u64 c = w[(size_t)t * L], pj = mods[L + t].q, h = hp[t];
+        const u32 c0 = w_lo30(c), c1 = w_hi30(c);
+        u64 y[EC];
+#pragma unroll
+        for (int j = 0; j < EC; j++) y[j] = src[(size_t)t * N + gi[j]];
+#pragma unroll
+        for (int j = 0; j < EC; j++) acc[j].mac(addmod(y[j], h, pj), c0, c1);
+        if ((t & 7) == 7 && t + 1 < ksp) {
+#pragma unroll
+            for (int j = 0; j < EC; j++) x[j] = addmod(x[j], acc[j].reduce(Mo), Mo.q), acc[j].clear();
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < EC; j++) x[j] = submod(addmod(x[j], acc[j].reduce(Mo), Mo.q), half_q, Mo.q);
+    u64 *out = tmp + (size_t)blockIdx.y * N;
+    auto nold = [](int) -> u64 { return 0; };
+    ntt_tile_x<K, LOGE, true, false, false, true, false>(x, Mo, tw + ((size_t)i << logN), logN, blockIdx.x, nold, [=](int gg, u64 v) { out[gg] = v; }, lds);
+}
+
+struct HybOut { // one key switch by value: out = (base0, base1) + KS(target)
+    CtView out;
+    const u64 *base0 = nullptr, *base1 = nullptr;
+};
+
+// ---- F9: last forward phase of the correction limbs with dst.c = base + (acc_c - t_c) P^-1 as its store epilogue.  y = z * ell + i.
+// MODE 0 rotation items (base of c0: the source's c0 through the Galois map; c1: none), 1 ct x ct items (base: the tensor product's c0 / c1
+// already in dst), 2 one key switch by value
+template <int K, int LOGE, int MODE>
+__global__ __launch_bounds__(kTileThreads) void hybf_frows_final_kernel(const u64 *__restrict__ tmp, const u64 *__restrict__ accq,
+                                                                         const void *__restrict__ items, KsItem rot_single, HybOut single, int ell,
+                                                                         int ksp, int L, const DModulus *__restrict__ mods,
+                                                                         const u64 *__restrict__ dn, const u64 *__restrict__ tw, int logN)
+{
+    __shared__ __attribute__((aligned(16))) u64 lds[TileGeo<LOGE>::LDS_ELEMS];
+    const size_t N = (size_t)1 << logN;
+    const int i = blockIdx.y % ell, z = blockIdx.y / ell, b = z >> 1, c = z & 1;
+    const DModulus M = mods[i];
+    const u64 pinv = dn[2 * ksp + L + i];
+    const u64 *in = tmp + (size_t)blockIdx.y * N, *ac = accq + (size_t)blockIdx.y * N;
+    u64 *dst;
+    const u64 *base = nullptr;
+    u32 elt = 0;
+    if (MODE == 0) {
+        const KsItem it = items ? static_cast<const KsItem *>(items)[b] : rot_single;
+        dst = it.dst.limb(c, i, N);
+        if (c == 0) base = it.src.limb(0, i, N), elt = it.elt;
+    } else if (MODE == 1) {
+        const MulItem it = static_cast<const MulItem *>(items)[b];
+        dst = it.dst.limb(c, i, N), base = dst;
+    } else {
+        dst = single.out.limb(c, i, N);
+        const u64 *bp = c == 0 ? single.base0 : single.base1;
+        base = bp ? bp + (size_t)i * N : nullptr;
+    }
+    ntt_tile<K, LOGE, false, false, true>(
+        M, tw + ((size_t)i << logN), logN, blockIdx.x, [=](int g) { return in[g]; },
+        [=](int g, u64 v) {
+            u64 r = mulmod(submod(ac[g], v, M.q), pinv, M);
+            if (base) r = addmod(r, base[(MODE == 0) ? hf_galois_idx((u32)g, elt, logN) : (u32)g], M.q);
+            dst[g] = r;
+        },
+        lds);
+}
+
+// ---- launchers ------------------------------------------------------------------------------------------------------------------
+template <int MODE>
+static void f1_irows(const Context &c, const KsItem *items, KsItem single, const u64 *target, u64 *digits, int B, int ell, int use_slots, hipStream_t s)
+{
+    DC_GEO_SWITCH(c.k2, B * ell, hipLaunchKernelGGL((hybf_irows_kernel<KK, LE, MODE>), grid, dim3(kTileThreads), 0, s, items, single, target, digits, ell,
+                                                    use_slots, c.d_mods, c.d_itw, c.logN));
+}
+static void f3_modup_fcols(const Context &c, const u64 *digits, u64 *ext, int U, int ell, hipStream_t s)
+{
+    const int E = c.hyb_ext(ell);
+    DC_GEO_SWITCH(c.k1, U * E, hipLaunchKernelGGL((hybf_modup_fcols_kernel<KK, LE>), grid, dim3(kTileThreads), 0, s, digits, ext, ell, c.ksp, c.alpha,
+                                                  c.max_level(), E, c.d_mods, c.hyb_up(ell), c.d_tw, c.logN));
+}
+static void f8_moddown_fcols(const Context &c, const u64 *accp, u64 *tmp, int polys, int ell, hipStream_t s)
+{
+    DC_GEO_SWITCH(c.k1, polys * ell, hipLaunchKernelGGL((hybf_moddown_fcols_kernel<KK, LE>), grid, dim3(kTileThreads), 0, s, accp, tmp, ell, c.ksp,
+                                                        c.max_level(), c.d_mods, c.d_hyb_dn, c.d_hyb_hp, c.d_tw, c.logN));
+}
+template <int MODE>
+static void f9_frows_final(const Context &c, const u64 *tmp, const u64 *accq, const void *items, KsItem rot_single, HybOut single, int polys, int ell,
+                           hipStream_t s)
+{
+    DC_GEO_SWITCH(c.k2, polys * ell, hipLaunchKernelGGL((hybf_frows_final_kernel<KK, LE, MODE>), grid, dim3(kTileThreads), 0, s, tmp, accq, items,
+                                                        rot_single, single, ell, c.ksp, c.max_level(), c.d_mods, c.d_hyb_dn, c.d_tw, c.logN));
+}
+
+// hybrid_ks.hip
+void hyb_launch_mac(Context &c, int mode, const BatchWs &w, const void *items, KsItem rot_single, const u64 *key, int B, int use_slots, int ell,
+                    hipStream_t s);
+void hyb_launch_conv(Context &c, bool down, bool prescaled, const u64 *in, u64 *out, int count, int ell, hipStream_t s);
+
+// everything after F1.  digits [U][ell][N] hold the inverse ROWS phase's output.
+template <int MODE>
+static void hybf_core(Context &c, const BatchWs &w, const void *items, KsItem rot_single, HybOut single, const u64 *key, int B, int U, int use_slots,
+                      int ell, hipStream_t s)
+{
+    const size_t N = c.N;
+    const int ksp = c.ksp, L = c.max_level(), E = c.hyb_ext(ell);
+    const bool separate_conv = option(OPT_HYB_FUSE) == 2 && c.hyb_mfma && N >= 512 && ell >= 4;
+    u64 *accq = w.acc, *accp = w.acc + (size_t)B * 2 * ell * N;
+    launch_ntt_cols_inv(c, w.digits, (long)N, U * ell, nullptr, 0, ell, s, c.hyb_upmods(ell));                    // F2
+    if (separate_conv) {
+        hyb_launch_conv(c, false, true, w.digits, w.ext, U, ell, s);
+        launch_ntt(c, false, w.ext, (long)N, U * E, c.hyb_pidx(ell), 0, E, s);
+    } else {
+        f3_modup_fcols(c, w.digits, w.ext, U, ell, s);                                                             // F3
+        launch_ntt_rows_fwd(c, w.ext, (long)N, U * E, c.hyb_pidx(ell), 0, E, s);                                   // F4
+    }
+    hyb_launch_mac(c, MODE, w, items, rot_single, key, B, use_slots, ell, s);                                      // F5
+    launch_ntt_rows_inv(c, accp, (long)N, 2 * B * ksp, nullptr, L, ksp, s);                                        // F6
+    launch_ntt_cols_inv(c, accp, (long)N, 2 * B * ksp, nullptr, L, ksp, s, c.d_hyb_dnmods);                        // F7
+    if (separate_conv) {
+        hyb_launch_conv(c, true, true, accp, w.tmp, 2 * B, ell, s);
+        launch_ntt_cols_fwd(c, w.tmp, (long)N, 2 * B * ell, nullptr, 0, ell, s);
+    } else
+        f8_moddown_fcols(c, accp, w.tmp, 2 * B, ell, s);                                                           // F8
+    f9_frows_final<MODE>(c, w.tmp, accq, items, rot_single, single, 2 * B, ell, s);                                // F9
+}
+
+void hybf_rotate_hops(Context &c, const BatchWs &w, const KsItem *d_items, int B, int ell, hipStream_t s, int unique)
+{
+    const int use_slots = unique > 0 ? 1 : 0, U = use_slots ? unique : B;
+    f1_irows<0>(c, d_items, KsItem{}, nullptr, w.digits, B, ell, use_slots, s);
+    hybf_core<0>(c, w, d_items, KsItem{}, HybOut{}, nullptr, B, U, use_slots, ell, s);
+}
+
+void hybf_rotate_hop_single(Context &c, const Workspace &w, CtView dst, CtView src, u32 galois_elt, const u64 *galois_key, int ell, hipStream_t s)
+{
+    const KsItem it{ src, dst, galois_key, galois_elt, 0 };
+    BatchWs bw{ nullptr, w.ks_digits, w.ks_ext, w.ks_acc, w.ks_tmp };
+    f1_irows<0>(c, nullptr, it, nullptr, w.ks_digits, 1, ell, 0, s);
+    hybf_core<0>(c, bw, nullptr, it, HybOut{}, nullptr, 1, 1, 0, ell, s);
+}
+
+// target [B][ell][N] = the tensor products' c2 (NTT form), dst.c0 / dst.c1 hold their c0 / c1 (hyb_prepare_mul_kernel has run)
+void hybf_mul_relin_tail(Context &c, const BatchWs &w, const MulItem *d_items, const u64 *relin_key, int B, int ell, hipStream_t s)
+{
+    f1_irows<1>(c, nullptr, KsItem{}, w.target, w.digits, B, ell, 0, s);
+    hybf_core<1>(c, w, d_items, KsItem{}, HybOut{}, relin_key, B, B, 0, ell, s);
+}
+
+void hybf_keyswitch(Context &c, const Workspace &w, CtView out, const u64 *base0, const u64 *base1, const u64 *target, const u64 *key, int ell,
+                    hipStream_t s)
+{
+    BatchWs bw{ const_cast<u64 *>(target), w.ks_digits, w.ks_ext, w.ks_acc, w.ks_tmp };
+    f1_irows<1>(c, nullptr, KsItem{}, target, w.ks_digits, 1, ell, 0, s);
+    hybf_core<2>(c, bw, nullptr, KsItem{}, HybOut{ out, base0, base1 }, key, 1, 1, 0, ell, s);
+}
+
+} // namespace dacapo

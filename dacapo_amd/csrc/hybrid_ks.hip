@@ -80,7 +80,7 @@ __global__ __launch_bounds__(kHT) void hyb_prepare_mul_kernel(const MulItem *__r
     *reinterpret_cast<u64x2 *>(it.dst.limb(1, i, N) + k) = c1;
     const size_t o = ((size_t)b * ell + i) * N + k;
     *reinterpret_cast<u64x2 *>(target + o) = c2;
-    *reinterpret_cast<u64x2 *>(digits + o) = c2;
+    if (digits) *reinterpret_cast<u64x2 *>(digits + o) = c2; // (the fused sequence's first inverse phase reads `target` itself)
 }
 
 __global__ __launch_bounds__(kHT) void hyb_copy_kernel(u64 *__restrict__ dst, const u64 *__restrict__ src)
@@ -271,10 +271,12 @@ __device__ __forceinline__ u64 hyb_recombine(const v4i (&c)[8], int j, const DMo
     return canon(reduce128_lazy(hi2, lo2, M.delta), M);
 }
 
-template <bool DOWN>
+// PRE: the inputs already carry the conversion's per-input constant (the fused sequence folds it into the inverse transform's N^-1 words,
+// hybrid_fused.hip); `pre` = floor(P/2) phat_inv_j mod p_j for DOWN
+template <bool DOWN, bool PRE>
 __global__ __launch_bounds__(kHT) void hyb_conv_mfma_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, int ell, int ksp, int alpha, int L, int E,
                                                              size_t N, const DModulus *__restrict__ mods, const u64 *__restrict__ cst,
-                                                             const v4i *__restrict__ btab, int nblk)
+                                                             const v4i *__restrict__ btab, int nblk, const u64 *__restrict__ pre)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 15, kb = lane >> 4;
     const size_t n0 = ((size_t)blockIdx.x * 4 + wave) * kConvStrip;
@@ -308,7 +310,7 @@ __global__ __launch_bounds__(kHT) void hyb_conv_mfma_kernel(const u64 *__restric
         const int t = 2 * kb + h, tt = t < a ? t : 0;
         mi[h] = mods[in_prime0 + tt];
         mul[h] = DOWN ? cst[tt] : cst[lo + tt];          // phat_inv[j] | qhat_inv[i]
-        add[h] = DOWN ? cst[ksp + tt] : 0;               // floor(P/2) mod p_j | -
+        add[h] = DOWN ? (PRE ? pre[tt] : cst[ksp + tt]) : 0; // floor(P/2) mod p_j (PRE: times phat_inv[j]) | -
     }
 #pragma unroll
     for (int tile = 0; tile < kConvStrip / 16; tile++) {
@@ -320,7 +322,8 @@ __global__ __launch_bounds__(kHT) void hyb_conv_mfma_kernel(const u64 *__restric
             if (t < a) {
                 u64 x = inp[(size_t)t * N + n];
                 if (DOWN) x = addmod(x, add[h], mi[h].q);
-                y[h] = (mulmod(x, mul[h], mi[h]) + C8) ^ C8;
+                if (!PRE) x = mulmod(x, mul[h], mi[h]);
+                y[h] = (x + C8) ^ C8;
             } else
                 y[h] = 0;
         }
@@ -363,6 +366,63 @@ __global__ __launch_bounds__(kHT) void hyb_conv_mfma_kernel(const u64 *__restric
     }
 }
 
+// the two base conversions (matrix cores when the context has their operand tables and the level is high enough, else the vector kernels).
+// `prescaled`: inputs already multiplied by the per-input constant (fused sequence).  count = decompositions (up) / polynomials (down).
+void hyb_launch_conv(Context &c, bool down, bool prescaled, const u64 *in, u64 *out, int count, int ell, hipStream_t s)
+{
+    const size_t N = c.N;
+    const int ksp = c.ksp, alpha = c.alpha, L = c.max_level(), G = c.hyb_groups(ell), E = c.hyb_ext(ell);
+    // (below 4 primes a conversion has at most a 3 x 11 matrix: the vector kernels are faster there -- 115 vs 127 us per hop at level 1, N = 2^17)
+    const bool mfma = c.hyb_mfma && N >= 4 * kConvStrip && ell >= 4;
+    const unsigned gc = (unsigned)(N / (4 * kConvStrip)), gx = (unsigned)(N / (2 * kHT));
+    if (prescaled && !mfma) {
+        fprintf(stderr, "[dacapo_amd] hyb_launch_conv: pre-scaled inputs need the matrix-core form\n");
+        abort();
+    }
+    const v4i *bup = reinterpret_cast<const v4i *>(c.d_hyb_bup + (mfma ? c.hyb_bup_off[(size_t)ell] : 0));
+    const v4i *bdn = reinterpret_cast<const v4i *>(c.d_hyb_bdn + (mfma ? c.hyb_bdn_off[(size_t)ell] : 0));
+    if (!down) {
+        if (mfma && prescaled)
+            hipLaunchKernelGGL((hyb_conv_mfma_kernel<false, true>), dim3(gc, (unsigned)G, (unsigned)count), dim3(kHT), 0, s, in, out, ell, ksp, alpha, L, E,
+                               N, c.d_mods, c.hyb_up(ell), bup, c.hyb_up_blocks(ell), (const u64 *)nullptr);
+        else if (mfma)
+            hipLaunchKernelGGL((hyb_conv_mfma_kernel<false, false>), dim3(gc, (unsigned)G, (unsigned)count), dim3(kHT), 0, s, in, out, ell, ksp, alpha, L, E,
+                               N, c.d_mods, c.hyb_up(ell), bup, c.hyb_up_blocks(ell), (const u64 *)nullptr);
+        else
+            hipLaunchKernelGGL(hyb_modup_kernel, dim3(gx, (unsigned)G, (unsigned)count), dim3(kHT), 0, s, in, out, ell, ksp, alpha, L, E, N, c.d_mods,
+                               c.hyb_up(ell));
+    } else {
+        if (mfma && prescaled)
+            hipLaunchKernelGGL((hyb_conv_mfma_kernel<true, true>), dim3(gc, 1, (unsigned)count), dim3(kHT), 0, s, in, out, ell, ksp, alpha, L, E, N,
+                               c.d_mods, c.d_hyb_dn, bdn, c.hyb_dn_blocks(ell), c.d_hyb_hp);
+        else if (mfma)
+            hipLaunchKernelGGL((hyb_conv_mfma_kernel<true, false>), dim3(gc, 1, (unsigned)count), dim3(kHT), 0, s, in, out, ell, ksp, alpha, L, E, N,
+                               c.d_mods, c.d_hyb_dn, bdn, c.hyb_dn_blocks(ell), (const u64 *)nullptr);
+        else
+            hipLaunchKernelGGL(hyb_moddown_kernel, dim3(gx, (unsigned)count), dim3(kHT), 0, s, in, out, ell, ksp, L, N, c.d_mods, c.d_hyb_dn);
+    }
+}
+
+// inner products with the key: w.ext [U][E][N] (NTT form), w.target (modes 1, 2) -> accq = w.acc [2B][ell][N], accp behind it [2B][ksp][N]
+void hyb_launch_mac(Context &c, int mode, const BatchWs &w, const void *items, KsItem rot_single, const u64 *key, int B, int use_slots, int ell,
+                    hipStream_t s)
+{
+    const size_t N = c.N;
+    const int ksp = c.ksp, alpha = c.alpha, L = c.max_level(), K = c.K, M = ell + ksp, E = c.hyb_ext(ell);
+    const dim3 grid((unsigned)(N / (2 * kHT)), (unsigned)M, (unsigned)B);
+    u64 *accq = w.acc, *accp = w.acc + (size_t)B * 2 * ell * N;
+#define DC_MAC(MD)                                                                                                                        \
+    hipLaunchKernelGGL(hyb_mac_kernel<MD>, grid, dim3(kHT), 0, s, accq, accp, w.ext, w.target, items, rot_single, key, ell, ksp, alpha, L, K, E, N, \
+                       c.logN, use_slots, c.d_mods)
+    if (mode == 0)
+        DC_MAC(0);
+    else if (mode == 1)
+        DC_MAC(1);
+    else
+        DC_MAC(2);
+#undef DC_MAC
+}
+
 // everything after `prepare`.  U = decompositions to compute (digits [U][l][N] in NTT form on entry, transformed in place here): U = B
 // except for rotation batches whose items share sources (use_slots); MODE 1 / 2: target [B][l][N] NTT form.
 template <int MODE>
@@ -370,35 +430,31 @@ static void hyb_core(Context &c, const BatchWs &w, const void *items, const u64 
                      int use_slots, int ell, hipStream_t s)
 {
     const size_t N = c.N;
-    const int ksp = c.ksp, alpha = c.alpha, L = c.max_level(), K = c.K, G = c.hyb_groups(ell), M = ell + ksp, E = c.hyb_ext(ell);
+    const int ksp = c.ksp, L = c.max_level(), E = c.hyb_ext(ell);
     const unsigned gx = (unsigned)(N / (2 * kHT));
     u64 *accq = w.acc, *accp = w.acc + (size_t)B * 2 * ell * N;
     launch_ntt(c, true, w.digits, (long)N, U * ell, nullptr, 0, ell, s);
-    // (below 4 primes a conversion has at most a 3 x 11 matrix: the vector kernels are faster there -- 115 vs 127 us per hop at level 1, N = 2^17)
-    const bool mfma = c.hyb_mfma && N >= 4 * kConvStrip && ell >= 4;
-    const unsigned gc = (unsigned)(N / (4 * kConvStrip));
-    if (mfma)
-        hipLaunchKernelGGL(hyb_conv_mfma_kernel<false>, dim3(gc, (unsigned)G, (unsigned)U), dim3(kHT), 0, s, w.digits, w.ext, ell, ksp, alpha, L, E, N,
-                           c.d_mods, c.hyb_up(ell), reinterpret_cast<const v4i *>(c.d_hyb_bup + c.hyb_bup_off[(size_t)ell]), c.hyb_up_blocks(ell));
-    else
-        hipLaunchKernelGGL(hyb_modup_kernel, dim3(gx, (unsigned)G, (unsigned)U), dim3(kHT), 0, s, w.digits, w.ext, ell, ksp, alpha, L, E, N, c.d_mods,
-                           c.hyb_up(ell));
+    hyb_launch_conv(c, false, false, w.digits, w.ext, U, ell, s);
     launch_ntt(c, false, w.ext, (long)N, U * E, c.hyb_pidx(ell), 0, E, s);
-    hipLaunchKernelGGL(hyb_mac_kernel<MODE>, dim3(gx, (unsigned)M, (unsigned)B), dim3(kHT), 0, s, accq, accp, w.ext, w.target, items, rot_single,
-                       MODE == 2 ? single.key : shared_key, ell, ksp, alpha, L, K, E, N, c.logN, use_slots, c.d_mods);
+    hyb_launch_mac(c, MODE, w, items, rot_single, MODE == 2 ? single.key : shared_key, B, use_slots, ell, s);
     launch_ntt(c, true, accp, (long)N, 2 * B * ksp, nullptr, L, ksp, s);
-    if (mfma)
-        hipLaunchKernelGGL(hyb_conv_mfma_kernel<true>, dim3(gc, 1, (unsigned)(2 * B)), dim3(kHT), 0, s, accp, w.tmp, ell, ksp, alpha, L, E, N, c.d_mods,
-                           c.d_hyb_dn, reinterpret_cast<const v4i *>(c.d_hyb_bdn + c.hyb_bdn_off[(size_t)ell]), c.hyb_dn_blocks(ell));
-    else
-        hipLaunchKernelGGL(hyb_moddown_kernel, dim3(gx, (unsigned)(2 * B)), dim3(kHT), 0, s, accp, w.tmp, ell, ksp, L, N, c.d_mods, c.d_hyb_dn);
+    hyb_launch_conv(c, true, false, accp, w.tmp, 2 * B, ell, s);
     launch_ntt(c, false, w.tmp, (long)N, 2 * B * ell, nullptr, 0, ell, s);
     hipLaunchKernelGGL(hyb_final_kernel<MODE>, dim3(gx, (unsigned)ell, (unsigned)(2 * B)), dim3(kHT), 0, s, accq, w.tmp, items, single, rot_single, ell,
                        ksp, L, N, c.d_mods, c.d_hyb_dn);
 }
 
+// the fused sequence (hybrid_fused.hip; option hyb_fuse != 0, the default)
+void hybf_rotate_hops(Context &c, const BatchWs &w, const KsItem *d_items, int B, int ell, hipStream_t s, int unique);
+void hybf_rotate_hop_single(Context &c, const Workspace &w, CtView dst, CtView src, u32 galois_elt, const u64 *galois_key, int ell, hipStream_t s);
+void hybf_mul_relin_tail(Context &c, const BatchWs &w, const MulItem *d_items, const u64 *relin_key, int B, int ell, hipStream_t s);
+void hybf_keyswitch(Context &c, const Workspace &w, CtView out, const u64 *base0, const u64 *base1, const u64 *target, const u64 *key, int ell,
+                    hipStream_t s);
+static bool hyb_fused() { return option(OPT_HYB_FUSE) != 0; }
+
 void hyb_rotate_hops(Context &c, const BatchWs &w, const KsItem *d_items, int B, int ell, hipStream_t s, int unique)
 {
+    if (hyb_fused()) return hybf_rotate_hops(c, w, d_items, B, ell, s, unique);
     const int use_slots = unique > 0 ? 1 : 0, U = use_slots ? unique : B;
     hipLaunchKernelGGL(hyb_prepare_rot_kernel, dim3((unsigned)(c.N / (2 * kHT)), (unsigned)ell, (unsigned)B), dim3(kHT), 0, s, d_items, KsItem{},
                        w.digits, ell, c.N, c.logN, use_slots);
@@ -407,6 +463,7 @@ void hyb_rotate_hops(Context &c, const BatchWs &w, const KsItem *d_items, int B,
 
 void hyb_rotate_hop_single(Context &c, const Workspace &w, CtView dst, CtView src, u32 galois_elt, const u64 *galois_key, int ell, hipStream_t s)
 {
+    if (hyb_fused()) return hybf_rotate_hop_single(c, w, dst, src, galois_elt, galois_key, ell, s);
     const KsItem it{ src, dst, galois_key, galois_elt, 0 };
     BatchWs bw{ nullptr, w.ks_digits, w.ks_ext, w.ks_acc, w.ks_tmp };
     hipLaunchKernelGGL(hyb_prepare_rot_kernel, dim3((unsigned)(c.N / (2 * kHT)), (unsigned)ell, 1), dim3(kHT), 0, s, (const KsItem *)nullptr, it,
@@ -417,7 +474,8 @@ void hyb_rotate_hop_single(Context &c, const Workspace &w, CtView dst, CtView sr
 void hyb_mul_relin(Context &c, const BatchWs &w, const MulItem *d_items, const u64 *relin_key, int B, int ell, hipStream_t s)
 {
     hipLaunchKernelGGL(hyb_prepare_mul_kernel, dim3((unsigned)(c.N / (2 * kHT)), (unsigned)ell, (unsigned)B), dim3(kHT), 0, s, d_items, w.target,
-                       w.digits, ell, c.N, c.d_mods);
+                       hyb_fused() ? (u64 *)nullptr : w.digits, ell, c.N, c.d_mods);
+    if (hyb_fused()) return hybf_mul_relin_tail(c, w, d_items, relin_key, B, ell, s);
     hyb_core<1>(c, w, d_items, relin_key, HybSingle{}, KsItem{}, B, B, 0, ell, s);
 }
 
@@ -425,6 +483,7 @@ void hyb_mul_relin(Context &c, const BatchWs &w, const MulItem *d_items, const u
 void hyb_keyswitch(Context &c, const Workspace &w, CtView out, const u64 *base0, const u64 *base1, const u64 *target, const u64 *key, int ell,
                    hipStream_t s)
 {
+    if (hyb_fused()) return hybf_keyswitch(c, w, out, base0, base1, target, key, ell, s);
     const size_t N = c.N;
     // the batch scratch of one item: target is read in place, digits / ext / acc / tmp are the workspace's
     BatchWs bw{ const_cast<u64 *>(target), w.ks_digits, w.ks_ext, w.ks_acc, w.ks_tmp };

@@ -40,7 +40,12 @@ void launch_ntt_cols_fwd(const Context &c, u64 *data, long limb_stride, int coun
                          int prime_period, hipStream_t s);
 
 // second (COLS) phase of an inverse NTT only: the input holds the output of an inverse ROWS phase
+// `mods`: another table of per-prime constants (indexed like Context::d_mods) -- the fused grouped-digit key switch passes copies whose
+// N^-1 words carry a base conversion's per-input constant, so that the transform's last stage applies it for free
 void launch_ntt_cols_inv(const Context &c, u64 *data, long limb_stride, int count, const int *d_prime_idx, int prime_base,
+                         int prime_period, hipStream_t s, const DModulus *mods = nullptr);
+// first (ROWS) phase of an inverse NTT only (lazy output)
+void launch_ntt_rows_inv(const Context &c, u64 *data, long limb_stride, int count, const int *d_prime_idx, int prime_base,
                          int prime_period, hipStream_t s);
 
 // ---- limb-wise kernels (poly_kernels.hip) -----------------------------------------------------------------

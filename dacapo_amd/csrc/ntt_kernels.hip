@@ -23,26 +23,26 @@ __global__ __launch_bounds__(kTileThreads) void ntt_phase_kernel(u64 *__restrict
 
 template <int K, int LOGE, bool COLS, bool INV, bool CANON>
 static void launch_phase(const Context &c, u64 *data, long limb_stride, int count, const int *d_prime_idx, int prime_base,
-                         int prime_period, hipStream_t s)
+                         int prime_period, hipStream_t s, const DModulus *mods)
 {
     dim3 grid((unsigned)(c.N >> TileGeo<LOGE>::LOG), (unsigned)count);
     hipLaunchKernelGGL((ntt_phase_kernel<K, LOGE, COLS, INV, CANON>), grid, dim3(kTileThreads), 0, s, data, limb_stride,
-                       d_prime_idx, prime_base, prime_period, c.d_mods, INV ? c.d_itw : c.d_tw, c.logN);
+                       d_prime_idx, prime_base, prime_period, mods ? mods : c.d_mods, INV ? c.d_itw : c.d_tw, c.logN);
 }
 
 template <bool COLS, bool INV, bool CANON>
 static void launch_phase_k(int K, const Context &c, u64 *data, long limb_stride, int count, const int *d_prime_idx,
-                           int prime_base, int prime_period, hipStream_t s)
+                           int prime_base, int prime_period, hipStream_t s, const DModulus *mods = nullptr)
 {
     const bool small = use_small_tiles(c.N, count), tiny = use_tiny_tiles(c.N, count);
 #define DC_PHASE(KK)                                                                                                           \
     case KK:                                                                                                                   \
         if (tiny)                                                                                                              \
-            launch_phase<KK, 1, COLS, INV, CANON>(c, data, limb_stride, count, d_prime_idx, prime_base, prime_period, s);       \
+            launch_phase<KK, 1, COLS, INV, CANON>(c, data, limb_stride, count, d_prime_idx, prime_base, prime_period, s, mods); \
         else if (small)                                                                                                        \
-            launch_phase<KK, 2, COLS, INV, CANON>(c, data, limb_stride, count, d_prime_idx, prime_base, prime_period, s);       \
+            launch_phase<KK, 2, COLS, INV, CANON>(c, data, limb_stride, count, d_prime_idx, prime_base, prime_period, s, mods); \
         else                                                                                                                   \
-            launch_phase<KK, 3, COLS, INV, CANON>(c, data, limb_stride, count, d_prime_idx, prime_base, prime_period, s);       \
+            launch_phase<KK, 3, COLS, INV, CANON>(c, data, limb_stride, count, d_prime_idx, prime_base, prime_period, s, mods); \
         break;
     switch (K) {
         DC_PHASE(6)
@@ -71,11 +71,19 @@ void launch_ntt_cols_fwd(const Context &c, u64 *data, long limb_stride, int coun
 }
 
 void launch_ntt_cols_inv(const Context &c, u64 *data, long limb_stride, int count, const int *d_prime_idx, int prime_base,
+                         int prime_period, hipStream_t s, const DModulus *mods)
+{
+    if (count <= 0) return;
+    if (prime_period <= 0) prime_period = 1 << 30;
+    launch_phase_k<true, true, true>(c.k1, c, data, limb_stride, count, d_prime_idx, prime_base, prime_period, s, mods);
+}
+
+void launch_ntt_rows_inv(const Context &c, u64 *data, long limb_stride, int count, const int *d_prime_idx, int prime_base,
                          int prime_period, hipStream_t s)
 {
     if (count <= 0) return;
     if (prime_period <= 0) prime_period = 1 << 30;
-    launch_phase_k<true, true, true>(c.k1, c, data, limb_stride, count, d_prime_idx, prime_base, prime_period, s);
+    launch_phase_k<false, true, false>(c.k2, c, data, limb_stride, count, d_prime_idx, prime_base, prime_period, s);
 }
 
 void launch_ntt(const Context &c, bool inverse, u64 *data, long limb_stride, int count, const int *d_prime_idx,

@@ -130,6 +130,20 @@ def get_option(name: str) -> int:
     return int(lw.hevm_get_option(name.encode()))
 
 
+def apply_cli_options(argv):
+    """tools: strip `--opt name=value` pairs from an argument list and set them (measurement sweeps without rebuilding or forking)"""
+    out, i = [], 0
+    while i < len(argv):
+        if argv[i] == "--opt" and i + 1 < len(argv):
+            name, _, value = argv[i + 1].partition("=")
+            set_option(name, int(value, 0))
+            i += 2
+        else:
+            out.append(argv[i])
+            i += 1
+    return out
+
+
 @contextlib.contextmanager
 def options(**kw):
     """set options for the duration of a with-block and put the previous values back: VM options are read when a VM is created, launch

@@ -142,3 +142,20 @@ def test_bench_under_an_external_launcher_uses_its_world_size():
 def test_bench_single_rank_dry_run():
     rows = _bench_lines(["--dry-run"])
     assert len(rows) == 1 and rows[0]["n_gpus"] == 1
+
+
+def test_bench_config5_code_path_two_ranks():
+    """BASELINE config 5 = one config-4 stream per GPU: `python bench.py --gpus N --program config4`.  Two gloo ranks through bench.py's own
+    launch code with --dry-run: each rank lowers the nt = 2^16 program to real bootstrapping and counts its NTT-equivalents as the real run
+    does, the replicas compare key digests, rank 0 reports the whole job (no hardware curve is claimed: measured_on_hardware is false)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    rows = _bench_lines(["--gpus", "2", "--program", "config4", "--steps", "2", "--warmup", "0", "--dry-run"], env)
+    assert len(rows) == 1
+    r = rows[0]
+    assert r["n_gpus"] == 2 and r["dry_run"] and r["measured_on_hardware"] is False and r["scaling"] == "weak"
+    c = r["config"]
+    assert "config 5" in c["workload"] and c["rotation_keys"] == 286 and c["key_switches_per_step"] == 10631
+    assert 1.9e6 < c["ntt_equivalents_per_step"] < 2.1e6
+    assert c["keys"]["keys"] == "shared" and c["parallelism"].startswith("replicas x2")
+    # whole-job value = both ranks' work over the slower rank's time
+    assert abs(r["value"] - 2 * c["ntt_equivalents_per_step"] * r["steps"] / (r["ms_per_step"] * 1e-3 * r["steps"])) < 1e-3 * r["value"]

@@ -22,6 +22,8 @@ from dacapo_amd import hevm_asm as ha  # noqa: E402
 from dacapo_amd import ckks_boot as cb  # noqa: E402
 from dacapo_amd import runner  # noqa: E402
 
+sys.argv = runner.apply_cli_options(sys.argv)  # --opt name=value (csrc/options.hpp)
+
 direct = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 name = sys.argv[2] if len(sys.argv) > 2 else "resnet20"
 logN = int(sys.argv[3]) if len(sys.argv) > 3 else 15
