@@ -59,6 +59,18 @@ dc_context *dc_context_create_hybrid(int logN, int num_primes, int special, int 
     c->ensure_scratch();
     return new dc_context{ c, true };
 }
+// ... on an explicit chain (a HEaaN-style mixed one: 60-bit base and special primes around 51-bit rescale primes; the generic-width build)
+dc_context *dc_context_create_hybrid_primes(int logN, const uint64_t *primes, int num_primes, int special, int alpha)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        fprintf(stderr, "[dacapo_amd] no HIP device: the HEVM runtime has no CPU fallback\n");
+        abort();
+    }
+    Context *c = new Context(logN, num_primes, kQBits, primes, special, alpha);
+    c->ensure_scratch();
+    return new dc_context{ c, true };
+}
 int dc_context_key_digits(const dc_context *ctx) { return ctx->c->key_digits(); }
 int dc_context_max_level(const dc_context *ctx) { return ctx->c->max_level(); }
 void dc_context_destroy(dc_context *ctx)

@@ -476,6 +476,7 @@ void HEVM::init_context(int logN, int K, const u64 *primes, int dir_ksp, int dir
     max_batch = std::max(1, (int)option(OPT_MAX_BATCH));
     chain_fusion = option(OPT_CHAIN_FUSION) != 0;
     secret_weight = (int)option(OPT_SECRET_HW);
+    rot_compose = option(OPT_ROT_COMPOSE) != 0;
     online_encode = option(OPT_ONLINE_ENCODE) != 0 && use_plan && !host_encoder;
     lanes.resize(1);
     DC_HIP_CHECK(hipStreamCreateWithFlags(&lanes[0].stream, hipStreamNonBlocking));
@@ -1334,6 +1335,16 @@ std::vector<u32> HEVM::rotate_hops(int steps) const
         hops.push_back((u32)elt);
         return hops;
     }
+    if (rot_compose) { // option rot_compose: the fewest hops over the keys this VM holds (see compose_rotation)
+        const std::vector<int> parts = compose_rotation(steps);
+        if (!parts.empty()) {
+            for (int p : parts) {
+                const std::vector<u32> h = rotate_hops(p); // (each part has a direct key)
+                hops.insert(hops.end(), h.begin(), h.end());
+            }
+            return hops;
+        }
+    }
     std::vector<int> naf;
     {
         int value = pos;
@@ -1354,6 +1365,43 @@ std::vector<u32> HEVM::rotate_hops(int steps) const
             hops.insert(hops.end(), h.begin(), h.end());
         }
     return hops;
+}
+
+// EXTENSION (option rot_compose = 1; off by default: SEAL's rotate_internal only ever composes from the power-of-two keys): a bounded key
+// set serving every offset, the way the reference's HEaaN runtime serves every rotation of a program from its 49 left-rotation keys
+// (HEAAN_HEVM.cpp:58-64,124-126).  A rotation without a direct key becomes the SHORTEST sum of offsets that have one -- two parts if any
+// pair fits, else three -- found in a fixed order (candidates ascending by |offset|, positive before negative), so that the oracle's
+// restatement (oracle/oracle.py rotate_hops) picks the same parts in the same order and limbs stay comparable.  Empty: no sum of <= 3.
+std::vector<int> HEVM::compose_rotation(int steps) const
+{
+    const int slots = (int)(ctx->N >> 1);
+    auto norm = [&](long v) {
+        v %= slots;
+        if (v > slots / 2) v -= slots;
+        if (v <= -slots / 2) v += slots;
+        return (int)v;
+    };
+    if (rot_offsets_epoch != keys.galois.size()) { // the offsets that have a key, from the Galois elements 3^k
+        rot_offsets.clear();
+        std::map<u32, int> step_of;
+        const u64 m = 2 * (u64)ctx->N;
+        u64 e = 1;
+        for (int k = 0; k < slots; k++, e = (e * 3) & (m - 1))
+            if (keys.galois.count((u32)e)) step_of[(u32)e] = norm(k);
+        for (auto &kv : step_of)
+            if (kv.second != 0) rot_offsets.push_back(kv.second);
+        std::sort(rot_offsets.begin(), rot_offsets.end(), [](int a, int b) { return std::abs(a) != std::abs(b) ? std::abs(a) < std::abs(b) : a > b; });
+        rot_offset_set.clear();
+        rot_offset_set.insert(rot_offsets.begin(), rot_offsets.end());
+        rot_offsets_epoch = keys.galois.size();
+    }
+    const int t = norm(steps);
+    for (int a : rot_offsets)
+        if (rot_offset_set.count(norm((long)t - a))) return { a, norm((long)t - a) };
+    for (int a : rot_offsets)
+        for (int b : rot_offsets)
+            if (rot_offset_set.count(norm((long)t - a - b))) return { a, b, norm((long)t - a - b) };
+    return {};
 }
 
 #define ks_ntts(ell) ks_ntt_count(*ctx, (ell))

@@ -5,6 +5,7 @@
 #include <complex>
 #include <deque>
 #include <map>
+#include <set>
 #include <memory>
 #include <string>
 #include <unordered_set>
@@ -246,6 +247,11 @@ class HEVM {
     void boot_item(CtView src, int src_level, double src_scale, hevm_ctxt &dst, int target_level);
     void plan_zero_encrypt(int first, int B, int t, hipStream_t s);
     void plan_boot_step(int first, int B, int ell, int t, int lane, hipStream_t s, const Handoff &h);
+    bool rot_compose = false; // option rot_compose: rotations without a direct key are the shortest sum of offsets that have one (HEVM::compose_rotation)
+    std::vector<int> compose_rotation(int steps) const;
+    mutable std::vector<int> rot_offsets;   // offsets with a key, in the search order; rebuilt when the key set changes
+    mutable std::set<int> rot_offset_set;
+    mutable size_t rot_offsets_epoch = (size_t)-1;
     int secret_weight = 0; // option secret_hw = h: key generation draws a ternary secret with exactly h non-zero coefficients (0: uniform ternary, SEAL's)
     bool chain_fusion = true; // option chain_fusion = 0: every step runs all of its own launches
     hipStream_t aux_stream = nullptr;

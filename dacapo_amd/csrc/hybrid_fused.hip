@@ -11,7 +11,7 @@
 //   mod-up                 (1)               | F3   forward COLS phase of every raised limb with the conversion as its LOADER: sum_t y_t w[t][e]
 //   NTT ext                (2)               |      in three 64-bit columns of 30-bit limb products (4 mads per term, no carries)
 //                                            | F4   forward ROWS phase
-//   mac                    (1)               | F5   inner products with the key (hyb_mac_kernel, unchanged: key-bound)
+//   mac                    (1)               | F5   inner products with the key (hyb_mac_kernel; a rotation's base term P galois(c0) joins the accumulator here)
 //   iNTT acc_P             (2)               | F6   inverse ROWS;  F7  inverse COLS with N^-1 phat_inv_j folded (Context::d_hyb_dnmods)
 //   mod-down               (1)               | F8   forward COLS phase of the 2 l correction limbs with the conversion as its loader
 //   NTT tmp                (2)               | F9   forward ROWS phase with (acc - t) P^-1 + base as its store epilogue
@@ -56,6 +56,9 @@ struct Acc3 {
         return reduce128_any(hi, l2, M);
     }
 };
+// inputs of a conversion whose loads are in flight together: 4 x 8 coefficients (64 VGPRs) for the radix-8 tiles, 8 x 4 / 8 x 2 below
+template <int LOGE>
+constexpr int kConvChunk = LOGE == 3 ? 4 : 8;
 __device__ __forceinline__ u32 w_lo30(u64 w) { return (u32)w & 0x3FFFFFFFu; }
 __device__ __forceinline__ u32 w_hi30(u64 w) { return (u32)(w >> 30); }
 
@@ -126,15 +129,26 @@ __global__ __launch_bounds__(kTileThreads) void hybf_modup_fcols_kernel(const u6
     u64 x[EC];
 #pragma unroll
     for (int j = 0; j < EC; j++) x[j] = 0;
-    for (int t = 0; t < a; t++) {
-        const u64 c = w[(size_t)t * M];
-        const u32 c0 = w_lo30(c), c1 = w_hi30(c);
-        u64 y[EC];
+    // the loads of kConvChunk inputs are issued together (one memory latency per chunk, not per input: the first version waited seven times)
+    for (int t0 = 0; t0 < a; t0 += kConvChunk<LOGE>) {
+        u64 y[kConvChunk<LOGE>][EC];
 #pragma unroll
-        for (int j = 0; j < EC; j++) y[j] = src[(size_t)t * N + gi[j]];
+        for (int tt = 0; tt < kConvChunk<LOGE>; tt++) {
+            if (t0 + tt < a) {
 #pragma unroll
-        for (int j = 0; j < EC; j++) acc[j].mac(y[j], c0, c1);
-        if ((t & 7) == 7 && t + 1 < a) { // more than 8 inputs (alpha up to 16): bank the columns
+                for (int j = 0; j < EC; j++) y[tt][j] = src[(size_t)(t0 + tt) * N + gi[j]];
+            }
+        }
+#pragma unroll
+        for (int tt = 0; tt < kConvChunk<LOGE>; tt++) {
+            if (t0 + tt < a) {
+                const u64 c = w[(size_t)(t0 + tt) * M];
+                const u32 c0 = w_lo30(c), c1 = w_hi30(c);
+#pragma unroll
+                for (int j = 0; j < EC; j++) acc[j].mac(y[tt][j], c0, c1);
+            }
+        }
+        if (((t0 + kConvChunk<LOGE>) & 7) == 0 && t0 + kConvChunk<LOGE> < a) { // more than 8 inputs (alpha up to 16): bank the columns
 #pragma unroll
             for (int j = 0; j < EC; j++) x[j] = addmod(x[j], acc[j].reduce(Mo), Mo.q), acc[j].clear();
         }
@@ -146,12 +160,28 @@ __global__ __launch_bounds__(kTileThreads) void hybf_modup_fcols_kernel(const u6
     ntt_tile_x<K, LOGE, true, false, false, true, false>(x, Mo, tw + ((size_t)pm << logN), logN, blockIdx.x, nold, [=](int gg, u64 v) { out[gg] = v; }, lds);
 }
 
+// ---- F7: second inverse phase of the special-prime accumulators, in place.  z = poly * ksp + j.  The constants passed in `dnmods` carry
+// N^-1 phat_j^-1, and the store adds floor(P/2) phat_j^-1 mod p_j: what leaves is [(r_j + floor(P/2)) phat_j^-1]_{p_j}, the mod-down's input,
+// computed once per coefficient instead of once per (coefficient, output modulus)
+template <int K, int LOGE>
+__global__ __launch_bounds__(kTileThreads) void hybf_icols_special_kernel(u64 *__restrict__ accp, int ksp, int L, const DModulus *__restrict__ dnmods,
+                                                                           const u64 *__restrict__ hp, const u64 *__restrict__ itw, int logN)
+{
+    __shared__ __attribute__((aligned(16))) u64 lds[TileGeo<LOGE>::LDS_ELEMS];
+    const int j = blockIdx.y % ksp, p = L + j;
+    const DModulus M = dnmods[p];
+    const u64 h = hp[j];
+    u64 *a = accp + ((size_t)blockIdx.y << logN);
+    ntt_tile<K, LOGE, true, true, true>(
+        M, itw + ((size_t)p << logN), logN, blockIdx.x, [=](int g) { return a[g]; }, [=](int g, u64 v) { a[g] = addmod(v, h, M.q); }, lds);
+}
+
 // ---- F8: mod-down as the loader of the correction limbs' first forward phase.  y = z * ell + i (polynomial z = 2 b + c, data prime i).
-// accp [2B][ksp][N]: r_j phat_j^-1 mod p_j (F7); t_i = sum_j [(r_j + floor(P/2)) phat_j^-1]_{p_j} (P / p_j) - floor(P/2)  mod q_i
+// accp [2B][ksp][N]: z_j = [(r_j + floor(P/2)) phat_j^-1]_{p_j} (F7); t_i = sum_j z_j (P / p_j) - floor(P/2)  mod q_i
 template <int K, int LOGE>
 __global__ __launch_bounds__(kTileThreads) void hybf_moddown_fcols_kernel(const u64 *__restrict__ accp, u64 *__restrict__ tmp, int ell, int ksp,
                                                                            int L, const DModulus *__restrict__ mods, const u64 *__restrict__ dn,
-                                                                           const u64 *__restrict__ hp, const u64 *__restrict__ tw, int logN)
+                                                                           const u64 *__restrict__ tw, int logN)
 {
     __shared__ __attribute__((aligned(16))) u64 lds[TileGeo<LOGE>::LDS_ELEMS];
     constexpr int EC = 1 << LOGE;
@@ -168,15 +198,25 @@ __global__ __launch_bounds__(kTileThreads) void hybf_moddown_fcols_kernel(const 
     u64 x[EC];
 #pragma unroll
     for (int j = 0; j < EC; j++) acc[j].clear(), x[j] = 0;
-    for (int t = 0; t < ksp; t++) {
-        const u64 c = w[(size_t)t * L], pj = mods[L + t].q, h = hp[t];
-        const u32 c0 = w_lo30(c), c1 = w_hi30(c);
-        u64 y[EC];
+    for (int t0 = 0; t0 < ksp; t0 += kConvChunk<LOGE>) {
+        u64 y[kConvChunk<LOGE>][EC];
 #pragma unroll
-        for (int j = 0; j < EC; j++) y[j] = src[(size_t)t * N + gi[j]];
+        for (int tt = 0; tt < kConvChunk<LOGE>; tt++) {
+            if (t0 + tt < ksp) {
 #pragma unroll
-        for (int j = 0; j < EC; j++) acc[j].mac(addmod(y[j], h, pj), c0, c1);
-        if ((t & 7) == 7 && t + 1 < ksp) {
+                for (int j = 0; j < EC; j++) y[tt][j] = src[(size_t)(t0 + tt) * N + gi[j]];
+            }
+        }
+#pragma unroll
+        for (int tt = 0; tt < kConvChunk<LOGE>; tt++) {
+            if (t0 + tt < ksp) {
+                const u64 c = w[(size_t)(t0 + tt) * L];
+                const u32 c0 = w_lo30(c), c1 = w_hi30(c);
+#pragma unroll
+                for (int j = 0; j < EC; j++) acc[j].mac(y[tt][j], c0, c1);
+            }
+        }
+        if (((t0 + kConvChunk<LOGE>) & 7) == 0 && t0 + kConvChunk<LOGE> < ksp) {
 #pragma unroll
             for (int j = 0; j < EC; j++) x[j] = addmod(x[j], acc[j].reduce(Mo), Mo.q), acc[j].clear();
         }
@@ -193,9 +233,13 @@ struct HybOut { // one key switch by value: out = (base0, base1) + KS(target)
     const u64 *base0 = nullptr, *base1 = nullptr;
 };
 
-// ---- F9: last forward phase of the correction limbs with dst.c = base + (acc_c - t_c) P^-1 as its store epilogue.  y = z * ell + i.
-// MODE 0 rotation items (base of c0: the source's c0 through the Galois map; c1: none), 1 ct x ct items (base: the tensor product's c0 / c1
-// already in dst), 2 one key switch by value
+// ---- F9: last forward phase of the correction limbs with dst.c = base + (acc_c - t_c) P^-1 as its epilogue.  y = z * ell + i.
+// MODE 0 rotation items: no base here -- F5 has added P galois(c0) to the accumulator (hyb_mac_kernel, fold_base); 1 ct x ct items (base: the
+// tensor product's c0 / c1 already in dst), 2 one key switch by value.
+// After its last pass a ROWS tile leaves every thread with E CONSECUTIVE coefficients (idx = (s << LOGE) | j), so the epilogue's three streams
+// (accumulator, base, destination) are 16-byte accesses, 64 contiguous bytes per thread.  (The first version of this kernel called a
+// per-coefficient store functor with a Galois gather inside: 8-byte accesses at a 64-byte lane stride, and the gather's 64 lanes in 64 different
+// cache lines -- 1 460 us per launch in the config-4 run against 570 for the separate transform + element-wise kernel it replaced.)
 template <int K, int LOGE, int MODE>
 __global__ __launch_bounds__(kTileThreads) void hybf_frows_final_kernel(const u64 *__restrict__ tmp, const u64 *__restrict__ accq,
                                                                          const void *__restrict__ items, KsItem rot_single, HybOut single, int ell,
@@ -203,6 +247,7 @@ __global__ __launch_bounds__(kTileThreads) void hybf_frows_final_kernel(const u6
                                                                          const u64 *__restrict__ dn, const u64 *__restrict__ tw, int logN)
 {
     __shared__ __attribute__((aligned(16))) u64 lds[TileGeo<LOGE>::LDS_ELEMS];
+    constexpr int EC = 1 << LOGE, NP = num_passes<LOGE>(K);
     const size_t N = (size_t)1 << logN;
     const int i = blockIdx.y % ell, z = blockIdx.y / ell, b = z >> 1, c = z & 1;
     const DModulus M = mods[i];
@@ -210,11 +255,9 @@ __global__ __launch_bounds__(kTileThreads) void hybf_frows_final_kernel(const u6
     const u64 *in = tmp + (size_t)blockIdx.y * N, *ac = accq + (size_t)blockIdx.y * N;
     u64 *dst;
     const u64 *base = nullptr;
-    u32 elt = 0;
     if (MODE == 0) {
         const KsItem it = items ? static_cast<const KsItem *>(items)[b] : rot_single;
         dst = it.dst.limb(c, i, N);
-        if (c == 0) base = it.src.limb(0, i, N), elt = it.elt;
     } else if (MODE == 1) {
         const MulItem it = static_cast<const MulItem *>(items)[b];
         dst = it.dst.limb(c, i, N), base = dst;
@@ -223,14 +266,22 @@ __global__ __launch_bounds__(kTileThreads) void hybf_frows_final_kernel(const u6
         const u64 *bp = c == 0 ? single.base0 : single.base1;
         base = bp ? bp + (size_t)i * N : nullptr;
     }
-    ntt_tile<K, LOGE, false, false, true>(
-        M, tw + ((size_t)i << logN), logN, blockIdx.x, [=](int g) { return in[g]; },
-        [=](int g, u64 v) {
-            u64 r = mulmod(submod(ac[g], v, M.q), pinv, M);
-            if (base) r = addmod(r, base[(MODE == 0) ? hf_galois_idx((u32)g, elt, logN) : (u32)g], M.q);
-            dst[g] = r;
-        },
-        lds);
+    u64 x[EC];
+    auto nost = [](int, u64) {};
+    ntt_tile_x<K, LOGE, false, false, true, false, true>(x, M, tw + ((size_t)i << logN), logN, blockIdx.x, [=](int g) { return in[g]; }, nost, lds);
+    const int g0 = tile_gidx<K, LOGE, false>(NP - 1, logN, blockIdx.x, 0); // register j holds coefficient g0 + j
+    typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int j = 0; j < EC; j += 2) {
+        const u64x2 a = *reinterpret_cast<const u64x2 *>(ac + g0 + j);
+        u64x2 r;
+        r.x = mulmod(submod(a.x, x[j], M.q), pinv, M), r.y = mulmod(submod(a.y, x[j + 1], M.q), pinv, M);
+        if (base) {
+            const u64x2 o = *reinterpret_cast<const u64x2 *>(base + g0 + j);
+            r.x = addmod(r.x, o.x, M.q), r.y = addmod(r.y, o.y, M.q);
+        }
+        *reinterpret_cast<u64x2 *>(dst + g0 + j) = r;
+    }
 }
 
 // ---- launchers ------------------------------------------------------------------------------------------------------------------
@@ -249,7 +300,12 @@ static void f3_modup_fcols(const Context &c, const u64 *digits, u64 *ext, int U,
 static void f8_moddown_fcols(const Context &c, const u64 *accp, u64 *tmp, int polys, int ell, hipStream_t s)
 {
     DC_GEO_SWITCH(c.k1, polys * ell, hipLaunchKernelGGL((hybf_moddown_fcols_kernel<KK, LE>), grid, dim3(kTileThreads), 0, s, accp, tmp, ell, c.ksp,
-                                                        c.max_level(), c.d_mods, c.d_hyb_dn, c.d_hyb_hp, c.d_tw, c.logN));
+                                                        c.max_level(), c.d_mods, c.d_hyb_dn, c.d_tw, c.logN));
+}
+static void f7_icols_special(const Context &c, u64 *accp, int polys, hipStream_t s)
+{
+    DC_GEO_SWITCH(c.k1, polys * c.ksp, hipLaunchKernelGGL((hybf_icols_special_kernel<KK, LE>), grid, dim3(kTileThreads), 0, s, accp, c.ksp, c.max_level(),
+                                                          c.d_hyb_dnmods, c.d_hyb_hp, c.d_itw, c.logN));
 }
 template <int MODE>
 static void f9_frows_final(const Context &c, const u64 *tmp, const u64 *accq, const void *items, KsItem rot_single, HybOut single, int polys, int ell,
@@ -261,7 +317,7 @@ static void f9_frows_final(const Context &c, const u64 *tmp, const u64 *accq, co
 
 // hybrid_ks.hip
 void hyb_launch_mac(Context &c, int mode, const BatchWs &w, const void *items, KsItem rot_single, const u64 *key, int B, int use_slots, int ell,
-                    hipStream_t s);
+                    hipStream_t s, bool fold_base);
 void hyb_launch_conv(Context &c, bool down, bool prescaled, const u64 *in, u64 *out, int count, int ell, hipStream_t s);
 
 // everything after F1.  digits [U][ell][N] hold the inverse ROWS phase's output.
@@ -281,9 +337,9 @@ static void hybf_core(Context &c, const BatchWs &w, const void *items, KsItem ro
         f3_modup_fcols(c, w.digits, w.ext, U, ell, s);                                                             // F3
         launch_ntt_rows_fwd(c, w.ext, (long)N, U * E, c.hyb_pidx(ell), 0, E, s);                                   // F4
     }
-    hyb_launch_mac(c, MODE, w, items, rot_single, key, B, use_slots, ell, s);                                      // F5
+    hyb_launch_mac(c, MODE, w, items, rot_single, key, B, use_slots, ell, s, MODE == 0);                           // F5
     launch_ntt_rows_inv(c, accp, (long)N, 2 * B * ksp, nullptr, L, ksp, s);                                        // F6
-    launch_ntt_cols_inv(c, accp, (long)N, 2 * B * ksp, nullptr, L, ksp, s, c.d_hyb_dnmods);                        // F7
+    f7_icols_special(c, accp, 2 * B, s);                                                                           // F7
     if (separate_conv) {
         hyb_launch_conv(c, true, true, accp, w.tmp, 2 * B, ell, s);
         launch_ntt_cols_fwd(c, w.tmp, (long)N, 2 * B * ell, nullptr, 0, ell, s);

@@ -117,8 +117,10 @@ __global__ __launch_bounds__(kHT) void hyb_modup_kernel(const u64 *__restrict__ 
         for (int t = 0; t < kHybMaxAlpha; t++) {
             if (t < a) {
                 const u64 c = w[(size_t)(lo + t) * M + mi];
-                a0.mac(y[t].x, c);
-                a1.mac(y[t].y, c);
+                // (mixed chains: a residue of a wider prime is reduced into a narrower target first, or the 128-bit sum leaves the range
+                // 2^(2b+4) its reduction takes -- the generic-width build only; wave-uniform)
+                a0.mac(fw_narrow(m.delta) ? canon(y[t].x, m) : y[t].x, c);
+                a1.mac(fw_narrow(m.delta) ? canon(y[t].y, m) : y[t].y, c);
             }
         }
         u64x2 r;
@@ -135,7 +137,7 @@ template <int MODE>
 __global__ __launch_bounds__(kHT) void hyb_mac_kernel(u64 *__restrict__ accq, u64 *__restrict__ accp, const u64 *__restrict__ ext,
                                                        const u64 *__restrict__ target, const void *__restrict__ items, KsItem single,
                                                        const u64 *__restrict__ shared_key, int ell, int ksp, int alpha, int L, int K, int E, size_t N,
-                                                       int logN, int use_slots, const DModulus *__restrict__ mods)
+                                                       int logN, int use_slots, const DModulus *__restrict__ mods, const u64 *__restrict__ pmod)
 {
     const int mi = blockIdx.y, b = blockIdx.z, M = ell + ksp, pm = mi < ell ? mi : L + (mi - ell);
     const DModulus Md = mods[pm];
@@ -172,6 +174,15 @@ __global__ __launch_bounds__(kHT) void hyb_mac_kernel(u64 *__restrict__ accq, u6
     u64x2 o0, o1;
 #pragma unroll
     for (int e = 0; e < 2; e++) o0[e] = a0[e].reduce(Md), o1[e] = a1[e].reduce(Md);
+    if (MODE == 0 && pmod && mi < ell) {
+        // fused sequence: the rotation's base term rides on the accumulator -- galois(c0) + (acc - t) P^-1 = ((acc + P galois(c0)) - t) P^-1
+        // exactly, so the last kernel has no gather to do and nobody materialises galois(c0) (this kernel has the Galois index in hand,
+        // 16-byte accesses, and arithmetic to spare next to the key's bytes)
+        const u64x2 v = *reinterpret_cast<const u64x2 *>(it.src.limb(0, mi, N) + (gsrc & ~1u));
+        const u64 P = pmod[pm];
+        o0.x = addmod(o0.x, mulmod((gsrc & 1u) ? v.y : v.x, P, Md), Md.q);
+        o0.y = addmod(o0.y, mulmod((gsrc & 1u) ? v.x : v.y, P, Md), Md.q);
+    }
     if (mi < ell) {
         *reinterpret_cast<u64x2 *>(accq + (((size_t)b * 2 + 0) * ell + mi) * N + k) = o0;
         *reinterpret_cast<u64x2 *>(accq + (((size_t)b * 2 + 1) * ell + mi) * N + k) = o1;
@@ -206,8 +217,8 @@ __global__ __launch_bounds__(kHT) void hyb_moddown_kernel(const u64 *__restrict_
         for (int j = 0; j < kHybMaxAlpha; j++) {
             if (j < ksp) {
                 const u64 c = w[(size_t)j * L + i];
-                a0.mac(zz[j].x, c);
-                a1.mac(zz[j].y, c);
+                a0.mac(fw_narrow(m.delta) ? canon(zz[j].x, m) : zz[j].x, c);
+                a1.mac(fw_narrow(m.delta) ? canon(zz[j].y, m) : zz[j].y, c);
             }
         }
         u64x2 r;
@@ -259,24 +270,40 @@ __global__ __launch_bounds__(kHT) void hyb_final_kernel(const u64 *__restrict__ 
 typedef int v4i __attribute__((ext_vector_type(4)));
 constexpr int kConvStrip = 128; // coefficients per wave
 
+// Recombination of the 8 accumulator planes, round 4 (round 3's form spent ~50 vector instructions per output on a signed 128-bit sum, and the
+// matrix pipes sat idle 93 % of the launch).  The accumulators START at 2^20 (the MFMA's C operand), so every plane value c'_r = C_r + 2^20 is
+// in [0, 2^21] and T' = sum_r c'_r 2^(8r) < 2^78 is an unsigned sum: two chains of three v_mad_u64_u32 (the shifts are multiplications by
+// constants), one 96-bit assembly, ONE fold (T' >> 60 < 2^18, so (T' >> 60) d + (T' mod 2^60) < 2q), one conditional subtraction -- and the
+// constant K0 = 2^20 (2^64 - 1) / 255 that the offsets added leaves with the caller's own final subtraction (k0 = K0 mod m, plus the
+// mod-down's floor(P/2)).  ~23 instructions.  The generic-width build keeps the 128-bit reduction (T' >> b can exceed 32 bits there).
+constexpr int kPlaneBias = 1 << 20;
 __device__ __forceinline__ u64 hyb_recombine(const v4i (&c)[8], int j, const DModulus &M)
 {
-    const int64_t slo = (int64_t)c[0][j] + ((int64_t)c[1][j] << 8) + ((int64_t)c[2][j] << 16) + ((int64_t)c[3][j] << 24);
-    const int64_t shi = (int64_t)c[4][j] + ((int64_t)c[5][j] << 8) + ((int64_t)c[6][j] << 16) + ((int64_t)c[7][j] << 24);
-    // T = slo + shi 2^32 as a 128-bit two's complement number, |T| < 2^78; T + (q << 19) is non-negative and congruent
-    const u64 lo = (u64)slo + ((u64)shi << 32);
-    const u64 hi = (u64)(slo >> 63) + (u64)(shi >> 32) + (lo < (u64)slo ? 1u : 0u);
-    const u64 lo2 = lo + (M.q << 19);
-    const u64 hi2 = hi + (M.q >> 45) + (lo2 < lo ? 1u : 0u);
-    return canon(reduce128_lazy(hi2, lo2, M.delta), M);
+    const u64 slo = mad32((u32)c[3][j], 1u << 24, mad32((u32)c[2][j], 1u << 16, mad32((u32)c[1][j], 1u << 8, (u64)(u32)c[0][j])));
+    const u64 shi = mad32((u32)c[7][j], 1u << 24, mad32((u32)c[6][j], 1u << 16, mad32((u32)c[5][j], 1u << 8, (u64)(u32)c[4][j])));
+    const u64 lo = slo + (shi << 32);
+    const u64 hi = (shi >> 32) + (lo < slo ? 1u : 0u);
+#if DC_GENERIC_WIDTH
+    return reduce128_any(hi, lo, M);
+#else
+    const u32 top = (u32)((hi << 4) | (lo >> 60));
+    const u64 r = mad32(top, M.delta, lo & ((1ull << 60) - 1));
+    return r >= M.q ? r - M.q : r;
+#endif
+}
+// K0 mod m, K0 = 2^20 * 0x0101010101010101 (what the plane biases add to every output)
+__device__ __forceinline__ u64 hyb_plane_bias_mod(const DModulus &M)
+{
+    const u64 ones = 0x0101010101010101ull;
+    return reduce128_any(ones >> 44, ones << 20, M);
 }
 
-// PRE: the inputs already carry the conversion's per-input constant (the fused sequence folds it into the inverse transform's N^-1 words,
-// hybrid_fused.hip); `pre` = floor(P/2) phat_inv_j mod p_j for DOWN
+// PRE: the inputs already carry the conversion's per-input constant -- and, for DOWN, the rounding offset floor(P/2) phat_inv_j -- (the fused
+// sequence folds them into the inverse transform's last stage and store, hybrid_fused.hip)
 template <bool DOWN, bool PRE>
 __global__ __launch_bounds__(kHT) void hyb_conv_mfma_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, int ell, int ksp, int alpha, int L, int E,
                                                              size_t N, const DModulus *__restrict__ mods, const u64 *__restrict__ cst,
-                                                             const v4i *__restrict__ btab, int nblk, const u64 *__restrict__ pre)
+                                                             const v4i *__restrict__ btab, int nblk)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 15, kb = lane >> 4;
     const size_t n0 = ((size_t)blockIdx.x * 4 + wave) * kConvStrip;
@@ -310,7 +337,7 @@ __global__ __launch_bounds__(kHT) void hyb_conv_mfma_kernel(const u64 *__restric
         const int t = 2 * kb + h, tt = t < a ? t : 0;
         mi[h] = mods[in_prime0 + tt];
         mul[h] = DOWN ? cst[tt] : cst[lo + tt];          // phat_inv[j] | qhat_inv[i]
-        add[h] = DOWN ? (PRE ? pre[tt] : cst[ksp + tt]) : 0; // floor(P/2) mod p_j (PRE: times phat_inv[j]) | -
+        add[h] = DOWN ? cst[ksp + tt] : 0;               // floor(P/2) mod p_j | -
     }
 #pragma unroll
     for (int tile = 0; tile < kConvStrip / 16; tile++) {
@@ -321,7 +348,7 @@ __global__ __launch_bounds__(kHT) void hyb_conv_mfma_kernel(const u64 *__restric
             const int t = 2 * kb + h;
             if (t < a) {
                 u64 x = inp[(size_t)t * N + n];
-                if (DOWN) x = addmod(x, add[h], mi[h].q);
+                if (DOWN && !PRE) x = addmod(x, add[h], mi[h].q);
                 if (!PRE) x = mulmod(x, mul[h], mi[h]);
                 y[h] = (x + C8) ^ C8;
             } else
@@ -346,18 +373,17 @@ __global__ __launch_bounds__(kHT) void hyb_conv_mfma_kernel(const u64 *__restric
             post = valid ? cst[2 * ksp + e] : 0; // floor(P/2) mod q_i
         }
         const DModulus Mo = mods[valid ? pm : 0];
+        const u64 k0 = addmod(hyb_plane_bias_mod(Mo), post, Mo.q); // (once per block of 16 moduli, not per coefficient)
 #pragma unroll
         for (int tile = 0; tile < kConvStrip / 16; tile++) {
             v4i c[8];
 #pragma unroll
-            for (int r = 0; r < 8; r++) c[r] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[tile], Bf[r], v4i{ 0, 0, 0, 0 }, 0, 0, 0);
+            for (int r = 0; r < 8; r++)
+                c[r] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[tile], Bf[r], v4i{ kPlaneBias, kPlaneBias, kPlaneBias, kPlaneBias }, 0, 0, 0);
             if (valid) { // this lane: rows 4 kb .. 4 kb + 3 of the tile, column `col`
                 u64 v[4];
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    v[j] = hyb_recombine(c, j, Mo);
-                    if (DOWN) v[j] = submod(v[j], post, Mo.q);
-                }
+                for (int j = 0; j < 4; j++) v[j] = submod(hyb_recombine(c, j, Mo), k0, Mo.q);
                 u64 *o = outp + (size_t)e * N + n0 + (size_t)tile * 16 + 4 * kb;
                 *reinterpret_cast<u64x2 *>(o) = u64x2{ v[0], v[1] };
                 *reinterpret_cast<u64x2 *>(o + 2) = u64x2{ v[2], v[3] };
@@ -384,20 +410,20 @@ void hyb_launch_conv(Context &c, bool down, bool prescaled, const u64 *in, u64 *
     if (!down) {
         if (mfma && prescaled)
             hipLaunchKernelGGL((hyb_conv_mfma_kernel<false, true>), dim3(gc, (unsigned)G, (unsigned)count), dim3(kHT), 0, s, in, out, ell, ksp, alpha, L, E,
-                               N, c.d_mods, c.hyb_up(ell), bup, c.hyb_up_blocks(ell), (const u64 *)nullptr);
+                               N, c.d_mods, c.hyb_up(ell), bup, c.hyb_up_blocks(ell));
         else if (mfma)
             hipLaunchKernelGGL((hyb_conv_mfma_kernel<false, false>), dim3(gc, (unsigned)G, (unsigned)count), dim3(kHT), 0, s, in, out, ell, ksp, alpha, L, E,
-                               N, c.d_mods, c.hyb_up(ell), bup, c.hyb_up_blocks(ell), (const u64 *)nullptr);
+                               N, c.d_mods, c.hyb_up(ell), bup, c.hyb_up_blocks(ell));
         else
             hipLaunchKernelGGL(hyb_modup_kernel, dim3(gx, (unsigned)G, (unsigned)count), dim3(kHT), 0, s, in, out, ell, ksp, alpha, L, E, N, c.d_mods,
                                c.hyb_up(ell));
     } else {
         if (mfma && prescaled)
             hipLaunchKernelGGL((hyb_conv_mfma_kernel<true, true>), dim3(gc, 1, (unsigned)count), dim3(kHT), 0, s, in, out, ell, ksp, alpha, L, E, N,
-                               c.d_mods, c.d_hyb_dn, bdn, c.hyb_dn_blocks(ell), c.d_hyb_hp);
+                               c.d_mods, c.d_hyb_dn, bdn, c.hyb_dn_blocks(ell));
         else if (mfma)
             hipLaunchKernelGGL((hyb_conv_mfma_kernel<true, false>), dim3(gc, 1, (unsigned)count), dim3(kHT), 0, s, in, out, ell, ksp, alpha, L, E, N,
-                               c.d_mods, c.d_hyb_dn, bdn, c.hyb_dn_blocks(ell), (const u64 *)nullptr);
+                               c.d_mods, c.d_hyb_dn, bdn, c.hyb_dn_blocks(ell));
         else
             hipLaunchKernelGGL(hyb_moddown_kernel, dim3(gx, (unsigned)count), dim3(kHT), 0, s, in, out, ell, ksp, L, N, c.d_mods, c.d_hyb_dn);
     }
@@ -405,7 +431,7 @@ void hyb_launch_conv(Context &c, bool down, bool prescaled, const u64 *in, u64 *
 
 // inner products with the key: w.ext [U][E][N] (NTT form), w.target (modes 1, 2) -> accq = w.acc [2B][ell][N], accp behind it [2B][ksp][N]
 void hyb_launch_mac(Context &c, int mode, const BatchWs &w, const void *items, KsItem rot_single, const u64 *key, int B, int use_slots, int ell,
-                    hipStream_t s)
+                    hipStream_t s, bool fold_base)
 {
     const size_t N = c.N;
     const int ksp = c.ksp, alpha = c.alpha, L = c.max_level(), K = c.K, M = ell + ksp, E = c.hyb_ext(ell);
@@ -413,7 +439,7 @@ void hyb_launch_mac(Context &c, int mode, const BatchWs &w, const void *items, K
     u64 *accq = w.acc, *accp = w.acc + (size_t)B * 2 * ell * N;
 #define DC_MAC(MD)                                                                                                                        \
     hipLaunchKernelGGL(hyb_mac_kernel<MD>, grid, dim3(kHT), 0, s, accq, accp, w.ext, w.target, items, rot_single, key, ell, ksp, alpha, L, K, E, N, \
-                       c.logN, use_slots, c.d_mods)
+                       c.logN, use_slots, c.d_mods, fold_base ? c.d_pmod : (const u64 *)nullptr)
     if (mode == 0)
         DC_MAC(0);
     else if (mode == 1)
@@ -436,7 +462,7 @@ static void hyb_core(Context &c, const BatchWs &w, const void *items, const u64 
     launch_ntt(c, true, w.digits, (long)N, U * ell, nullptr, 0, ell, s);
     hyb_launch_conv(c, false, false, w.digits, w.ext, U, ell, s);
     launch_ntt(c, false, w.ext, (long)N, U * E, c.hyb_pidx(ell), 0, E, s);
-    hyb_launch_mac(c, MODE, w, items, rot_single, MODE == 2 ? single.key : shared_key, B, use_slots, ell, s);
+    hyb_launch_mac(c, MODE, w, items, rot_single, MODE == 2 ? single.key : shared_key, B, use_slots, ell, s, false);
     launch_ntt(c, true, accp, (long)N, 2 * B * ksp, nullptr, L, ksp, s);
     hyb_launch_conv(c, true, false, accp, w.tmp, 2 * B, ell, s);
     launch_ntt(c, false, w.tmp, (long)N, 2 * B * ell, nullptr, 0, ell, s);

@@ -22,6 +22,7 @@ static const OptDef kDefs[OPT_COUNT] = {
     { "ks_special", 1 },
     { "ks_alpha", 0 },
     { "secret_hw", 0 },
+    { "rot_compose", 0 },
     { "plan", 1 },
     { "plan_graph", 1 },
     { "plan_lanes", 2 },

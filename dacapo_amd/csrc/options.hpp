@@ -23,6 +23,7 @@ enum Opt : int {
     OPT_KS_SPECIAL,        // grouped-digit key switching: special primes (1 = SEAL's scheme)
     OPT_KS_ALPHA,          // ... data primes per digit (0 = same as ks_special)
     OPT_SECRET_HW,         // Hamming weight of the ternary secret (0 = SEAL's uniform ternary)
+    OPT_ROT_COMPOSE,       // rotations without a direct key: shortest sum of offsets that have one (0: SEAL's NAF over the power-of-two keys)
     OPT_PLAN,              // 1: batched execution plan; 0: the reference's loop, one instruction at a time
     OPT_PLAN_GRAPH,        // replay the plan as one HIP graph
     OPT_PLAN_LANES,        // streams the plan's independent steps are spread over (1 or 2)

@@ -45,6 +45,8 @@ def _bind(path):
         L.dc_context_create.argtypes = [i32, i32, i32, vp]
         L.dc_context_create_hybrid.restype = vp
         L.dc_context_create_hybrid.argtypes = [i32, i32, i32, i32]
+        L.dc_context_create_hybrid_primes.restype = vp
+        L.dc_context_create_hybrid_primes.argtypes = [i32, vp, i32, i32, i32]
         L.dc_context_key_digits.argtypes = [vp]
         L.dc_context_max_level.argtypes = [vp]
         L.dc_context_destroy.argtypes = [vp]
@@ -140,8 +142,10 @@ class Context:
             arr = (C.c_uint64 * len(primes))(*[int(p) for p in primes])
             num_primes = len(primes)
         alpha = special if alpha is None else alpha
-        if (special, alpha) != (1, 1):
-            assert primes is None and bit_size == 60
+        if (special, alpha) != (1, 1) and primes is not None:
+            self.h = L.dc_context_create_hybrid_primes(logN, arr, num_primes, special, alpha)
+        elif (special, alpha) != (1, 1):
+            assert bit_size == 60
             self.h = L.dc_context_create_hybrid(logN, num_primes, special, alpha)
         else:
             self.h = L.dc_context_create(logN, num_primes, bit_size, arr)

@@ -38,6 +38,8 @@ dc_context *dc_context_create(int logN, int num_primes, int bit_size, const uint
  * (alpha <= special), key-switch keys are [dc_context_key_digits()][2][K][N] and data levels run up to dc_context_max_level() =
  * num_primes - special.  special = alpha = 1 is dc_context_create's (SEAL's) scheme. */
 dc_context *dc_context_create_hybrid(int logN, int num_primes, int special, int alpha);
+/* ... on an explicit prime chain (each prime 2^b - d as for dc_context_create; widths other than 60 bits: libSEAL_HEVM_gw.so) */
+dc_context *dc_context_create_hybrid_primes(int logN, const uint64_t *primes, int num_primes, int special, int alpha);
 int dc_context_key_digits(const dc_context *ctx);
 int dc_context_max_level(const dc_context *ctx);
 void dc_context_destroy(dc_context *ctx);

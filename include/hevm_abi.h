@@ -134,7 +134,7 @@ void hevm_save_ctxt(void *vm, int64_t reg, const char *path);
 void hevm_load_ctxt(void *vm, int64_t reg, const char *path);
 
 /* Run-time options (dacapo_amd/csrc/options.hpp holds the ONE table: names, defaults, meaning).  VM options -- "logn", "primes",
- * "prime_bits", "ks_special", "ks_alpha", "secret_hw", "plan", "plan_graph", "plan_lanes", "max_batch", "chain_fusion", "host_encoder",
+ * "prime_bits", "ks_special", "ks_alpha", "secret_hw", "rot_compose", "plan", "plan_graph", "plan_lanes", "max_batch", "chain_fusion", "host_encoder",
  * "online_encode", "fold_rescale_boot", "hyb_mfma", "hyb_fuse", "seal_compr", "trace", "step_profile" -- are read when a VM (or kernel-level
  * context) is created; launch-shape thresholds -- "small_tile_wgs", "tiny_tile_wgs", "ntt_full_min_limbs", ... -- at every launch.
  * Process-wide, not thread-safe (like the rest of this ABI).  An unknown name aborts with the list of names.  A caller that only knows

@@ -428,6 +428,38 @@ class Oracle:
         self.keyswitch(temp, self.galois[elt], c0, c1)
         return Ciphertext(np.stack([c0, c1]), a.scale)
 
+    rot_compose = False  # EXTENSION (the GPU VM's option rot_compose): see compose_rotation
+
+    def compose_rotation(self, steps: int):
+        """the GPU VM's HEVM::compose_rotation (hevm_vm.hip), restated: a rotation without a direct key as the SHORTEST sum (two parts, else
+        three) of offsets that have one, candidates ascending by |offset|, positive before negative -- what lets a bounded key set serve every
+        offset of a program, like the 49 left-rotation keys of the reference's HEaaN runtime (HEAAN_HEVM.cpp:58-64,124-126)"""
+        slots = self.slots
+
+        def norm(v):
+            v %= slots
+            if v > slots // 2:
+                v -= slots
+            if v <= -slots // 2:
+                v += slots
+            return v
+
+        have, e, m = set(), 1, 2 * self.N
+        for k in range(slots):
+            if e in self.galois and norm(k) != 0:
+                have.add(norm(k))
+            e = (e * 3) % m
+        order = sorted(have, key=lambda a: (abs(a), -a))
+        t = norm(steps)
+        for a in order:
+            if norm(t - a) in have:
+                return [a, norm(t - a)]
+        for a in order:
+            for b in order:
+                if norm(t - a - b) in have:
+                    return [a, b, norm(t - a - b)]
+        return []
+
     def rotate_hops(self, steps: int):
         """Evaluator::rotate_internal's decomposition: list of galois elements applied in order."""
         if steps == 0:
@@ -435,6 +467,10 @@ class Oracle:
         elt = self.elt_from_step(steps)
         if elt in self.galois:
             return [elt]
+        if self.rot_compose:
+            parts = self.compose_rotation(steps)
+            if parts:
+                return [self.elt_from_step(p) for p in parts]
         naf = self.naf(steps)
         if len(naf) == 1:
             raise KeyError("Galois key not present")

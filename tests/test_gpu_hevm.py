@@ -767,3 +767,53 @@ def test_options_table_round_trips_and_rejects_nothing_silently():
     runner.set_option("max_batch", 16)
     runner.lw.hevm_reset_options()
     assert runner.get_option("max_batch") == 64
+
+
+@pytest.mark.parametrize("plan,ks", [(1, 1), (0, 1), (1, 2)])
+def test_bounded_rotation_key_set_serves_every_offset(tmp_path, plan, ks):
+    """option rot_compose (extension; the reference's HEaaN runtime serves every rotation of a program from 49 left-rotation keys,
+    HEAAN_HEVM.cpp:58-64,124-126): a rotation without a direct key is the SHORTEST sum of offsets that have one, found in a fixed order
+    (HEVM::compose_rotation; restated in oracle/oracle.py).  Key set = SEAL's default +-2^k plus a few of that list's other offsets; the
+    program rotates by offsets outside it.  GPU VM == oracle VM limb for limb (plan and one-at-a-time loop, SEAL-style and grouped-digit
+    keys), fewer key switches than SEAL's NAF over the power-of-two keys would take, and the slots land where they should."""
+    from dacapo_amd import hevm_asm as ha
+    from dacapo_amd import lowlevel as ll
+    from dacapo_amd import runner
+
+    logN, K = 12, 5 + ks
+    slots = 1 << (logN - 1)
+    extra = [3, 5, 6, 7, 24, 96, 160, 192, 224, 768]
+    offsets = [9, 11, 100, 777, -3, 1000, 23, -97, 455]
+    rng = np.random.default_rng(2)
+    b = ha.Builder(slots=slots, init_level=K - ks, policy="lazy", boot_level=K - ks, shadow=True)
+    x = b.input(rng.uniform(-1, 1, slots))
+    acc = None
+    for k, o in enumerate(offsets):
+        t = b.mul_plain(b.rotate(x, o), [0.1 * (k + 1)])
+        acc = t if acc is None else b.add(acc, t)
+    b.output(b.finish(acc))
+    cst, hv, _ = b.assemble()
+    hevm = runner.HEVM(seed=13, logN=logN, num_primes=K, ks_special=ks, vm_options={"plan": plan, "rot_compose": 1})
+    hevm.addRotationKeys(extra)
+    o = Oracle(logN, K)
+    if ks > 1:
+        o.set_hybrid(ks)
+    o.rot_compose = True
+    elts = sorted(set(o.default_galois_elts()) | {o.elt_from_step(s) for s in extra})
+    _import_keys(o, hevm, ll, elts=elts)
+    hops = {off: o.rotate_hops(off) for off in offsets}
+    assert all(1 <= len(h) <= 3 for h in hops.values()) and len(hops[9]) == 2 and len(hops[777]) == 3
+    hevm.load_mem(cst, hv)
+    ovm = _mirror_vm(hevm, ll, o, cst, hv, tmp_path)
+    hevm.setInput(0, x.plain)
+    ovm.ciphers[0] = _get_ct(hevm, ll, 0)
+    hevm.run()
+    ovm.run()
+    r = ovm.prog.res_dst[0]
+    got, want = _get_ct(hevm, ll, r), ovm.ciphers[r]
+    assert got.ell == want.ell and got.scale == want.scale and (got.data == want.data).all()
+    assert np.abs(hevm.getOutput()[0] - b.expected()[0]).max() < 1e-4
+    assert hevm.stats()["keyswitches"] == sum(len(h) for h in hops.values())
+    o.rot_compose = False
+    assert sum(len(o.rotate_hops(off)) for off in offsets) > hevm.stats()["keyswitches"]      # SEAL's NAF over +-2^k takes more hops
+    hevm.close()

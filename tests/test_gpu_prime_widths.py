@@ -67,6 +67,43 @@ def test_ntt_and_evaluator_ops_on_other_prime_widths(logN, widths):
             assert (dd.to_host()[:, : ell - 1] == o.rescale(want).data).all(), ("rescale", ell)
 
 
+@pytest.mark.parametrize("fuse", [1, 2, 0])
+@pytest.mark.parametrize("logN,widths,ks,alpha", [(12, [60, 51, 51, 51, 51, 51, 51, 60, 60], 2, 2), (12, [60] + [51] * 9 + [60] * 5, 5, 4),
+                                                  (12, [58, 45, 51, 60, 48, 51, 60, 55], 3, 2)])
+def test_grouped_digit_key_switch_on_mixed_chains(logN, widths, ks, alpha, fuse, request):
+    """grouped-digit hybrid key switching on HEaaN-style MIXED chains -- a 60-bit base prime, 51-bit rescale primes, 60-bit special primes
+    (HEAAN_HEVM.cpp:55-56, profiled_HEAAN_GPU.json: rescalingFactor 51) -- and on a deliberately ragged one: the base conversions move
+    residues between width classes (a 60-bit residue into a 51-bit target and back), in all three launch sequences (fused with the conversions
+    in the transforms' loaders / as matrix-core launches / round 3's).  Rotation hop and ct x ct + relinearise at every level == the oracle's
+    orc_keyswitch_hybrid on the same primes, limb for limb.  (Round 3 computed garbage here without saying so: advisor finding 1.)"""
+    from dacapo_amd import lowlevel as ll
+    from dacapo_amd import runner
+
+    primes = _chain(logN, widths)
+    K, N = len(primes), 1 << logN
+    o = Oracle(logN, K, primes=primes)
+    o.set_hybrid(ks, alpha)
+    elt = o.elt_from_step(5)
+    o.keygen(seed=11, galois_elts=[elt])
+    ctx = ll.Context(logN, primes=primes, special=ks, alpha=alpha)
+    L = ctx.L
+    assert L is ll.lib_gw() and ctx.primes == primes and ctx.key_digits == o.dnum and ctx.max_level == o.max_level
+    runner.set_option("hyb_fuse", fuse)
+    request.addfinalizer(lambda: runner.set_option("hyb_fuse", 1))
+    dk, dr = ll.DeviceBuffer.from_host(o.galois[elt]), ll.DeviceBuffer.from_host(o.relin)
+    for ell in range(1, o.max_level + 1):
+        q = np.array(primes[:ell], dtype=np.uint64)[:, None]
+        x = np.stack([np.stack([splitmix_fill(1 + 7 * p + i + 100 * ell, N) for i in range(ell)]) % q for p in range(2)])
+        y = np.stack([np.stack([splitmix_fill(99 + 7 * p + i + 100 * ell, N) for i in range(ell)]) % q for p in range(2)])
+        dx, dy, dd = ll.DeviceBuffer.from_host(x), ll.DeviceBuffer.from_host(y), ll.DeviceBuffer((2, ell, N))
+        st = ell * N
+        X, Y = Ciphertext(x, 2.0**40), Ciphertext(y, 2.0**40)
+        L.dc_ct_rotate_hop(ctx.h, dd.ptr, st, dx.ptr, st, elt, dk.ptr, ell, None)
+        assert (dd.to_host() == o.apply_galois(X, elt).data).all(), ("rotate", ell)
+        L.dc_ct_mul_relin(ctx.h, dd.ptr, st, dx.ptr, st, dy.ptr, st, dr.ptr, ell, None)
+        assert (dd.to_host() == o.mul_relin(X, Y).data).all(), ("mul_relin", ell)
+
+
 def test_both_builds_agree_on_the_reference_chain():
     """the generic-width build computes the 60-bit chain too (tag 0): same limbs as the default build, which keeps round 2's instruction
     streams (immediate shifts, no third fold)"""

@@ -2,7 +2,7 @@
 """The reference's ResNet-20 with REAL CKKS bootstrapping at every bootstrap site (the headline program tests/golden/resnet20.*, every
 opcode 10 rewritten by dacapo_amd/ckks_boot.lower_bootstraps): BASELINE config 4 in spirit -- the reference
 runs it on HEaaN (HEAAN_HEVM.cpp:386-399) at N = 2^17; here on SEAL-style 60-bit primes, N = 2^15, 20 primes, sparse secret.
-    python tools/resnet_real_boot.py [direct_keys=1|2] [fixture=resnet20] [logN=15] [msg_bits=4] [lowering=""] [ks_special=1] [ks_alpha=ks_special]
+    python tools/resnet_real_boot.py [direct_keys=1|2|49|<n>] [fixture=resnet20] [logN=15] [msg_bits=4] [lowering=""] [ks_special=1] [ks_alpha=ks_special]
 lowering: another lowering of the same trace (tests/golden/<fixture>.<lowering>.hevm.gz, same constants), e.g. b14 = bootstraps placed at the
 model script's own hints, restoring 14 primes (38 bootstraps instead of 541); ks_special > 1: grouped-digit hybrid key switching with that
 many special primes (dacapo_amd/csrc/hybrid_ks.hip), which is what makes a 31-level chain affordable at N = 2^17.
@@ -48,12 +48,37 @@ h = ha.unpack_hevm(fx["hevm"])
 ops = h["ops"]
 print(f"{len(ops)} instructions, {h['num_ptxt']} plaintext registers, {int((ops[:, 0] == ha.OP_MODRAISE).sum())} real bootstraps", flush=True)
 t0 = time.time()
-hevm = runner.HEVM(seed=0x4845564D, logN=logN, num_primes=KB, ks_special=ks, ks_alpha=alpha, vm_options={"secret_hw": 64})
-if direct:
+# direct_keys >= 49: a BOUNDED key set -- the reference's HEaaN runtime serves every rotation of a program from its 49 left-rotation keys
+# (HEAAN_HEVM.cpp:58-64,124-126).  49 = exactly that list (31 of its offsets are the +-2^k this VM has anyway); n > 49: that list plus the
+# program's most frequently used other offsets up to n keys.  Rotations without a direct key are composed from the set (option rot_compose).
+HEAAN_OFFSETS = [1, 2, 3, 4, 5, 6, 7, 8, 16, 24, 32, 64, 96, 128, 160, 192, 224, 256, 512, 768, 1024, 2048, 3072, 4096, 5120, 6144, 7168, 8192,
+                 16384, 24576, 32768, 40960, 49152, 57344, 61440, 63488, 64512, 64768, 65024, 65280, 65408, 65472, 65504, 65512, 65520, 65528,
+                 65532, 65534, 65535]
+bounded = direct >= 49
+hevm = runner.HEVM(seed=0x4845564D, logN=logN, num_primes=KB, ks_special=ks, ks_alpha=alpha, vm_options={"secret_hw": 64, "rot_compose": int(bounded)})
+n_keys = 0
+if bounded:
+    import collections
+
+    slots = 1 << (logN - 1)
+    assert slots == 65536, "the reference's offset list is for 2^16 slots"
+    norm = lambda o: (o % slots) - (slots if (o % slots) > slots // 2 else 0)
+    offs = sorted({norm(o) for o in HEAAN_OFFSETS})
+    used = collections.Counter(norm(int(q)) for o, _, _, q in ops.tolist() if o == ha.OP_ROTATE)
+    for off, _ in used.most_common():
+        if len(offs) >= direct:
+            break
+        if off != 0 and off not in offs:
+            offs.append(off)
+    hevm.addRotationKeys(offs)
+    n_keys = len(offs)
+    print(f"bounded key set: {n_keys} rotation keys (the reference HEaaN runtime's 49 offsets{' + the most used others' if direct > 49 else ''}), other offsets composed", flush=True)
+elif direct:
     offs = cb.rotation_offsets(fx["hevm"])
     if direct == 2:  # direct keys for the bootstraps' own rotations only (they run at up to 19 primes); the model's rotations run at 1-3 primes,
         offs = cb.rotation_offsets(cb.single_bootstrap_program(logN, target=boot_target, ks=ks)[2])  # where a NAF hop pair under the default keys costs little
     hevm.addRotationKeys(offs)
+    n_keys = len(offs)
     print(f"{len(offs)} direct rotation keys", flush=True)
 print(f"context + keys {time.time()-t0:.1f} s", flush=True)
 t0 = time.time()
@@ -68,7 +93,9 @@ hevm.run()                                   # the same program on the same inpu
 dt = time.perf_counter() - t0
 out = hevm.getOutput()[0]
 st = hevm.stats()
-res = {"fixture": name + ("." + lowering if lowering else ""), "special_primes": ks, "primes_per_digit": alpha, "bootstrap_restores_primes": boot_target, "N": 1 << logN, "slots": 1 << (logN - 1), "primes": KB, "msg_bits": msg_bits, "instructions": int(len(ops)), "run_s": round(dt, 3), "first_run_s": round(dt_first, 3), "key_switches": st["keyswitches"], "ntt_equivalents": st["ntts"], "ntt_per_s": round(st["ntts"] / dt),
+key_limbs = hevm.key_digits * 2 * KB
+res = {"rotation_keys": n_keys, "rotation_key_bytes": n_keys * key_limbs * (8 << logN), "rot_compose": bool(bounded),
+       "fixture": name + ("." + lowering if lowering else ""), "special_primes": ks, "primes_per_digit": alpha, "bootstrap_restores_primes": boot_target, "N": 1 << logN, "slots": 1 << (logN - 1), "primes": KB, "msg_bits": msg_bits, "instructions": int(len(ops)), "run_s": round(dt, 3), "first_run_s": round(dt_first, 3), "key_switches": st["keyswitches"], "ntt_equivalents": st["ntts"], "ntt_per_s": round(st["ntts"] / dt),
        "real_bootstraps": int((ops[:, 0] == ha.OP_MODRAISE).sum()),
        "rms_vs_torch": float(np.sqrt(np.mean((out[:10] * 32 - fx["torch_result"]) ** 2))),
        "rms_vs_plaintext_evaluation": float(np.sqrt(np.mean((out - fx["expected"]) ** 2))),
