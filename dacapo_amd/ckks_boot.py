@@ -66,6 +66,22 @@ def seal_prime_chain(logN: int, count: int, bits: int = 60):
     return found[::-1]
 
 
+def mixed_prime_chain(logN: int, widths):
+    """one prime per entry of `widths` (bits), CoeffModulus::Create style per width class: scan down from 2^b in steps of 2N, no repeats, in
+    the order given -- e.g. [60] + [51] * 30 + [60] * 7: a HEaaN-style chain, 60-bit base and special primes around 51-bit rescale primes
+    (HEAAN_HEVM.cpp:55-56, profiled_HEAAN_GPU.json: rescalingFactor 51).  Every prime is 2^b - d, d < 2^28: what the runtime's arithmetic takes."""
+    out, nxt = [], {}
+    for b in widths:
+        v = nxt.get(b, (1 << b) + 1)
+        while True:
+            v -= 2 << logN
+            if _is_prime(v):
+                break
+        nxt[b] = v
+        out.append(v)
+    return out
+
+
 def boot_levels(r: int = 5, groups: int = 3, taylor_terms: int = 16) -> int:
     """primes one bootstrap consumes: CoeffToSlot `groups` + 1, EvalMod 5 + r, SlotToCoeff `groups`"""
     return 2 * groups + 1 + 5 + r - (1 if taylor_terms == 8 else 0)
@@ -167,10 +183,15 @@ class BootstrapEmitter:
     """Emits the bootstrap of one ciphertext into `b`.  Plaintext registers of the matrices are shared by all bootstraps of a program."""
 
     def __init__(self, b: ha.Builder, logN: int, num_primes: int, target_level: int, r: int = 5, taylor_terms: int = 16, k_range: float = 16.0,
-                 msg_bits: int = 0, diag_bits: int = 55, out_bits: int = 40, groups: int = 3, cts_bits: int = 60, ks: int = 1):
+                 msg_bits: int = 0, diag_bits: int | None = None, out_bits: int = 40, groups: int = 3, cts_bits: int = 60, ks: int = 1, primes=None):
+        """primes: the VM's chain when it is not CoeffModulus::Create(N, {60 x num_primes}) -- round 4: any chain of 45..60-bit primes, in
+        particular a HEaaN-style mixed one (mixed_prime_chain).  Every scale below is tracked with the exact primes; the handful of places
+        that used to say "60" now read the width of the prime they mean (self.qb)."""
         self.b, self.logN, self.N, self.n = b, logN, 1 << logN, 1 << (logN - 1)
-        self.primes = seal_prime_chain(logN, num_primes)
+        self.primes = [int(q) for q in primes] if primes is not None else seal_prime_chain(logN, num_primes)
+        assert len(self.primes) == num_primes
         self.top = num_primes - ks  # ks special primes at the end of the chain (1 in SEAL's scheme; more with grouped-digit key switching)
+        diag_bits = (self.qb(self.top) - 5) if diag_bits is None else diag_bits  # matrix / coefficient plaintexts: 55 bits next to 60-bit primes
         self.target, self.r, self.terms, self.k_range = target_level, r, taylor_terms, k_range
         self.msg_bits, self.diag_bits, self.out_bits, self.groups, self.cts_bits = msg_bits, diag_bits, out_bits, groups, cts_bits
         assert taylor_terms in (8, 16), "the polynomial in theta^2 is evaluated as a complete binary tree"
@@ -180,7 +201,11 @@ class BootstrapEmitter:
             f"{num_primes} primes leave {self.top - self.levels_needed} levels after a bootstrap, not {target_level}")
         self._plain_cache: dict = {}
         self._mats = None
-        self.boot_in_bits = 60 - 10 - msg_bits  # scale of the ciphertext entering ModRaise: eps = p / q0 <= 2^-10 for |message| < 2^msg_bits
+        self.boot_in_bits = self.qb(1) - 10 - msg_bits  # scale of the ciphertext entering ModRaise: eps = p / q0 <= 2^-10 for |message| < 2^msg_bits
+
+    def qb(self, level: int) -> int:
+        """bits of the prime a rescale at `level` divides by"""
+        return int(self.primes[level - 1]).bit_length()
 
     # -- low-level emitters (explicit levels, exact scales) -------------------------------------------------------------------
     def _val(self, level, s):
@@ -316,7 +341,7 @@ class BootstrapEmitter:
         a = [(-1.0) ** i * c2**i / math.factorial(2 * i) for i in range(T)]  # cos(theta) = sum a_i w^i
         depth = int(math.log2(T))
         out_level = w.level - depth
-        P = self._poly(a, pw, depth, out_level, 2.0**60)
+        P = self._poly(a, pw, depth, out_level, 2.0 ** self.qb(out_level))  # a scale of one rescale prime: squaring + rescaling keeps it there
         for i in range(r):                                      # cos(2 t) = 2 cos^2 t - 1
             sq = self.mul(P, P)
             if i < r - 1:
@@ -369,8 +394,11 @@ class BootstrapEmitter:
         # conjugation's key switch on the transform's output.  So: the raised ciphertext is multiplied by the integer 2^boost first
         # (exact: the all-ones "upscale" constant), the matrices are encoded at 2^60, and the transform ends with conj + add on the
         # un-rescaled sum followed by TWO rescales -- one level more than round 2, (a)-(c) pushed ~2^6 .. 2^40 further down.
-        total = int(round(60 * (self.groups + 1) - math.log2(self.k_range + 0.25) - self.logN))
-        cbits = [min(60, self.cts_bits)] * self.groups
+        # (x - 1/4) / kp must enter EvalMod at a true scale of about one of ITS rescale primes (2^sw):
+        #     2^(boost + sum cbits) N q0 kp / (the groups + 1 primes CoeffToSlot rescales by)  =  2^sw
+        sw = self.qb(self.top - self.groups - 1)
+        total = int(round(sum(self.qb(self.top - j) for j in range(self.groups + 1)) + sw - self.qb(1) - math.log2(self.k_range + 0.25) - self.logN))
+        cbits = [min(self.qb(self.top - gi), self.cts_bits) for gi in range(self.groups)]
         boost = total - sum(cbits)
         assert 0 < boost < 60, boost
         reg = b._encode(0xFFFF, self.top, boost)
@@ -538,13 +566,14 @@ def simulate(hevm: bytes, cst: bytes, inputs, logN: int, primes, secret_weight: 
 
 
 # ---- a bootstrap on its own (tools/boot_demo.py, bench.py, tests) ------------------------------------------------------------------
-def single_bootstrap_program(logN: int, target: int = 3, r: int = 5, msg_bits: int = 0, ks: int = 1):
+def single_bootstrap_program(logN: int, target: int = 3, r: int = 5, msg_bits: int = 0, ks: int = 1, primes=None):
     """(num_primes, cst, hevm, rotation offsets, emitter) of the program `one ciphertext at 1 prime, scale 2^40 -> bootstrap -> output`;
-    ks = number of special primes of the chain (the VM must be created with ks_special = ks)"""
+    ks = number of special primes of the chain (the VM must be created with ks_special = ks); primes: the VM's chain when it is not the
+    all-60-bit one (target + boot_levels(r) + ks of them)"""
     K = target + boot_levels(r) + ks
     b = ha.Builder(slots=1 << (logN - 1), init_level=1, shadow=False)
     x = b.input(None, level=1, scale_bits=40)
-    em = BootstrapEmitter(b, logN, K, target, r=r, msg_bits=msg_bits, ks=ks)
+    em = BootstrapEmitter(b, logN, K, target, r=r, msg_bits=msg_bits, ks=ks, primes=primes)
     y, _ = em.bootstrap(x, 2.0**40)
     b.output(y)
     cst, hv, _ = b.assemble()
@@ -557,7 +586,7 @@ def rotation_offsets(hevm: bytes):
 
 
 # ---- compiled programs: opcode 10 -> real bootstrapping ------------------------------------------------------------------------------
-def lower_bootstraps(hevm: bytes, cst: bytes, logN: int, num_primes: int, msg_bits: int = 4, r: int = 5, ks: int = 1):
+def lower_bootstraps(hevm: bytes, cst: bytes, logN: int, num_primes: int, msg_bits: int = 4, r: int = 5, ks: int = 1, primes=None):
     """Rewrites a program (e.g. one emitted by the reference's compiler) so that every opcode 10 -- `bootstrap`, a decrypt / re-encrypt
     stand-in in the SEAL runtime (SEAL_HEVM.cpp:324-334), the real thing in the HEaaN runtime (HEAAN_HEVM.cpp:386-399) -- becomes the
     real bootstrapping sequence of this module.  Everything else is re-emitted unchanged (same instructions, same constants, registers
@@ -566,7 +595,9 @@ def lower_bootstraps(hevm: bytes, cst: bytes, logN: int, num_primes: int, msg_bi
     h = ha.unpack_hevm(hevm)
     consts = ha.unpack_cst(cst)
     slots = 1 << (logN - 1)
-    b = ha.Builder(slots=slots, init_level=int(h["init_level"]), shadow=False, real_boot=dict(num_primes=num_primes, msg_bits=msg_bits, r=r, ks=ks))
+    qbits = [int(q).bit_length() for q in primes] if primes is not None else [60] * num_primes
+    b = ha.Builder(slots=slots, init_level=int(h["init_level"]), shadow=False,
+                   real_boot=dict(num_primes=num_primes, msg_bits=msg_bits, r=r, ks=ks, primes=primes))
     b.constants = [np.asarray(c, dtype=np.float64) for c in consts]
     b._const_index = {c.tobytes(): i for i, c in enumerate(b.constants)}
     cur = {}
@@ -593,7 +624,7 @@ def lower_bootstraps(hevm: bytes, cst: bytes, logN: int, num_primes: int, msg_bi
                 continue
             lvl -= d
         elif opc == OP_RESCALE:
-            lvl, bits = lvl - 1, bits - 60
+            lvl, bits = lvl - 1, bits - qbits[lvl - 1]
         elif opc == OP_ADDCC:
             bits = cur[rhs].scale_bits
         elif opc == OP_ADDCP:

@@ -46,6 +46,7 @@ struct TileGeo {
     static constexpr int LDS_ELEMS = E * (kTileThreads + kLdsPad);
 };
 // the throughput geometry's constants, used by host code to size grids
+constexpr long kSmallTileWgsN16 = 5000; // (N = 2^16: config 3's ring)
 constexpr int kTileLog = TileGeo<3>::LOG;
 constexpr int kTileElems = TileGeo<3>::ELEMS;
 constexpr int kTileLdsElems = TileGeo<3>::LDS_ELEMS;
@@ -296,8 +297,17 @@ __device__ __forceinline__ void ntt_tile(const DModulus M, const u64 *__restrict
 
 // geometry choice for a launch of `limbs` limb-phases: the latency geometry while the throughput one would leave most
 // of the 256 CUs without a workgroup, the one-butterfly geometry while even that leaves SIMDs without a wave
-inline long small_tile_threshold() { return (long)option(OPT_SMALL_TILE_WGS); }
-inline bool use_small_tiles(size_t N, long limbs) { return (long)(N >> kTileLog) * limbs < small_tile_threshold(); }
+// The launch-shape table, keyed by the ring: launches below this many 2048-coefficient tiles take the radix-4 geometry.  Measured per ring
+// (profiles/r02_experiments.txt for N = 2^15; profiles/r04_experiments.txt for 2^16 / 2^17: a grouped-digit hop at N = 2^17, level 12, takes
+// 235 us with the N = 2^15 value and 205 with this one -- a limb there is 64 tiles, and the radix-8 tiles win from a handful of limbs on).
+// option small_tile_wgs >= 0 overrides the table.
+inline long small_tile_threshold(size_t N)
+{
+    const long o = (long)option(OPT_SMALL_TILE_WGS);
+    if (o >= 0) return o;
+    return N <= ((size_t)1 << 15) ? 5000 : N == ((size_t)1 << 16) ? kSmallTileWgsN16 : 400;
+}
+inline bool use_small_tiles(size_t N, long limbs) { return (long)(N >> kTileLog) * limbs < small_tile_threshold(N); }
 // in 512-coefficient workgroups (4 waves each): 256 = one wave on each of the 1024 SIMDs
 inline long tiny_tile_threshold() { return (long)option(OPT_TINY_TILE_WGS); }
 inline bool use_tiny_tiles(size_t N, long limbs) { return (long)(N >> TileGeo<1>::LOG) * limbs <= tiny_tile_threshold(); }

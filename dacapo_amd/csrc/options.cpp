@@ -32,11 +32,11 @@ static const OptDef kDefs[OPT_COUNT] = {
     { "online_encode", 0 },
     { "fold_rescale_boot", 0 },
     { "hyb_mfma", 1 },
-    { "hyb_fuse", 1 },
+    { "hyb_fuse", 2 },
     { "seal_compr", 0 },
     { "trace", 0 },
     { "step_profile", 0 },
-    { "small_tile_wgs", 5000 },
+    { "small_tile_wgs", -1 },
     { "tiny_tile_wgs", 512 },
     { "ntt_full_min_limbs", 640 },
     { "ntt_full_inv_min_limbs", 2048 },

@@ -33,12 +33,12 @@ enum Opt : int {
     OPT_ONLINE_ENCODE,     // encode plaintexts at use instead of pre-encoding the pool
     OPT_FOLD_RESCALE_BOOT, // opcode 10 absorbs a rescale that only it consumes (changes what is computed homomorphically: off)
     OPT_HYB_MFMA,          // grouped-digit base conversions on the matrix cores (0: vector kernels)
-    OPT_HYB_FUSE,          // grouped-digit key switch: fused launch sequence (0: round 3's nine-launch sequence, kept as a second implementation)
+    OPT_HYB_FUSE,          // grouped-digit key switch: 2 (default) fused sequence, base conversions as pre-scaled matrix-core launches; 1 fused, conversions in the transforms' loaders; 0 round 3's sequence
     OPT_SEAL_COMPR,        // compression of written .seal files: 0 none, 1 zlib, 2 zstd
     OPT_TRACE,             // plan statistics on stderr (2: per wave)
     OPT_STEP_PROFILE,      // per-step timing of an un-graphed plan on stderr
     // ---- launch shapes ---------------------------------------------------------------------------------------------------------------
-    OPT_SMALL_TILE_WGS,          // launches below this many 2048-coefficient tiles take the 1024-coefficient (radix-4) geometry
+    OPT_SMALL_TILE_WGS,          // launches below this many 2048-coefficient tiles take the 1024-coefficient (radix-4) geometry (-1: the per-ring table of ntt_tile.hpp)
     OPT_TINY_TILE_WGS,           // launches of at most this many 512-coefficient tiles take the one-butterfly geometry
     OPT_NTT_FULL_MIN_LIMBS,      // N = 2^15: forward launches of at least this many limbs take the single-crossing kernel (0 = never)
     OPT_NTT_FULL_INV_MIN_LIMBS,  // ... inverse launches

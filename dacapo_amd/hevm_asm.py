@@ -335,7 +335,7 @@ class Builder:
         logN = self.slots.bit_length()  # slots = N / 2
         if self._boot_emitter is None:
             self._boot_emitter = ckks_boot.BootstrapEmitter(self, logN, rb["num_primes"], t, r=rb.get("r", 5), msg_bits=rb.get("msg_bits", 0),
-                                                            out_bits=self.waterline, ks=rb.get("ks", 1))
+                                                            out_bits=self.waterline, ks=rb.get("ks", 1), primes=rb.get("primes"))
             self._scale_mirror = ckks_boot.ScaleMirror(self, self._boot_emitter.primes)
         em = self._boot_emitter
         assert t == em.target, "every real bootstrap of a program restores the same number of primes"

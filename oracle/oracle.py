@@ -317,7 +317,7 @@ class Oracle:
             m = np.where(neg, q0 - c, c)
             for i in range(target):
                 qi = np.uint64(self.primes[i])
-                r = np.where(m >= qi, m - qi, m)          # all primes lie in (2^60 - 2^28, 2^60)
+                r = m % qi                                 # (a single conditional subtraction on the reference's chain; mixed chains: 60-bit residues into 51-bit primes)
                 out[p, i] = np.where(neg & (r != 0), qi - r, r)
             out[p] = self.ntt_fwd(out[p], list(range(target)))
         return Ciphertext(out, a.scale)

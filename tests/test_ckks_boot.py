@@ -120,3 +120,61 @@ def test_lowering_opcode_10_of_a_compiled_program_to_real_bootstrapping():
     assert int((ops[:, 0] == ha.OP_BOOTSTRAP).sum()) == 0 and int((ops[:, 0] == ha.OP_MODRAISE).sum()) == info["op_mix"]["bootstrap"]
     out = cb.simulate(hv2, cst2, [x.plain], logN, cb.seal_prime_chain(logN, 21))[0]
     assert np.abs(out.real - b.expected()[0]).max() < 1e-5 and np.abs(out.imag).max() < 1e-5
+
+
+def _mixed_chain(logN, target=3, ks=1, r=5):
+    """a HEaaN-style chain: 60-bit base prime, 51-bit rescale primes, 60-bit special primes (HEAAN_HEVM.cpp:55-56; profiled_HEAAN_GPU.json:
+    rescalingFactor 51)"""
+    K = target + cb.boot_levels(r) + ks
+    return K, cb.mixed_prime_chain(logN, [60] + [51] * (K - 1 - ks) + [60] * ks)
+
+
+def test_mixed_prime_chain_is_what_the_oracle_and_the_runtime_take():
+    from oracle.oracle import Oracle
+
+    K, primes = _mixed_chain(11)
+    assert [int(q).bit_length() for q in primes] == [60] + [51] * (K - 2) + [60] and len(set(primes)) == K
+    assert all(q % (2 << 11) == 1 and cb._is_prime(q) and (1 << q.bit_length()) - q < (1 << 28) for q in primes)
+    assert Oracle(11, K, primes=primes).primes == primes
+    assert cb.mixed_prime_chain(11, [60, 60, 60]) == cb.seal_prime_chain(11, 3)[::-1]     # same scan, CoeffModulus::Create lists it reversed
+
+
+def test_bootstrap_on_a_mixed_60_51_bit_chain_cleartext_and_oracle(tmp_path):
+    """round 4: the emitter's scale bookkeeping follows the chain it is given (every "60" became the width of the prime it meant): on a
+    mixed chain EvalMod runs at scale ~2^51, the matrices are encoded at 2^51 / 2^46, ModRaise starts from the 60-bit base prime.  Cleartext
+    slots with the VM's scale semantics: 1e-7; a real ciphertext through the CPU oracle (plain and grouped-digit keys): 1 prime -> 3 primes,
+    label exactly 2^40, the message back within 2e-6 (20.4 - 20.7 bits measured: the 60-bit chain gives the same at this ring)."""
+    from oracle.oracle import Oracle, OracleVM
+
+    logN = 11
+    K, primes = _mixed_chain(logN)
+    b = ha.Builder(slots=1 << (logN - 1), init_level=1, shadow=False)
+    x = b.input(None, level=1, scale_bits=40)
+    em = cb.BootstrapEmitter(b, logN, K, 3, primes=primes)
+    y, label = em.bootstrap(x, 2.0**40)
+    b.output(y)
+    cst, hv, info = b.assemble()
+    assert label == 2.0**40 and em.diag_bits == 46 and em.boot_in_bits == 50
+    msg = np.random.default_rng(3).uniform(-1, 1, 1 << (logN - 1))
+    outs, trace = cb.simulate(hv, cst, [msg], logN, primes, secret_weight=64, return_trace=True)
+    assert np.abs(outs[0] - msg).max() < 1e-7 and trace[-1][2] == 3 and trace[-1][3] == 2.0**40
+    for ks in (1, 2):
+        logN = 10
+        K, primes = _mixed_chain(logN, ks=ks)
+        K2, cst, hv, offs, em = cb.single_bootstrap_program(logN, ks=ks, primes=primes)
+        assert K2 == K
+        o = Oracle(logN, K, primes=primes)
+        if ks > 1:
+            o.set_hybrid(ks, ks)
+        o.keygen_sparse(32, seed=3, galois_elts=sorted(set(o.default_galois_elts()) | {o.elt_from_step(s) for s in offs}))
+        (tmp_path / "p.cst").write_bytes(cst)
+        (tmp_path / "p.hevm").write_bytes(hv)
+        vm = OracleVM(o)
+        vm.load(tmp_path / "p.cst", tmp_path / "p.hevm")
+        vm.preprocess()
+        msg = np.random.default_rng(1).uniform(-1, 1, o.slots)
+        vm.encrypt(0, msg)
+        vm.run()
+        out_ct = vm.ciphers[vm.prog.res_dst[0]]
+        assert out_ct.ell == 3 and out_ct.scale == 2.0**40
+        assert np.abs(vm.decrypt_result(0) - msg).max() < 2e-6, ks

@@ -122,7 +122,7 @@ def test_hoisted_rotation_batch_at_config4_geometry_matches_the_oracle_vm(tmp_pa
     for i in range(2):                                                 # (switching noise at N = 2^17 with 7-prime digits: 4e-5 measured)
         assert np.abs(out[i] - b.expected()[i]).max() < 5e-4
     hevm.close()
-    runner.set_option("hyb_fuse", 1)
+    runner.set_option("hyb_fuse", 2)
 
 
 def test_nt16_prefix_bit_exact_at_n17_on_grouped_digit_keys(tmp_path):

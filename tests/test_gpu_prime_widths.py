@@ -89,7 +89,7 @@ def test_grouped_digit_key_switch_on_mixed_chains(logN, widths, ks, alpha, fuse,
     L = ctx.L
     assert L is ll.lib_gw() and ctx.primes == primes and ctx.key_digits == o.dnum and ctx.max_level == o.max_level
     runner.set_option("hyb_fuse", fuse)
-    request.addfinalizer(lambda: runner.set_option("hyb_fuse", 1))
+    request.addfinalizer(lambda: runner.set_option("hyb_fuse", 2))
     dk, dr = ll.DeviceBuffer.from_host(o.galois[elt]), ll.DeviceBuffer.from_host(o.relin)
     for ell in range(1, o.max_level + 1):
         q = np.array(primes[:ell], dtype=np.uint64)[:, None]
