@@ -53,12 +53,17 @@ __global__ __launch_bounds__(kVmThreads) void sample_uniform_kernel(u64 *__restr
 {
     const int i = blockIdx.y;
     const u64 q = mods[i].q;
+    // draws of the prime's own width b (the fold word's tag is 60 - b: 0 on the reference's chain, where this is the 60-bit draw it always
+    // was).  Round 3 drew 60 bits whatever the prime: for a 51-bit prime 255 retries almost never produced a residue, the key's uniform
+    // halves came out non-canonical (and not uniform), and deep key switches on such keys left the lazy accumulators' range (round 4,
+    // found by the mixed-chain bootstrap test).
+    const u32 sh = 4 + (mods[i].delta >> 28);
     const size_t blk = (size_t)blockIdx.x * kVmThreads + threadIdx.x;
     u64 w[kRngCoefs], r[kRngCoefs];
     rng_words8(key, object * 64 + (u64)i, blk, 0, 0, domain, w);
 #pragma unroll
-    for (int e = 0; e < kRngCoefs; e++) r[e] = w[e] >> 4;
-    for (u32 attempt = 1; attempt < 256; attempt++) { // a 60-bit draw is >= q with probability ~2^-35: retry that word from a fresh block
+    for (int e = 0; e < kRngCoefs; e++) r[e] = w[e] >> sh;
+    for (u32 attempt = 1; attempt < 256; attempt++) { // a b-bit draw is >= q with probability d / 2^b (~2^-35 for the reference's primes): retry that word from a fresh block
         bool again = false;
 #pragma unroll
         for (int e = 0; e < kRngCoefs; e++) again |= r[e] >= q;
@@ -66,7 +71,7 @@ __global__ __launch_bounds__(kVmThreads) void sample_uniform_kernel(u64 *__restr
         rng_words8(key, object * 64 + (u64)i, blk, 0, attempt, domain, w);
 #pragma unroll
         for (int e = 0; e < kRngCoefs; e++)
-            if (r[e] >= q) r[e] = w[e] >> 4;
+            if (r[e] >= q) r[e] = w[e] >> sh;
     }
     u64x2 *o = reinterpret_cast<u64x2 *>(out + (size_t)i * N + blk * kRngCoefs);
 #pragma unroll

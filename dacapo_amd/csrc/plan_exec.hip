@@ -867,6 +867,8 @@ void HEVM::issue_plan(hipStream_t s)
     // diagnosis mode (every step then pays a full launch round trip, as the steps of a dependent chain do anyway)
     const bool step_profile = option(OPT_STEP_PROFILE) != 0 && !plan_graph;
     std::map<std::tuple<int, int, int>, std::pair<int, double>> prof;
+    double wave_max = 0, wave_sum = 0, crit_path = 0, all_steps = 0;
+    size_t waves_seen = 0, wide_waves = 0;
     size_t ev = 0, eg = 0;
     for (size_t a = 0; a < P.steps.size();) {
         size_t b = a;
@@ -907,7 +909,9 @@ void HEVM::issue_plan(hipStream_t s)
                 const auto t1 = std::chrono::steady_clock::now();
                 const int bucket = st.count <= 1 ? 1 : st.count <= 2 ? 2 : st.count <= 4 ? 4 : st.count <= 8 ? 8 : st.count <= 32 ? 32 : 128;
                 auto &e = prof[std::make_tuple((int)st.kind, st.level, bucket)];
-                e.first++, e.second += std::chrono::duration<double>(t1 - t_prev).count();
+                const double dt = std::chrono::duration<double>(t1 - t_prev).count();
+                e.first++, e.second += dt;
+                wave_max = std::max(wave_max, dt), wave_sum += dt;
                 t_prev = t1;
             }
         }
@@ -915,6 +919,10 @@ void HEVM::issue_plan(hipStream_t s)
             DC_HIP_CHECK(hipEventRecord(P.events[ev], aux_stream));
             DC_HIP_CHECK(hipStreamWaitEvent(s, P.events[ev], 0));
             ev++;
+        }
+        if (step_profile) { // what a scheduler with unlimited concurrency inside a wave could reach: the wave's longest step
+            crit_path += wave_max, all_steps += wave_sum, waves_seen++, wide_waves += (b - a) > 1;
+            wave_max = wave_sum = 0;
         }
         a = b;
     }
@@ -924,6 +932,10 @@ void HEVM::issue_plan(hipStream_t s)
         double total = 0;
         for (auto &kv : prof) total += kv.second.second;
         fprintf(stderr, "[dacapo_amd] step profile (synchronised after every step): %.2f ms in %zu steps\n", total * 1e3, P.steps.size());
+        // the dataflow graph's width: if every wave ran its steps perfectly overlapped, the run would take the sum of the waves' longest
+        // steps -- the bound on what ANY scheduler of this plan's DAG (more streams, an explicitly built graph) can gain over one queue
+        fprintf(stderr, "[dacapo_amd]   %zu waves, %zu of them with more than one step; sum of all steps %.2f ms, sum over waves of the longest step %.2f ms "
+                        "(= %.1f %% of the serial time)\n", waves_seen, wide_waves, all_steps * 1e3, crit_path * 1e3, 100.0 * crit_path / all_steps);
         for (auto &kv : prof)
             fprintf(stderr, "[dacapo_amd]   %-8s level %2d  batch<=%-3d  %5d steps  %8.3f ms  %7.2f us/step\n", kn[std::get<0>(kv.first)],
                     std::get<1>(kv.first), std::get<2>(kv.first), kv.second.first, kv.second.second * 1e3,

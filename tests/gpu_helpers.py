@@ -7,9 +7,7 @@ from oracle.oracle import Ciphertext, Oracle, OracleVM, Plaintext
 def _import_keys(o: Oracle, hevm, ll, elts=None, relin=True):
     """pull the GPU VM's key material into the oracle so both interpret the program on identical limbs.  `elts`: the Galois elements to
     import (default: SEAL's default set); at N = 2^17 / 39 primes a key is 0.4 GB, so the big-geometry tests name the ones they use."""
-    from dacapo_amd import runner
-
-    lw = runner.lw
+    lw = hevm.lw   # (the build of the library this VM lives in: the generic-width one for chains with narrow primes)
     K, N = o.K, o.N
     D = o.dnum if (o.ks, o.alpha) != (1, 1) else K - 1   # grouped digits: [dnum][2][K][N]
     o.sk = ll.read_device(lw.hevm_secret_key(hevm.vm), (K, N))
@@ -81,7 +79,7 @@ def _mirror_vm(hevm, ll, o, cst, hv, tmp_path):
     ovm.load(tmp_path / "p.cst", tmp_path / "p.hevm")
     for i in range(ovm.prog.num_ptxt):
         lvl, sc = ctypes.c_int32(), ctypes.c_double()
-        p = runner.lw.hevm_plain(hevm.vm, i, ctypes.byref(lvl), ctypes.byref(sc))
+        p = hevm.lw.hevm_plain(hevm.vm, i, ctypes.byref(lvl), ctypes.byref(sc))
         if p:
             ovm.plains[i] = Plaintext(ll.read_device(p, (lvl.value, o.N)), sc.value)
     return ovm

@@ -14,14 +14,14 @@ from gpu_helpers import _get_ct, _import_keys, _mirror_vm  # noqa: E402
 from oracle.oracle import Ciphertext, Oracle  # noqa: E402
 
 
-def _program(logN, target=3, r=5):
+def _program(logN, target=3, r=5, ks=1, primes=None):
     from dacapo_amd import ckks_boot as cb
     from dacapo_amd import hevm_asm as ha
 
-    K = target + cb.boot_levels(r) + 1
+    K = target + cb.boot_levels(r) + ks
     b = ha.Builder(slots=1 << (logN - 1), init_level=1, shadow=False)
     x = b.input(None, level=1, scale_bits=40)
-    em = cb.BootstrapEmitter(b, logN, K, target, r=r)
+    em = cb.BootstrapEmitter(b, logN, K, target, r=r, ks=ks, primes=primes)
     y, _ = em.bootstrap(x, 2.0**40)
     b.output(y)
     cst, hv, info = b.assemble()
@@ -29,10 +29,10 @@ def _program(logN, target=3, r=5):
     return K, cst, hv, offs
 
 
-def _vm(logN, K, weight, offs, opts=None):
+def _vm(logN, K, weight, offs, opts=None, ks=1, primes=None):
     from dacapo_amd import runner
 
-    hevm = runner.HEVM(seed=21, logN=logN, num_primes=K, vm_options=dict(opts or {}, secret_hw=weight))
+    hevm = runner.HEVM(seed=21, logN=logN, num_primes=K, vm_options=dict(opts or {}, secret_hw=weight), ks_special=ks, primes=primes)
     if offs:
         hevm.addRotationKeys(offs)
     return hevm
@@ -83,20 +83,30 @@ def test_sparse_secret_and_extension_opcodes_against_the_oracle(tmp_path):
     assert (o.ntt_inv(o.decrypt(ovm.ciphers[1]).data[:1], [0])[0] == m1).all()
 
 
-@pytest.mark.parametrize("plan", [1, 0])
-def test_bootstrap_limbs_bit_identical_to_the_oracle(tmp_path, plan):
+@pytest.mark.parametrize("plan,chain,ks", [(1, "60", 1), (0, "60", 1), (1, "mixed", 1), (1, "mixed", 3), (0, "mixed", 3)])
+def test_bootstrap_limbs_bit_identical_to_the_oracle(tmp_path, plan, chain, ks):
+    """chain "mixed" (round 4): a HEaaN-style chain -- 60-bit base prime, 51-bit rescale primes, 60-bit special primes (HEAAN_HEVM.cpp:55-56,
+    profiled_HEAAN_GPU.json: rescalingFactor 51) -- on the generic-width build of the library, with SEAL-style (ks = 1) and grouped-digit
+    (ks = 3) keys: the whole bootstrap, ~1 100 instructions incl. ModRaise from the 60-bit base into 51-bit primes, limb for limb."""
+    from dacapo_amd import ckks_boot as cb
     from dacapo_amd import lowlevel as ll
 
     logN = 12
-    K, cst, hv, offs = _program(logN)
-    hevm = _vm(logN, K, 32, offs, {"plan": plan})
-    o = Oracle(logN, K)
+    primes = None
+    if chain == "mixed":
+        K0 = 3 + cb.boot_levels() + ks
+        primes = cb.mixed_prime_chain(logN, [60] + [51] * (K0 - 1 - ks) + [60] * ks)
+    K, cst, hv, offs = _program(logN, ks=ks, primes=primes)
+    hevm = _vm(logN, K, 32, offs, {"plan": plan}, ks=ks, primes=primes)
+    o = Oracle(logN, K, primes=primes)
+    if ks > 1:
+        o.set_hybrid(ks)
+    assert o.primes == (primes or cb.seal_prime_chain(logN, K))
     _import_keys(o, hevm, ll)
-    from dacapo_amd import runner
-
+    D = o.dnum if ks > 1 else K - 1
     for step in offs:
         elt = o.elt_from_step(step)
-        o.galois[elt] = ll.read_device(runner.lw.hevm_galois_key(hevm.vm, elt), (K - 1, 2, K, o.N))
+        o.galois[elt] = ll.read_device(hevm.lw.hevm_galois_key(hevm.vm, elt), (D, 2, K, o.N))
     hevm.load_mem(cst, hv)
     ovm = _mirror_vm(hevm, ll, o, cst, hv, tmp_path)
     msg = np.random.default_rng(8).uniform(-1, 1, o.slots)

@@ -27,7 +27,8 @@ def _chain(logN, widths):
     return out
 
 
-@pytest.mark.parametrize("logN,widths", [(12, [51] * 5), (13, [48, 48, 48, 48]), (12, [60, 51, 51, 51, 60]), (12, [55, 60, 45, 51, 58, 60])])
+@pytest.mark.parametrize("logN,widths", [(12, [51] * 5), (13, [48, 48, 48, 48]), (12, [60, 51, 51, 51, 60]), (12, [55, 60, 45, 51, 58, 60]),
+                                         (12, [51] * 21), (12, [60] + [51] * 19 + [60])])  # (deep chains: more than 16 digits per inner product)
 def test_ntt_and_evaluator_ops_on_other_prime_widths(logN, widths):
     from dacapo_amd import lowlevel as ll
 
@@ -153,6 +154,11 @@ def test_vm_program_on_a_51_bit_chain_matches_the_oracle_vm(tmp_path):
     o = Oracle(logN, K, bit_size=bits)
     assert [int(p).bit_length() for p in o.primes] == [bits] * K
     _import_keys(o, hevm, ll)
+    # every key limb the GPU generated is a canonical residue of ITS prime (round 3's uniform sampler drew 60 bits whatever the width: on
+    # narrow primes the keys' uniform halves came out non-canonical, and deep key switches then left the lazy accumulators' range)
+    pr = np.array(o.primes, dtype=np.uint64)
+    assert (o.sk < pr[:, None]).all() and (o.pk < pr[None, :, None]).all() and (o.relin < pr[None, None, :, None]).all()
+    assert all((k < pr[None, None, :, None]).all() for k in o.galois.values())
     hevm.load_mem(cst, hv)
     ovm = _mirror_vm(hevm, ll, o, cst, hv, tmp_path)
     for i, a in enumerate(b.args):

@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""How wide is the headline program's dataflow graph?  Runs the ResNet-20 HEVM program with the plan issued step by step, synchronised
+after every step (option step_profile), and prints (stderr of the library) the sum of all step times next to the sum over waves of each
+wave's LONGEST step: the second number is what a scheduler with unlimited concurrency inside a wave -- more streams, an explicitly
+built HIP graph with the plan's own dependencies -- could reach at best.     python tools/dag_width.py [fixture=resnet20]"""
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+from dacapo_amd import hevm_asm as ha  # noqa: E402
+from dacapo_amd import runner  # noqa: E402
+
+name = sys.argv[1] if len(sys.argv) > 1 else "resnet20"
+fx = ha.read_fixture(ROOT / "tests" / "golden" / name)
+runner.set_option("step_profile", 1)
+vm = runner.HEVM(seed=0x4845564D, logN=15, num_primes=14, vm_options={"plan_graph": 0, "plan_lanes": 1})
+vm.load_mem(fx["cst"], fx["hevm"])
+vm.setInput(0, fx["packed"])
+runner.set_option("step_profile", 0)
+vm.run()                       # warm
+runner.set_option("step_profile", 1)
+vm.run()
