@@ -401,29 +401,54 @@ def build_parser():
     return ap
 
 
-def config4_child():
-    """--config4: BASELINE config 4's shape -- ResNet-20 traced at the reference script's own nt = 2^16 slots (examples/benchmarks/
-    ResNet.py:50), run on N = 2^17 (HEAAN_HEVM.cpp:55-56) with a real bootstrap at every bootstrap site (tools/resnet_real_boot.py).
-    About 180 GB of keys and plaintexts: it runs in a CHILD process started before this one touches the GPU (the reference's ABI has no
-    destroy symbol, so the other legs' VMs stay resident until exit), about two minutes."""
+def _config4_run(args):
     import subprocess
 
-    cmd = [sys.executable, str(ROOT / "tools" / "resnet_real_boot.py"), "1", "resnet20_nt16", "17", "1", "b14", "8", "7"]
+    cmd = [sys.executable, str(ROOT / "tools" / "resnet_real_boot.py")] + [str(a) for a in args]
     r = subprocess.run(cmd, capture_output=True, text=True)
     last = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     if r.returncode != 0 or not last:
         return {"error": f"tools/resnet_real_boot.py exited with {r.returncode}", "stderr_tail": r.stderr[-400:]}
     res = json.loads(last[-1])
-    res["command"] = "python tools/resnet_real_boot.py 1 resnet20_nt16 17 1 b14 8 7"
+    res["command"] = "python tools/resnet_real_boot.py " + " ".join(str(a) for a in args)
+    return res
+
+
+def config4_child():
+    """--config4: BASELINE config 4's shape -- ResNet-20 traced at the reference script's own nt = 2^16 slots (examples/benchmarks/
+    ResNet.py:50), run on N = 2^17 (HEAAN_HEVM.cpp:55-56) with a real bootstrap at every bootstrap site (tools/resnet_real_boot.py).
+    About 180 GB of keys and plaintexts: it runs in CHILD processes started before this one touches the GPU (the reference's ABI has no
+    destroy symbol, so the other legs' VMs stay resident until exit).  Round 4: the same program also on a mixed 60 / 51-bit chain
+    (`chains`) and under bounded rotation-key sets (`key_sets`: the reference HEaaN runtime's 49 offsets, 96 keys, one per offset)."""
+    res = _config4_run([1, "resnet20_nt16", 17, 1, "b14", 8, 7])
+    if "error" in res:
+        return res
     res["program"] = ("tests/golden/resnet20_nt16.b14: bootstraps at the model script's own hints (before every activation), each restoring 14 "
                       "primes -> 38 real bootstraps (round 2: 541 restoring 3); 31 data + 8 special 60-bit primes")
-    res["keys"] = ("grouped-digit hybrid key switching (extension, hybrid_ks.hip): 5 digits of 7 primes, P = 8 primes; one direct Galois key per "
-                   "rotation offset (286 keys x 0.39 GB)")
+    res["keys"] = ("grouped-digit hybrid key switching (extension, hybrid_ks.hip / hybrid_fused.hip): 5 digits of 7 primes, P = 8 primes; one direct "
+                   "Galois key per rotation offset (286 keys x 0.39 GB)")
     res["security"] = "N = 2^17, log2(QP) = 39 x 60 = 2340 bits, sparse ternary secret (h = 64): inside the 128-bit range for N = 2^17"
-    res["round2"] = "47.2 s, rms_vs_torch 0.152 (541 bootstraps restoring 3 primes, one-prime-per-digit keys)"
+    res["history"] = "round 2: 47.2 s, rms_vs_torch 0.152 (541 bootstraps restoring 3 primes, one-prime-per-digit keys); round 3: 4.0 s"
     res["ntt_equivalents_note"] = ("counted per key switch as G (l + k) + 2 k + 2 l; rotations of one ciphertext in a wave share their decomposition "
                                    "(hoisting), so fewer transforms than that are executed")
     res["reference"] = "README.md:131-136: DaCapo's cost model estimates 13.6 s for its 19-bootstrap HEaaN plan (not measured)"
+    brief = lambda r: ({k: r.get(k) for k in ("chain", "log2_QP", "primes", "special_primes", "primes_per_digit", "rotation_keys", "rotation_key_bytes",
+                                             "rot_compose", "run_s", "key_switches", "ntt_equivalents", "rms_vs_torch", "fixture", "command")}
+                       if "error" not in r else r)
+    mixed = _config4_run([1, "resnet20_nt16", 17, 1, "b14r51", 8, 7, "mixed_app"])
+    res["chains"] = {"what": "the same trace on the 60-bit chain (libSEAL_HEVM.so) and on a HEaaN-style mixed chain -- 60-bit base prime, 51-bit rescale "
+                             "primes for the program's 13 levels, 60-bit primes for the bootstrap's 17 levels and the 8 special ones -- through the "
+                             "generic-width build (libSEAL_HEVM_gw.so); the program is lowered for the chain's rescale width (b14 / b14r51)",
+                     "chain_60": brief(res), "chain_mixed": brief(mixed),
+                     "note": "the mixed chain has the same number of limbs: it buys modulus bits (2223 instead of 2340), not speed, and the "
+                             "generic-width build's run-time shifts and third fold cost ~13 % (DESIGN.md section 3).  With EVERY rescale prime at 51 "
+                             "bits the bootstraps run at a 2^51 scale: rms vs torch 1.2e-2 (measured, profiles/r04_experiments.txt)"}
+    res["key_sets"] = {"what": "the 60-bit run under bounded rotation-key sets: the reference HEaaN runtime's 49 left-rotation offsets (HEAAN_HEVM.cpp:"
+                               "58-64), that list plus the program's most used other offsets up to 96 keys, and one key per offset (286); rotations "
+                               "without a direct key are the shortest sum of offsets that have one (option rot_compose)",
+                       "49": brief(_config4_run([49, "resnet20_nt16", 17, 1, "b14", 8, 7])),
+                       "96": brief(_config4_run([96, "resnet20_nt16", 17, 1, "b14", 8, 7])),
+                       "286": brief(res)}
     return res
 
 

@@ -119,3 +119,67 @@ def test_config4_resnet20_nt16_with_real_bootstraps_decrypts_to_the_torch_logits
     assert rms_plain < 2e-6                                                        # measured 1.3e-7 (round 2: 1.6e-4)
     assert hevm.stats()["keyswitches"] < 12000                                     # 10 631 (round 2: 132 347)
     hevm.close()
+
+
+def test_config4_on_a_mixed_60_51_bit_chain(fixture_nt16):
+    """round 4: BASELINE config 4 on a HEaaN-style MIXED chain (HEAAN_HEVM.cpp:55-56; profiled_HEAAN_GPU.json: rescalingFactor 51) through the
+    generic-width build of the library: 60-bit base prime, 51-bit rescale primes for the program's 13 levels, 60-bit primes for the
+    bootstrap's own 17 levels and the 8 special ones -- log2(QP) = 2223 instead of 2340.  The program is the same trace lowered for 51-bit
+    rescale primes (tests/golden/resnet20_nt16.b14r51: ciphertexts at 2^40, plaintexts at 2^51, the same 38 bootstrap sites; tools/
+    trace_reference_model.py --rescale-bits 51 --headroom 11), dacapo_amd/ckks_boot.py follows the chain it is given.  Same logits.
+    (With EVERY rescale prime at 51 bits the bootstraps run at a 2^51 scale and keep ~7 bits less: rms vs torch 1.2e-2, measured; and the
+    generic-width build costs 13 % of the run time -- 4.15 s against 3.67 s: a mixed chain buys modulus bits here, not speed.)"""
+    import gzip
+
+    from dacapo_amd import ckks_boot as cb
+    from dacapo_amd import hevm_asm as ha
+    from dacapo_amd import runner
+
+    fx = fixture_nt16
+    hv0 = gzip.open(str(GOLDEN) + ".b14r51.hevm.gz").read()
+    assert {int(r) for o, _, _, r in ha.unpack_hevm(hv0)["ops"].tolist() if o == ha.OP_BOOTSTRAP} == {14}
+    ks, alpha, target = 8, 7, 14
+    K = target + cb.boot_levels() + ks
+    primes = cb.mixed_prime_chain(17, [60] + [51] * (target - 1) + [60] * (K - target))
+    assert sum(int(q).bit_length() for q in primes) == 2223
+    hv, cst = cb.lower_bootstraps(hv0, fx["cst"], 17, K, msg_bits=1, ks=ks, primes=primes)
+    hevm = runner.HEVM(seed=0x4845564D, logN=17, num_primes=K, ks_special=ks, ks_alpha=alpha, vm_options={"secret_hw": 64}, primes=primes)
+    assert hevm.lw is not runner.lw and hevm.max_level == 31                      # the generic-width build
+    hevm.addRotationKeys(cb.rotation_offsets(hv))
+    hevm.load_mem(cst, hv)
+    hevm.setInput(0, fx["packed"])
+    hevm.run()
+    out = hevm.getOutput()[0]
+    rms_torch = float(np.sqrt(np.mean((out[:10] * 32 - fx["torch_result"]) ** 2)))
+    print(f"config 4 on the mixed chain: rms vs torch {rms_torch:.3e}")
+    assert int(np.argmax(out[:10])) == int(np.argmax(fx["torch_result"])) and rms_torch < 1e-3     # measured 6.2e-4
+    hevm.close()
+
+
+def test_config4_under_the_reference_runtime_s_49_rotation_keys(fixture_nt16):
+    """round 4: the reference's HEaaN runtime serves every rotation of a program from 49 left-rotation keys (HEAAN_HEVM.cpp:58-64,124-126);
+    round 3's config 4 needed one direct key per offset, 286 keys = 117 GB.  With option rot_compose a rotation without a direct key is the
+    shortest sum of offsets that have one: the same program under exactly that list (31 of its offsets are the +-2^k this VM has anyway) --
+    20 GB of rotation keys, 15 353 key switches instead of 10 631, the same logits."""
+    import gzip
+
+    from dacapo_amd import ckks_boot as cb
+    from dacapo_amd import runner
+
+    heaan = [1, 2, 3, 4, 5, 6, 7, 8, 16, 24, 32, 64, 96, 128, 160, 192, 224, 256, 512, 768, 1024, 2048, 3072, 4096, 5120, 6144, 7168, 8192, 16384,
+             24576, 32768, 40960, 49152, 57344, 61440, 63488, 64512, 64768, 65024, 65280, 65408, 65472, 65504, 65512, 65520, 65528, 65532, 65534, 65535]
+    fx = fixture_nt16
+    hv0 = gzip.open(str(GOLDEN) + ".b14.hevm.gz").read()
+    ks, alpha = 8, 7
+    K = 14 + cb.boot_levels() + ks
+    hv, cst = cb.lower_bootstraps(hv0, fx["cst"], 17, K, msg_bits=1, ks=ks)
+    hevm = runner.HEVM(seed=0x4845564D, logN=17, num_primes=K, ks_special=ks, ks_alpha=alpha, vm_options={"secret_hw": 64, "rot_compose": 1})
+    hevm.addRotationKeys(heaan)
+    hevm.load_mem(cst, hv)
+    hevm.setInput(0, fx["packed"])
+    hevm.run()
+    out = hevm.getOutput()[0]
+    rms_torch = float(np.sqrt(np.mean((out[:10] * 32 - fx["torch_result"]) ** 2)))
+    assert int(np.argmax(out[:10])) == int(np.argmax(fx["torch_result"])) and rms_torch < 1e-3     # measured 5.7e-4
+    assert 10631 < hevm.stats()["keyswitches"] < 17000                                             # 15 353: composed rotations take 2-3 hops
+    hevm.close()

@@ -21,3 +21,20 @@ runner.set_option("step_profile", 0)
 vm.run()                       # warm
 runner.set_option("step_profile", 1)
 vm.run()
+vm.close()
+# ... and what the two-stream graph gets out of that width today: the same program replayed as a HIP graph on one stream and on two
+import time
+
+runner.set_option("step_profile", 0)
+for lanes in (1, 2):
+    vm = runner.HEVM(seed=0x4845564D, logN=15, num_primes=14, vm_options={"plan_graph": 1, "plan_lanes": lanes})
+    vm.load_mem(fx["cst"], fx["hevm"])
+    vm.setInput(0, fx["packed"])
+    vm.run()
+    ts = []
+    for _ in range(10):
+        t0 = time.perf_counter()
+        vm.run()
+        ts.append((time.perf_counter() - t0) * 1e3)
+    print(f"graph replay, {lanes} stream(s): best {min(ts):.2f} ms, median {sorted(ts)[len(ts) // 2]:.2f} ms", file=sys.stderr)
+    vm.close()

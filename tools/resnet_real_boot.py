@@ -2,7 +2,9 @@
 """The reference's ResNet-20 with REAL CKKS bootstrapping at every bootstrap site (the headline program tests/golden/resnet20.*, every
 opcode 10 rewritten by dacapo_amd/ckks_boot.lower_bootstraps): BASELINE config 4 in spirit -- the reference
 runs it on HEaaN (HEAAN_HEVM.cpp:386-399) at N = 2^17; here on SEAL-style 60-bit primes, N = 2^15, 20 primes, sparse secret.
-    python tools/resnet_real_boot.py [direct_keys=1|2|49|<n>] [fixture=resnet20] [logN=15] [msg_bits=4] [lowering=""] [ks_special=1] [ks_alpha=ks_special]
+    python tools/resnet_real_boot.py [direct_keys=1|2|49|<n>] [fixture=resnet20] [logN=15] [msg_bits=4] [lowering=""] [ks_special=1] [ks_alpha=ks_special] [chain=60|mixed]
+chain mixed: a HEaaN-style chain -- 60-bit base prime, 51-bit rescale primes, 60-bit special primes (HEAAN_HEVM.cpp:55-56, profiled_HEAAN_GPU.json:
+rescalingFactor 51) -- on the generic-width build; the lowering must then have been traced with --rescale-bits 51.
 lowering: another lowering of the same trace (tests/golden/<fixture>.<lowering>.hevm.gz, same constants), e.g. b14 = bootstraps placed at the
 model script's own hints, restoring 14 primes (38 bootstraps instead of 541); ks_special > 1: grouped-digit hybrid key switching with that
 many special primes (dacapo_amd/csrc/hybrid_ks.hip), which is what makes a 31-level chain affordable at N = 2^17.
@@ -31,6 +33,7 @@ msg_bits = int(sys.argv[4]) if len(sys.argv) > 4 else 4
 lowering = sys.argv[5] if len(sys.argv) > 5 else ""
 ks = int(sys.argv[6]) if len(sys.argv) > 6 else 1
 alpha = int(sys.argv[7]) if len(sys.argv) > 7 else ks  # primes per digit (alpha < ks: P exceeds a digit's modulus, the switching noise shrinks by the ratio)
+chain = sys.argv[8] if len(sys.argv) > 8 else "60"
 fx = ha.read_fixture(ROOT / "tests" / "golden" / name)
 if lowering:
     import gzip
@@ -41,8 +44,16 @@ assert len(boot_target) == 1, "every opcode 10 of the program must restore the s
 boot_target = boot_target.pop()
 KB = boot_target + cb.boot_levels() + ks  # primes left after a bootstrap + the bootstrap's own levels + the special primes
 assert fx["meta"]["slots"] == 1 << (logN - 1), "the fixture was traced for another slot count"
+# mixed: every rescale prime 51 bits (the HEaaN configuration's literal shape: bootstrapping then runs at a 2^51 scale and keeps ~7 bits
+# less); mixed_app: 51-bit primes for the PROGRAM's levels only, the bootstrap's own 17 levels stay 60-bit (its precision is the 60-bit chain's)
+if chain == "mixed":
+    primes = cb.mixed_prime_chain(logN, [60] + [51] * (KB - ks - 1) + [60] * ks)
+elif chain == "mixed_app":
+    primes = cb.mixed_prime_chain(logN, [60] + [51] * (boot_target - 1) + [60] * (KB - boot_target))
+else:
+    primes = None
 t0 = time.time()
-fx["hevm"], fx["cst"] = cb.lower_bootstraps(fx["hevm"], fx["cst"], logN, KB, msg_bits=msg_bits, ks=ks)
+fx["hevm"], fx["cst"] = cb.lower_bootstraps(fx["hevm"], fx["cst"], logN, KB, msg_bits=msg_bits, ks=ks, primes=primes)
 print(f"opcode 10 -> real bootstrapping: {time.time()-t0:.1f} s", flush=True)
 h = ha.unpack_hevm(fx["hevm"])
 ops = h["ops"]
@@ -55,7 +66,8 @@ HEAAN_OFFSETS = [1, 2, 3, 4, 5, 6, 7, 8, 16, 24, 32, 64, 96, 128, 160, 192, 224,
                  16384, 24576, 32768, 40960, 49152, 57344, 61440, 63488, 64512, 64768, 65024, 65280, 65408, 65472, 65504, 65512, 65520, 65528,
                  65532, 65534, 65535]
 bounded = direct >= 49
-hevm = runner.HEVM(seed=0x4845564D, logN=logN, num_primes=KB, ks_special=ks, ks_alpha=alpha, vm_options={"secret_hw": 64, "rot_compose": int(bounded)})
+hevm = runner.HEVM(seed=0x4845564D, logN=logN, num_primes=KB, ks_special=ks, ks_alpha=alpha, vm_options={"secret_hw": 64, "rot_compose": int(bounded)},
+                   primes=primes)
 n_keys = 0
 if bounded:
     import collections
@@ -94,7 +106,11 @@ dt = time.perf_counter() - t0
 out = hevm.getOutput()[0]
 st = hevm.stats()
 key_limbs = hevm.key_digits * 2 * KB
-res = {"rotation_keys": n_keys, "rotation_key_bytes": n_keys * key_limbs * (8 << logN), "rot_compose": bool(bounded),
+res = {"chain": "60-bit" if primes is None else ("mixed: 60-bit base and special primes, 51-bit rescale primes" if chain == "mixed" else
+                                                "mixed_app: 51-bit rescale primes for the program's levels, 60-bit base, bootstrapping and special primes"),
+       "prime_bits": [int(q).bit_length() for q in primes] if primes else None,
+       "log2_QP": sum(int(q).bit_length() for q in (primes or cb.seal_prime_chain(logN, KB))),
+       "rotation_keys": n_keys, "rotation_key_bytes": n_keys * key_limbs * (8 << logN), "rot_compose": bool(bounded),
        "fixture": name + ("." + lowering if lowering else ""), "special_primes": ks, "primes_per_digit": alpha, "bootstrap_restores_primes": boot_target, "N": 1 << logN, "slots": 1 << (logN - 1), "primes": KB, "msg_bits": msg_bits, "instructions": int(len(ops)), "run_s": round(dt, 3), "first_run_s": round(dt_first, 3), "key_switches": st["keyswitches"], "ntt_equivalents": st["ntts"], "ntt_per_s": round(st["ntts"] / dt),
        "real_bootstraps": int((ops[:, 0] == ha.OP_MODRAISE).sum()),
        "rms_vs_torch": float(np.sqrt(np.mean((out[:10] * 32 - fx["torch_result"]) ** 2))),

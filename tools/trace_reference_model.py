@@ -385,6 +385,10 @@ def main():
     ap.add_argument("--init-level", type=int, default=3)
     ap.add_argument("--waterline", type=int, default=40)
     ap.add_argument("--rotate-reserve", type=int, default=0)
+    ap.add_argument("--headroom", type=int, default=16,
+                    help="bits kept free above a value's scale for the magnitude of its slots when deciding how many primes it needs (16 next "
+                         "to 60-bit primes; 11 gives 51-bit primes the same level structure: 2 x 51 - 91 = 11 where 2 x 60 - 100 = 20).  The shadow "
+                         "evaluation still refuses a value that does not fit its primes")
     ap.add_argument("--rescale-bits", type=int, default=60,
                     help="width of the chain's rescale primes the program's scale management assumes: 60 = the reference's SEAL chain; 51 = the "
                          "HEaaN configuration's rescalingFactor (profiled_HEAAN_GPU.json), for a mixed 60/51-bit chain")
@@ -420,7 +424,7 @@ def main():
 
     slots = 1 << a.slots_log
     b = hevm_asm.Builder(slots=slots, waterline=a.waterline, init_level=a.init_level, policy="lazy", boot_level=a.boot_level, rotate_reserve=a.rotate_reserve, carry_scale=a.carry_scale,
-                         rescale_bits=a.rescale_bits,
+                         rescale_bits=a.rescale_bits, headroom=a.headroom,
                          shadow=not a.no_shadow,
                          real_boot=dict(num_primes=a.real_boot_primes, msg_bits=a.msg_bits) if a.real_boot_primes else None)
     b.hint_need = a.hint_need
@@ -439,7 +443,7 @@ def main():
     meta = {
         "source": f"examples/benchmarks/{a.model}.py traced through python/poly with tools/trace_reference_model.py",
         "slots": slots, "waterline": a.waterline, "init_level": a.init_level, "boot_level": a.boot_level, "hint_need": a.hint_need,
-        "rescale_bits": a.rescale_bits,
+        "rescale_bits": a.rescale_bits, "headroom": a.headroom,
         "input": {"packed_len": int(len(packed)), "seed": a.seed, "kind": "smooth synthetic 3x32x32 image, CIFAR-normalised"},
         "torch_result": [float(v) for v in torch_res],
         "info": info,
