@@ -32,6 +32,7 @@ import numpy as np  # noqa: E402
 
 KEY_SEED = 0x4845564D  # every replica expands the same key set from it (bench keys are reproducible, hence NOT secure: hevm_init_seeded)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
+PROF = "r04"  # the round whose profiles/ records this file reads (each is used only when its lib_sha256 is the library being timed)
 
 
 def ntt_equivalents(stats_or_counts):
@@ -73,32 +74,32 @@ def roofline_leg(ll, ctx, limbs=4096, iters=10):
     copy_gbs = 2.0 * buf.nbytes / (L.dc_event_elapsed_ms(e0, e1) / iters * 1e-3) / 1e9
     del buf, dst
     # HBM bytes per launch: rocprofv3 --pmc passes cannot run inside this process (they need their own runs with the program directly
-    # after `--`, tools/ntt_variant_only.py).  profiles/r03_ntt_hbm_traffic.json holds FETCH_SIZE (x2, the gfx950 correction) + WRITE_SIZE
+    # after `--`, tools/ntt_variant_only.py).  profiles/<round>_ntt_hbm_traffic.json holds FETCH_SIZE (x2, the gfx950 correction) + WRITE_SIZE
     # for the same launches; it is reported only when it was collected on exactly this build of the library.
     traffic, traffic_source = None, "not collected for this build (recipe: profiles/README.md, `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE`)"
-    tf = ROOT / "profiles" / "r03_ntt_hbm_traffic.json"
+    tf = ROOT / "profiles" / f"{PROF}_ntt_hbm_traffic.json"
     if tf.exists() and limbs == 4096 and N == 32768:
         rec = json.loads(tf.read_text())
         if rec.get("lib_sha256") == lib_sha256():
-            traffic, traffic_source = rec.get("forward_ntt_hbm_bytes"), "profiles/r03_ntt_hbm_traffic.json (PMC passes on this build)"
+            traffic, traffic_source = rec.get("forward_ntt_hbm_bytes"), f"profiles/{PROF}_ntt_hbm_traffic.json (PMC passes on this build)"
         else:
-            traffic_source = "profiles/r03_ntt_hbm_traffic.json was collected on another build of the library: not reported"
+            traffic_source = f"profiles/{PROF}_ntt_hbm_traffic.json was collected on another build of the library: not reported"
     floor_us = alg_bytes / (copy_gbs * 1e9) * 1e6
     # what actually bounds the kernel: the vector ALUs' issue rate (profiles/r03_ntt_full.txt).  The counters come from their own rocprofv3
     # --pmc run (tools/ntt_valu.py) and are reported only for exactly this build of the library.
     valu = {"source": "not collected for this build (recipe: tools/collect_profiles.sh B4b, tools/ntt_valu.py)"}
-    vf = ROOT / "profiles" / "r03_ntt_valu.json"
+    vf = ROOT / "profiles" / f"{PROF}_ntt_valu.json"
     if vf.exists() and limbs == 4096 and N == 32768:
         rec = json.loads(vf.read_text())
         if rec.get("lib_sha256") == lib_sha256():
             k = next((v for n, v in rec.get("kernels", {}).items() if n.startswith("ntt_full15_kernel<false")), None)
             if k:
-                valu = {"source": "profiles/r03_ntt_valu.json (rocprofv3 --pmc on this build)",
+                valu = {"source": f"profiles/{PROF}_ntt_valu.json (rocprofv3 --pmc on this build)",
                         "valu_instructions_per_wave_per_limb": k.get("valu_instructions_per_wave_per_limb"),
                         "simd_valu_busy_frac": k.get("simd_valu_busy_frac"),
                         "clock_ghz_if_counter_sums_8_xcds": k.get("clock_ghz_if_counter_sums_8_xcds")}
         else:
-            valu = {"source": "profiles/r03_ntt_valu.json was collected on another build of the library: not reported"}
+            valu = {"source": f"profiles/{PROF}_ntt_valu.json was collected on another build of the library: not reported"}
     return {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
             "traffic": traffic, "traffic_source": traffic_source,
             "kernel": "ntt_full15_kernel<fwd> (a 1024-thread workgroup owns a limb, one HBM crossing; persistent grid of one workgroup per CU; "
@@ -107,14 +108,16 @@ def roofline_leg(ll, ctx, limbs=4096, iters=10):
                        "ntt_per_s": round(limbs / (ms * 1e-3)),
                        "timing": "HIP events around 10 back-to-back launches; 20 warm-up launches, then best of three alternating rounds",
                        "rounds_us": [[round(a * 1e3, 1), round(b * 1e3, 1)] for a, b in rounds]},
-            "limiting_resource": "VALU issue and the twiddles' vector-memory path: with the loads and the stores removed the kernel keeps 91 % of its "
-                                 "time, and the SIMDs' vector ALUs are busy 82-91 % of it (60-bit modular butterflies on 32-bit ALUs: 15-19 VALU "
-                                 "instructions each, 5-7 of them v_mad_u64_u32); the HBM fraction is what that arithmetic leaves",
+            # (no measured figure is hard-coded here: the counters of THIS build are in `valu`, reported only when their lib_sha256 matches;
+            # the ablations behind the statement are a record of round 3's build of the same kernel source)
+            "limiting_resource": "VALU issue and the twiddles' vector-memory path (60-bit modular butterflies on 32-bit ALUs); the HBM fraction is "
+                                 "what that arithmetic leaves.  Evidence: `valu` (this build's counters, when collected) and the ablation record "
+                                 "profiles/r03_ntt_full.txt (round 3's build of the same kernel: loads / stores / both removed)",
             "valu": valu,
             "single_crossing": {"hbm_crossings_per_limb": 1, "copy_floor_us": round(floor_us, 1), "frac_of_copy_floor": round(floor_us / (ms * 1e3), 4),
-                                "source": "profiles/r03_ntt_full.txt (ablations: no loads / no stores / neither 813 / 844 / 796 of 874 us; exchanges "
-                                          "2 and 3 through LDS; the modular multiply's carries; persistent grid walking prime by prime; "
-                                          "twiddle pairs in passes A and B; variants that lost)"},
+                                "source": "profiles/r03_ntt_full.txt (round 3's record of this kernel: ablations, exchanges 2 and 3 through LDS, the "
+                                          "modular multiply's carries, persistent grid walking prime by prime, twiddle pairs in passes A and B, "
+                                          "variants that lost)"},
             "two_launch_transform": {"avg_us": round(two_ms * 1e3, 2), "frac": round(alg_bytes / (two_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                      "note": "round 2's COLS + ROWS launch pair on the same buffer (still used below 640 limbs forward / 2048 "
                                              "inverse, and for N != 2^15)"},
@@ -794,13 +797,13 @@ def main():
     # the timed step's own kernels: durations, PMC traffic and (where the grid encodes level and batch) algorithmic bytes per kernel,
     # collected by tools/kernel_traffic.py on exactly this build of the library (else a note)
     top, dominant, moved = None, None, None
-    tk = ROOT / "profiles" / "r03_step_kernels.json"
+    tk = ROOT / "profiles" / f"{PROF}_step_kernels.json"
     if tk.exists():
         rec = json.loads(tk.read_text())
         if rec.get("lib_sha256") == lib_sha256():
             top, dominant, moved = rec.get("top_kernels"), rec.get("dominant"), rec.get("bytes_actually_moved_in_run")
         else:
-            top = {"note": "profiles/r03_step_kernels.json was collected on another build"}
+            top = {"note": f"profiles/{PROF}_step_kernels.json was collected on another build"}
     folded = sum(v for k, v in pst["algorithmic_bytes_by_opcode"].items() if k in ("2", "4", "6", "7", "9"))  # negate, modswitch, addcc, addcp, mulcp
     roof["leg"] = {k: roof[k] for k in ("kernel", "achieved", "frac", "traffic", "launch")}
     roof["step"] = {"what": "one run() of the headline program", "algorithmic_bytes": pst["algorithmic_bytes"],
@@ -810,7 +813,7 @@ def main():
                     "bytes_actually_moved": moved,
                     "bytes_actually_moved_gbs": (round(moved / (ms_per_step * 1e-3) / 1e9, 1) if moved else None),
                     "dominant": dominant, "top_kernels": top,
-                    "note": "latency-bound: ~5 300 dependent launches of 4-30 us (profiles/r03_timeline.txt); most of the elementwise opcodes' "
+                    "note": "latency-bound: ~5 300 dependent launches of 4-30 us (profiles/r04_timeline.txt); most of the elementwise opcodes' "
                             "section-8(d) bytes are never moved -- the plan folds those ops into their consumers' loaders -- which is why "
                             "bytes_actually_moved (FETCH_SIZE x 2 + WRITE_SIZE over one run) is the honest numerator"}
     micro = ntt_micro_leg(ll)
