@@ -475,6 +475,7 @@ void HEVM::init_context(int logN, int K, const u64 *primes, int dir_ksp, int dir
     encoder.reset(new HostEncoder(logN));
     use_plan = option(OPT_PLAN) != 0;
     plan_graph = option(OPT_PLAN_GRAPH) != 0;
+    plan_dag = option(OPT_PLAN_GRAPH) == 2;
     plan_lanes = option(OPT_PLAN_LANES) >= 2 ? 2 : 1;
     host_encoder = option(OPT_HOST_ENCODER) != 0;
     fold_rescale_into_boot = option(OPT_FOLD_RESCALE_BOOT) != 0;

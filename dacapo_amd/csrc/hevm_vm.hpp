@@ -188,6 +188,9 @@ class HEVM {
         Handoff h;                          // link to a fused producer (h.in) / consumer (h.cont, h.out) step, plan.hpp
         int fused_consumer = -1;            // index of the step whose first phase this step's last kernel computes
         int unique = 0;                     // P_ROT, grouped-digit mode: distinct source ciphertexts among the items (shared decompositions)
+        // what the step's launches read and write, by pool buffer (a value and its modswitch views share one): the edges of the explicitly
+        // built graph (option plan_graph = 2, capture_plan_dag)
+        std::vector<const u64 *> reads, writes;
     };
     struct Plan {
         bool ready = false;
@@ -229,7 +232,10 @@ class HEVM {
         hipGraphExec_t graph_exec = nullptr;
     } plan;
     bool plan_graph = true; // replay the plan's launch sequence as one HIP graph (option plan_graph = 0: issue it launch by launch)
+    bool plan_dag = false;  // option plan_graph = 2: the graph is BUILT from the plan's own dependencies instead of captured from two streams
     void capture_plan();
+    bool capture_plan_dag();
+    void issue_step(const Step &st, hipStream_t q);
     void drop_plan_graph();
     void issue_plan(hipStream_t s);
     bool use_plan = true;

@@ -26,6 +26,7 @@ static const OptDef kDefs[OPT_COUNT] = {
     { "plan", 1 },
     { "plan_graph", 1 },
     { "plan_lanes", 2 },
+    { "plan_aux_min_cost", 3 },
     { "max_batch", 64 },
     { "chain_fusion", 1 },
     { "host_encoder", 0 },

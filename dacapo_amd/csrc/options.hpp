@@ -25,8 +25,9 @@ enum Opt : int {
     OPT_SECRET_HW,         // Hamming weight of the ternary secret (0 = SEAL's uniform ternary)
     OPT_ROT_COMPOSE,       // rotations without a direct key: shortest sum of offsets that have one (0: SEAL's NAF over the power-of-two keys)
     OPT_PLAN,              // 1: batched execution plan; 0: the reference's loop, one instruction at a time
-    OPT_PLAN_GRAPH,        // replay the plan as one HIP graph
+    OPT_PLAN_GRAPH,        // replay the plan as one HIP graph: 1 captured from two streams (fork / join per wave), 2 built from the plan's own dependencies, 0 off
     OPT_PLAN_LANES,        // streams the plan's independent steps are spread over (1 or 2)
+    OPT_PLAN_AUX_MIN_COST, // a wave's auxiliary-stream share must be worth a fork / join: at least this many cost units (key switch 8, opcode 10 5, rescale 3, element-wise 1)
     OPT_MAX_BATCH,         // items per heavy batched step
     OPT_CHAIN_FUSION,      // producer's last kernel runs the consumer's first phase
     OPT_HOST_ENCODER,      // encode / decode on the host (comparison only)

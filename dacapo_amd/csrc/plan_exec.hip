@@ -7,7 +7,9 @@
 #include <algorithm>
 #include <chrono>
 #include <map>
+#include <functional>
 #include <queue>
+#include <set>
 #include <tuple>
 
 #include "hevm_vm.hpp"
@@ -447,7 +449,7 @@ void HEVM::build_plan()
                 const int lane = load[1] < load[0] ? 1 : 0;
                 P.steps[i].lane = lane, load[lane] += cost(P.steps[i]);
             }
-            if (load[1] < 3)
+            if (load[1] < (int)option(OPT_PLAN_AUX_MIN_COST))
                 for (size_t i = a; i < b; i++) P.steps[i].lane = 0;
             a = b;
         }
@@ -685,6 +687,23 @@ void HEVM::build_plan()
         } else
             P.launches += st.kind == P_BOOT ? 5 : 1;
     }
+    // what every step reads and writes, by pool buffer: the dependencies of the explicitly built graph (capture_plan_dag)
+    for (size_t s = 0; s < P.steps.size(); s++) {
+        Step &st = P.steps[s];
+        st.reads.clear(), st.writes.clear();
+        for (int pi : step_pops[s]) {
+            const Pop &p = O[(size_t)pi];
+            for (int v : p.srcs) st.reads.push_back(V[(size_t)V[(size_t)v].root].buf);
+            st.writes.push_back(V[(size_t)V[(size_t)p.dst].root].buf);
+        }
+        if (st.fused_consumer >= 0 && st.h.cont == CONT_MUL) // the producer's last kernel multiplies by the consumer's OTHER operand
+            for (int pi : step_pops[(size_t)st.fused_consumer])
+                for (int v : O[(size_t)pi].srcs) st.reads.push_back(V[(size_t)V[(size_t)v].root].buf);
+        for (auto *vec : { &st.reads, &st.writes }) {
+            std::sort(vec->begin(), vec->end());
+            vec->erase(std::unique(vec->begin(), vec->end()), vec->end());
+        }
+    }
     // opcode 10: every item owns a slot of the zero-encryption arena; the zero-encryptions are made in chunks of items with
     // the same target level at the start of each run (plan_zero_encrypt)
     if (!h_boot_pops.empty()) {
@@ -855,6 +874,26 @@ void HEVM::build_plan()
                 max_wave, P.launches, P.max_live, (double)P.pool.size() * buf_elems * 8 / 1e9);
 }
 
+// the launches of one step, on stream q, with the scratch of the step's lane
+void HEVM::issue_step(const Step &st, hipStream_t q)
+{
+    Context &c = *ctx;
+    Plan &P = plan;
+    const BatchWs &w = P.ws[st.lane];
+    switch (st.kind) {
+    case P_ROT: b_rotate_hops(c, w, P.d_ks + st.first, st.count, st.level, q, st.h, st.unique); break;
+    case P_MULCC: b_mul_relin(c, w, P.d_mul + st.first, keys.relin, st.count, st.level, q, st.h); break;
+    case P_RESCALE: b_rescale(c, w, P.d_rs + st.first, st.count, st.level, q, P.d_sum_srcs, st.h); break;
+    case P_SUM: b_sum(c, P.d_sum + st.first, P.d_sum_srcs, st.count, st.level, q); break;
+    case P_NEG: b_ew(c, EwOp::Neg, P.d_ew + st.first, st.count, 2, 2, st.level, q); break;
+    case P_COPY: b_ew(c, EwOp::Copy, P.d_ew + st.first, st.count, 2, 2, st.level, q); break;
+    case P_MODRAISE: modraise(c, w.digits, P.h_ew.data() + st.first, st.count, st.target, q, P.d_ew + st.first); break;
+    case P_MULP: b_ew(c, EwOp::Mul, P.d_ew + st.first, st.count, 2, 1, st.level, q); break;
+    case P_ADDP: b_add_plain(c, P.d_ew + st.first, st.count, st.level, q); break;
+    case P_BOOT: plan_boot_step(st.first, st.count, st.level, st.target, st.lane, q, st.h); break;
+    }
+}
+
 void HEVM::issue_plan(hipStream_t s)
 {
     Context &c = *ctx;
@@ -886,19 +925,7 @@ void HEVM::issue_plan(hipStream_t s)
         for (size_t i = a; i < b; i++) {
             const Step &st = P.steps[i];
             hipStream_t q = st.lane ? aux_stream : s;
-            const BatchWs &w = P.ws[st.lane];
-            switch (st.kind) {
-            case P_ROT: b_rotate_hops(c, w, P.d_ks + st.first, st.count, st.level, q, st.h, st.unique); break;
-            case P_MULCC: b_mul_relin(c, w, P.d_mul + st.first, keys.relin, st.count, st.level, q, st.h); break;
-            case P_RESCALE: b_rescale(c, w, P.d_rs + st.first, st.count, st.level, q, P.d_sum_srcs, st.h); break;
-            case P_SUM: b_sum(c, P.d_sum + st.first, P.d_sum_srcs, st.count, st.level, q); break;
-            case P_NEG: b_ew(c, EwOp::Neg, P.d_ew + st.first, st.count, 2, 2, st.level, q); break;
-            case P_COPY: b_ew(c, EwOp::Copy, P.d_ew + st.first, st.count, 2, 2, st.level, q); break;
-            case P_MODRAISE: modraise(c, w.digits, P.h_ew.data() + st.first, st.count, st.target, q, P.d_ew + st.first); break;
-            case P_MULP: b_ew(c, EwOp::Mul, P.d_ew + st.first, st.count, 2, 1, st.level, q); break;
-            case P_ADDP: b_add_plain(c, P.d_ew + st.first, st.count, st.level, q); break;
-            case P_BOOT: plan_boot_step(st.first, st.count, st.level, st.target, st.lane, q, st.h); break;
-            }
+            issue_step(st, q);
             if (step_profile) {
                 static auto t_prev = std::chrono::steady_clock::now();
                 if (i == 0) {
@@ -953,11 +980,128 @@ void HEVM::capture_plan()
     // ROCm 7.2's capture walks the recorded nodes recursively: beyond roughly 1.5e5 of them hipStreamEndCapture overflows its stack
     // (seen with the 783 k-instruction real-bootstrap ResNet in on-line encode mode).  Such plans are issued launch by launch.
     if (P.launches + P.enc_groups.size() * (size_t)(ctx->logN + 4) > 120000) return;
+    if (plan_dag && capture_plan_dag()) return;
     hipStream_t s = S();
     DC_HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
     issue_plan(s);
     DC_HIP_CHECK(hipStreamEndCapture(s, &P.graph));
     DC_HIP_CHECK(hipGraphInstantiate(&P.graph_exec, P.graph, nullptr, nullptr, 0));
+}
+
+// option plan_graph = 2: the graph BUILT from the plan's own dependencies.  Every step's launch sequence is captured on ONE stream into a
+// scratch graph (a chain of kernel nodes: no stream ever waits on another inside a capture, which is what overflows ROCm 7.2's
+// hipStreamEndCapture beyond two streams), its nodes are copied into the plan's graph, and the first of them gets explicit edges: to the last
+// kernel of every step that wrote a buffer this step reads (or read / wrote one it writes: the pool recycles buffers), to the previous
+// user of its lane's scratch, and -- opcode 10 -- to the zero-encryptions at the head of the run.  No per-wave fork / join: a step waits for
+// what it needs and nothing else.  false = a node this builder does not copy turned up (the caller falls back to the two-stream capture).
+bool HEVM::capture_plan_dag()
+{
+    Plan &P = plan;
+    if (!P.enc_groups.empty()) return false; // (on-line encode interleaves encoder launches with the waves: captured form only)
+    hipStream_t cs = S();
+    hipGraph_t main = nullptr;
+    DC_HIP_CHECK(hipGraphCreate(&main, 0));
+    bool ok = true;
+    // captures `issue` on cs and appends its kernels to `main` as a chain hanging off `deps`; returns the chain's last node (nullptr: no launch)
+    auto add_unit = [&](const std::function<void(hipStream_t)> &issue, std::vector<hipGraphNode_t> deps) -> hipGraphNode_t {
+        DC_HIP_CHECK(hipStreamBeginCapture(cs, hipStreamCaptureModeRelaxed));
+        issue(cs);
+        hipGraph_t g = nullptr;
+        DC_HIP_CHECK(hipStreamEndCapture(cs, &g));
+        size_t nn = 0, ne = 0;
+        DC_HIP_CHECK(hipGraphGetNodes(g, nullptr, &nn));
+        std::vector<hipGraphNode_t> nodes(nn);
+        if (nn) DC_HIP_CHECK(hipGraphGetNodes(g, nodes.data(), &nn));
+        DC_HIP_CHECK(hipGraphGetEdges(g, nullptr, nullptr, &ne));
+        std::vector<hipGraphNode_t> from(ne), to(ne);
+        if (ne) DC_HIP_CHECK(hipGraphGetEdges(g, from.data(), to.data(), &ne));
+        // a single-stream capture is a chain: order it by its edges
+        std::map<hipGraphNode_t, hipGraphNode_t> next;
+        std::set<hipGraphNode_t> has_pred;
+        for (size_t e = 0; e < ne; e++) next[from[e]] = to[e], has_pred.insert(to[e]);
+        hipGraphNode_t cur = nullptr;
+        for (hipGraphNode_t n : nodes)
+            if (!has_pred.count(n)) {
+                if (cur) ok = false; // two roots: not a chain
+                cur = n;
+            }
+        if (ne + 1 != nn && nn) ok = false;
+        hipGraphNode_t tail = nullptr;
+        deps.erase(std::remove(deps.begin(), deps.end(), (hipGraphNode_t) nullptr), deps.end());
+        std::sort(deps.begin(), deps.end());
+        deps.erase(std::unique(deps.begin(), deps.end()), deps.end());
+        for (size_t k = 0; k < nn && ok && cur; k++) {
+            hipGraphNodeType ty;
+            DC_HIP_CHECK(hipGraphNodeGetType(cur, &ty));
+            hipGraphNode_t nw = nullptr;
+            const hipGraphNode_t *dp = tail ? &tail : deps.data();
+            const size_t nd = tail ? 1 : deps.size();
+            if (ty == hipGraphNodeTypeKernel) {
+                hipKernelNodeParams kp;
+                DC_HIP_CHECK(hipGraphKernelNodeGetParams(cur, &kp));
+                DC_HIP_CHECK(hipGraphAddKernelNode(&nw, main, dp, nd, &kp));
+            } else if (ty == hipGraphNodeTypeMemset) {
+                hipMemsetParams mp;
+                DC_HIP_CHECK(hipGraphMemsetNodeGetParams(cur, &mp));
+                DC_HIP_CHECK(hipGraphAddMemsetNode(&nw, main, dp, nd, &mp));
+            } else
+                ok = false;
+            tail = nw;
+            auto it = next.find(cur);
+            cur = it == next.end() ? nullptr : it->second;
+        }
+        (void)hipGraphDestroy(g);
+        return tail;
+    };
+    // head of the run: the zero-encryptions of every opcode-10 item, then the epoch bump (the next run's randomness)
+    hipGraphNode_t zenc_tail = add_unit([&](hipStream_t s) {
+        if (test_zero_enc) {
+            if (P.zenc) DC_HIP_CHECK(hipMemsetAsync(P.zenc, 0, P.zenc_bytes, s));
+        } else
+            for (const Plan::BootChunk &bc : P.boot_chunks) plan_zero_encrypt(bc.first, bc.count, bc.target, s);
+        bump_epoch(s);
+    }, {});
+    // Every step sits on one of the two scratch lanes, and a lane is a chain (its steps share the batch scratch): a dependency on a step is
+    // implied by a dependency on any LATER step of the same lane.  So a step needs at most two edges -- its own lane's tail and the latest
+    // step it depends on in the other lane -- and none to the other lane when nothing it touches was touched there since.
+    struct Ref { int lane = -1; long seq = -1; hipGraphNode_t node = nullptr; }; // the step that last wrote / read a buffer
+    std::map<const u64 *, Ref> writer;
+    std::map<const u64 *, Ref> reader[2]; // latest reader per lane
+    Ref lane_tail[2] = { Ref{ 0, 0, zenc_tail }, Ref{ 1, 0, zenc_tail } }; // (the head uses the lanes' batch scratch too)
+    long seq = 0;
+    for (size_t i = 0; i < P.steps.size() && ok; i++) {
+        const Step &st = P.steps[i];
+        const int other = 1 - st.lane;
+        Ref cross; // latest step of the other lane this one must follow
+        auto need = [&](const Ref &r) {
+            if (r.node && r.lane == other && r.seq > cross.seq) cross = r;
+        };
+        for (const u64 *b : st.reads) {
+            auto it = writer.find(b);
+            if (it != writer.end()) need(it->second);
+        }
+        for (const u64 *b : st.writes) {
+            auto it = writer.find(b);
+            if (it != writer.end()) need(it->second);
+            auto rt = reader[other].find(b);
+            if (rt != reader[other].end()) need(rt->second);
+        }
+        std::vector<hipGraphNode_t> deps{ lane_tail[st.lane].node };
+        if (cross.node) deps.push_back(cross.node);
+        const hipGraphNode_t tail = add_unit([&](hipStream_t s) { issue_step(st, s); }, deps);
+        if (!tail) continue;
+        const Ref me{ st.lane, ++seq, tail };
+        lane_tail[st.lane] = me;
+        for (const u64 *b : st.reads) reader[st.lane][b] = me;
+        for (const u64 *b : st.writes) writer[b] = me;
+    }
+    if (!ok) {
+        (void)hipGraphDestroy(main);
+        return false;
+    }
+    P.graph = main;
+    DC_HIP_CHECK(hipGraphInstantiate(&P.graph_exec, P.graph, nullptr, nullptr, 0));
+    return true;
 }
 
 void HEVM::drop_plan_graph()

@@ -12,16 +12,18 @@ from oracle.oracle import Ciphertext, Oracle, OracleVM, Plaintext, read_cst, rea
 from gpu_helpers import _get_ct, _import_keys, _mirror_vm  # noqa: E402
 
 
-@pytest.fixture(scope="module", params=["plan", "eager", "plan1"])
+@pytest.fixture(scope="module", params=["plan", "eager", "plan1", "dag"])
 def vm13(request):
     """plan   = default: the batched execution plan (SSA-renamed registers, one batched launch sequence per wave; independent
              steps of a wave on an auxiliary stream; the whole sequence replayed as one HIP graph);
     eager  = the reference's dispatch loop, one instruction at a time on one stream (option plan = 0);
-    plan1  = the plan issued launch by launch on one stream (no graph, no auxiliary stream)."""
+    plan1  = the plan issued launch by launch on one stream (no graph, no auxiliary stream);
+    dag    = the plan's graph BUILT from its own dependencies (option plan_graph = 2: per-step single-stream captures copied into one
+             graph with explicit edges, no per-wave fork / join) instead of captured from two streams."""
     from dacapo_amd import lowlevel as ll
     from dacapo_amd import runner
 
-    opts = {"plan": {}, "eager": {"plan": 0}, "plan1": {"plan_lanes": 1, "plan_graph": 0}}[request.param]
+    opts = {"plan": {}, "eager": {"plan": 0}, "plan1": {"plan_lanes": 1, "plan_graph": 0}, "dag": {"plan_graph": 2}}[request.param]
     hevm = runner.HEVM(seed=0x4845564D, logN=13, num_primes=7, vm_options=opts)
     hevm.mode = request.param
     o = Oracle(13, 7)

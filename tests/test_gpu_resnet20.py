@@ -55,6 +55,22 @@ def test_resnet20_first_layer_bit_exact(vm15, fixture20, tmp_path):
     assert (got.data == want.data).all()
 
 
+def test_resnet20_explicitly_built_graph(fixture20):
+    """option plan_graph = 2: the plan's graph built from its own dependencies (HEVM::capture_plan_dag) -- the first layer limb for limb like
+    the default, the whole inference to the same logits, twice (a replayed graph re-encrypts freshly)"""
+    from dacapo_amd import runner
+
+    hevm = runner.HEVM(seed=0x4845564D + 2, logN=15, num_primes=14, vm_options={"plan_graph": 2})
+    hevm.load_mem(fixture20["cst"], fixture20["hevm"])
+    hevm.setInput(0, fixture20["packed"])
+    for _ in range(2):
+        hevm.run()
+        out = hevm.getOutput()[0]
+        assert float(np.sqrt(np.mean((out - fixture20["expected"]) ** 2))) < 1e-3
+        assert float(np.sqrt(np.mean((out[:10] * 32 - fixture20["torch_result"]) ** 2))) < 2e-3
+    hevm.close()
+
+
 def test_resnet20_single_stream_no_graph(fixture20):
     """the plan issued launch by launch on one stream (the default replays it as one HIP graph with an auxiliary stream)"""
     from dacapo_amd import runner

@@ -40,8 +40,8 @@ cd /tmp
 C4="$ROOT/tools/resnet_real_boot.py 1 resnet20_nt16 17 1 b14 8 7"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c4 -- python3 $C4 > $OUT/${R}_config4_under_profiler.txt 2> $OUT/c4.err
 cp $(ls $OUT/c4/*/*kernel_stats.csv | head -1) $OUT/${R}_config4_kernel_stats.csv
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/c4f -- python3 $C4 > /dev/null 2> $OUT/c4f.err
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/c4w -- python3 $C4 > /dev/null 2> $OUT/c4w.err
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/c4f -- python3 $C4 --opt plan_graph=0 > /dev/null 2> $OUT/c4f.err
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/c4w -- python3 $C4 --opt plan_graph=0 > /dev/null 2> $OUT/c4w.err
 cd $ROOT
 python tools/kernel_bytes.py $(kt $OUT/c4) $(cc $OUT/c4f) $(cc $OUT/c4w) top=30 > $OUT/${R}_config4_kernel_bytes.txt
 rm -rf $OUT/c4 $OUT/c4f $OUT/c4w

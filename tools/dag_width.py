@@ -26,8 +26,8 @@ vm.close()
 import time
 
 runner.set_option("step_profile", 0)
-for lanes in (1, 2):
-    vm = runner.HEVM(seed=0x4845564D, logN=15, num_primes=14, vm_options={"plan_graph": 1, "plan_lanes": lanes})
+for lanes, graph in ((1, 1), (2, 1), (2, 2), (1, 2)):
+    vm = runner.HEVM(seed=0x4845564D, logN=15, num_primes=14, vm_options={"plan_graph": graph, "plan_lanes": lanes})
     vm.load_mem(fx["cst"], fx["hevm"])
     vm.setInput(0, fx["packed"])
     vm.run()
@@ -36,5 +36,20 @@ for lanes in (1, 2):
         t0 = time.perf_counter()
         vm.run()
         ts.append((time.perf_counter() - t0) * 1e3)
-    print(f"graph replay, {lanes} stream(s): best {min(ts):.2f} ms, median {sorted(ts)[len(ts) // 2]:.2f} ms", file=sys.stderr)
+    what = "captured from the streams (fork / join per wave)" if graph == 1 else "built from the plan's dependencies (plan_graph = 2)"
+    print(f"graph replay, {lanes} scratch lane(s), {what}: best {min(ts):.2f} ms, median {sorted(ts)[len(ts) // 2]:.2f} ms", file=sys.stderr)
+    vm.close()
+
+# the fork / join threshold of the two-stream capture (option plan_aux_min_cost)
+for cost in (1, 3, 5, 8, 11, 16):
+    vm = runner.HEVM(seed=0x4845564D, logN=15, num_primes=14, vm_options={"plan_aux_min_cost": cost})
+    vm.load_mem(fx["cst"], fx["hevm"])
+    vm.setInput(0, fx["packed"])
+    vm.run()
+    ts = []
+    for _ in range(10):
+        t0 = time.perf_counter()
+        vm.run()
+        ts.append((time.perf_counter() - t0) * 1e3)
+    print(f"two-stream capture, auxiliary share >= {cost} cost units: best {min(ts):.2f} ms, median {sorted(ts)[len(ts) // 2]:.2f} ms", file=sys.stderr)
     vm.close()
