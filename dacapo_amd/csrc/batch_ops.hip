@@ -360,12 +360,28 @@ __global__ __launch_bounds__(kBT) void b_sum_pair_kernel(const SumItem *__restri
 #pragma unroll
     for (int p = 0; p < 2; p++) a[p][0].clear(), a[p][1].clear();
     int n_plain = 0, n_prod = 0;
+    // (term t + 1's three loads are issued before term t's products: every term costs a dependent chain item table -> pointers -> limbs, and
+    // with one term in flight per thread the kernel waited on it)
+    // (and term t + 2's table entry with them)
+    auto fetch = [&](const SumSrc &src, const u64 *&pl, u64x2 &v0, u64x2 &v1, u64x2 &w) {
+        pl = src.plain;
+        v0 = *reinterpret_cast<const u64x2 *>(src.v.limb(0, i, N) + k);
+        v1 = *reinterpret_cast<const u64x2 *>(src.v.limb(1, i, N) + k);
+        if (pl) w = *reinterpret_cast<const u64x2 *>(pl + (size_t)i * N + k);
+    };
+    const u64 *pln = nullptr;
+    u64x2 v0n{}, v1n{}, wn{};
+    SumSrc sn{};
+    if (it.count > 0) fetch(srcs[it.first], pln, v0n, v1n, wn);
+    if (it.count > 1) sn = srcs[it.first + 1];
     for (int t = 0; t < it.count; t++) {
-        const SumSrc src = srcs[it.first + t];
-        const u64x2 v0 = *reinterpret_cast<const u64x2 *>(src.v.limb(0, i, N) + k);
-        const u64x2 v1 = *reinterpret_cast<const u64x2 *>(src.v.limb(1, i, N) + k);
-        if (src.plain) {
-            const u64x2 w = *reinterpret_cast<const u64x2 *>(src.plain + (size_t)i * N + k);
+        const u64 *plain = pln;
+        const u64x2 v0 = v0n, v1 = v1n, w = wn;
+        if (t + 1 < it.count) {
+            fetch(sn, pln, v0n, v1n, wn);
+            if (t + 2 < it.count) sn = srcs[it.first + t + 2];
+        }
+        if (plain) {
             a[0][0].mac(v0.x, w.x), a[0][1].mac(v0.y, w.y);
             a[1][0].mac(v1.x, w.x), a[1][1].mac(v1.y, w.y);
             if ((++n_prod & 15) == 0) {

@@ -570,10 +570,69 @@ __global__ __launch_bounds__(kTileThreads) void f_ks_frows_mac_kernel(const u64 
 #pragma unroll
     for (int e = 0; e < E; e++) a0[e].clear(), a1[e].clear();
     auto nost = [](int, u64) {};
+    auto nold = [](int) -> u64 { return 0; };
     bool lds_used = false;
+    // Latency-shaped launches (not MERGE; one or two workgroups per CU, each walking its digits serially): the walk is software-pipelined.
+    //   * the tile's twiddles are the same for every digit (same prime, same tile): fetched once (tile_twiddles), not once per transform
+    //   * digit j + 1's coefficients and digit j's key limbs are requested BEFORE digit j's transform: the loads fly under its passes
+    // so that a digit costs its butterflies and LDS exchanges, not a memory round trip before and another after them.  The extra live
+    // registers (twiddles, next coefficients, key limbs) do not cost occupancy where this form runs: such launches have at most two waves per SIMD.
+    constexpr bool PF = !MERGE && LOGE <= 2;
+    u64 wtw[PF ? NP : 1][E];
+    // a ROWS tile's first forward pass holds coefficients gin0 + e * SUBT, its last pass leaves g[0] + e (PassMap::idx_of)
+    constexpr int SUBT = (1 << K) >> LOGE;
+    int gin0 = 0;
+    if (PF) {
+        tile_twiddles<K, PF ? LOGE : 1, false, false>(reinterpret_cast<u64 (&)[num_passes<PF ? LOGE : 1>(K)][1 << (PF ? LOGE : 1)]>(wtw), tw + ((size_t)pm << logN),
+                                                      logN, blockIdx.x);
+        gin0 = tile_gidx<K, LOGE, false>(0, logN, blockIdx.x, 0);
+    }
+    // digit j's operand at this tile: its own limb (j == m: NTT form already, thread <-> coefficient map g) or the raised limb's first-pass image
+    auto own_on_the_fly = [&](int j) { return j == m && MODE != 0 && !target; };
+    auto fetch_x = [&](int j, u64 (&x)[E]) {
+        const bool own = j == m;
+        if (MODE == 0 && own) {
+            const KsItem &it = items[b];
+            const u64 *c1 = it.src.limb(1, j, N);
+#pragma unroll
+            for (int e = 0; e < E; e++) x[e] = c1[galois_idx((u32)g[e], it.elt, logN)];
+        } else if (!own || target) { // (one load path with a selected base and stride: two index arrays made the compiler select between them in memory)
+            const u64 *src = own ? target + ((size_t)b * ell + j) * N : ext + (((size_t)b * ell + j) * ell + (m < j ? m : m - 1)) * N;
+            const int base = own ? g[0] : gin0, stride = own ? 1 : SUBT;
+#pragma unroll
+            for (int e = 0; e < E; e++) x[e] = src[base + e * stride];
+        }
+    };
+    u64 xn[E];
+    if (PF) fetch_x(0, xn);
     for (int j = 0; j < ell; j++) {
         u64 x[E];
-        if (j == m) {
+        const u64 *k0 = key + (((size_t)j * 2 + 0) * Kp + pm) * N, *k1 = key + (((size_t)j * 2 + 1) * Kp + pm) * N;
+        u64 kv0[E], kv1[E];
+        if (PF && psel != 1) {
+#pragma unroll
+            for (int e = 0; e < E; e++) kv0[e] = k0[g[e]];
+        }
+        if (PF && psel != 0) {
+#pragma unroll
+            for (int e = 0; e < E; e++) kv1[e] = k1[g[e]];
+        }
+        if (PF) {
+#pragma unroll
+            for (int e = 0; e < E; e++) x[e] = xn[e];
+            if (j + 1 < ell) fetch_x(j + 1, xn);
+            if (own_on_the_fly(j)) { // c2 = a1*b1 on the fly (items points at the MulItem table)
+                const MulItem &it = reinterpret_cast<const MulItem *>(items)[b];
+                const u64 *a1 = it.a.limb(1, j, N), *b1 = it.b.limb(1, j, N);
+#pragma unroll
+                for (int e = 0; e < E; e++) x[e] = mulmod(a1[g[e]], b1[g[e]], M);
+            } else if (j != m) {
+                if (lds_used) __syncthreads(); // the previous tile's last LDS image has been read by everyone
+                ntt_tile_x<K, LOGE, false, false, true, true, true>(x, M, tw + ((size_t)pm << logN), logN, blockIdx.x, nold, nost, lds,
+                                                                    PF ? wtw : nullptr);
+                lds_used = true;
+            }
+        } else if (j == m) {
             if (MODE == 0) {
                 const KsItem &it = items[b];
                 const u64 *c1 = it.src.limb(1, j, N);
@@ -596,14 +655,13 @@ __global__ __launch_bounds__(kTileThreads) void f_ks_frows_mac_kernel(const u64 
                                                                  [=](int gi) { return in[gi]; }, nost, lds);
             lds_used = true;
         }
-        const u64 *k0 = key + (((size_t)j * 2 + 0) * Kp + pm) * N, *k1 = key + (((size_t)j * 2 + 1) * Kp + pm) * N;
         if (psel != 1) {
 #pragma unroll
-            for (int e = 0; e < E; e++) a0[e].mac(x[e], k0[g[e]]);
+            for (int e = 0; e < E; e++) a0[e].mac(x[e], PF ? kv0[e] : k0[g[e]]);
         }
         if (psel != 0) {
 #pragma unroll
-            for (int e = 0; e < E; e++) a1[e].mac(x[e], k1[g[e]]);
+            for (int e = 0; e < E; e++) a1[e].mac(x[e], PF ? kv1[e] : k1[g[e]]);
         }
         if ((j & 15) == 15 && j + 1 < ell) { // a 128-bit accumulator holds 16 products of canonical residues (Acc128): fold it into a word
 #pragma unroll
@@ -627,7 +685,6 @@ __global__ __launch_bounds__(kTileThreads) void f_ks_frows_mac_kernel(const u64 
             for (int e = 0; e < E; e++) r[e] = p == 0 ? a0[e].reduce(M) : a1[e].reduce(M);
             u64 *o = acc + (((size_t)b * 2 + p) * (ell + 1) + ell) * N;
             if (lds_used) __syncthreads();
-            auto nold = [](int) -> u64 { return 0; };
             ntt_tile_x<K, LOGE, false, true, false, true, false>(r, M, itw + ((size_t)sp << logN), logN, blockIdx.x, nold,
                                                                  [=](int gi, u64 v) { o[gi] = v; }, lds);
             lds_used = true;

@@ -116,15 +116,36 @@ __device__ __forceinline__ void gs_bfly(u64 &x, u64 &y, u64 w, const DModulus &M
     y = mulmod_lazy(w, d, M.delta);           // < 4q
 }
 
+// XCD-aware placement of COLS tiles.  A COLS tile touches row segments of B * 8 bytes (64 for the radix-8 tiles of a 256-row phase, 32 / 16
+// for the latency geometries) while the memory side moves 128-byte lines, so 16 / B neighbouring tiles share every line they touch; workgroup w
+// of a launch runs on XCD w mod 8 (tools/experiments/xcc_probe.hip), each XCD with its own L2 -- in launch order the sharers sat on different
+// XCDs and every line was fetched 16 / B times (measured: the COLS phases read 2.0x their limbs, profiles/r04_hybrid_ks_kernels.txt).  The map
+// below hands the tiles of one line to workgroups w, w + 8, ...: same XCD, dispatched together, the later ones hit the first one's line.
+// A bijection on the tiles of a limb; every address of a COLS tile comes from ntt_tile_x / tile_gidx, which both apply it.
+template <int K, int LOGE>
+__device__ __forceinline__ int cols_tile_of(int bx, int logN)
+{
+    constexpr int LOGB = TileGeo<LOGE>::LOG - K;
+    constexpr int LOGS = LOGB >= 4 ? 0 : 4 - LOGB; // log2(tiles per 128-byte line)
+#if defined(DC_EXP_NO_COLS_REMAP)
+    return bx;
+#endif
+    if (LOGS == 0 || logN - TileGeo<LOGE>::LOG < 3 + LOGS) return bx; // (fewer than 8 line groups in a limb: launch order)
+    const int r = bx & ((8 << LOGS) - 1);
+    return (bx & ~((8 << LOGS) - 1)) | ((r & 7) << LOGS) | (r >> 3);
+}
+
 // Ld: u64 operator()(int gidx)            coefficient gidx (0..N-1) of this limb: canonical, or what a previous phase stored
 // St: void operator()(int gidx, u64 v)    v canonical if CANON else lazy (any of the ranges of the schedule above)
 // PRELOADED: x[] already holds the first pass's coefficients (register j <-> idx_of(first pass, s, j)); ld unused.
 // KEEP     : leave the result in x[] (canonical if CANON) instead of calling st.  The last pass of an inverse phase and
 //            the first pass of a forward phase of the same shape use the same thread<->coefficient map, so an inverse
 //            tile can hand its output to a forward tile in registers (the fused iNTT -> base change -> NTT kernels).
+// wext (latency geometries only): the tile's twiddles as tile_twiddles() fetched them -- a kernel that runs the same tile of the same prime
+// several times (the digits of a key switch) fetches them once, not once per transform behind the exchanges' memory fences.
 template <int K, int LOGE, bool COLS, bool INV, bool CANON, bool PRELOADED, bool KEEP, class Ld, class St>
 __device__ __forceinline__ void ntt_tile_x(u64 (&x)[1 << LOGE], const DModulus M, const u64 *__restrict__ tw, int logN, int tile,
-                                           Ld ld, St st, u64 *__restrict__ lds)
+                                           Ld ld, St st, u64 *__restrict__ lds, const u64 (*wext)[1 << LOGE] = nullptr)
 {
     constexpr int E = 1 << LOGE, n = 1 << K, LOGB = TileGeo<LOGE>::LOG - K, B = 1 << LOGB, T = kTileThreads, SUBT = n / E;
     constexpr int NP = num_passes<LOGE>(K);
@@ -150,6 +171,7 @@ __device__ __forceinline__ void ntt_tile_x(u64 (&x)[1 << LOGE], const DModulus M
         b = t / SUBT;
     }
     const int sh = logN - K; // COLS: log2(column stride) ; ROWS: log2(N1)
+    if (COLS) tile = cols_tile_of<K, LOGE>(tile, logN);
     const int lane_id = tile * B + b;
     const u32 twroot = COLS ? 1u : ((1u << sh) + (u32)lane_id);
     auto gidx = [&](int idx) -> int { return COLS ? ((idx << sh) + lane_id) : ((lane_id << K) + idx); };
@@ -157,7 +179,7 @@ __device__ __forceinline__ void ntt_tile_x(u64 (&x)[1 << LOGE], const DModulus M
     // passes pin memory operations in place, so otherwise each pass starts by waiting for its own twiddle loads.
     constexpr bool PF = (LOGE <= 2);
     u64 wpre[PF ? NP : 1][E];
-    if (PF) {
+    if (PF && !wext) {
 #pragma unroll
         for (int pp = 0; pp < NP; pp++) {
             const int p = INV ? (NP - 1 - pp) : pp;
@@ -209,7 +231,7 @@ __device__ __forceinline__ void ntt_tile_x(u64 (&x)[1 << LOGE], const DModulus M
 #if defined(DC_EXP_NO_TWLOAD) // timing experiment only (wrong results; profiles/r02_experiments.txt): twiddles from registers, not memory
                     const u64 w = M.inv_n + twi;
 #else
-                    const u64 w = PF ? wpre[PF ? pp : 0][(u << r) | ((1 << st_) + g)] : tw[twi];
+                    const u64 w = PF ? (wext ? wext[PF ? pp : 0][(u << r) | ((1 << st_) + g)] : wpre[PF ? pp : 0][(u << r) | ((1 << st_) + g)]) : tw[twi];
 #endif
 #pragma unroll
 #if defined(DC_EXP_NO_BFLY) // timing experiment only (wrong results): loads, exchanges and stores without the arithmetic
@@ -283,8 +305,36 @@ __device__ __forceinline__ int tile_gidx(int p, int logN, int tile, int j)
     constexpr int LOGB = TileGeo<LOGE>::LOG - K, B = 1 << LOGB, SUBT = (1 << K) >> LOGE;
     const int t = threadIdx.x;
     const int b = COLS ? (t & (B - 1)) : (t / SUBT), s = COLS ? (t >> LOGB) : (t & (SUBT - 1));
+    if (COLS) tile = cols_tile_of<K, LOGE>(tile, logN);
     const int lane_id = tile * B + b, idx = PassMap<K, LOGE>::idx_of(p, s, j);
     return COLS ? ((idx << (logN - K)) + lane_id) : ((lane_id << K) + idx);
+}
+
+// every pass's twiddles of this thread, in the layout ntt_tile_x keeps them in (its `wext` argument); LOGE <= 2
+template <int K, int LOGE, bool COLS, bool INV>
+__device__ __forceinline__ void tile_twiddles(u64 (&w)[num_passes<LOGE>(K)][1 << LOGE], const u64 *__restrict__ tw, int logN, int tile)
+{
+    static_assert(LOGE <= 2, "the radix-8 tiles read their twiddles pass by pass");
+    constexpr int n = 1 << K, LOGB = TileGeo<LOGE>::LOG - K, B = 1 << LOGB, SUBT = n >> LOGE, NP = num_passes<LOGE>(K);
+    const int t = threadIdx.x;
+    const int b = COLS ? (t & (B - 1)) : (t / SUBT), s = COLS ? (t >> LOGB) : (t & (SUBT - 1));
+    if (COLS) tile = cols_tile_of<K, LOGE>(tile, logN);
+    const u32 twroot = COLS ? 1u : ((1u << (logN - K)) + (u32)(tile * B + b));
+#pragma unroll
+    for (int pp = 0; pp < NP; pp++) {
+        const int p = INV ? (NP - 1 - pp) : pp;
+        const int s0 = LOGE * p, r = pass_stages<LOGE>(K, p);
+#pragma unroll
+        for (int u = 0; u < (1 << (LOGE - r)); u++) {
+            const int vt = (s << (LOGE - r)) | u;
+            const int hi = vt >> (K - s0 - r);
+#pragma unroll
+            for (int st_ = 0; st_ < r; st_++) {
+#pragma unroll
+                for (int g = 0; g < (1 << st_); g++) w[pp][(u << r) | ((1 << st_) + g)] = tw[(twroot << (s0 + st_)) + (u32)((hi << st_) | g)];
+            }
+        }
+    }
 }
 
 template <int K, int LOGE, bool COLS, bool INV, bool CANON, class Ld, class St>
