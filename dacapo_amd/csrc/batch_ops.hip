@@ -410,6 +410,77 @@ __global__ __launch_bounds__(kBT) void b_sum_pair_kernel(const SumItem *__restri
     }
 }
 
+// Sums of one step that share sources, up to kSumGroup items to a thread (plan.hpp SumGroup): the group's sources are walked once, every
+// ciphertext limb read once for all the items that use it; the plaintexts (one per item and source) are the only per-item reads.  One
+// coefficient per thread (8 items x 2 polynomials of 128-bit accumulators are the register budget); grid = (N/256, l, groups).
+// Exact arithmetic: every destination receives the canonical residue of the same integer sum as b_sum_kernel's.
+__global__ __launch_bounds__(kBT) void b_sum_group_kernel(const SumGroup *__restrict__ groups, const SumGroupSrc *__restrict__ gsrcs, size_t N,
+                                                           const DModulus *__restrict__ mods)
+{
+    const int i = blockIdx.y;
+    const SumGroup &g = groups[blockIdx.z];
+    const DModulus M = mods[i];
+    const size_t k = (size_t)blockIdx.x * kBT + threadIdx.x;
+    const int first = g.first, count = g.count, items = g.items;
+    Acc128 a[kSumGroup][2];
+#pragma unroll
+    for (int b = 0; b < kSumGroup; b++) a[b][0].clear(), a[b][1].clear();
+    // (source t + 1's loads are issued before source t's products, as in b_sum_pair_kernel)
+    auto fetch = [&](int t, u64 &v0, u64 &v1, u64 (&w)[kSumGroup], unsigned &mul, unsigned &add) {
+        const SumGroupSrc &src = gsrcs[first + t];
+        v0 = src.v.limb(0, i, N)[k], v1 = src.v.limb(1, i, N)[k];
+        mul = add = 0;
+#pragma unroll
+        for (int b = 0; b < kSumGroup; b++) {
+            const u64 *p = src.plain[b]; // wave-uniform
+            if (p == sum_add_only())
+                add |= 1u << b;
+            else if (p)
+                mul |= 1u << b, w[b] = p[(size_t)i * N + k];
+        }
+    };
+    u64 v0n = 0, v1n = 0, wn[kSumGroup];
+    unsigned muln = 0, addn = 0;
+#pragma unroll
+    for (int b = 0; b < kSumGroup; b++) wn[b] = 0;
+    if (count > 0) fetch(0, v0n, v1n, wn, muln, addn);
+    for (int t = 0; t < count; t++) {
+        const u64 v0 = v0n, v1 = v1n;
+        const unsigned mul = muln, add = addn;
+        u64 w[kSumGroup];
+#pragma unroll
+        for (int b = 0; b < kSumGroup; b++) w[b] = wn[b];
+        if (t + 1 < count) fetch(t + 1, v0n, v1n, wn, muln, addn);
+#pragma unroll
+        for (int b = 0; b < kSumGroup; b++) {
+            if (mul >> b & 1u)
+                a[b][0].mac(v0, w[b]), a[b][1].mac(v1, w[b]);
+            else if (add >> b & 1u)
+                a[b][0].lo += v0, a[b][0].hi += a[b][0].lo < v0, a[b][1].lo += v1, a[b][1].hi += a[b][1].lo < v1;
+        }
+        if ((t & 15) == 15 && t + 1 < count) { // a 128-bit accumulator holds 16 products of canonical residues: fold it into a word
+#pragma unroll
+            for (int b = 0; b < kSumGroup; b++)
+#pragma unroll
+                for (int p = 0; p < 2; p++) {
+                    const u64 f = a[b][p].reduce(M);
+                    a[b][p].clear(), a[b][p].lo = f; // (counts as one more, tiny, term: 16 products + 2^60 < 2^124)
+                }
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < kSumGroup; b++)
+        if (b < items) {
+            g.dst[b].limb(0, i, N)[k] = a[b][0].reduce(M);
+            g.dst[b].limb(1, i, N)[k] = a[b][1].reduce(M);
+        }
+}
+
+void b_sum_group(Context &c, const SumGroup *d_groups, const SumGroupSrc *d_gsrcs, int G, int ell, hipStream_t s)
+{
+    hipLaunchKernelGGL(b_sum_group_kernel, dim3((unsigned)(c.N / kBT), (unsigned)ell, (unsigned)G), dim3(kBT), 0, s, d_groups, d_gsrcs, c.N, c.d_mods);
+}
+
 static long sum_pair_min_workgroups()
 { // option sum_pair_min_wgs: workgroups the paired form must still have (default 4 per CU); 0 = always, a huge value = never
     return (long)option(OPT_SUM_PAIR_MIN_WGS);

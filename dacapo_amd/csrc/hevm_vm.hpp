@@ -187,6 +187,7 @@ class HEVM {
         int wave = 0, lane = 0;             // steps of one wave are independent: lane 1 runs on the auxiliary stream
         Handoff h;                          // link to a fused producer (h.in) / consumer (h.cont, h.out) step, plan.hpp
         int fused_consumer = -1;            // index of the step whose first phase this step's last kernel computes
+        int gfirst = 0, gcount = 0;         // P_SUM: the step's items as groups that share sources (plan.hpp SumGroup), when it runs that way
         int unique = 0;                     // P_ROT, grouped-digit mode: distinct source ciphertexts among the items (shared decompositions)
         // what the step's launches read and write, by pool buffer (a value and its modswitch views share one): the edges of the explicitly
         // built graph (option plan_graph = 2, capture_plan_dag)
@@ -204,6 +205,8 @@ class HEVM {
         EwItem *d_ew = nullptr;
         SumItem *d_sum = nullptr;
         SumSrc *d_sum_srcs = nullptr;
+        SumGroup *d_sumg = nullptr;
+        SumGroupSrc *d_sumg_srcs = nullptr;
         CtView *d_cont_other = nullptr;      // CONT_MUL links: the consumers' other operands
         // on-line encode: per wave, the plaintext registers first read in it, encoded into a window recycled at wave granularity
         struct EncGroup { int wave, level, first, count; u64 *out; };

@@ -50,6 +50,7 @@ static const OptDef kDefs[OPT_COUNT] = {
     { "ks_big_tiles", 4096 },
     { "ks_fuse_mac_tiles", 1LL << 40 },
     { "sum_pair_min_wgs", 1024 },
+    { "sum_group_min_wgs", 2048 },
 };
 
 static long long g_val[OPT_COUNT];

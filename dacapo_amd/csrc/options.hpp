@@ -52,6 +52,7 @@ enum Opt : int {
     OPT_KS_BIG_TILES,            // work (1024-coefficient tiles of lifted digits) from which a key switch takes the large-batch sequence
     OPT_KS_FUSE_MAC_TILES,       // ... and up to which its middle stays one launch
     OPT_SUM_PAIR_MIN_WGS,        // n-ary sum: both polynomials per workgroup while this many workgroups remain
+    OPT_SUM_GROUP_MIN_WGS,       // n-ary sums of a step that share sources run up to 8 to a thread (each shared ciphertext limb read once) while this many workgroups remain (-1: never)
     OPT_COUNT
 };
 

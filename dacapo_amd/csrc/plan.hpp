@@ -44,6 +44,20 @@ struct SumItem {  // dst = sum of `count` terms srcs[first ...]
     int first, count;
 };
 
+// n-ary sums of one step that name the same ciphertexts, run together (batch_ops.hip b_sum_group_kernel): up to kSumGroup items to a thread,
+// the union of their sources walked once -- a rotated ciphertext that feeds 8 output channels of a convolution, or 8 giant steps of a
+// matrix-vector product, is read once instead of 8 times.
+constexpr int kSumGroup = 8;
+struct SumGroupSrc { // one source of a group and, per item, what multiplies it
+    CtView v;
+    const u64 *plain[kSumGroup]; // [level][N]; null: the item does not use this source; kSumAddOnly: the item adds it as it is
+};
+struct SumGroup {
+    CtView dst[kSumGroup];
+    int first, count, items; // sources gsrcs[first ... first + count), items <= kSumGroup
+};
+__host__ __device__ inline const u64 *sum_add_only() { return reinterpret_cast<const u64 *>((uintptr_t)8); }
+
 struct BootItem { // opcode 10: dst = Enc(re-encode(Dec(src))) = zenc + (plaintext, 0)
     CtView src, dst;
     const u64 *zenc; // fresh public-key encryption of zero at the target level, [2][t][N], made at the start of the run
@@ -105,6 +119,7 @@ inline int64_t ks_ntt_count(const Context &c, int ell)
 void b_ew(Context &c, EwOp op, const EwItem *d_items, int B, int polys, int b_polys, int ell, hipStream_t s);
 void b_add_plain(Context &c, const EwItem *d_items, int B, int ell, hipStream_t s);
 void b_sum(Context &c, const SumItem *d_items, const SumSrc *d_srcs, int B, int ell, hipStream_t s);
+void b_sum_group(Context &c, const SumGroup *d_groups, const SumGroupSrc *d_gsrcs, int G, int ell, hipStream_t s);
 // ModRaise (extension opcode 18): items[b].a at 1 prime -> items[b].dst at `target` primes, the centred residues mod q_0 re-read
 // modulo every prime.  `scratch` holds [B][2][N]; h_items is the host copy of the items (the forward NTTs are launched per item).
 void modraise(Context &c, u64 *scratch, const EwItem *h_items, int B, int target, hipStream_t s, const EwItem *d_items = nullptr);

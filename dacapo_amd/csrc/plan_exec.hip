@@ -39,7 +39,7 @@ void HEVM::build_plan()
     P.d_enc_items = nullptr, P.enc_arena = nullptr, P.enc_scratch = nullptr, P.d_enc_overflow = nullptr;
     P.enc_groups.clear(), P.enc_arena_bytes = P.enc_scratch_bytes = 0;
     if (P.d_cont_other) (void)vm_free(P.d_cont_other), P.d_cont_other = nullptr;
-    for (void *p : { (void *)P.d_ks, (void *)P.d_mul, (void *)P.d_rs, (void *)P.d_ew, (void *)P.d_sum, (void *)P.d_sum_srcs, (void *)P.d_boot,
+    for (void *p : { (void *)P.d_ks, (void *)P.d_mul, (void *)P.d_rs, (void *)P.d_ew, (void *)P.d_sum, (void *)P.d_sum_srcs, (void *)P.d_sumg, (void *)P.d_sumg_srcs, (void *)P.d_boot,
                      (void *)P.d_boot_rs, (void *)P.zenc, (void *)P.boot_ue, (void *)P.boot_tmp, (void *)P.boot_pt[0], (void *)P.boot_ptx[0],
                      (void *)P.boot_pt[1], (void *)P.boot_ptx[1] })
         if (p) (void)vm_free(p);
@@ -344,6 +344,9 @@ void HEVM::build_plan()
     std::vector<RsItem> h_rs;
     std::vector<EwItem> h_ew;
     std::vector<SumItem> h_sum;
+    std::vector<SumGroup> h_sumg;
+    std::vector<SumGroupSrc> h_sumg_srcs;
+    double sum_stat[5] = { 0, 0, 0, 0, 0 }; // option trace: sharing of sources between the items of an n-ary sum step
     std::vector<SumSrc> h_srcs;
     std::vector<std::vector<int>> step_pops;
     for (int w = 1; w <= max_wave; w++) {
@@ -641,6 +644,20 @@ void HEVM::build_plan()
             break;
         case P_SUM:
             st.first = (int)h_sum.size();
+            if (option(OPT_TRACE)) { // how many of a step's ciphertext reads name a (source list) another item of the step names too
+                std::map<std::vector<int>, int> lists;
+                std::set<int> distinct;
+                size_t terms = 0;
+                for (int pi : step_pops[s]) {
+                    lists[O[(size_t)pi].srcs]++, terms += O[(size_t)pi].srcs.size();
+                    distinct.insert(O[(size_t)pi].srcs.begin(), O[(size_t)pi].srcs.end());
+                }
+                size_t grouped4 = 0, grouped8 = 0; // ciphertext reads if items with one source list ran 4 / 8 to a thread
+                for (auto &kv : lists) grouped4 += kv.first.size() * (size_t)((kv.second + 3) / 4), grouped8 += kv.first.size() * (size_t)((kv.second + 7) / 8);
+                sum_stat[0] += (double)st.level * (double)terms, sum_stat[1] += (double)st.level * (double)distinct.size();
+                sum_stat[2] += (double)st.level * (double)grouped4, sum_stat[3] += (double)st.level * (double)step_pops[s].size();
+                sum_stat[4] += (double)st.level * (double)grouped8;
+            }
             for (int pi : step_pops[s])
                 for (int q = 0; q < S; q++) {
                     h_sum.push_back(SumItem{ view(O[(size_t)pi].dst, q), (int)h_srcs.size(), (int)O[(size_t)pi].srcs.size() });
@@ -649,6 +666,79 @@ void HEVM::build_plan()
                         h_srcs.push_back(SumSrc{ view(O[(size_t)pi].srcs[k], q), pl >= 0 ? plains.at((size_t)pl).d : nullptr });
                     }
                 }
+            // The same items as groups that share sources (plan.hpp SumGroup): the output channels of a convolution, the giant steps of a
+            // matrix-vector product name the same rotated ciphertexts.  Greedy: an item joins the open group while at least half of its
+            // sources are in the group's union already (candidates: the next 64 items of the step, program order keeps relatives close).
+            // A source an item names twice gets one union entry per occurrence.  Taken when it saves a fifth of the step's ciphertext reads
+            // and leaves option sum_group_min_wgs workgroups.
+            if (option(OPT_SUM_GROUP_MIN_WGS) >= 0 && step_pops[s].size() > 1) {
+                const std::vector<int> &pops = step_pops[s];
+                auto keys_of = [&](int pi) { // (source value, occurrence) keys of an item, in term order
+                    std::vector<std::pair<int, int>> ks;
+                    std::map<int, int> occ;
+                    for (int sv : O[(size_t)pi].srcs) ks.push_back({ sv, occ[sv]++ });
+                    return ks;
+                };
+                std::vector<std::vector<int>> groups;
+                std::vector<std::vector<std::pair<int, int>>> unions;
+                std::vector<char> used(pops.size(), 0);
+                size_t reads_before = 0, reads_after = 0;
+                for (size_t a0 = 0; a0 < pops.size(); a0++) {
+                    if (used[a0]) continue;
+                    used[a0] = 1;
+                    std::vector<int> grp{ (int)a0 };
+                    std::vector<std::pair<int, int>> uni = keys_of(pops[a0]);
+                    std::set<std::pair<int, int>> in_uni(uni.begin(), uni.end());
+                    while ((int)grp.size() < kSumGroup) {
+                        int best = -1;
+                        size_t best_sh = 0;
+                        for (size_t b0 = a0 + 1; b0 < pops.size() && b0 < a0 + 64; b0++) {
+                            if (used[b0]) continue;
+                            const auto kb = keys_of(pops[b0]);
+                            size_t sh = 0;
+                            for (auto &kk : kb) sh += in_uni.count(kk);
+                            if (sh * 2 >= kb.size() && sh > best_sh) best = (int)b0, best_sh = sh;
+                        }
+                        if (best < 0) break;
+                        used[(size_t)best] = 1, grp.push_back(best);
+                        for (auto &kk : keys_of(pops[(size_t)best]))
+                            if (in_uni.insert(kk).second) uni.push_back(kk);
+                    }
+                    for (int m : grp) reads_before += O[(size_t)pops[(size_t)m]].srcs.size();
+                    reads_after += uni.size();
+                    groups.push_back(grp), unions.push_back(uni);
+                }
+                const long wgs = (long)(N / 256) * st.level * (long)groups.size() * S;
+                if (option(OPT_TRACE) >= 2)
+                    fprintf(stderr, "[dacapo_amd] plan:   sum step at level %d: %zu items, %zu ciphertext reads, %zu as %zu groups\n", st.level, pops.size(),
+                            reads_before, reads_after, groups.size());
+                if (reads_after * 5 <= reads_before * 4 && wgs >= (long)option(OPT_SUM_GROUP_MIN_WGS)) {
+                    st.gfirst = (int)h_sumg.size();
+                    for (int q = 0; q < S; q++)
+                        for (size_t gi = 0; gi < groups.size(); gi++) {
+                            SumGroup sg{};
+                            sg.first = (int)h_sumg_srcs.size(), sg.count = (int)unions[gi].size(), sg.items = (int)groups[gi].size();
+                            std::map<std::pair<int, int>, size_t> pos;
+                            for (auto &kk : unions[gi]) {
+                                SumGroupSrc gs{};
+                                gs.v = view(kk.first, q);
+                                pos[kk] = h_sumg_srcs.size();
+                                h_sumg_srcs.push_back(gs);
+                            }
+                            for (size_t m = 0; m < groups[gi].size(); m++) {
+                                const Pop &p = O[(size_t)pops[(size_t)groups[gi][m]]];
+                                sg.dst[m] = view(p.dst, q);
+                                const auto km = keys_of(pops[(size_t)groups[gi][m]]);
+                                for (size_t k = 0; k < km.size(); k++) {
+                                    const int pl = p.src_plain.empty() ? -1 : p.src_plain[k];
+                                    h_sumg_srcs[pos[km[k]]].plain[m] = pl >= 0 ? plains.at((size_t)pl).d : sum_add_only();
+                                }
+                            }
+                            h_sumg.push_back(sg);
+                        }
+                    st.gcount = (int)h_sumg.size() - st.gfirst;
+                }
+            }
             break;
         case P_MODRAISE:
             need_d = std::max(need_d, B * 2);
@@ -767,6 +857,7 @@ void HEVM::build_plan()
     P.d_ks = upload(h_ks), P.d_mul = upload(h_mul), P.d_rs = upload(h_rs), P.d_ew = upload(h_ew), P.d_sum = upload(h_sum);
     P.h_ew = h_ew;
     P.d_sum_srcs = upload(h_srcs);
+    P.d_sumg = upload(h_sumg), P.d_sumg_srcs = upload(h_sumg_srcs);
     // fused links: the consumer's first-phase buffer (owned by the link, so the two steps may sit on different streams / waves)
     // and, for multiplies, the table of the consumers' other operands in item order
     {
@@ -847,6 +938,15 @@ void HEVM::build_plan()
         }
         for (int k = 0; k < 10; k++)
             if (nsteps[k]) fprintf(stderr, "[dacapo_amd] plan:   %-8s %5zu steps %6zu items\n", kn[k], nsteps[k], nitems[k]);
+        {
+            size_t gsteps = 0, ggroups = 0, gitems = 0;
+            for (const Step &st : P.steps)
+                if (st.kind == P_SUM && st.gcount > 0) gsteps++, ggroups += (size_t)st.gcount, gitems += (size_t)st.count;
+            fprintf(stderr, "[dacapo_amd] plan:   sums sharing sources: %zu steps run %zu items as %zu groups\n", gsteps, gitems, ggroups);
+        }
+        fprintf(stderr, "[dacapo_amd] plan:   sums, in limbs: %.0f terms (each 2 ciphertext limbs + at most 1 plaintext limb read), %.0f items (2 limbs written); "
+                        "distinct sources per step %.0f; ciphertext reads with equal source lists 4 / 8 to a thread %.0f / %.0f\n",
+                sum_stat[0], sum_stat[3], sum_stat[1], sum_stat[2], sum_stat[4]);
         { // who consumes what: candidates for handing a result to its consumer's first phase inside one launch
             std::map<std::tuple<int, int, int, int>, int> edges; // (producer kind, consumer kind, uses, same level) -> count
             std::vector<std::vector<int>> users(V.size());
@@ -884,7 +984,12 @@ void HEVM::issue_step(const Step &st, hipStream_t q)
     case P_ROT: b_rotate_hops(c, w, P.d_ks + st.first, st.count, st.level, q, st.h, st.unique); break;
     case P_MULCC: b_mul_relin(c, w, P.d_mul + st.first, keys.relin, st.count, st.level, q, st.h); break;
     case P_RESCALE: b_rescale(c, w, P.d_rs + st.first, st.count, st.level, q, P.d_sum_srcs, st.h); break;
-    case P_SUM: b_sum(c, P.d_sum + st.first, P.d_sum_srcs, st.count, st.level, q); break;
+    case P_SUM:
+        if (st.gcount > 0)
+            b_sum_group(c, P.d_sumg + st.gfirst, P.d_sumg_srcs, st.gcount, st.level, q);
+        else
+            b_sum(c, P.d_sum + st.first, P.d_sum_srcs, st.count, st.level, q);
+        break;
     case P_NEG: b_ew(c, EwOp::Neg, P.d_ew + st.first, st.count, 2, 2, st.level, q); break;
     case P_COPY: b_ew(c, EwOp::Copy, P.d_ew + st.first, st.count, 2, 2, st.level, q); break;
     case P_MODRAISE: modraise(c, w.digits, P.h_ew.data() + st.first, st.count, st.target, q, P.d_ew + st.first); break;

@@ -62,6 +62,60 @@ def run_conv_shaped_program(logN, K, tmp_path, seed=31):
     return res
 
 
+def run_multi_output_conv_program(logN, K, tmp_path, seed=37, outputs=11):
+    """a convolution with several output channels: 12 rotated inputs (6 offsets of two ciphertexts), every output channel a sum over them with
+    its own plaintexts -- some channels skip taps, one names a tap twice, some add a bare rotated ciphertext -- and every channel read by a
+    rotation and by an addition afterwards (two readers: the sums are materialised, not folded into a rescale), on the GPU VM and on the oracle VM.  The sums of the channels form one step of the
+    plan and share their sources: what batch_ops.hip b_sum_group_kernel is for."""
+    from dacapo_amd import hevm_asm as ha
+    from dacapo_amd import lowlevel as ll
+    from dacapo_amd import runner
+
+    slots = 1 << (logN - 1)
+    rng = np.random.default_rng(11)
+    b = ha.Builder(slots=slots, init_level=K - 1, policy="lazy", boot_level=K - 1, shadow=True)
+    x, y = b.input(rng.uniform(-1, 1, slots)), b.input(rng.uniform(-1, 1, slots))
+    taps = [b.rotate(x if t % 2 else y, 1 + 3 * (t // 2)) for t in range(12)]
+    bare = b.mul_plain(x, rng.uniform(-1, 1, slots))  # a value at the products' scale, added as it is
+    chans = []
+    for c in range(outputs):
+        acc = None
+        for t, r in enumerate(taps):
+            if (c * 5 + t) % 7 == 0 and c % 3 == 1:
+                continue  # this channel skips the tap
+            term = b.mul_plain(r, rng.uniform(-1, 1, slots))
+            acc = term if acc is None else b.add(acc, term)
+            if c == 4 and t == 3:  # the same tap again, another plaintext
+                acc = b.add(acc, b.mul_plain(r, rng.uniform(-1, 1, slots)))
+        if c % 4 == 2:
+            acc = b.add(acc, bare)
+        chans.append(acc)
+    total, extra = None, None
+    for c, ch in enumerate(chans):  # two readers per channel: a rotation (behind the lazy policy's rescale) and a plain addition
+        r = b.rotate(ch, 2 + c)
+        total = r if total is None else b.add(total, r)
+        extra = ch if extra is None else b.add(extra, ch)
+    b.output(b.finish(b.add(total, b.rescale(extra))))
+    cst, hv, info = b.assemble()
+    hevm = runner.HEVM(seed=seed, logN=logN, num_primes=K)
+    o = Oracle(logN, K)
+    _import_keys(o, hevm, ll)
+    hevm.load_mem(cst, hv)
+    ovm = _mirror_vm(hevm, ll, o, cst, hv, tmp_path)
+    for i, a in enumerate(b.args):
+        hevm.setInput(i, a.plain)
+        ovm.ciphers[i] = _get_ct(hevm, ll, i)
+    hevm.run()
+    ovm.run()
+    r = ovm.prog.res_dst[0]
+    got, want = _get_ct(hevm, ll, r), ovm.ciphers[r]
+    out = hevm.getOutput()[0]
+    res = {"limbs_identical": bool(got.ell == want.ell and (got.data == want.data).all()), "scale_identical": bool(got.scale == want.scale),
+           "max_error_vs_cleartext": float(np.abs(out - b.expected()[0]).max()), "op_mix": info["op_mix"], "stats": hevm.stats()}
+    hevm.close()
+    return res
+
+
 def _get_ct(hevm, ll, reg):
     c = hevm.getCtxt(reg)
     full = ll.read_device(c.data, (2, c.poly_stride // hevm.N, hevm.N))

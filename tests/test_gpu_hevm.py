@@ -742,6 +742,30 @@ def test_n_ary_sum_kernels_match_the_oracle_vm(tmp_path, min_wgs):
     assert res["op_mix"]["mulcp"] >= 20 and res["op_mix"]["addcc"] >= 27
 
 
+@pytest.mark.parametrize("min_wgs", [0, -1])
+def test_sums_sharing_sources_match_the_oracle_vm(tmp_path, capfd, min_wgs):
+    """batch_ops.hip b_sum_group_kernel (up to 8 sums of a step to a thread, the union of their sources read once) against one launch item per
+    sum (option sum_group_min_wgs = -1): 11 output channels over 12 shared rotated inputs -- channels that skip taps, one that names a tap twice,
+    bare ciphertext terms, a group of 8 and one of 3 -- both equal the oracle VM's multiply_plain / add sequence limb for limb; the plan's trace
+    says which form ran."""
+    import re
+
+    from dacapo_amd import runner
+    from gpu_helpers import run_multi_output_conv_program
+
+    with runner.options(sum_group_min_wgs=min_wgs, trace=1):
+        res = run_multi_output_conv_program(13, 5, tmp_path)
+    err = capfd.readouterr().err
+    m = re.search(r"sums sharing sources: (\d+) steps run (\d+) items as (\d+) groups", err)
+    assert m, err[-2000:]
+    if min_wgs == 0:
+        assert int(m.group(1)) >= 1 and int(m.group(2)) >= 11 and int(m.group(3)) < int(m.group(2))
+    else:
+        assert int(m.group(1)) == 0
+    assert res["limbs_identical"] and res["scale_identical"] and res["max_error_vs_cleartext"] < 1e-4
+    assert res["op_mix"]["mulcp"] >= 100
+
+
 @pytest.mark.parametrize("min_wgs", [0, 10**12])
 def test_merged_and_fine_launch_shapes_of_the_key_switch_match_the_oracle_vm(tmp_path, min_wgs):
     """fused_ks.hip: the MERGE instantiations of L2 / L6 (one inverse COLS phase per source limb for all its target moduli) and of the fused

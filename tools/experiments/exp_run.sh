@@ -1,8 +1,9 @@
 set -u
-O=$GRAFT_REPO_ROOT/gpurun_out/x5; mkdir -p $O
-cd /tmp; export TMPDIR=/tmp
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/c4 -- python3 $GRAFT_REPO_ROOT/tools/resnet_real_boot.py 1 resnet20_nt16 17 1 b14 8 7 > $O/c4.txt 2> $O/c4.err
-cp $(ls $O/c4/*/*kernel_stats.csv | head -1) $O/c4_kernel_stats.csv; rm -rf $O/c4
-tail -1 $O/c4.txt | cut -c1-400
-cd $GRAFT_REPO_ROOT
-timeout 2400 python -m pytest tests -x -q -m gpu 2>&1 | tail -5
+O=$GRAFT_REPO_ROOT/gpurun_out/x7; mkdir -p $O
+timeout 900 python -m pytest tests/test_gpu_hevm.py -x -q -m gpu -k "sums or n_ary or conv" 2>&1 | tail -15
+for g in 2048 -1; do
+  echo "== sum_group_min_wgs=$g"
+  timeout 300 python tools/boot_demo.py 17 5 1 14 8 7 --opt sum_group_min_wgs=$g --opt trace=1 2>&1 | grep -E "sums sharing|bootstrap:|decrypted"
+  timeout 300 python tools/experiments/quick_headline.py 10 resnet20 --opt sum_group_min_wgs=$g 2>&1 | tail -1
+done
+timeout 600 python tools/resnet_real_boot.py 1 resnet20_nt16 17 1 b14 8 7 --opt trace=1 > $O/c4.txt 2>&1; grep -E "sums sharing|sums, in limbs" $O/c4.txt; tail -1 $O/c4.txt | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['run_s'], d['first_run_s'], d['rms_vs_torch'])"
