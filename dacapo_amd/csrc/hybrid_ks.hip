@@ -130,7 +130,7 @@ __global__ __launch_bounds__(kHT) void hyb_modup_kernel(const u64 *__restrict__ 
     }
 }
 
-// inner products with the key.  grid = (N/512, M, B).  MODE 0 rotation items (per-item key; every operand -- a raised limb of the item's
+// inner products with the key.  grid = (N/512, B, M).  MODE 0 rotation items (per-item key; every operand -- a raised limb of the item's
 // slot, or the NTT-form limb of src.c1 itself where the modulus belongs to the digit -- is read THROUGH the item's Galois permutation),
 // 1 ct x ct items (shared key), 2 one key switch by value
 template <int MODE>
@@ -139,7 +139,9 @@ __global__ __launch_bounds__(kHT) void hyb_mac_kernel(u64 *__restrict__ accq, u6
                                                        const u64 *__restrict__ shared_key, int ell, int ksp, int alpha, int L, int K, int E, size_t N,
                                                        int logN, int use_slots, const DModulus *__restrict__ mods, const u64 *__restrict__ pmod)
 {
-    const int mi = blockIdx.y, b = blockIdx.z, M = ell + ksp, pm = mi < ell ? mi : L + (mi - ell);
+    // (items fastest: the items of a hoisted batch read the same raised limbs -- through their own Galois maps -- within a few MiB of traffic
+    // of each other instead of a whole pass over the key apart)
+    const int mi = blockIdx.z, b = blockIdx.y, M = ell + ksp, pm = mi < ell ? mi : L + (mi - ell);
     const DModulus Md = mods[pm];
     KsItem it{};
     if (MODE == 0) it = items ? static_cast<const KsItem *>(items)[b] : single;
@@ -440,7 +442,7 @@ void hyb_launch_mac(Context &c, int mode, const BatchWs &w, const void *items, K
 {
     const size_t N = c.N;
     const int ksp = c.ksp, alpha = c.alpha, L = c.max_level(), K = c.K, M = ell + ksp, E = c.hyb_ext(ell);
-    const dim3 grid((unsigned)(N / (2 * kHT)), (unsigned)M, (unsigned)B);
+    const dim3 grid((unsigned)(N / (2 * kHT)), (unsigned)B, (unsigned)M);
     u64 *accq = w.acc, *accp = w.acc + (size_t)B * 2 * ell * N;
 #define DC_MAC(MD)                                                                                                                        \
     hipLaunchKernelGGL(hyb_mac_kernel<MD>, grid, dim3(kHT), 0, s, accq, accp, w.ext, w.target, items, rot_single, key, ell, ksp, alpha, L, K, E, N, \
