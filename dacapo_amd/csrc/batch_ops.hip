@@ -412,13 +412,14 @@ __global__ __launch_bounds__(kBT) void b_sum_pair_kernel(const SumItem *__restri
 
 // Sums of one step that share sources, up to kSumGroup items to a thread (plan.hpp SumGroup): the group's sources are walked once, every
 // ciphertext limb read once for all the items that use it; the plaintexts (one per item and source) are the only per-item reads.  One
-// coefficient per thread (8 items x 2 polynomials of 128-bit accumulators are the register budget); grid = (N/256, l, groups).
+// coefficient per thread (8 items x 2 polynomials of 128-bit accumulators are the register budget); grid = (N/256, groups, l).
 // Exact arithmetic: every destination receives the canonical residue of the same integer sum as b_sum_kernel's.
 __global__ __launch_bounds__(kBT) void b_sum_group_kernel(const SumGroup *__restrict__ groups, const SumGroupSrc *__restrict__ gsrcs, size_t N,
                                                            const DModulus *__restrict__ mods)
 {
-    const int i = blockIdx.y;
-    const SumGroup &g = groups[blockIdx.z];
+    // (groups fastest: the groups of a step mostly share their sources too -- two groups of 7 giant steps over the same 16 baby steps)
+    const int i = blockIdx.z;
+    const SumGroup &g = groups[blockIdx.y];
     const DModulus M = mods[i];
     const size_t k = (size_t)blockIdx.x * kBT + threadIdx.x;
     const int first = g.first, count = g.count, items = g.items;
@@ -478,7 +479,7 @@ __global__ __launch_bounds__(kBT) void b_sum_group_kernel(const SumGroup *__rest
 
 void b_sum_group(Context &c, const SumGroup *d_groups, const SumGroupSrc *d_gsrcs, int G, int ell, hipStream_t s)
 {
-    hipLaunchKernelGGL(b_sum_group_kernel, dim3((unsigned)(c.N / kBT), (unsigned)ell, (unsigned)G), dim3(kBT), 0, s, d_groups, d_gsrcs, c.N, c.d_mods);
+    hipLaunchKernelGGL(b_sum_group_kernel, dim3((unsigned)(c.N / kBT), (unsigned)G, (unsigned)ell), dim3(kBT), 0, s, d_groups, d_gsrcs, c.N, c.d_mods);
 }
 
 static long sum_pair_min_workgroups()
