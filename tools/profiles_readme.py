@@ -112,9 +112,12 @@ rows = [bench_row("r04"), traffic_row("r04"), step_row("r04"), valu_row("r04"),
         f"three launch sequences, the matrix-core counters, and all levels under HIP events (levels 1 / 7 / 12 / 14 / 31): {hop_levels('r04_hybrid_ks_kernels.txt')}. "
         f"Sequence totals: {first_lines('r04_hybrid_ks_kernels.txt', 'sum of the kernels listed')} (µs per hop, read MB, write MB, GB/s; fuse = 2, 1, 0) | "
         "`tools/collect_profiles.sh` B4: three passes of `tools/hybrid_ks_bench.py 17 39 8 7 10 31 --opt hyb_fuse=f`, `tools/kernel_bytes.py` |",
-        f"| `r04_config4_kernel_stats.csv`, `r04_config4_under_profiler.txt`, `r04_config4_kernel_bytes.txt` | BASELINE config 4 under the kernel trace: {stats('r04_config4_kernel_stats.csv')}; "
-        "per kernel the measured HBM bytes and GB/s (the PMC passes run the plan launch by launch: the profiler's counter mode does not survive the 100 k-node graph) | "
-        "`rocprofv3 --kernel-trace --stats -- python3 tools/resnet_real_boot.py 1 resnet20_nt16 17 1 b14 8 7`, `--pmc FETCH_SIZE` / `WRITE_SIZE` passes with `--opt plan_graph=0`, `tools/kernel_bytes.py` |",
+        f"| `r04_config4_kernel_stats.csv`, `r04_config4_under_profiler.txt` | BASELINE config 4 under the kernel trace: {stats('r04_config4_kernel_stats.csv')} | "
+        "`rocprofv3 --kernel-trace --stats -- python3 tools/resnet_real_boot.py 1 resnet20_nt16 17 1 b14 8 7` |",
+        f"| `r04_boot_kernel_bytes.txt` | ONE real bootstrap at config 4's geometry (38 of them are 93 % of config 4), per kernel the measured HBM bytes and GB/s -- the n-ary sums "
+        f"and the inner products among them: {first_lines('r04_boot_kernel_bytes.txt', 'bootstrap:', 1)}; {first_lines('r04_boot_kernel_bytes.txt', 'hyb_mac_kernel<0>|b_sum_group_kernel|b_sum_pair_kernel', 3)} "
+        "(columns: calls, µs per launch, µs in the process, share, read MB, write MB, GB/s, fraction of 8 TB/s).  The counter passes run on one bootstrap because rocprofv3's counter mode "
+        "crashes or hangs on the whole config-4 program (`r04_experiments.txt` item 12) | three passes of `tools/boot_demo.py 17 5 1 14 8 7` (`--pmc FETCH_SIZE` / `WRITE_SIZE` with `--opt plan_graph=0`), `tools/kernel_bytes.py` |",
         f"| `r04_dag_width.txt` | the headline program's dataflow graph: {first_lines('r04_dag_width.txt', 'waves,')}; replay times: {first_lines('r04_dag_width.txt', 'graph replay', 4)} | `python tools/dag_width.py` |",
         f"| `r04_per_op.json`, `r04_per_op_kernel_stats.csv` | the three expensive opcodes at 13 primes and config 3, kernel by kernel: {stats('r04_per_op_kernel_stats.csv', 3)} | `rocprofv3 --kernel-trace --stats -- python3 tools/per_op_only.py 20` |",
         f"| `r04_kernel_stats.csv`, `r04_by_kernel_and_grid.txt`, `r04_timeline.txt`, `r04_top_kernels.json` | the bench command under the kernel trace: {first_lines('r04_timeline.txt', 'last run', 1)} | `rocprofv3 --kernel-trace --stats … -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-lowerings --no-config4` |",
