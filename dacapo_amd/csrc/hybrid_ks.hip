@@ -271,11 +271,13 @@ __global__ __launch_bounds__(kHT) void hyb_final_kernel(const u64 *__restrict__ 
 // ---- the two base conversions on the matrix cores ------------------------------------------------------------------------------
 // out[e][n] = sum_t y_t[n] w[t][e] mod m_e for 16 coefficients x 16 output moduli per MFMA tile (see context.hip for the operand
 // encoding: balanced base-256 digits of y on the A side, of w 2^(8p) mod m on the B side; 8 accumulator planes r recombined as
-// sum_r C_r 2^(8r), a signed 80-bit integer, then reduced).  One wave = a strip of 128 coefficients (8 A fragments kept in registers),
+// sum_r C_r 2^(8r), a signed 80-bit integer, then reduced).  One wave = a strip of 64 coefficients (4 A fragments kept in registers),
 // one workgroup = 4 waves; the B fragments of a block of 16 moduli (8 x 16 bytes per lane) are loaded once per strip.
 // DOWN = false: mod-up of digit g = blockIdx.y of item blockIdx.z; DOWN = true: mod-down of polynomial blockIdx.z (= 2 b + c).
 typedef int v4i __attribute__((ext_vector_type(4)));
-constexpr int kConvStrip = 128; // coefficients per wave
+// (128 coefficients per wave = 8 A fragments kept 132 VGPRs alive: three waves per SIMD; with 64 it is 116 and four, and twice the waves to
+// hide the strip's load -> MFMA -> store chain: hop at 7 / 14 primes 133 -> 127 / 199 -> 193 us, profiles/r04_experiments.txt)
+constexpr int kConvStrip = 64; // coefficients per wave
 
 // Recombination of the 8 accumulator planes, round 4 (round 3's form spent ~50 vector instructions per output on a signed 128-bit sum, and the
 // matrix pipes sat idle 93 % of the launch).  The accumulators START at 2^20 (the MFMA's C operand), so every plane value c'_r = C_r + 2^20 is
