@@ -175,9 +175,12 @@ __device__ __forceinline__ void ntt_tile_x(u64 (&x)[1 << LOGE], const DModulus M
     const int lane_id = tile * B + b;
     const u32 twroot = COLS ? 1u : ((1u << sh) + (u32)lane_id);
     auto gidx = [&](int idx) -> int { return COLS ? ((idx << sh) + lane_id) : ((lane_id << K) + idx); };
-    // Latency geometries: fetch every pass's twiddles (<= E - 1 per pass) before the first butterfly.  The barriers between
+    // Fetch every pass's twiddles (<= E - 1 per pass) before the first butterfly.  The barriers between
     // passes pin memory operations in place, so otherwise each pass starts by waiting for its own twiddle loads.
-    constexpr bool PF = (LOGE <= 2);
+    // The radix-8 ROWS tiles too (round 4): their late stages' twiddles are one load per lane and butterfly, and issued pass by pass they were
+    // waited for -- 160 limbs at N = 2^17: inverse ROWS 98 -> 82 us, forward ROWS 87 -> 80 us (44 / 50 -> 65 / 64 VGPRs).  A radix-8 COLS tile's
+    // twiddles are a 256-entry table shared by its columns: cache hits, left where they are used.
+    constexpr bool PF = (LOGE <= 2) || !COLS;
     u64 wpre[PF ? NP : 1][E];
     if (PF && !wext) {
 #pragma unroll
