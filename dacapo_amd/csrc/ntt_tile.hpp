@@ -180,7 +180,7 @@ __device__ __forceinline__ void ntt_tile_x(u64 (&x)[1 << LOGE], const DModulus M
     // The radix-8 ROWS tiles too (round 4): their late stages' twiddles are one load per lane and butterfly, and issued pass by pass they were
     // waited for -- 160 limbs at N = 2^17: inverse ROWS 98 -> 82 us, forward ROWS 87 -> 80 us (44 / 50 -> 65 / 64 VGPRs).  A radix-8 COLS tile's
     // twiddles are a 256-entry table shared by its columns: cache hits, left where they are used.
-    constexpr bool PF = (LOGE <= 2) || !COLS;
+    constexpr bool PF = (LOGE <= 2) || !COLS; // (radix-8 COLS tiles with the prefetch: 69.8 -> 67.7 us forward, 83.7 -> 82.2 inverse: not worth their fused forms' registers)
     u64 wpre[PF ? NP : 1][E];
     if (PF && !wext) {
 #pragma unroll
