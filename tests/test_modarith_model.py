@@ -152,3 +152,36 @@ def test_forward_fold_schedule_keeps_sums_in_64_bits():
         assert bound <= (15 << 63) // 8      # the multiplicand of THIS stage is a previous output
         bound = max(xf + t_max, xf + 4 * q)  # x' = xf + t ; y' = xf + 4q - t
         assert bound <= M64
+
+
+def cols_tile_of(bx, K, LOGE, logN):
+    """ntt_tile.hpp cols_tile_of, restated: workgroup index of a COLS launch -> tile of the limb"""
+    log_tile = 8 + LOGE
+    logb = log_tile - K                       # log2(columns of a tile)
+    logs = 0 if logb >= 4 else 4 - logb       # log2(tiles that share a 128-byte line)
+    if logs == 0 or logN - log_tile < 3 + logs:
+        return bx
+    span = 8 << logs
+    r = bx & (span - 1)
+    return (bx & ~(span - 1)) | ((r & 7) << logs) | (r >> 3)
+
+
+@pytest.mark.parametrize("logN,K", [(15, 7), (16, 8), (17, 8), (14, 7), (13, 6)])
+@pytest.mark.parametrize("LOGE", [1, 2, 3])
+def test_cols_tile_placement_is_a_bijection_and_line_sharers_share_an_xcd(logN, K, LOGE):
+    """ntt_tile.hpp cols_tile_of: a COLS tile is 2^(8 + LOGE - K) columns = that many 8-byte words of every row it touches; the tiles whose
+    columns fall into one 128-byte line (16 words) must be handed to workgroups that are congruent mod 8 (workgroup w runs on XCD w mod 8:
+    tools/experiments/xcc_probe.hip) and close in launch order, and the map must stay a permutation of the limb's tiles"""
+    tiles = 1 << (logN - 8 - LOGE)
+    cols = 1 << (8 + LOGE - K)
+    img = [cols_tile_of(bx, K, LOGE, logN) for bx in range(tiles)]
+    assert sorted(img) == list(range(tiles))
+    sharers = max(1, 16 // cols)
+    if sharers > 1 and tiles >= 8 * sharers:
+        wg_of = {t: bx for bx, t in enumerate(img)}
+        for line in range(tiles // sharers):
+            wgs = [wg_of[line * sharers + j] for j in range(sharers)]
+            assert len({w % 8 for w in wgs}) == 1, (line, wgs)            # one XCD
+            assert max(wgs) - min(wgs) == 8 * (sharers - 1), (line, wgs)  # dispatched within 8 * sharers workgroups of each other
+    else:
+        assert img == list(range(tiles))
