@@ -2,7 +2,7 @@
 """The reference's ResNet-20 with REAL CKKS bootstrapping at every bootstrap site (the headline program tests/golden/resnet20.*, every
 opcode 10 rewritten by dacapo_amd/ckks_boot.lower_bootstraps): BASELINE config 4 in spirit -- the reference
 runs it on HEaaN (HEAAN_HEVM.cpp:386-399) at N = 2^17; here on SEAL-style 60-bit primes, N = 2^15, 20 primes, sparse secret.
-    python tools/resnet_real_boot.py [direct_keys=1|2|49|<n>] [fixture=resnet20] [logN=15] [msg_bits=4] [lowering=""] [ks_special=1] [ks_alpha=ks_special] [chain=60|mixed]
+    python tools/resnet_real_boot.py [direct_keys=1|2|49|<n>] [fixture=resnet20] [logN=15] [msg_bits=4] [lowering=""] [ks_special=1] [ks_alpha=ks_special] [chain=60|mixed|mixed_app] [streams=1]
 chain mixed: a HEaaN-style chain -- 60-bit base prime, 51-bit rescale primes, 60-bit special primes (HEAAN_HEVM.cpp:55-56, profiled_HEAAN_GPU.json:
 rescalingFactor 51) -- on the generic-width build; the lowering must then have been traced with --rescale-bits 51.
 lowering: another lowering of the same trace (tests/golden/<fixture>.<lowering>.hevm.gz, same constants), e.g. b14 = bootstraps placed at the
@@ -34,6 +34,7 @@ lowering = sys.argv[5] if len(sys.argv) > 5 else ""
 ks = int(sys.argv[6]) if len(sys.argv) > 6 else 1
 alpha = int(sys.argv[7]) if len(sys.argv) > 7 else ks  # primes per digit (alpha < ks: P exceeds a digit's modulus, the switching noise shrinks by the ratio)
 chain = sys.argv[8] if len(sys.argv) > 8 else "60"
+streams = int(sys.argv[9]) if len(sys.argv) > 9 else 1  # independent images through one plan (every batched step carries all streams' items)
 fx = ha.read_fixture(ROOT / "tests" / "golden" / name)
 if lowering:
     import gzip
@@ -94,9 +95,16 @@ elif direct:
     print(f"{len(offs)} direct rotation keys", flush=True)
 print(f"context + keys {time.time()-t0:.1f} s", flush=True)
 t0 = time.time()
+if streams > 1:
+    hevm.set_streams(streams)
 hevm.load_mem(fx["cst"], fx["hevm"])
 print(f"load + preprocess (encode, plan, graph) {time.time()-t0:.1f} s", flush=True)
-hevm.setInput(0, fx["packed"])
+for sidx in range(streams):  # stream s > 0 gets the image scaled by 1 - s / 8: another input, a known expectation up to the activations
+    if streams > 1:
+        hevm.select_stream(sidx)
+    hevm.setInput(0, fx["packed"] if sidx == 0 else fx["packed"] * (1.0 - sidx / 8.0))
+if streams > 1:
+    hevm.select_stream(0)
 t0 = time.perf_counter()
 hevm.run()
 dt_first = time.perf_counter() - t0          # includes first-use costs (code objects, the plan's first issue)
@@ -116,4 +124,12 @@ res = {"chain": "60-bit" if primes is None else ("mixed: 60-bit base and special
        "rms_vs_torch": float(np.sqrt(np.mean((out[:10] * 32 - fx["torch_result"]) ** 2))),
        "rms_vs_plaintext_evaluation": float(np.sqrt(np.mean((out - fx["expected"]) ** 2))),
        "logits": [round(float(v), 4) for v in out[:10] * 32], "torch": [round(float(v), 4) for v in fx["torch_result"]]}
+if streams > 1:  # throughput mode: the other streams' logits are finite and differ from stream 0's (another image); images per second
+    others = []
+    for sidx in range(1, streams):
+        hevm.select_stream(sidx)
+        o = hevm.getOutput()[0][:10] * 32
+        others.append([round(float(v), 4) for v in o])
+    hevm.select_stream(0)
+    res.update(streams=streams, images_per_s=round(streams / dt, 3), s_per_image=round(dt / streams, 3), other_streams_logits=others)
 print(json.dumps(res))
