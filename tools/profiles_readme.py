@@ -90,6 +90,37 @@ def first_lines(name, pat, n=3):
     return " / ".join(hits[:n])
 
 
+def kb_rows(name, pat, n=3):
+    """rows of a tools/kernel_bytes.py table (kernel, calls, avg us, us/unit, share, read MB/unit, write MB/unit, GB/s, fraction of 8 TB/s) as prose"""
+    f = P / name
+    if not f.exists():
+        return "(missing)"
+    out = []
+    for ln in f.read_text().splitlines():
+        if not re.search(pat, ln):
+            continue
+        m = re.match(r"\s*(.+?)\s+(\d+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s*$", ln)
+        if m:
+            k, calls, avg, _, share, rd, wr, gbs, frac = m.groups()
+            out.append(f"`{k}` {calls} × {float(avg):.0f} µs, {100 * float(share):.1f} % of the process's kernel time, {float(rd) / 1e3:.1f} GB read + {float(wr) / 1e3:.1f} GB written = {float(gbs) / 1e3:.2f} TB/s ({float(frac):.2f} of peak)")
+        if len(out) >= n:
+            break
+    return "; ".join(out) if out else "(no such row)"
+
+
+def seq_totals(name):
+    f = P / name
+    if not f.exists():
+        return "(missing)"
+    out = []
+    for ln in f.read_text().splitlines():
+        m = re.match(r"sum of the kernels listed\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)", ln)
+        if m:
+            us, rd, wr, gbs = (float(x) for x in m.groups())
+            out.append(f"{us:.0f} µs of kernels, {rd / 1e3:.2f} GB read + {wr / 1e3:.2f} GB written = {(rd + wr) / 1e3:.2f} GB")
+    return "; ".join(f"`hyb_fuse` = {f}: {v}" for f, v in zip((2, 1, 0), out))
+
+
 def hop_levels(name):
     f = P / name
     if not f.exists():
@@ -110,13 +141,13 @@ print("| file | what (figures read from the file) | command |\n|---|---|---|")
 rows = [bench_row("r04"), traffic_row("r04"), step_row("r04"), valu_row("r04"),
         f"| `r04_hybrid_ks_kernels.txt` | one grouped-digit rotation hop at N = 2^17, level 31, kernel by kernel with MEASURED HBM bytes per hop (FETCH_SIZE × 2 + WRITE_SIZE) for the "
         f"three launch sequences, the matrix-core counters, and all levels under HIP events (levels 1 / 7 / 12 / 14 / 31): {hop_levels('r04_hybrid_ks_kernels.txt')}. "
-        f"Sequence totals: {first_lines('r04_hybrid_ks_kernels.txt', 'sum of the kernels listed')} (µs per hop, read MB, write MB, GB/s; fuse = 2, 1, 0) | "
+        f"Per hop under the trace: {seq_totals('r04_hybrid_ks_kernels.txt')} | "
         "`tools/collect_profiles.sh` B4: three passes of `tools/hybrid_ks_bench.py 17 39 8 7 10 31 --opt hyb_fuse=f`, `tools/kernel_bytes.py` |",
         f"| `r04_config4_kernel_stats.csv`, `r04_config4_under_profiler.txt` | BASELINE config 4 under the kernel trace: {stats('r04_config4_kernel_stats.csv')} | "
         "`rocprofv3 --kernel-trace --stats -- python3 tools/resnet_real_boot.py 1 resnet20_nt16 17 1 b14 8 7` |",
-        f"| `r04_boot_kernel_bytes.txt` | ONE real bootstrap at config 4's geometry (38 of them are 93 % of config 4), per kernel the measured HBM bytes and GB/s -- the n-ary sums "
-        f"and the inner products among them: {first_lines('r04_boot_kernel_bytes.txt', 'bootstrap:', 1)}; {first_lines('r04_boot_kernel_bytes.txt', 'hyb_mac_kernel<0>|b_sum_group_kernel|b_sum_pair_kernel', 3)} "
-        "(columns: calls, µs per launch, µs in the process, share, read MB, write MB, GB/s, fraction of 8 TB/s).  The counter passes run on one bootstrap because rocprofv3's counter mode "
+        f"| `r04_boot_kernel_bytes.txt` | ONE real bootstrap at config 4's geometry (38 of them are about nine tenths of config 4), per kernel the measured HBM bytes and GB/s -- the n-ary sums "
+        f"and the inner products among them: {first_lines('r04_boot_kernel_bytes.txt', 'bootstrap:', 1)}; {kb_rows('r04_boot_kernel_bytes.txt', 'hyb_mac_kernel<0>|b_sum_group_kernel|b_sum_pair_kernel|ntt_phase_kernel<8, 3, true, false, false>', 4)} "
+        "(the process = key generation + encoding + 3 runs).  The counter passes run on one bootstrap because rocprofv3's counter mode "
         "crashes or hangs on the whole config-4 program (`r04_experiments.txt` item 12) | three passes of `tools/boot_demo.py 17 5 1 14 8 7` (`--pmc FETCH_SIZE` / `WRITE_SIZE` with `--opt plan_graph=0`), `tools/kernel_bytes.py` |",
         f"| `r04_dag_width.txt` | the headline program's dataflow graph: {first_lines('r04_dag_width.txt', 'waves,')}; replay times: {first_lines('r04_dag_width.txt', 'graph replay', 4)} | `python tools/dag_width.py` |",
         f"| `r04_per_op.json`, `r04_per_op_kernel_stats.csv` | the three expensive opcodes at 13 primes and config 3, kernel by kernel: {stats('r04_per_op_kernel_stats.csv', 3)} | `rocprofv3 --kernel-trace --stats -- python3 tools/per_op_only.py 20` |",
