@@ -138,13 +138,14 @@ static void b_ks_tail(Context &c, const BatchWs &w, u64 *digits, const KsItem *i
         f_irows_strided(c, acc_last, acc_ps, sp, 1, acc_last, acc_ps, 2 * B, s);
     } else // MODE 1: the operand a1*b1 is recomputed from the MulItem table (no tensor launch, see b_mul_relin)
         f_ks_frows_mac(c, MODE, w.ext, MODE == 1 ? nullptr : w.target, MODE == 1 ? reinterpret_cast<const KsItem *>(final_items) : items,
-                       shared_key, w.acc, B, ell, s);
+                       shared_key, w.acc, B, ell, s, MODE == 0);
     if (big) {
         launch_ntt_cols_inv(c, acc_last, acc_ps, 2 * B, nullptr, sp, 1, s);
         f_dr_lift_fcols(c, acc_last, acc_ps, w.tmp, 2 * B, ell, sp, s);
     } else
         f_dr_icols_lift_fcols(c, acc_last, acc_ps, w.tmp, 2 * B, ell, sp, s);
-    f_frows_final(c, (MODE == 1 && fused_mac) ? 4 : MODE, w.tmp, final_items, w.acc, 2 * B, ell, sp, s, RsItem{}, nullptr, nullptr, h);
+    f_frows_final(c, (MODE == 1 && fused_mac) ? 4 : MODE, w.tmp, final_items, w.acc, 2 * B, ell, sp, s, RsItem{}, nullptr, nullptr, h,
+                  MODE == 0 && fused_mac); // (a rotation's base term was folded into the fused middle's accumulators)
 }
 
 void b_rotate_hops(Context &c, const BatchWs &w, const KsItem *d_items, int B, int ell, hipStream_t s, const Handoff &h, int unique)

@@ -28,6 +28,22 @@ __device__ __forceinline__ u32 galois_idx(u32 k, u32 elt, int logN)
     return __brev(idx) >> (32 - logN);
 }
 
+// E consecutive coefficients k0 .. k0 + E - 1 (k0 a multiple of E >= 2) of galois(p): the index map sends an aligned pair of outputs to an
+// aligned pair of inputs, possibly swapped (brev(k + 1) = brev(k) + N/2, elt odd: the source index moves by N/2 before its own bit
+// reversal, i.e. its lowest bit flips), so a pair is ONE 16-byte load
+template <int E>
+__device__ __forceinline__ void galois_gather(u64 (&x)[E], const u64 *__restrict__ p, u32 k0, u32 elt, int logN)
+{
+    static_assert(E >= 2 && E % 2 == 0, "pairs");
+    typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int e = 0; e < E; e += 2) {
+        const u32 gi = galois_idx(k0 + (u32)e, elt, logN);
+        const u64x2 v = *reinterpret_cast<const u64x2 *>(p + (gi & ~1u));
+        x[e] = (gi & 1u) ? v.y : v.x, x[e + 1] = (gi & 1u) ? v.x : v.y;
+    }
+}
+
 // ---- operand sources of the first inverse phase ----------------------------------------------------------------------
 struct SrcStrided { // limb z at base + z*stride, modulo prime prime_base + z % period
     const u64 *base;
@@ -35,16 +51,6 @@ struct SrcStrided { // limb z at base + z*stride, modulo prime prime_base + z % 
     int prime_base, period;
     __device__ int prime(int z) const { return prime_base + z % period; }
     __device__ u64 load(int z, int g, int) const { return base[(long)z * stride + g]; }
-};
-struct SrcRotC1 { // limb z = b*l + j : c1 of item b, limb j, read through the item's Galois permutation
-    const KsItem *items;
-    int ell;
-    __device__ int prime(int z) const { return z % ell; }
-    __device__ u64 load(int z, int g, int logN) const
-    {
-        const KsItem &it = items[z / ell];
-        return it.src.limb(1, z % ell, (size_t)1 << logN)[galois_idx((u32)g, it.elt, logN)];
-    }
 };
 // Operand of a rescale item (plan.hpp RsItem) for the E coefficients a thread owns: elementwise producers (n-ary sum,
 // + plaintext, * plaintext) that nothing else reads are evaluated here instead of being materialised.  Modular
@@ -328,7 +334,7 @@ __global__ __launch_bounds__(kTileThreads) void f_frows_final_kernel(const u64 *
                                                                       const u64 *__restrict__ acc, int cnt, int l, int Kp,
                                                                       const DModulus *__restrict__ mods,
                                                                       const u64 *__restrict__ inv_last, const u64 *__restrict__ tw,
-                                                                      int logN)
+                                                                      int logN, int base_folded)
 {
     __shared__ __attribute__((aligned(16))) u64 lds[TileGeo<LOGE>::LDS_ELEMS];
     const int z = blockIdx.y, i = z % cnt, bp = z / cnt, b = bp >> 1, p = bp & 1;
@@ -336,7 +342,29 @@ __global__ __launch_bounds__(kTileThreads) void f_frows_final_kernel(const u64 *
     const DModulus M = mods[i];
     const u64 inv = inv_last[(size_t)l * Kp + i];
     const u64 *in = tmp + (size_t)z * N;
-    if (MODE == 0) {
+    if (MODE == 0 && base_folded) {
+        // The rotation's base term galois(c0) already rides on the accumulator (f_ks_frows_mac_kernel added P galois(c0) to it:
+        // galois(c0) + (acc - t) P^-1 = ((acc + P galois(c0)) - t) P^-1 exactly), so this kernel has no gather: a ROWS tile leaves a thread
+        // 2^LOGE CONSECUTIVE coefficients and the epilogue runs on 16-byte vectors.  (The per-coefficient store functor below -- 8-byte accesses
+        // at a 2^LOGE-word lane stride, a Galois gather with 64 lanes in 64 cache lines -- is what hybrid_fused.hip's last kernel measured 2.5x
+        // slower than this form.)
+        constexpr int E = 1 << LOGE;
+        const KsItem it = reinterpret_cast<const KsItem *>(items_)[b];
+        const u64 *x = acc + (((size_t)bp) * (cnt + 1) + i) * N;
+        u64 *o = it.dst.limb(p, i, N);
+        u64 v[E];
+        auto nost = [](int, u64) {};
+        ntt_tile_x<K, LOGE, false, false, true, false, true>(v, M, tw + ((size_t)i << logN), logN, blockIdx.x, [=](int gi) { return in[gi]; }, nost, lds);
+        const int g0 = tile_gidx<K, LOGE, false>(num_passes<LOGE>(K) - 1, logN, blockIdx.x, 0);
+        typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int j = 0; j < E; j += 2) {
+            const u64x2 a = *reinterpret_cast<const u64x2 *>(x + g0 + j);
+            u64x2 r;
+            r.x = mulmod(submod(a.x, v[j], M.q), inv, M), r.y = mulmod(submod(a.y, v[j + 1], M.q), inv, M);
+            *reinterpret_cast<u64x2 *>(o + g0 + j) = r;
+        }
+    } else if (MODE == 0) {
         const KsItem it = reinterpret_cast<const KsItem *>(items_)[b];
         const u64 *x = acc + (((size_t)bp) * (cnt + 1) + i) * N;
         const u64 *c0 = it.src.limb(0, i, N);
@@ -417,7 +445,8 @@ __global__ __launch_bounds__(kTileThreads) void f_frows_final_kernel(const u64 *
 template <int K, int LOGE, int MODE>
 __device__ __forceinline__ void final_value(u64 (&v)[1 << LOGE], const int (&g)[1 << LOGE], const u64 *__restrict__ in, const void *__restrict__ items_,
                                             const SumSrc *__restrict__ srcs, const u64 *__restrict__ acc, int b, int p, int i, int cnt,
-                                            const DModulus &M, u64 inv, const u64 *__restrict__ tw, int logN, u64 *__restrict__ lds)
+                                            const DModulus &M, u64 inv, const u64 *__restrict__ tw, int logN, u64 *__restrict__ lds,
+                                            bool base_folded = false)
 {
     constexpr int E = 1 << LOGE;
     const size_t N = (size_t)1 << logN;
@@ -451,7 +480,7 @@ __device__ __forceinline__ void final_value(u64 (&v)[1 << LOGE], const int (&g)[
         u64 *o = it.dst.limb(p, i, N);
 #pragma unroll
         for (int j = 0; j < E; j++) {
-            const u64 base = p == 0 ? c0[galois_idx((u32)g[j], it.elt, logN)] : 0;
+            const u64 base = (p == 0 && !base_folded) ? c0[galois_idx((u32)g[j], it.elt, logN)] : 0; // (folded: the accumulator carries it)
             v[j] = addmod(base, mulmod(submod(ac[g[j]], x[j], M.q), inv, M), M.q);
             o[g[j]] = v[j];
         }
@@ -476,7 +505,7 @@ __global__ __launch_bounds__(kTileThreads) void f_frows_final_cont_kernel(const 
                                                                            const SumSrc *__restrict__ srcs, const u64 *__restrict__ acc, int cnt,
                                                                            int l, int Kp, const DModulus *__restrict__ mods,
                                                                            const u64 *__restrict__ inv_last, const u64 *__restrict__ tw,
-                                                                           const u64 *__restrict__ itw, int logN, Handoff h)
+                                                                           const u64 *__restrict__ itw, int logN, Handoff h, int base_folded)
 {
     __shared__ __attribute__((aligned(16))) u64 lds[TileGeo<LOGE>::LDS_ELEMS];
     constexpr int E = 1 << LOGE, NP = num_passes<LOGE>(K);
@@ -490,9 +519,9 @@ __global__ __launch_bounds__(kTileThreads) void f_frows_final_cont_kernel(const 
         const DModulus M = mods[i];
         const u64 inv = inv_last[(size_t)l * Kp + i];
         u64 v0[E], v1[E];
-        final_value<K, LOGE, MODE>(v0, g, tmp + ((size_t)(b * 2 + 0) * cnt + i) * N, items_, srcs, acc, b, 0, i, cnt, M, inv, tw, logN, lds);
+        final_value<K, LOGE, MODE>(v0, g, tmp + ((size_t)(b * 2 + 0) * cnt + i) * N, items_, srcs, acc, b, 0, i, cnt, M, inv, tw, logN, lds, base_folded != 0);
         __syncthreads(); // the tile's last LDS image has been read by everyone
-        final_value<K, LOGE, MODE>(v1, g, tmp + ((size_t)(b * 2 + 1) * cnt + i) * N, items_, srcs, acc, b, 1, i, cnt, M, inv, tw, logN, lds);
+        final_value<K, LOGE, MODE>(v1, g, tmp + ((size_t)(b * 2 + 1) * cnt + i) * N, items_, srcs, acc, b, 1, i, cnt, M, inv, tw, logN, lds, base_folded != 0);
         const u64 *sk = h.sk + (size_t)i * N;
 #pragma unroll
         for (int j = 0; j < E; j++) v0[j] = addmod(v0[j], mulmod(v1[j], sk[g[j]], M), M.q);
@@ -504,7 +533,7 @@ __global__ __launch_bounds__(kTileThreads) void f_frows_final_cont_kernel(const 
         const DModulus M = mods[i];
         const u64 inv = inv_last[(size_t)l * Kp + i];
         u64 v[E];
-        final_value<K, LOGE, MODE>(v, g, tmp + (size_t)z * N, items_, srcs, acc, b, p, i, cnt, M, inv, tw, logN, lds);
+        final_value<K, LOGE, MODE>(v, g, tmp + (size_t)z * N, items_, srcs, acc, b, p, i, cnt, M, inv, tw, logN, lds, base_folded != 0);
         if (CONT == CONT_RS) {
             if (i != cnt - 1) return; // the consumer drops the last limb: only its workgroups continue (uniform per workgroup)
             const RsItem cit = h.rs_items[b]; // single-use "+ plaintext" / "* plaintext" folded into the consumer (rs_operand's order)
@@ -550,7 +579,8 @@ __global__ __launch_bounds__(kTileThreads) void f_ks_frows_mac_kernel(const u64 
                                                                        const KsItem *__restrict__ items,
                                                                        const u64 *__restrict__ shared_key, u64 *__restrict__ acc, int ell,
                                                                        int Kp, const DModulus *__restrict__ mods,
-                                                                       const u64 *__restrict__ tw, const u64 *__restrict__ itw, int logN)
+                                                                       const u64 *__restrict__ tw, const u64 *__restrict__ itw, int logN,
+                                                                       const u64 *__restrict__ pmod)
 {
     __shared__ __attribute__((aligned(16))) u64 lds[TileGeo<LOGE>::LDS_ELEMS];
     constexpr int E = 1 << LOGE, NP = num_passes<LOGE>(K);
@@ -569,6 +599,19 @@ __global__ __launch_bounds__(kTileThreads) void f_ks_frows_mac_kernel(const u64 
     Acc128 a0[E], a1[E];
 #pragma unroll
     for (int e = 0; e < E; e++) a0[e].clear(), a1[e].clear();
+    if (MODE == 0 && pmod && m < ell) {
+        // A rotation's base term rides on the accumulator: galois(c0) + (acc - t) P^-1 = ((acc + P galois(c0)) - t) P^-1 exactly, so the last
+        // kernel of the key switch has no gather to do (this one has the Galois map in hand for c1 anyway).  The residue P galois(c0) mod q
+        // is the accumulator's START value -- below 2^60 like a folded window, so the 16-products-per-window bound is unchanged -- and it is
+        // computed here, before anything else is live (added in the epilogue it cost the merged form 6 VGPRs and a wave per SIMD).
+        const KsItem &it = items[b];
+        const u64 *c0 = it.src.limb(0, m, N);
+        const u64 P = pmod[m];
+        u64 cv[E];
+        galois_gather<E>(cv, c0, (u32)g[0], it.elt, logN);
+#pragma unroll
+        for (int e = 0; e < E; e++) a0[e].lo = mulmod(cv[e], P, M);
+    }
     auto nost = [](int, u64) {};
     auto nold = [](int) -> u64 { return 0; };
     bool lds_used = false;
@@ -593,9 +636,7 @@ __global__ __launch_bounds__(kTileThreads) void f_ks_frows_mac_kernel(const u64 
         const bool own = j == m;
         if (MODE == 0 && own) {
             const KsItem &it = items[b];
-            const u64 *c1 = it.src.limb(1, j, N);
-#pragma unroll
-            for (int e = 0; e < E; e++) x[e] = c1[galois_idx((u32)g[e], it.elt, logN)];
+            galois_gather<E>(x, it.src.limb(1, j, N), (u32)g[0], it.elt, logN);
         } else if (!own || target) { // (one load path with a selected base and stride: two index arrays made the compiler select between them in memory)
             const u64 *src = own ? target + ((size_t)b * ell + j) * N : ext + (((size_t)b * ell + j) * ell + (m < j ? m : m - 1)) * N;
             const int base = own ? g[0] : gin0, stride = own ? 1 : SUBT;
@@ -635,9 +676,7 @@ __global__ __launch_bounds__(kTileThreads) void f_ks_frows_mac_kernel(const u64 
         } else if (j == m) {
             if (MODE == 0) {
                 const KsItem &it = items[b];
-                const u64 *c1 = it.src.limb(1, j, N);
-#pragma unroll
-                for (int e = 0; e < E; e++) x[e] = c1[galois_idx((u32)g[e], it.elt, logN)];
+                galois_gather<E>(x, it.src.limb(1, j, N), (u32)g[0], it.elt, logN);
             } else if (target) {
                 const u64 *tg = target + ((size_t)b * ell + j) * N;
 #pragma unroll
@@ -751,9 +790,30 @@ void f_irows_strided(const Context &c, const u64 *base, long stride, int prime_b
 {
     launch_irows(c, SrcStrided{ base, stride, prime_base, period }, out, out_stride, count, s);
 }
+// L1 of a rotation batch: inverse ROWS phase of galois(c1).  z = b*l + j.  An inverse ROWS tile starts with 2^LOGE CONSECUTIVE coefficients per
+// thread, so the Galois gather is 16-byte loads of aligned pairs (galois_gather) instead of one 8-byte load per coefficient through a loader
+// functor (the geometries with at least two coefficients per thread: all three)
+template <int K, int LOGE>
+__global__ __launch_bounds__(kTileThreads) void f_irows_rot_kernel(const KsItem *__restrict__ items, int ell, u64 *__restrict__ out,
+                                                                    const DModulus *__restrict__ mods, const u64 *__restrict__ itw, int logN)
+{
+    __shared__ __attribute__((aligned(16))) u64 lds[TileGeo<LOGE>::LDS_ELEMS];
+    constexpr int E = 1 << LOGE;
+    const int z = blockIdx.y, j = z % ell;
+    const size_t N = (size_t)1 << logN;
+    const KsItem &it = items[z / ell];
+    u64 *o = out + (size_t)z * N;
+    u64 x[E];
+    galois_gather<E>(x, it.src.limb(1, j, N), (u32)tile_gidx<K, LOGE, false>(num_passes<LOGE>(K) - 1, logN, blockIdx.x, 0), it.elt, logN);
+    auto nold = [](int) -> u64 { return 0; };
+    ntt_tile_x<K, LOGE, false, true, false, true, false>(x, mods[j], itw + ((size_t)j << logN), logN, blockIdx.x, nold,
+                                                         [=](int gi, u64 v) { o[gi] = v; }, lds);
+}
+
 void f_irows_rot_c1(const Context &c, const KsItem *items, int ell, u64 *out, int B, hipStream_t s)
 {
-    launch_irows(c, SrcRotC1{ items, ell }, out, (long)c.N, B * ell, s);
+    DC_GEO_SWITCH(c.k2, B * ell, hipLaunchKernelGGL((f_irows_rot_kernel<KK, LE>), grid, dim3(kTileThreads), 0, s, items, ell, out, c.d_mods, c.d_itw,
+                                                    c.logN));
 }
 void f_irows_rs_last(const Context &c, const RsItem *items, const SumSrc *srcs, int l, u64 *out, int B, hipStream_t s)
 {
@@ -803,8 +863,9 @@ static long ks_merge_special_min_wgs()
 }
 
 void f_ks_frows_mac(const Context &c, int mode, const u64 *ext, const u64 *target, const KsItem *items, const u64 *shared_key, u64 *acc,
-                    int B, int ell, hipStream_t s)
+                    int B, int ell, hipStream_t s, bool fold_base)
 {
+    const u64 *pmod = (fold_base && mode == 0) ? c.d_pmod : nullptr;
 #define DC_FMAC(LEV, MD)                                                                                                                  \
     {                                                                                                                                     \
         constexpr int LE = LEV;                                                                                                           \
@@ -813,10 +874,10 @@ void f_ks_frows_mac(const Context &c, int mode, const u64 *ext, const u64 *targe
         const dim3 grid((unsigned)(c.N >> TileGeo<LE>::LOG), (unsigned)(ell + 2 - merge), (unsigned)B);                                  \
         if (merge) {                                                                                                                      \
             DC_K_SWITCH(c.k2, hipLaunchKernelGGL((f_ks_frows_mac_kernel<KK, LE, MD, true>), grid, dim3(kTileThreads), 0, s, ext, target, items,   \
-                                                 shared_key, acc, ell, c.K, c.d_mods, c.d_tw, c.d_itw, c.logN));                         \
+                                                 shared_key, acc, ell, c.K, c.d_mods, c.d_tw, c.d_itw, c.logN, pmod));                   \
         } else {                                                                                                                          \
             DC_K_SWITCH(c.k2, hipLaunchKernelGGL((f_ks_frows_mac_kernel<KK, LE, MD, false>), grid, dim3(kTileThreads), 0, s, ext, target, items,  \
-                                                 shared_key, acc, ell, c.K, c.d_mods, c.d_tw, c.d_itw, c.logN));                         \
+                                                 shared_key, acc, ell, c.K, c.d_mods, c.d_tw, c.d_itw, c.logN, pmod));                   \
         }                                                                                                                                 \
     }
     // (the radix-8 geometry was measured for this kernel too: 8 coefficients x two 128-bit accumulators per thread cost more in
@@ -883,13 +944,14 @@ void f_dr_lift_fcols(const Context &c, const u64 *last, long last_stride, u64 *t
 }
 
 void f_frows_final(const Context &c, int mode, const u64 *tmp, const void *items, const u64 *acc, int polys, int cnt, int l,
-                   hipStream_t s, RsItem single, const u64 *plain, const SumSrc *srcs, const Handoff &h)
+                   hipStream_t s, RsItem single, const u64 *plain, const SumSrc *srcs, const Handoff &h, bool base_folded)
 {
+    const int folded = base_folded ? 1 : 0;
     if (h.cont != CONT_NONE) {
         const int groups = h.cont == CONT_BOOT ? polys / 2 : polys; // CONT_BOOT: one workgroup per (item, limb) does both polynomials
 #define DC_CONT(MD, CT)                                                                                                                \
     DC_GEO_SWITCH(c.k2, groups * cnt, hipLaunchKernelGGL((f_frows_final_cont_kernel<KK, LE, MD, CT>), grid, dim3(kTileThreads), 0, s, tmp, items, \
-                                                         srcs, acc, cnt, l, c.K, c.d_mods, c.d_inv_last, c.d_tw, c.d_itw, c.logN, h))
+                                                         srcs, acc, cnt, l, c.K, c.d_mods, c.d_inv_last, c.d_tw, c.d_itw, c.logN, h, folded))
         if (mode == 4 && h.cont == CONT_RS) {
             DC_CONT(4, CONT_RS);
         } else if (mode == 2 && h.cont == CONT_MUL) {
@@ -907,7 +969,7 @@ void f_frows_final(const Context &c, int mode, const u64 *tmp, const void *items
     }
 #define DC_FINAL(MD)                                                                                                                   \
     DC_GEO_SWITCH(c.k2, polys * cnt, hipLaunchKernelGGL((f_frows_final_kernel<KK, LE, MD>), grid, dim3(kTileThreads), 0, s, tmp, items, single, \
-                                                        plain, srcs, acc, cnt, l, c.K, c.d_mods, c.d_inv_last, c.d_tw, c.logN))
+                                                        plain, srcs, acc, cnt, l, c.K, c.d_mods, c.d_inv_last, c.d_tw, c.logN, folded))
     switch (mode) {
     case 0: DC_FINAL(0); break;
     case 1: DC_FINAL(1); break;

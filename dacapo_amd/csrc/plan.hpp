@@ -146,8 +146,9 @@ void f_ks_icols_lift_fcols(const Context &c, const u64 *digits, u64 *ext, int B,
 void f_dr_icols_lift_fcols(const Context &c, const u64 *last, long last_stride, u64 *tmp, int polys, int cnt, int l, hipStream_t s);
 // L3 + L4 + L5 fused (small batches): second NTT phase of the lifted digits, inner products with the key, first inverse phase of
 // the special-prime accumulators.  mode 0 rotation (items[b].key, operand through the Galois permutation) / 1 relinearisation
+// fold_base (rotations): the accumulators of the data primes leave with P galois(c0) added, and f_frows_final is told so (base_folded)
 void f_ks_frows_mac(const Context &c, int mode, const u64 *ext, const u64 *target, const KsItem *items, const u64 *shared_key, u64 *acc,
-                    int B, int ell, hipStream_t s);
+                    int B, int ell, hipStream_t s, bool fold_base = false);
 // large-batch variants: inverse COLS phase run separately (once per source limb), then base change + forward COLS
 void f_ks_lift_fcols(const Context &c, const u64 *digits, u64 *ext, int B, int ell, hipStream_t s);
 void f_dr_lift_fcols(const Context &c, const u64 *last, long last_stride, u64 *tmp, int polys, int cnt, int l, hipStream_t s);
@@ -155,7 +156,7 @@ void f_dr_lift_fcols(const Context &c, const u64 *last, long last_stride, u64 *t
 // 4 relinearisation with the c0, c1 tensor terms computed in the epilogue (small batches: no tensor launch)
 void f_frows_final(const Context &c, int mode, const u64 *tmp, const void *items, const u64 *acc, int polys, int cnt, int l,
                    hipStream_t s, RsItem single = RsItem{}, const u64 *plain = nullptr, const SumSrc *srcs = nullptr,
-                   const Handoff &h = Handoff{});
+                   const Handoff &h = Handoff{}, bool base_folded = false);
 // a single rescale_to_next of `src` (level ell) into dst, optionally adding a level-(ell-1) plaintext to c0: 3 launches
 void rescale_fused(Context &c, const Workspace &w, CtView dst, CtView src, int ell, const u64 *plain, hipStream_t s);
 
