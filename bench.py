@@ -198,9 +198,10 @@ def lib_sha256():
     return hashlib.sha256(Path(LIB_PATH).read_bytes()).hexdigest()
 
 
-def per_op_leg(ll, ell=13, iters=20):
+def per_op_leg(ll, ell=13, iters=20, only=None):
     """the three expensive opcodes alone at the reference's top level (13 primes, N = 2^15), next to the reference's own
-    per-op table for SEAL on a CPU (profiled_SEAL_CPU.json:10-45); algorithmic bytes per SURVEY.md 8(d)"""
+    per-op table for SEAL on a CPU (profiled_SEAL_CPU.json:10-45); algorithmic bytes per SURVEY.md 8(d).  `only`: one op's name
+    (the profiler passes of tools/per_op_budget.py run one op per process)"""
     L = ll.lib()
     ctx = ll.Context(15, 14)
     N, K = ctx.N, ctx.K
@@ -219,6 +220,8 @@ def per_op_leg(ll, ell=13, iters=20):
     }
     out = {}
     for name, (fn, nbytes, ref_us) in ops.items():
+        if only and name != only:
+            continue
         fn()
         L.dc_event_record(e0, None)
         for _ in range(iters):

@@ -133,7 +133,7 @@ static void b_ks_tail(Context &c, const BatchWs &w, u64 *digits, const KsItem *i
     const long acc_ps = (long)(ell + 1) * (long)N;
     if (!fused_mac) {
         launch_ntt_rows_fwd(c, w.ext, (long)N, B * ell * ell, c.ks_prime_idx(ell), 0, ell * ell, s);
-        hipLaunchKernelGGL(b_ks_mac_kernel<MODE>, dim3((unsigned)(N / (2 * kBT)), ell + 1, B), dim3(kBT), 0, s, w.acc, w.ext, w.target, items,
+        DC_LAUNCH(b_ks_mac_kernel<MODE>, dim3((unsigned)(N / (2 * kBT)), ell + 1, B), dim3(kBT), 0, s, w.acc, w.ext, w.target, items,
                            shared_key, ell, K, N, c.logN, c.d_mods);
         f_irows_strided(c, acc_last, acc_ps, sp, 1, acc_last, acc_ps, 2 * B, s);
     } else // MODE 1: the operand a1*b1 is recomputed from the MulItem table (no tensor launch, see b_mul_relin)
@@ -170,7 +170,7 @@ void b_mul_relin(Context &c, const BatchWs &w, const MulItem *d_items, const u64
     if (h.in) // a fused producer already ran the inverse ROWS phase of a1*b1 (the plan only links steps when fuse_mac() holds)
         digits = const_cast<u64 *>(h.in);
     else if (!fused_mac) {
-        hipLaunchKernelGGL(b_tensor_kernel, dim3((unsigned)(N / (2 * kBT)), ell, B), dim3(kBT), 0, s, d_items, w.target, ell, N, c.d_mods);
+        DC_LAUNCH(b_tensor_kernel, dim3((unsigned)(N / (2 * kBT)), ell, B), dim3(kBT), 0, s, d_items, w.target, ell, N, c.d_mods);
         f_irows_strided(c, w.target, (long)N, 0, ell, w.digits, (long)N, B * ell, s);
     } else // small batches: a1*b1 is formed in the loaders and a0*b0, a0*b1 + a1*b0 in the last kernel's epilogue
         f_irows_tensor_c2(c, d_items, ell, w.digits, B, s);
@@ -222,9 +222,9 @@ void b_ew(Context &c, EwOp op, const EwItem *d_items, int B, int polys, int b_po
 {
     dim3 grid((unsigned)(c.N / (2 * kBT)), (unsigned)ell, (unsigned)(polys * B)), block(kBT);
     switch (op) {
-    case EwOp::Neg: hipLaunchKernelGGL(b_ew_kernel<2>, grid, block, 0, s, d_items, polys, b_polys, c.N, c.d_mods); break;
-    case EwOp::Mul: hipLaunchKernelGGL(b_ew_kernel<3>, grid, block, 0, s, d_items, polys, b_polys, c.N, c.d_mods); break;
-    case EwOp::Copy: hipLaunchKernelGGL(b_ew_kernel<4>, grid, block, 0, s, d_items, polys, b_polys, c.N, c.d_mods); break;
+    case EwOp::Neg: DC_LAUNCH(b_ew_kernel<2>, grid, block, 0, s, d_items, polys, b_polys, c.N, c.d_mods); break;
+    case EwOp::Mul: DC_LAUNCH(b_ew_kernel<3>, grid, block, 0, s, d_items, polys, b_polys, c.N, c.d_mods); break;
+    case EwOp::Copy: DC_LAUNCH(b_ew_kernel<4>, grid, block, 0, s, d_items, polys, b_polys, c.N, c.d_mods); break;
     default: fprintf(stderr, "[dacapo_amd] b_ew: unsupported op\n"); abort();
     }
 }
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(kBT) void b_add_plain_kernel(const EwItem *__restri
 
 void b_add_plain(Context &c, const EwItem *d_items, int B, int ell, hipStream_t s)
 {
-    hipLaunchKernelGGL(b_add_plain_kernel, dim3((unsigned)(c.N / (2 * kBT)), (unsigned)ell, (unsigned)(2 * B)), dim3(kBT), 0, s, d_items,
+    DC_LAUNCH(b_add_plain_kernel, dim3((unsigned)(c.N / (2 * kBT)), (unsigned)ell, (unsigned)(2 * B)), dim3(kBT), 0, s, d_items,
                        c.N, c.d_mods);
 }
 
@@ -334,9 +334,9 @@ void modraise(Context &c, u64 *scratch, const EwItem *h_items, int B, int target
         abort();
     }
     const EwItem single = d_items ? EwItem{} : h_items[0]; // eager path: the one item travels as a kernel argument
-    hipLaunchKernelGGL(b_modraise_gather_kernel, dim3((unsigned)(N / (2 * kBT)), (unsigned)(2 * B)), dim3(kBT), 0, s, scratch, d_items, single, N);
+    DC_LAUNCH(b_modraise_gather_kernel, dim3((unsigned)(N / (2 * kBT)), (unsigned)(2 * B)), dim3(kBT), 0, s, scratch, d_items, single, N);
     launch_ntt(c, true, scratch, (long)N, 2 * B, nullptr, 0, 1, s);
-    hipLaunchKernelGGL(b_modraise_lift_kernel, dim3((unsigned)(N / (2 * kBT)), (unsigned)target, (unsigned)(2 * B)), dim3(kBT), 0, s, scratch,
+    DC_LAUNCH(b_modraise_lift_kernel, dim3((unsigned)(N / (2 * kBT)), (unsigned)target, (unsigned)(2 * B)), dim3(kBT), 0, s, scratch,
                        d_items, single, N, c.d_mods);
     for (int b = 0; b < B; b++) { // one forward transform over both polynomials of an item: [2][target] limbs, the register's poly stride apart
         const CtView d = h_items[b].dst;
@@ -480,7 +480,7 @@ __global__ __launch_bounds__(kBT) void b_sum_group_kernel(const SumGroup *__rest
 
 void b_sum_group(Context &c, const SumGroup *d_groups, const SumGroupSrc *d_gsrcs, int G, int ell, hipStream_t s)
 {
-    hipLaunchKernelGGL(b_sum_group_kernel, dim3((unsigned)(c.N / kBT), (unsigned)G, (unsigned)ell), dim3(kBT), 0, s, d_groups, d_gsrcs, c.N, c.d_mods);
+    DC_LAUNCH(b_sum_group_kernel, dim3((unsigned)(c.N / kBT), (unsigned)G, (unsigned)ell), dim3(kBT), 0, s, d_groups, d_gsrcs, c.N, c.d_mods);
 }
 
 static long sum_pair_min_workgroups()
@@ -491,11 +491,11 @@ static long sum_pair_min_workgroups()
 void b_sum(Context &c, const SumItem *d_items, const SumSrc *d_srcs, int B, int ell, hipStream_t s)
 {
     if ((long)(c.N / (2 * kBT)) * ell * B >= sum_pair_min_workgroups()) {
-        hipLaunchKernelGGL(b_sum_pair_kernel, dim3((unsigned)(c.N / (2 * kBT)), (unsigned)ell, (unsigned)B), dim3(kBT), 0, s, d_items, d_srcs, c.N,
+        DC_LAUNCH(b_sum_pair_kernel, dim3((unsigned)(c.N / (2 * kBT)), (unsigned)ell, (unsigned)B), dim3(kBT), 0, s, d_items, d_srcs, c.N,
                            c.d_mods);
         return;
     }
-    hipLaunchKernelGGL(b_sum_kernel, dim3((unsigned)(c.N / (2 * kBT)), (unsigned)ell, (unsigned)(2 * B)), dim3(kBT), 0, s, d_items, d_srcs,
+    DC_LAUNCH(b_sum_kernel, dim3((unsigned)(c.N / (2 * kBT)), (unsigned)ell, (unsigned)(2 * B)), dim3(kBT), 0, s, d_items, d_srcs,
                        c.N, c.d_mods);
 }
 

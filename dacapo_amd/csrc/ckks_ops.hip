@@ -141,23 +141,23 @@ void keyswitch(Context &c, const Workspace &w, CtView out, const u64 *base0, con
     const int K = c.K, sp = K - 1;
     const unsigned gx = (unsigned)(N / (2 * kOpThreads));
     // (1) digits = iNTT(target)
-    hipLaunchKernelGGL(copy_limbs_kernel, dim3(gx, ell), dim3(kOpThreads), 0, s, w.ks_digits, (long)N, target, (long)N);
+    DC_LAUNCH(copy_limbs_kernel, dim3(gx, ell), dim3(kOpThreads), 0, s, w.ks_digits, (long)N, target, (long)N);
     launch_ntt(c, true, w.ks_digits, (long)N, ell, nullptr, 0, 0, s);
     // (2) lift every digit to every other modulus, forward NTT there
-    hipLaunchKernelGGL(ks_lift_kernel, dim3(gx, ell, ell), dim3(kOpThreads), 0, s, w.ks_ext, w.ks_digits, ell, sp, N,
+    DC_LAUNCH(ks_lift_kernel, dim3(gx, ell, ell), dim3(kOpThreads), 0, s, w.ks_ext, w.ks_digits, ell, sp, N,
                        c.d_mods);
     launch_ntt(c, false, w.ks_ext, (long)N, ell * ell, c.ks_prime_idx(ell), 0, 0, s);
     // (3) inner products with the key
-    hipLaunchKernelGGL(ks_mac_kernel, dim3(gx, ell + 1), dim3(kOpThreads), 0, s, w.ks_acc, w.ks_ext, target, key, ell, K, N,
+    DC_LAUNCH(ks_mac_kernel, dim3(gx, ell + 1), dim3(kOpThreads), 0, s, w.ks_acc, w.ks_ext, target, key, ell, K, N,
                        c.d_mods);
     // (4) mod-down by the special prime
     u64 *acc_last = w.ks_acc + (size_t)ell * N;
     const long acc_ps = (long)(ell + 1) * (long)N;
     launch_ntt(c, true, acc_last, acc_ps, 2, nullptr, sp, 1, s);
-    hipLaunchKernelGGL(dr_lift_kernel, dim3(gx, ell, 2), dim3(kOpThreads), 0, s, w.ks_tmp, (long)ell * (long)N, acc_last,
+    DC_LAUNCH(dr_lift_kernel, dim3(gx, ell, 2), dim3(kOpThreads), 0, s, w.ks_tmp, (long)ell * (long)N, acc_last,
                        acc_ps, sp, K, N, c.d_mods, c.d_half_mod);
     launch_ntt(c, false, w.ks_tmp, (long)N, 2 * ell, nullptr, 0, ell, s);
-    hipLaunchKernelGGL(dr_final_kernel, dim3(gx, ell, 2), dim3(kOpThreads), 0, s, out, w.ks_acc, acc_ps, w.ks_tmp,
+    DC_LAUNCH(dr_final_kernel, dim3(gx, ell, 2), dim3(kOpThreads), 0, s, out, w.ks_acc, acc_ps, w.ks_tmp,
                        (long)ell * (long)N, base0, base1, sp, K, N, c.d_mods, c.d_inv_last);
 }
 
@@ -167,14 +167,14 @@ void rescale(Context &c, const Workspace &w, CtView dst, CtView src, int ell, hi
     const int l = ell - 1;
     const unsigned gx = (unsigned)(N / (2 * kOpThreads));
     u64 *last = w.ks_digits; // [2][N]
-    hipLaunchKernelGGL(copy_limbs_kernel, dim3(gx, 2), dim3(kOpThreads), 0, s, last, (long)N, src.limb(0, l, N),
+    DC_LAUNCH(copy_limbs_kernel, dim3(gx, 2), dim3(kOpThreads), 0, s, last, (long)N, src.limb(0, l, N),
                        src.poly_stride);
     launch_ntt(c, true, last, (long)N, 2, nullptr, l, 1, s);
     if (l == 0) return;
-    hipLaunchKernelGGL(dr_lift_kernel, dim3(gx, l, 2), dim3(kOpThreads), 0, s, w.ks_tmp, (long)l * (long)N, last, (long)N, l,
+    DC_LAUNCH(dr_lift_kernel, dim3(gx, l, 2), dim3(kOpThreads), 0, s, w.ks_tmp, (long)l * (long)N, last, (long)N, l,
                        c.K, N, c.d_mods, c.d_half_mod);
     launch_ntt(c, false, w.ks_tmp, (long)N, 2 * l, nullptr, 0, l, s);
-    hipLaunchKernelGGL(dr_final_kernel, dim3(gx, l, 2), dim3(kOpThreads), 0, s, dst, src.p, src.poly_stride, w.ks_tmp,
+    DC_LAUNCH(dr_final_kernel, dim3(gx, l, 2), dim3(kOpThreads), 0, s, dst, src.p, src.poly_stride, w.ks_tmp,
                        (long)l * (long)N, (const u64 *)nullptr, (const u64 *)nullptr, l, c.K, N, c.d_mods, c.d_inv_last);
 }
 

@@ -147,6 +147,18 @@ Context::Context(int logN_, int K_, int bits, const u64 *primes_or_null, int ksp
         DC_HIP_CHECK(hipMemcpy(d_tw2, pr.data(), pr.size() * 8, hipMemcpyHostToDevice));
     }
 
+    if (!DC_GENERIC_WIDTH) {
+        const size_t n1 = (size_t)1 << k1;
+        std::vector<u64> pr((size_t)K * n1 * 2);
+        for (int i = 0; i < K; i++)
+            for (size_t k = 0; k < n1; k++) {
+                const u64 w = tw[(size_t)i * N + k];
+                pr[2 * ((size_t)i * n1 + k)] = w, pr[2 * ((size_t)i * n1 + k) + 1] = h_mulmod(w, 1ull << 31, primes[(size_t)i]);
+            }
+        DC_HIP_CHECK(hipMalloc(&d_twc2, pr.size() * 8));
+        DC_HIP_CHECK(hipMemcpy(d_twc2, pr.data(), pr.size() * 8, hipMemcpyHostToDevice));
+    }
+
     // divide-and-round constants for every (dropped prime l, remaining prime i) pair
     std::vector<u64> inv_last((size_t)K * K, 0), half_mod((size_t)K * K, 0);
     for (int l = 0; l < K; l++)
@@ -340,7 +352,7 @@ void Context::ensure_scratch()
 
 Context::~Context()
 {
-    for (void *p : { (void *)d_mods, (void *)d_tw, (void *)d_itw, (void *)d_tw2, (void *)d_inv_last, (void *)d_half_mod, (void *)d_ks_pidx, (void *)d_pmod,
+    for (void *p : { (void *)d_mods, (void *)d_tw, (void *)d_itw, (void *)d_tw2, (void *)d_twc2, (void *)d_inv_last, (void *)d_half_mod, (void *)d_ks_pidx, (void *)d_pmod,
                      (void *)d_hyb_up, (void *)d_hyb_pidx, (void *)d_hyb_dn, (void *)d_hyb_bup, (void *)d_hyb_bdn, (void *)d_hyb_upmods, (void *)d_hyb_dnmods,
                      (void *)d_hyb_hp })
         if (p) (void)hipFree(p);

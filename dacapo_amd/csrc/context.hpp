@@ -24,6 +24,16 @@ namespace dacapo {
         }                                                                                                      \
     } while (0)
 
+// Every kernel launch of the library goes through this: hipLaunchKernelGGL + a check of the launch itself (a grid or block the device
+// refuses, too much LDS or too many registers for the block size, an invalid function) at the launch site, not at some later synchronise.
+// hipGetLastError is a host-side read of the thread's last error: free outside a capture, and inside a stream capture it still reports
+// what the record-time validation of the launch found.
+#define DC_LAUNCH(...)                                                                                          \
+    do {                                                                                                       \
+        hipLaunchKernelGGL(__VA_ARGS__);                                                                       \
+        DC_HIP_CHECK(hipGetLastError());                                                                       \
+    } while (0)
+
 typedef unsigned __int128 u128;
 
 // ---- host number theory (setup only; every polynomial operation runs on the GPU) -----------------------
@@ -107,6 +117,11 @@ struct Context {
     // N = 2^15, 60-bit build: the forward table as pairs (w, w 2^31 mod q), 16 bytes per entry, for the single-crossing kernel's twiddle-pair
     // multiply (ntt_full.hip, modarith.hpp mulmod_pair); nullptr otherwise
     u64 *d_tw2 = nullptr;
+    // 60-bit build, every ring: the first 2^k1 entries of each prime's forward table as pairs, [K][2^k1][2] -- all the twiddles a forward COLS
+    // phase uses (they depend on the row group only), for ntt_tile.hpp's pair butterflies; nullptr in the generic-width build.
+    // option cols_pairs = 0 makes twc2() return nullptr: the tiles then run on words (A/B measurements, and a second implementation for the tests)
+    u64 *d_twc2 = nullptr;
+    const u64 *twc2() const { return option(OPT_COLS_PAIRS) ? d_twc2 : nullptr; }
     Workspace ws0;                     // default workspace (kernel-level C ABI, set-up work)
     std::vector<Workspace> workspaces; // everything ever handed out, for the destructor
     u64 *d_inv_last = nullptr;  // [K][K] : inv_last[l*K + i] = q_l^{-1} mod q_i (i != l)

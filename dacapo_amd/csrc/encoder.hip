@@ -108,20 +108,20 @@ void dec_fft(const Context &c, const EncTables &tb, double2 *v, double *out, hip
 {
     const size_t N = c.N;
     for (int lg = c.logN - 1; lg >= 0; lg--) // m = 1, 2, ..., N/2  <=>  gap = N/2, ..., 1
-        hipLaunchKernelGGL(dec_stage_kernel, dim3((unsigned)(N / 2 / kEncThreads)), dim3(kEncThreads), 0, s, v, tb.roots, N, (unsigned)lg);
-    hipLaunchKernelGGL(dec_gather_kernel, dim3((unsigned)(N / 2 / kEncThreads)), dim3(kEncThreads), 0, s, out, v, tb.slot_map);
+        DC_LAUNCH(dec_stage_kernel, dim3((unsigned)(N / 2 / kEncThreads)), dim3(kEncThreads), 0, s, v, tb.roots, N, (unsigned)lg);
+    DC_LAUNCH(dec_gather_kernel, dim3((unsigned)(N / 2 / kEncThreads)), dim3(kEncThreads), 0, s, out, v, tb.slot_map);
 }
 
 void enc_batch(const Context &c, const EncTables &tb, const double *d_consts, const EncItem *d_items, int P, int level, double2 *scratch,
                u64 *out, int *d_overflow, hipStream_t s)
 {
     const size_t N = c.N;
-    hipLaunchKernelGGL(enc_scatter_kernel, dim3((unsigned)(N / 2 / kEncThreads), (unsigned)P), dim3(kEncThreads), 0, s, scratch, d_consts, d_items,
+    DC_LAUNCH(enc_scatter_kernel, dim3((unsigned)(N / 2 / kEncThreads), (unsigned)P), dim3(kEncThreads), 0, s, scratch, d_consts, d_items,
                        tb.slot_map, N);
     for (int lg = 0; lg < c.logN; lg++) // gap = 1, 2, ..., N/2  <=>  m = N/2, ..., 1
-        hipLaunchKernelGGL(enc_stage_kernel, dim3((unsigned)(N / 2 / kEncThreads), (unsigned)P), dim3(kEncThreads), 0, s, scratch, tb.roots, d_items,
+        DC_LAUNCH(enc_stage_kernel, dim3((unsigned)(N / 2 / kEncThreads), (unsigned)P), dim3(kEncThreads), 0, s, scratch, tb.roots, d_items,
                            N, (unsigned)lg, lg == c.logN - 1 ? 1 : 0);
-    hipLaunchKernelGGL(enc_round_lift_kernel, dim3((unsigned)(N / kEncThreads), (unsigned)P), dim3(kEncThreads), 0, s, out, scratch, level, N,
+    DC_LAUNCH(enc_round_lift_kernel, dim3((unsigned)(N / kEncThreads), (unsigned)P), dim3(kEncThreads), 0, s, out, scratch, level, N,
                        c.d_mods, d_overflow);
     launch_ntt(c, false, out, (long)N, P * level, nullptr, 0, level, s);
 }

@@ -211,7 +211,7 @@ template <int K, int LOGE, bool MERGE>
 __global__ __launch_bounds__(kTileThreads) void f_ks_icols_lift_fcols_kernel(const u64 *__restrict__ digits, u64 *__restrict__ ext,
                                                                               int ell, int sp, const DModulus *__restrict__ mods,
                                                                               const u64 *__restrict__ tw, const u64 *__restrict__ itw,
-                                                                              int logN)
+                                                                              int logN, const u64 *__restrict__ tw2)
 {
     __shared__ __attribute__((aligned(16))) u64 lds[TileGeo<LOGE>::LDS_ELEMS];
     const int z = blockIdx.y, dj = MERGE ? z : z / ell, j = dj % ell;
@@ -230,8 +230,8 @@ __global__ __launch_bounds__(kTileThreads) void f_ks_icols_lift_fcols_kernel(con
 #pragma unroll
         for (int r = 0; r < (1 << LOGE); r++) y[r] = recanon(x[r], Mm); // one conditional subtraction within a width class (modarith.hpp)
         __syncthreads(); // the previous tile's last LDS image has been read by everyone
-        ntt_tile_x<K, LOGE, true, false, false, true, false>(
-            y, Mm, tw + ((size_t)pm << logN), logN, blockIdx.x, nold, [=](int g, u64 v) { out[g] = v; }, lds);
+        ntt_tile_fcols<K, LOGE, false, true, false>(
+            y, Mm, tw + ((size_t)pm << logN), tw2 ? tw2 + ((size_t)pm << (K + 1)) : nullptr, logN, blockIdx.x, nold, [=](int g, u64 v) { out[g] = v; }, lds);
     }
 }
 
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(kTileThreads) void f_dr_icols_lift_fcols_kernel(con
                                                                               const DModulus *__restrict__ mods,
                                                                               const u64 *__restrict__ half_mod,
                                                                               const u64 *__restrict__ tw, const u64 *__restrict__ itw,
-                                                                              int logN)
+                                                                              int logN, const u64 *__restrict__ tw2)
 {
     __shared__ __attribute__((aligned(16))) u64 lds[TileGeo<LOGE>::LDS_ELEMS];
     const int z = blockIdx.y, bp = MERGE ? z : z / cnt;
@@ -271,8 +271,8 @@ __global__ __launch_bounds__(kTileThreads) void f_dr_icols_lift_fcols_kernel(con
             y[r] = v >= qi ? v - qi : v;
         }
         __syncthreads();
-        ntt_tile_x<K, LOGE, true, false, false, true, false>(
-            y, Mi, tw + ((size_t)i << logN), logN, blockIdx.x, nold, [=](int g, u64 v) { out[g] = v; }, lds);
+        ntt_tile_fcols<K, LOGE, false, true, false>(
+            y, Mi, tw + ((size_t)i << logN), tw2 ? tw2 + ((size_t)i << (K + 1)) : nullptr, logN, blockIdx.x, nold, [=](int g, u64 v) { out[g] = v; }, lds);
     }
 }
 
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(kTileThreads) void f_dr_icols_lift_fcols_kernel(con
 template <int K, int LOGE>
 __global__ __launch_bounds__(kTileThreads) void f_ks_lift_fcols_kernel(const u64 *__restrict__ digits, u64 *__restrict__ ext, int ell,
                                                                         int sp, const DModulus *__restrict__ mods,
-                                                                        const u64 *__restrict__ tw, int logN)
+                                                                        const u64 *__restrict__ tw, int logN, const u64 *__restrict__ tw2)
 {
     __shared__ __attribute__((aligned(16))) u64 lds[TileGeo<LOGE>::LDS_ELEMS];
     const int z = blockIdx.y, e = z % ell, dj = z / ell, j = dj % ell;
@@ -291,8 +291,9 @@ __global__ __launch_bounds__(kTileThreads) void f_ks_lift_fcols_kernel(const u64
     u64 *out = ext + (size_t)z * N;
     const int pm = ks_other_prime(j, e, ell, sp);
     const DModulus Mm = mods[pm];
-    ntt_tile<K, LOGE, true, false, false>(
-        Mm, tw + ((size_t)pm << logN), logN, blockIdx.x,
+    u64 x[1 << LOGE];
+    ntt_tile_fcols<K, LOGE, false, false, false>(
+        x, Mm, tw + ((size_t)pm << logN), tw2 ? tw2 + ((size_t)pm << (K + 1)) : nullptr, logN, blockIdx.x,
         [=](int g) {
             return recanon(in[g], Mm);
         },
@@ -304,7 +305,7 @@ __global__ __launch_bounds__(kTileThreads) void f_dr_lift_fcols_kernel(const u64
                                                                         u64 *__restrict__ tmp, int cnt, int l, int Kp,
                                                                         const DModulus *__restrict__ mods,
                                                                         const u64 *__restrict__ half_mod, const u64 *__restrict__ tw,
-                                                                        int logN)
+                                                                        int logN, const u64 *__restrict__ tw2)
 {
     __shared__ __attribute__((aligned(16))) u64 lds[TileGeo<LOGE>::LDS_ELEMS];
     const int z = blockIdx.y, i = z % cnt, bp = z / cnt;
@@ -314,8 +315,9 @@ __global__ __launch_bounds__(kTileThreads) void f_dr_lift_fcols_kernel(const u64
     const DModulus Mi = mods[i];
     const u64 ql = mods[l].q, qi = Mi.q, half = ql >> 1;
     const u64 neg_half = qi - half_mod[(size_t)l * Kp + i];
-    ntt_tile<K, LOGE, true, false, false>(
-        Mi, tw + ((size_t)i << logN), logN, blockIdx.x,
+    u64 x[1 << LOGE];
+    ntt_tile_fcols<K, LOGE, false, false, false>(
+        x, Mi, tw + ((size_t)i << logN), tw2 ? tw2 + ((size_t)i << (K + 1)) : nullptr, logN, blockIdx.x,
         [=](int g) {
             u64 y = in[g] + half;
             y = y >= ql ? y - ql : y;
@@ -580,11 +582,16 @@ __global__ __launch_bounds__(kTileThreads) void f_ks_frows_mac_kernel(const u64 
                                                                        const u64 *__restrict__ shared_key, u64 *__restrict__ acc, int ell,
                                                                        int Kp, const DModulus *__restrict__ mods,
                                                                        const u64 *__restrict__ tw, const u64 *__restrict__ itw, int logN,
-                                                                       const u64 *__restrict__ pmod)
+                                                                       const u64 *__restrict__ pmod, int items_fast)
 {
     __shared__ __attribute__((aligned(16))) u64 lds[TileGeo<LOGE>::LDS_ELEMS];
     constexpr int E = 1 << LOGE, NP = num_passes<LOGE>(K);
-    const int y = blockIdx.y, b = blockIdx.z, sp = Kp - 1;
+    // items_fast: grid = (tiles, B, rows) instead of (tiles, rows, B).  The workgroups (tile, row) of consecutive items are then 2^k tiles apart
+    // in launch order -- the same XCD (workgroup w runs on XCD w mod 8), dispatched together -- and items that use the same key (the plan
+    // sorts a rotation step's items by Galois element; a relinearisation step has one key) read each key tile out of that XCD's L2 after
+    // the first of them fetched it.  SEAL's default key set has 28 elements, so a 64-item step of a convolution names each key several times:
+    // with the rows slower than the items, two readers of a key tile were a whole item (~150 MB of traffic at 13 primes) apart.
+    const int y = items_fast ? blockIdx.z : blockIdx.y, b = items_fast ? blockIdx.y : blockIdx.z, sp = Kp - 1;
     // psel < 0: both accumulators.  MERGE (grid.y = l + 1, throughput-bound launches): ONE workgroup row does the special prime for both
     // accumulators -- the l transforms of the lifted digits once instead of twice, then the two inverse ROWS phases one after the other
     // (its own instantiation: both accumulators live through the epilogue cost 16-20 VGPRs, a wave per SIMD)
@@ -644,6 +651,9 @@ __global__ __launch_bounds__(kTileThreads) void f_ks_frows_mac_kernel(const u64 
             for (int e = 0; e < E; e++) x[e] = src[base + e * stride];
         }
     };
+    // (round 5, measured and not kept: TWO digits ahead -- digit j + 2's coefficients and digit j + 1's key limbs requested before digit j's
+    // transform, +24 VGPRs -- does nothing for a 13-prime hop (84.9 against 84.6-86.1 us) and costs config 3 a workgroup per CU: its 1 664
+    // workgroups at 178 VGPRs run 2 to a CU instead of 3, 459 against 430-443 us; profiles/r05_experiments.txt)
     u64 xn[E];
     if (PF) fetch_x(0, xn);
     for (int j = 0; j < ell; j++) {
@@ -781,7 +791,7 @@ __global__ __launch_bounds__(kTileThreads) void f_frows_boot_final_kernel(const 
 template <class Src>
 static void launch_irows(const Context &c, Src src, u64 *out, long out_stride, int count, hipStream_t s)
 {
-    DC_GEO_SWITCH(c.k2, count, hipLaunchKernelGGL((f_irows_kernel<KK, LE, Src>), grid, dim3(kTileThreads), 0, s, src, out, out_stride,
+    DC_GEO_SWITCH(c.k2, count, DC_LAUNCH((f_irows_kernel<KK, LE, Src>), grid, dim3(kTileThreads), 0, s, src, out, out_stride,
                                                   c.d_mods, c.d_itw, c.logN));
 }
 
@@ -812,12 +822,12 @@ __global__ __launch_bounds__(kTileThreads) void f_irows_rot_kernel(const KsItem 
 
 void f_irows_rot_c1(const Context &c, const KsItem *items, int ell, u64 *out, int B, hipStream_t s)
 {
-    DC_GEO_SWITCH(c.k2, B * ell, hipLaunchKernelGGL((f_irows_rot_kernel<KK, LE>), grid, dim3(kTileThreads), 0, s, items, ell, out, c.d_mods, c.d_itw,
+    DC_GEO_SWITCH(c.k2, B * ell, DC_LAUNCH((f_irows_rot_kernel<KK, LE>), grid, dim3(kTileThreads), 0, s, items, ell, out, c.d_mods, c.d_itw,
                                                     c.logN));
 }
 void f_irows_rs_last(const Context &c, const RsItem *items, const SumSrc *srcs, int l, u64 *out, int B, hipStream_t s)
 {
-    DC_GEO_SWITCH(c.k2, 2 * B, hipLaunchKernelGGL((f_irows_rs_kernel<KK, LE>), grid, dim3(kTileThreads), 0, s, items, srcs, l, out, c.d_mods,
+    DC_GEO_SWITCH(c.k2, 2 * B, DC_LAUNCH((f_irows_rs_kernel<KK, LE>), grid, dim3(kTileThreads), 0, s, items, srcs, l, out, c.d_mods,
                                                   c.d_itw, c.logN));
 }
 void f_irows_rs_single(const Context &c, CtView src, int l, u64 *out, hipStream_t s)
@@ -836,14 +846,14 @@ void f_irows_tensor_c2(const Context &c, const MulItem *items, int ell, u64 *out
 void f_irows_decrypt_items(const Context &c, const BootItem *items, const SumSrc *srcs, const u64 *sk, int ell, u64 *out, int B,
                            hipStream_t s)
 {
-    DC_GEO_SWITCH(c.k2, B * ell, hipLaunchKernelGGL((f_irows_boot_kernel<KK, LE>), grid, dim3(kTileThreads), 0, s, items, srcs, sk, ell, out,
+    DC_GEO_SWITCH(c.k2, B * ell, DC_LAUNCH((f_irows_boot_kernel<KK, LE>), grid, dim3(kTileThreads), 0, s, items, srcs, sk, ell, out,
                                                     c.d_mods, c.d_itw, c.logN));
 }
 void f_boot_reencode_fcols(const Context &c, const u64 *pt, u64 *ptx, const BootItem *items, int B, int ell, int t, CrtDev crt,
                            hipStream_t s)
 {
     if (ell == 1) {
-        DC_GEO_SWITCH(c.k1, B * t, hipLaunchKernelGGL((f_boot_reencode_fcols_kernel<KK, LE, 1>), grid, dim3(kTileThreads), 0, s, pt, ptx, items,
+        DC_GEO_SWITCH(c.k1, B * t, DC_LAUNCH((f_boot_reencode_fcols_kernel<KK, LE, 1>), grid, dim3(kTileThreads), 0, s, pt, ptx, items,
                                                       t, c.d_mods, crt, c.d_tw, c.logN));
     } else {
         fprintf(stderr, "[dacapo_amd] f_boot_reencode_fcols: source level %d not instantiated\n", ell);
@@ -852,7 +862,7 @@ void f_boot_reencode_fcols(const Context &c, const u64 *pt, u64 *ptx, const Boot
 }
 void f_frows_boot_final(const Context &c, const u64 *ptx, const BootItem *items, int B, int t, hipStream_t s)
 {
-    DC_GEO_SWITCH(c.k2, B * t, hipLaunchKernelGGL((f_frows_boot_final_kernel<KK, LE>), grid, dim3(kTileThreads), 0, s, ptx, items, t,
+    DC_GEO_SWITCH(c.k2, B * t, DC_LAUNCH((f_frows_boot_final_kernel<KK, LE>), grid, dim3(kTileThreads), 0, s, ptx, items, t,
                                                   c.d_mods, c.d_tw, c.logN));
 }
 
@@ -871,13 +881,14 @@ void f_ks_frows_mac(const Context &c, int mode, const u64 *ext, const u64 *targe
         constexpr int LE = LEV;                                                                                                           \
         const long wgs = (long)(c.N >> TileGeo<LE>::LOG) * (ell + 2) * B;                                                                \
         const int merge = wgs >= ks_merge_special_min_wgs() ? 1 : 0;                                                                      \
-        const dim3 grid((unsigned)(c.N >> TileGeo<LE>::LOG), (unsigned)(ell + 2 - merge), (unsigned)B);                                  \
+        const int items_fast = (B > 1 && B <= 65535 && option(OPT_KS_ITEMS_FAST)) ? 1 : 0;                                               \
+        const dim3 grid((unsigned)(c.N >> TileGeo<LE>::LOG), (unsigned)(items_fast ? B : ell + 2 - merge), (unsigned)(items_fast ? ell + 2 - merge : B)); \
         if (merge) {                                                                                                                      \
-            DC_K_SWITCH(c.k2, hipLaunchKernelGGL((f_ks_frows_mac_kernel<KK, LE, MD, true>), grid, dim3(kTileThreads), 0, s, ext, target, items,   \
-                                                 shared_key, acc, ell, c.K, c.d_mods, c.d_tw, c.d_itw, c.logN, pmod));                   \
+            DC_K_SWITCH(c.k2, DC_LAUNCH((f_ks_frows_mac_kernel<KK, LE, MD, true>), grid, dim3(kTileThreads), 0, s, ext, target, items,   \
+                                                 shared_key, acc, ell, c.K, c.d_mods, c.d_tw, c.d_itw, c.logN, pmod, items_fast));       \
         } else {                                                                                                                          \
-            DC_K_SWITCH(c.k2, hipLaunchKernelGGL((f_ks_frows_mac_kernel<KK, LE, MD, false>), grid, dim3(kTileThreads), 0, s, ext, target, items,  \
-                                                 shared_key, acc, ell, c.K, c.d_mods, c.d_tw, c.d_itw, c.logN, pmod));                   \
+            DC_K_SWITCH(c.k2, DC_LAUNCH((f_ks_frows_mac_kernel<KK, LE, MD, false>), grid, dim3(kTileThreads), 0, s, ext, target, items,  \
+                                                 shared_key, acc, ell, c.K, c.d_mods, c.d_tw, c.d_itw, c.logN, pmod, items_fast));       \
         }                                                                                                                                 \
     }
     // (the radix-8 geometry was measured for this kernel too: 8 coefficients x two 128-bit accumulators per thread cost more in
@@ -903,44 +914,44 @@ static long ks_merge_lift_min_wgs()
         const int le = tiny ? 1 : small ? 2 : 3;                                                                                          \
         const bool merge = (per_source) > 1 && (long)(c.N >> (le == 1 ? TileGeo<1>::LOG : le == 2 ? TileGeo<2>::LOG : TileGeo<3>::LOG)) * (sources) >= ks_merge_lift_min_wgs(); \
         if (!merge) {                                                                                                                     \
-            DC_GEO_SWITCH(c.k1, (limbs), hipLaunchKernelGGL((KERNEL<KK, LE, false>), grid, dim3(kTileThreads), 0, s, __VA_ARGS__));      \
+            DC_GEO_SWITCH(c.k1, (limbs), DC_LAUNCH((KERNEL<KK, LE, false>), grid, dim3(kTileThreads), 0, s, __VA_ARGS__));      \
         } else if (le == 1) {                                                                                                             \
             constexpr int LE = 1;                                                                                                         \
             const dim3 grid((unsigned)(c.N >> TileGeo<LE>::LOG), (unsigned)(sources));                                                    \
-            DC_K_SWITCH(c.k1, hipLaunchKernelGGL((KERNEL<KK, LE, true>), grid, dim3(kTileThreads), 0, s, __VA_ARGS__))                    \
+            DC_K_SWITCH(c.k1, DC_LAUNCH((KERNEL<KK, LE, true>), grid, dim3(kTileThreads), 0, s, __VA_ARGS__))                    \
         } else if (le == 2) {                                                                                                             \
             constexpr int LE = 2;                                                                                                         \
             const dim3 grid((unsigned)(c.N >> TileGeo<LE>::LOG), (unsigned)(sources));                                                    \
-            DC_K_SWITCH(c.k1, hipLaunchKernelGGL((KERNEL<KK, LE, true>), grid, dim3(kTileThreads), 0, s, __VA_ARGS__))                    \
+            DC_K_SWITCH(c.k1, DC_LAUNCH((KERNEL<KK, LE, true>), grid, dim3(kTileThreads), 0, s, __VA_ARGS__))                    \
         } else {                                                                                                                          \
             constexpr int LE = 3;                                                                                                         \
             const dim3 grid((unsigned)(c.N >> TileGeo<LE>::LOG), (unsigned)(sources));                                                    \
-            DC_K_SWITCH(c.k1, hipLaunchKernelGGL((KERNEL<KK, LE, true>), grid, dim3(kTileThreads), 0, s, __VA_ARGS__))                    \
+            DC_K_SWITCH(c.k1, DC_LAUNCH((KERNEL<KK, LE, true>), grid, dim3(kTileThreads), 0, s, __VA_ARGS__))                    \
         }                                                                                                                                 \
     }
 
 void f_ks_icols_lift_fcols(const Context &c, const u64 *digits, u64 *ext, int B, int ell, hipStream_t s)
 {
-    DC_MERGED_LAUNCH(B * ell * ell, B * ell, ell, f_ks_icols_lift_fcols_kernel, digits, ext, ell, c.K - 1, c.d_mods, c.d_tw, c.d_itw, c.logN)
+    DC_MERGED_LAUNCH(B * ell * ell, B * ell, ell, f_ks_icols_lift_fcols_kernel, digits, ext, ell, c.K - 1, c.d_mods, c.d_tw, c.d_itw, c.logN, c.twc2())
 }
 
 void f_dr_icols_lift_fcols(const Context &c, const u64 *last, long last_stride, u64 *tmp, int polys, int cnt, int l, hipStream_t s)
 {
     DC_MERGED_LAUNCH(polys * cnt, polys, cnt, f_dr_icols_lift_fcols_kernel, last, last_stride, tmp, cnt, l, c.K, c.d_mods, c.d_half_mod, c.d_tw,
-                     c.d_itw, c.logN)
+                     c.d_itw, c.logN, c.twc2())
 }
 #undef DC_MERGED_LAUNCH
 
 void f_ks_lift_fcols(const Context &c, const u64 *digits, u64 *ext, int B, int ell, hipStream_t s)
 {
-    DC_GEO_SWITCH(c.k1, B * ell * ell, hipLaunchKernelGGL((f_ks_lift_fcols_kernel<KK, LE>), grid, dim3(kTileThreads), 0, s, digits, ext, ell,
-                                                          c.K - 1, c.d_mods, c.d_tw, c.logN));
+    DC_GEO_SWITCH(c.k1, B * ell * ell, DC_LAUNCH((f_ks_lift_fcols_kernel<KK, LE>), grid, dim3(kTileThreads), 0, s, digits, ext, ell,
+                                                          c.K - 1, c.d_mods, c.d_tw, c.logN, c.twc2()));
 }
 
 void f_dr_lift_fcols(const Context &c, const u64 *last, long last_stride, u64 *tmp, int polys, int cnt, int l, hipStream_t s)
 {
-    DC_GEO_SWITCH(c.k1, polys * cnt, hipLaunchKernelGGL((f_dr_lift_fcols_kernel<KK, LE>), grid, dim3(kTileThreads), 0, s, last, last_stride,
-                                                        tmp, cnt, l, c.K, c.d_mods, c.d_half_mod, c.d_tw, c.logN));
+    DC_GEO_SWITCH(c.k1, polys * cnt, DC_LAUNCH((f_dr_lift_fcols_kernel<KK, LE>), grid, dim3(kTileThreads), 0, s, last, last_stride,
+                                                        tmp, cnt, l, c.K, c.d_mods, c.d_half_mod, c.d_tw, c.logN, c.twc2()));
 }
 
 void f_frows_final(const Context &c, int mode, const u64 *tmp, const void *items, const u64 *acc, int polys, int cnt, int l,
@@ -950,7 +961,7 @@ void f_frows_final(const Context &c, int mode, const u64 *tmp, const void *items
     if (h.cont != CONT_NONE) {
         const int groups = h.cont == CONT_BOOT ? polys / 2 : polys; // CONT_BOOT: one workgroup per (item, limb) does both polynomials
 #define DC_CONT(MD, CT)                                                                                                                \
-    DC_GEO_SWITCH(c.k2, groups * cnt, hipLaunchKernelGGL((f_frows_final_cont_kernel<KK, LE, MD, CT>), grid, dim3(kTileThreads), 0, s, tmp, items, \
+    DC_GEO_SWITCH(c.k2, groups * cnt, DC_LAUNCH((f_frows_final_cont_kernel<KK, LE, MD, CT>), grid, dim3(kTileThreads), 0, s, tmp, items, \
                                                          srcs, acc, cnt, l, c.K, c.d_mods, c.d_inv_last, c.d_tw, c.d_itw, c.logN, h, folded))
         if (mode == 4 && h.cont == CONT_RS) {
             DC_CONT(4, CONT_RS);
@@ -968,7 +979,7 @@ void f_frows_final(const Context &c, int mode, const u64 *tmp, const void *items
         return;
     }
 #define DC_FINAL(MD)                                                                                                                   \
-    DC_GEO_SWITCH(c.k2, polys * cnt, hipLaunchKernelGGL((f_frows_final_kernel<KK, LE, MD>), grid, dim3(kTileThreads), 0, s, tmp, items, single, \
+    DC_GEO_SWITCH(c.k2, polys * cnt, DC_LAUNCH((f_frows_final_kernel<KK, LE, MD>), grid, dim3(kTileThreads), 0, s, tmp, items, single, \
                                                         plain, srcs, acc, cnt, l, c.K, c.d_mods, c.d_inv_last, c.d_tw, c.logN, folded))
     switch (mode) {
     case 0: DC_FINAL(0); break;

@@ -506,11 +506,11 @@ void HEVM::gen_kswitch_key(u64 *key, const u64 *new_key, u64 key_id)
     for (int j = 0; j < c.key_digits(); j++) {
         u64 *c0 = key + (size_t)j * 2 * K * N, *c1 = c0 + (size_t)K * N;
         const u64 object = key_id * 64 + (u64)j; // one object per (key, digit)
-        hipLaunchKernelGGL(sample_uniform_kernel, gu, dim3(kVmThreads), 0, S(), c1, N, rng.pub, object, (u32)RNG_KSK_A, c.d_mods);
-        hipLaunchKernelGGL(sample_small_kernel, gs, dim3(kVmThreads), 0, S(), c0, N, K, 1, rng.secret, object, (u32)RNG_KSK_E, c.d_mods);
+        DC_LAUNCH(sample_uniform_kernel, gu, dim3(kVmThreads), 0, S(), c1, N, rng.pub, object, (u32)RNG_KSK_A, c.d_mods);
+        DC_LAUNCH(sample_small_kernel, gs, dim3(kVmThreads), 0, S(), c0, N, K, 1, rng.secret, object, (u32)RNG_KSK_E, c.d_mods);
         launch_ntt(c, false, c0, (long)N, K, nullptr, 0, 0, S());
         const int lo = c.hybrid() ? j * c.alpha : j, hi = c.hybrid() ? std::min(lo + c.alpha, L) : j + 1;
-        hipLaunchKernelGGL(ezs_final_kernel, g2, dim3(kVmThreads), 0, S(), c0, c1, keys.sk, new_key, lo, hi, c.d_pmod, N, c.d_mods);
+        DC_LAUNCH(ezs_final_kernel, g2, dim3(kVmThreads), 0, S(), c0, c1, keys.sk, new_key, lo, hi, c.d_pmod, N, c.d_mods);
     }
 }
 
@@ -561,15 +561,15 @@ void HEVM::generate_keys(const RngKeys &rng_, bool secret, bool pub, bool eval)
         DC_HIP_CHECK(hipMemcpyAsync(keys.sk, h.data(), h.size() * 8, hipMemcpyHostToDevice, S()));
         DC_HIP_CHECK(hipStreamSynchronize(S()));
     } else
-        hipLaunchKernelGGL(sample_small_kernel, gs, dim3(kVmThreads), 0, S(), keys.sk, N, K, 0, rng.secret, (u64)0, (u32)RNG_SK, c.d_mods);
+        DC_LAUNCH(sample_small_kernel, gs, dim3(kVmThreads), 0, S(), keys.sk, N, K, 0, rng.secret, (u64)0, (u32)RNG_SK, c.d_mods);
     launch_ntt(c, false, keys.sk, (long)N, K, nullptr, 0, 0, S());
     if (pub) {
         keys.pk = dalloc((size_t)2 * K * N);
         u64 *c0 = keys.pk, *c1 = keys.pk + (size_t)K * N;
-        hipLaunchKernelGGL(sample_uniform_kernel, gu, dim3(kVmThreads), 0, S(), c1, N, rng.pub, (u64)0, (u32)RNG_PK_A, c.d_mods);
-        hipLaunchKernelGGL(sample_small_kernel, gs, dim3(kVmThreads), 0, S(), c0, N, K, 1, rng.secret, (u64)0, (u32)RNG_PK_E, c.d_mods);
+        DC_LAUNCH(sample_uniform_kernel, gu, dim3(kVmThreads), 0, S(), c1, N, rng.pub, (u64)0, (u32)RNG_PK_A, c.d_mods);
+        DC_LAUNCH(sample_small_kernel, gs, dim3(kVmThreads), 0, S(), c0, N, K, 1, rng.secret, (u64)0, (u32)RNG_PK_E, c.d_mods);
         launch_ntt(c, false, c0, (long)N, K, nullptr, 0, 0, S());
-        hipLaunchKernelGGL(ezs_final_kernel, g2, dim3(kVmThreads), 0, S(), c0, c1, keys.sk, (const u64 *)nullptr, -1, -1, (const u64 *)nullptr, N,
+        DC_LAUNCH(ezs_final_kernel, g2, dim3(kVmThreads), 0, S(), c0, c1, keys.sk, (const u64 *)nullptr, -1, -1, (const u64 *)nullptr, N,
                            c.d_mods);
     }
     if (eval) {
@@ -757,15 +757,18 @@ void HEVM::load_keys(const std::string &dir, bool need_secret, bool need_public,
         int dir_ksp = 0, dir_alpha = 0;
         if (FILE *f = fopen(join(dir, "hybrid.txt").c_str(), "r")) {
             if (fscanf(f, "ks_special=%d ks_alpha=%d", &dir_ksp, &dir_alpha) != 2 || dir_ksp < 1 || dir_alpha < 1 || dir_alpha > dir_ksp) {
-                fprintf(stderr, "[dacapo_amd] %s/hybrid.txt is malformed\n", dir.c_str());
+                fclose(f);
+                fprintf(stderr, "[dacapo_amd] %s/hybrid.txt is malformed (expected \"ks_special=<k> ks_alpha=<a>\" with 1 <= a <= k)\n", dir.c_str());
                 abort();
             }
             fclose(f);
         }
         init_context(logN, (int)p.primes.size(), p.primes.data(), dir_ksp, dir_alpha);
         if (ctx->hybrid() && dir_ksp == 0) {
-            fprintf(stderr, "[dacapo_amd] options ask for grouped-digit key switching (ks_special = %d, ks_alpha = %d) but %s holds SEAL-format keys "
-                            "(no hybrid.txt)\n", ctx->ksp, ctx->alpha, dir.c_str());
+            fprintf(stderr, "[dacapo_amd] options ask for grouped-digit key switching (ks_special = %d, ks_alpha = %d) but %s has no hybrid.txt: it holds "
+                            "SEAL-format keys, or grouped-digit keys written before the sidecar existed (round 3).  For the latter, regenerate the "
+                            "keys (create_context) or write \"ks_special=%d ks_alpha=%d\" into %s/hybrid.txt by hand\n",
+                    ctx->ksp, ctx->alpha, dir.c_str(), ctx->ksp, ctx->alpha, dir.c_str());
             abort();
         }
     }
@@ -849,98 +852,29 @@ void HEVM::load_ctxt(size_t r, const std::string &path)
 // ---------------------------------------------------------------------------------------------------------
 void HEVM::load_constants(const void *data, size_t len)
 {
-    const char *p = (const char *)data, *end = p + len;
-    auto need = [&](size_t n) {
-        if ((size_t)(end - p) < n) {
-            fprintf(stderr, "[dacapo_amd] truncated .cst file\n");
-            abort();
-        }
-    };
-    need(8);
-    int64_t count;
-    memcpy(&count, p, 8), p += 8;
-    if (count < 0 || (uint64_t)count > (uint64_t)(end - p) / 8) { // every vector needs at least its 8-byte length
-        fprintf(stderr, "[dacapo_amd] .cst file: implausible constant count %lld\n", (long long)count);
+    std::string err;
+    if (!wire::parse_constants(data, len, buffer, err)) { // (wire_parse.cpp: every count held against the bytes that are there)
+        fprintf(stderr, "[dacapo_amd] %s\n", err.c_str());
         abort();
-    }
-    buffer.assign((size_t)count, {});
-    for (int64_t i = 0; i < count; i++) {
-        need(8);
-        int64_t veclen;
-        memcpy(&veclen, p, 8), p += 8;
-        if (veclen < 0 || (uint64_t)veclen > (uint64_t)(end - p) / 8) {
-            fprintf(stderr, "[dacapo_amd] truncated .cst file (constant %lld claims %lld values)\n", (long long)i, (long long)veclen);
-            abort();
-        }
-        buffer[i].resize((size_t)veclen);
-        memcpy(buffer[i].data(), p, (size_t)veclen * 8), p += veclen * 8;
     }
 }
 
 void HEVM::load_program(const void *data, size_t len, bool header_only)
 {
-    const char *p = (const char *)data, *end = p + len;
-    auto take = [&](void *dst, size_t n) {
-        if ((size_t)(end - p) < n) {
-            fprintf(stderr, "[dacapo_amd] truncated .hevm file\n");
-            abort();
-        }
-        memcpy(dst, p, n), p += n;
-    };
-    take(&header, sizeof(header));
-    take(&config, sizeof(config));
-    if (header.magic_number != 0x4845564D) {
-        fprintf(stderr, "[dacapo_amd] bad .hevm magic 0x%x\n", header.magic_number);
+    wire::Program pr;
+    std::string err;
+    if (!wire::parse_program(data, len, header_only, buffer, pr, err)) { // (wire_parse.cpp: bounds and operand validation before anything is allocated)
+        fprintf(stderr, "[dacapo_amd] %s\n", err.c_str());
         abort();
     }
-    const size_t na = header.arg_length, nr = header.res_length;
-    if (na > (size_t)(end - p) / 16 || nr > (size_t)(end - p) / 24 || config.num_operations > (size_t)(end - p) / sizeof(WireOp) ||
-        config.num_ctxt_buffer > 65536 || config.num_ptxt_buffer > 65536) { // operands are 16-bit register numbers
-        fprintf(stderr, "[dacapo_amd] .hevm header claims more arguments / results / operations / registers than the file can hold\n");
-        abort();
-    }
-    arg_scale.resize(na), arg_level.resize(na), res_scale.resize(nr), res_level.resize(nr), res_dst.resize(nr);
-    take(arg_scale.data(), na * 8), take(arg_level.data(), na * 8);
-    take(res_scale.data(), nr * 8), take(res_level.data(), nr * 8), take(res_dst.data(), nr * 8);
-    size_t nct = na + nr;
+    header = pr.header, config = pr.config;
+    arg_scale = std::move(pr.arg_scale), arg_level = std::move(pr.arg_level);
+    res_scale = std::move(pr.res_scale), res_level = std::move(pr.res_level), res_dst = std::move(pr.res_dst);
+    const size_t nct = pr.cipher_registers;
     if (!header_only) {
-        ops.resize(config.num_operations);
-        take(ops.data(), ops.size() * sizeof(WireOp));
-        nct = std::max<size_t>(nct, config.num_ctxt_buffer);
+        ops = std::move(pr.ops);
         free_plains();
         plains.assign(config.num_ptxt_buffer, Plain{});
-        // Operand validation, once: the reference indexes its register vectors unchecked (SEAL_HEVM.cpp:268-334); here a program
-        // may name cipher registers beyond num_ctxt_buffer (the file grows with them) but never a plaintext register that does not exist.
-        for (const WireOp &op : ops) {
-            if (op.opcode > 10 && (op.opcode < kOpEncodeComplex || op.opcode > kOpSetScale)) continue;
-            if (op.opcode == kOpSetScale) { // its operand is a constant that must exist NOW (the run path indexes it unchecked), hold a value, and be a scale
-                if (op.rhs >= buffer.size() || buffer[op.rhs].empty() || !(buffer[op.rhs][0] > 0.0) || !std::isfinite(buffer[op.rhs][0])) {
-                    fprintf(stderr, "[dacapo_amd] .hevm: setscale needs constant %u of %zu to hold a finite positive scale (load the constants before the program)\n",
-                            (unsigned)op.rhs, buffer.size());
-                    abort();
-                }
-            }
-            if (op.opcode == 0 || op.opcode == kOpEncodeComplex) {
-                if (op.dst >= plains.size()) {
-                    fprintf(stderr, "[dacapo_amd] .hevm: encode into plaintext register %u of %zu\n", (unsigned)op.dst, plains.size());
-                    abort();
-                }
-                continue;
-            }
-            nct = std::max<size_t>(nct, (size_t)std::max(op.dst, op.lhs) + 1);
-            if (op.opcode == 6 || op.opcode == 8) nct = std::max<size_t>(nct, (size_t)op.rhs + 1);
-            if ((op.opcode == 7 || op.opcode == 9) && op.rhs >= plains.size()) {
-                fprintf(stderr, "[dacapo_amd] .hevm: opcode %u reads plaintext register %u of %zu\n", (unsigned)op.opcode, (unsigned)op.rhs, plains.size());
-                abort();
-            }
-        }
-        for (uint64_t r : res_dst) {
-            if (r >= 65536) {
-                fprintf(stderr, "[dacapo_amd] .hevm: result register %llu outside the 16-bit register space\n", (unsigned long long)r);
-                abort();
-            }
-            nct = std::max<size_t>(nct, (size_t)r + 1);
-        }
     }
     while (ciphers.size() < nct) ciphers.push_back(hevm_ctxt{ nullptr, 0, 0, 0, 1.0 });
     for (size_t i = 0; i < nct; i++) reg(i); // allocate now: nothing may call hipMalloc while run() is being captured
@@ -997,7 +931,7 @@ void HEVM::select_stream(int s)
         if (reg_base[i]) ciphers[i].data = reg_base[i] + (size_t)sel * slice;
 }
 
-void HEVM::bump_epoch(hipStream_t s) { hipLaunchKernelGGL(bump_epoch_kernel, dim3(1), dim3(1), 0, s, d_epoch); }
+void HEVM::bump_epoch(hipStream_t s) { DC_LAUNCH(bump_epoch_kernel, dim3(1), dim3(1), 0, s, d_epoch); }
 
 // ---------------------------------------------------------------------------------------------------------
 // encode / encrypt / decrypt (SEAL_HEVM.cpp:242-267, :439-455)
@@ -1028,7 +962,7 @@ void HEVM::encode_internal(Plain &dst, const double *src, size_t len, int level,
     if (!dst.d) dst.d = dalloc((size_t)level * N);
     dst.level = level;
     dst.scale = scale;
-    hipLaunchKernelGGL(lift_i128_kernel, dim3((unsigned)(N / kVmThreads), (unsigned)level), dim3(kVmThreads), 0, S(), dst.d,
+    DC_LAUNCH(lift_i128_kernel, dim3((unsigned)(N / kVmThreads), (unsigned)level), dim3(kVmThreads), 0, S(), dst.d,
                        stage, stage + N, N, c.d_mods);
     launch_ntt(c, false, dst.d, (long)N, level, nullptr, 0, 0, S());
     DC_HIP_CHECK(hipStreamSynchronize(S())); // `lohi` and the staging buffer are reused by the next call
@@ -1195,10 +1129,10 @@ void HEVM::encrypt_plain(hevm_ctxt &dst, const Plain &pt)
     u64 *ue = W().ks_ext; // [3][cnt][N]: u, e0, e1
     const CtView tmp{ dst.data, (long)dst.poly_stride };
     // one object per encryption of this VM's lifetime (opcode-10 items of a plan use the range above 2^32)
-    hipLaunchKernelGGL(sample_enc_batch_kernel, dim3((unsigned)(N / (kRngCoefs * kVmThreads)), 3), dim3(kVmThreads), 0, S(), ue, N, cnt,
+    DC_LAUNCH(sample_enc_batch_kernel, dim3((unsigned)(N / (kRngCoefs * kVmThreads)), 3), dim3(kVmThreads), 0, S(), ue, N, cnt,
                        rng.secret, enc_counter++, c.d_mods, d_epoch);
     launch_ntt(c, false, ue, (long)N, 3 * cnt, nullptr, 0, cnt, S());
-    hipLaunchKernelGGL(pk_encrypt_kernel, dim3((unsigned)(N / (2 * kVmThreads)), (unsigned)cnt, 2), dim3(kVmThreads), 0, S(),
+    DC_LAUNCH(pk_encrypt_kernel, dim3((unsigned)(N / (2 * kVmThreads)), (unsigned)cnt, 2), dim3(kVmThreads), 0, S(),
                        tmp.p, tmp.poly_stride, keys.pk, (long)c.K * (long)N, ue, ue + (size_t)cnt * N, (long)cnt * (long)N, N, c.d_mods);
     rescale_fused(c, W(), tmp, tmp, cnt, pt.d, S()); // divide-and-round by the extra prime, then + plaintext on c0
     dst.level = ell;
@@ -1233,7 +1167,7 @@ void HEVM::decrypt(int64_t i, double *out)
     // any admissible scale is not a CKKS message but overflowed noise), and then its centred representative mod Q_16 is the one mod Q_ell.
     // Limbs are independent, so decrypting and inverse-transforming only those 16 changes nothing about them.
     const int ell = !host_encoder && ct.level > 16 ? 16 : ct.level;
-    hipLaunchKernelGGL(decrypt_kernel, dim3((unsigned)(N / (2 * kVmThreads)), (unsigned)ell), dim3(kVmThreads), 0, S(), pt,
+    DC_LAUNCH(decrypt_kernel, dim3((unsigned)(N / (2 * kVmThreads)), (unsigned)ell), dim3(kVmThreads), 0, S(), pt,
                        view(ct), keys.sk, N, c.d_mods);
     launch_ntt(c, true, pt, (long)N, ell, nullptr, 0, 0, S());
     if (!host_encoder) { // compose + forward special FFT + slot gather on the device; only the N/2 slot values cross PCIe
@@ -1242,7 +1176,7 @@ void HEVM::decrypt(int64_t i, double *out)
         const CrtDev cd{ tb.inv, tb.mmod, tb.hmod, tb.hdig, tb.mdbl };
         double2 *v = reinterpret_cast<double2 *>(W().ks_ext); // >= 3K limbs = 3K*N u64 >= 2N doubles
         double *slots = reinterpret_cast<double *>(W().ks_acc);
-        hipLaunchKernelGGL(dec_crt_kernel, dim3((unsigned)(N / kVmThreads)), dim3(kVmThreads), 0, S(), v, pt, ell, N, c.d_mods, cd, 1.0 / ct.scale);
+        DC_LAUNCH(dec_crt_kernel, dim3((unsigned)(N / kVmThreads)), dim3(kVmThreads), 0, S(), v, pt, ell, N, c.d_mods, cd, 1.0 / ct.scale);
         dec_fft(c, enc_tables, v, slots, S());
         DC_HIP_CHECK(hipMemcpyAsync(out, slots, (N / 2) * sizeof(double), hipMemcpyDeviceToHost, S()));
         DC_HIP_CHECK(hipStreamSynchronize(S()));
@@ -1387,7 +1321,10 @@ std::vector<int> HEVM::compose_rotation(int steps) const
         if (v <= -slots / 2) v += slots;
         return (int)v;
     };
-    if (rot_offsets_epoch != keys.galois.size()) { // the offsets that have a key, from the Galois elements 3^k
+    // (the cache is keyed on the SET of Galois elements held, not on its size: a key set replaced by another of equal size has other offsets)
+    size_t stamp = keys.galois.size();
+    for (const auto &kv : keys.galois) stamp = stamp * 0x9E3779B97F4A7C15ull + kv.first;
+    if (rot_offsets_epoch != stamp) { // the offsets that have a key, from the Galois elements 3^k
         rot_offsets.clear();
         std::map<u32, int> step_of;
         const u64 m = 2 * (u64)ctx->N;
@@ -1399,7 +1336,7 @@ std::vector<int> HEVM::compose_rotation(int steps) const
         std::sort(rot_offsets.begin(), rot_offsets.end(), [](int a, int b) { return std::abs(a) != std::abs(b) ? std::abs(a) < std::abs(b) : a > b; });
         rot_offset_set.clear();
         rot_offset_set.insert(rot_offsets.begin(), rot_offsets.end());
-        rot_offsets_epoch = keys.galois.size();
+        rot_offsets_epoch = stamp;
     }
     const int t = norm(steps);
     for (int a : rot_offsets)
@@ -1649,10 +1586,10 @@ void HEVM::boot_item(CtView src, int ell, double src_scale, hevm_ctxt &dst, int 
     f_irows_decrypt(c, src, keys.sk, ell, pt, S()); // c0 + c1*s fused into the first inverse phase
     launch_ntt_cols_inv(c, pt, (long)N, ell, nullptr, 0, 0, S());
     const CrtDev cd{ tb.inv, tb.mmod, tb.hmod, tb.hdig, tb.mdbl };
-    hipLaunchKernelGGL(reencode_kernel, dim3((unsigned)((N / 2 + kVmThreads) / kVmThreads)), dim3(kVmThreads), 0, S(), lohi,
+    DC_LAUNCH(reencode_kernel, dim3((unsigned)((N / 2 + kVmThreads) / kVmThreads)), dim3(kVmThreads), 0, S(), lohi,
                        lohi + N, pt, ell, N, c.d_mods, cd, new_scale / src_scale);
     Plain ptx{ lanes[cur].boot_plain.d, target_level, new_scale };
-    hipLaunchKernelGGL(lift_i128_kernel, dim3((unsigned)(N / kVmThreads), (unsigned)target_level), dim3(kVmThreads), 0, S(),
+    DC_LAUNCH(lift_i128_kernel, dim3((unsigned)(N / kVmThreads), (unsigned)target_level), dim3(kVmThreads), 0, S(),
                        ptx.d, lohi, lohi + N, N, c.d_mods);
     launch_ntt(c, false, ptx.d, (long)N, target_level, nullptr, 0, 0, S());
     encrypt_plain(dst, ptx);
@@ -1670,10 +1607,10 @@ void HEVM::plan_zero_encrypt(int first, int B, int t, hipStream_t s)
         abort();
     }
     Plan &P = plan;
-    hipLaunchKernelGGL(sample_enc_batch_kernel, dim3((unsigned)(N / (kRngCoefs * kVmThreads)), (unsigned)(3 * B)), dim3(kVmThreads), 0, s,
+    DC_LAUNCH(sample_enc_batch_kernel, dim3((unsigned)(N / (kRngCoefs * kVmThreads)), (unsigned)(3 * B)), dim3(kVmThreads), 0, s,
                        P.boot_ue, N, cnt, rng.secret, ((u64)1 << 32) + (u64)first, c.d_mods, d_epoch);
     launch_ntt(c, false, P.boot_ue, (long)N, 3 * cnt * B, nullptr, 0, cnt, s);
-    hipLaunchKernelGGL(pk_encrypt_batch_kernel, dim3((unsigned)(N / (2 * kVmThreads)), (unsigned)cnt, (unsigned)(2 * B)), dim3(kVmThreads),
+    DC_LAUNCH(pk_encrypt_batch_kernel, dim3((unsigned)(N / (2 * kVmThreads)), (unsigned)cnt, (unsigned)(2 * B)), dim3(kVmThreads),
                        0, s, P.boot_tmp, keys.pk, (long)c.K * (long)N, P.boot_ue, cnt, N, c.d_mods);
     b_rescale(c, P.ws[0], P.d_boot_rs + first, B, cnt, s); // divide-and-round by the extra prime, straight into the zenc slots
 }
@@ -1700,7 +1637,7 @@ void HEVM::plan_boot_step(int first, int B, int ell, int t, int lane, hipStream_
     if (ell == 1) // trivial composition: re-encode inside the first forward phase's loader (4 launches per batch)
         f_boot_reencode_fcols(c, pt, ptx, items, B, ell, t, cd, s);
     else {
-        hipLaunchKernelGGL(reencode_lift_batch_kernel, dim3((unsigned)((N / 2 + kVmThreads) / kVmThreads), (unsigned)B), dim3(kVmThreads), 0,
+        DC_LAUNCH(reencode_lift_batch_kernel, dim3((unsigned)((N / 2 + kVmThreads) / kVmThreads), (unsigned)B), dim3(kVmThreads), 0,
                            s, ptx, pt, items, ell, t, N, c.d_mods, cd);
         launch_ntt_cols_fwd(c, ptx, (long)N, B * t, nullptr, 0, t, s);
     }
@@ -2001,7 +1938,7 @@ uint64_t hevm_key_digest(void *vm)
     u64 digest = 0x9E3779B97F4A7C15ull;
     for (int i = 0; i < n; i++) {
         DC_HIP_CHECK(hipMemsetAsync(d, 0, 8, h->S()));
-        hipLaunchKernelGGL(key_checksum_kernel, dim3(1024), dim3(256), 0, h->S(), ptrs[(size_t)i], (size_t)words[(size_t)i], d);
+        DC_LAUNCH(key_checksum_kernel, dim3(1024), dim3(256), 0, h->S(), ptrs[(size_t)i], (size_t)words[(size_t)i], d);
         DC_HIP_CHECK(hipMemcpyAsync(&out, d, 8, hipMemcpyDeviceToHost, h->S()));
         DC_HIP_CHECK(hipStreamSynchronize(h->S()));
         digest = (digest ^ (u64)out) * 0xBF58476D1CE4E5B9ull + (u64)words[(size_t)i];
@@ -2096,7 +2033,7 @@ void hevm_chacha20_blocks_device(const uint32_t key[8], uint64_t counter, uint64
     memcpy(k.w, key, 32);
     uint32_t *d = nullptr;
     DC_HIP_CHECK(hipMalloc(&d, (size_t)blocks * 64));
-    hipLaunchKernelGGL(dacapo::chacha_blocks_kernel, dim3((unsigned)((blocks + 63) / 64)), dim3(64), 0, 0, d, k, counter, nonce, blocks);
+    DC_LAUNCH(dacapo::chacha_blocks_kernel, dim3((unsigned)((blocks + 63) / 64)), dim3(64), 0, 0, d, k, counter, nonce, blocks);
     DC_HIP_CHECK(hipMemcpy(out_host, d, (size_t)blocks * 64, hipMemcpyDeviceToHost));
     (void)hipFree(d);
 }

@@ -2,6 +2,7 @@
 // include/hevm_abi.h.  Mirrors struct SEAL_HEVM (/root/reference/lib/Runtime/SEAL_HEVM.cpp:15-402) with the
 // SEAL objects replaced by HBM-resident limb arrays and HIP launches.
 #pragma once
+#include "wire_parse.hpp"
 #include <complex>
 #include <deque>
 #include <map>
@@ -41,26 +42,7 @@ inline hipError_t vm_free(void *p)
 }
 
 
-// wire format of include/hecate/Support/HEVMHeader.h:10-35 (little endian, natural alignment)
-struct WireHeader {
-    uint32_t magic_number;
-    uint32_t hevm_header_size;
-    uint64_t arg_length;
-    uint64_t res_length;
-};
-struct WireConfigBody {
-    uint64_t config_body_length;
-    uint64_t num_operations;
-    uint64_t num_ctxt_buffer;
-    uint64_t num_ptxt_buffer;
-    uint64_t init_level;
-};
-struct WireOp {
-    uint16_t opcode, dst, lhs, rhs;
-};
-// extension opcodes (dacapo_amd/hevm_asm.py OP_ENCODE_COMPLEX ...): not emitted by the reference's compiler, skipped by its VMs
-constexpr uint16_t kOpEncodeComplex = 16, kOpConj = 17, kOpModRaise = 18, kOpSetScale = 19;
-static_assert(sizeof(WireHeader) == 24 && sizeof(WireConfigBody) == 40 && sizeof(WireOp) == 8, "HEVM wire format");
+// the wire structs (WireHeader, WireConfigBody, WireOp) and the two files' parsers live in a host-only TU: wire_parse.hpp
 
 // CKKSEncoder restated on the host (encode/decode are untimed set-up work in the reference: SEAL_HEVM.cpp:242-267,
 // :439-455); the RNS lift and every NTT run on the GPU.

@@ -288,30 +288,30 @@ __global__ __launch_bounds__(kTileThreads) void hybf_frows_final_kernel(const u6
 template <int MODE>
 static void f1_irows(const Context &c, const KsItem *items, KsItem single, const u64 *target, u64 *digits, int B, int ell, int use_slots, hipStream_t s)
 {
-    DC_GEO_SWITCH(c.k2, B * ell, hipLaunchKernelGGL((hybf_irows_kernel<KK, LE, MODE>), grid, dim3(kTileThreads), 0, s, items, single, target, digits, ell,
+    DC_GEO_SWITCH(c.k2, B * ell, DC_LAUNCH((hybf_irows_kernel<KK, LE, MODE>), grid, dim3(kTileThreads), 0, s, items, single, target, digits, ell,
                                                     use_slots, c.d_mods, c.d_itw, c.logN));
 }
 static void f3_modup_fcols(const Context &c, const u64 *digits, u64 *ext, int U, int ell, hipStream_t s)
 {
     const int E = c.hyb_ext(ell);
-    DC_GEO_SWITCH(c.k1, U * E, hipLaunchKernelGGL((hybf_modup_fcols_kernel<KK, LE>), grid, dim3(kTileThreads), 0, s, digits, ext, ell, c.ksp, c.alpha,
+    DC_GEO_SWITCH(c.k1, U * E, DC_LAUNCH((hybf_modup_fcols_kernel<KK, LE>), grid, dim3(kTileThreads), 0, s, digits, ext, ell, c.ksp, c.alpha,
                                                   c.max_level(), E, c.d_mods, c.hyb_up(ell), c.d_tw, c.logN));
 }
 static void f8_moddown_fcols(const Context &c, const u64 *accp, u64 *tmp, int polys, int ell, hipStream_t s)
 {
-    DC_GEO_SWITCH(c.k1, polys * ell, hipLaunchKernelGGL((hybf_moddown_fcols_kernel<KK, LE>), grid, dim3(kTileThreads), 0, s, accp, tmp, ell, c.ksp,
+    DC_GEO_SWITCH(c.k1, polys * ell, DC_LAUNCH((hybf_moddown_fcols_kernel<KK, LE>), grid, dim3(kTileThreads), 0, s, accp, tmp, ell, c.ksp,
                                                         c.max_level(), c.d_mods, c.d_hyb_dn, c.d_tw, c.logN));
 }
 static void f7_icols_special(const Context &c, u64 *accp, int polys, hipStream_t s)
 {
-    DC_GEO_SWITCH(c.k1, polys * c.ksp, hipLaunchKernelGGL((hybf_icols_special_kernel<KK, LE>), grid, dim3(kTileThreads), 0, s, accp, c.ksp, c.max_level(),
+    DC_GEO_SWITCH(c.k1, polys * c.ksp, DC_LAUNCH((hybf_icols_special_kernel<KK, LE>), grid, dim3(kTileThreads), 0, s, accp, c.ksp, c.max_level(),
                                                           c.d_hyb_dnmods, c.d_hyb_hp, c.d_itw, c.logN));
 }
 template <int MODE>
 static void f9_frows_final(const Context &c, const u64 *tmp, const u64 *accq, const void *items, KsItem rot_single, HybOut single, int polys, int ell,
                            hipStream_t s)
 {
-    DC_GEO_SWITCH(c.k2, polys * ell, hipLaunchKernelGGL((hybf_frows_final_kernel<KK, LE, MODE>), grid, dim3(kTileThreads), 0, s, tmp, accq, items,
+    DC_GEO_SWITCH(c.k2, polys * ell, DC_LAUNCH((hybf_frows_final_kernel<KK, LE, MODE>), grid, dim3(kTileThreads), 0, s, tmp, accq, items,
                                                         rot_single, single, ell, c.ksp, c.max_level(), c.d_mods, c.d_hyb_dn, c.d_tw, c.logN));
 }
 

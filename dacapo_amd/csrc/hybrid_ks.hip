@@ -418,23 +418,23 @@ void hyb_launch_conv(Context &c, bool down, bool prescaled, const u64 *in, u64 *
     const v4i *bdn = reinterpret_cast<const v4i *>(c.d_hyb_bdn + (mfma ? c.hyb_bdn_off[(size_t)ell] : 0));
     if (!down) {
         if (mfma && prescaled)
-            hipLaunchKernelGGL((hyb_conv_mfma_kernel<false, true>), dim3(gc, (unsigned)G, (unsigned)count), dim3(kHT), 0, s, in, out, ell, ksp, alpha, L, E,
+            DC_LAUNCH((hyb_conv_mfma_kernel<false, true>), dim3(gc, (unsigned)G, (unsigned)count), dim3(kHT), 0, s, in, out, ell, ksp, alpha, L, E,
                                N, c.d_mods, c.hyb_up(ell), bup, c.hyb_up_blocks(ell));
         else if (mfma)
-            hipLaunchKernelGGL((hyb_conv_mfma_kernel<false, false>), dim3(gc, (unsigned)G, (unsigned)count), dim3(kHT), 0, s, in, out, ell, ksp, alpha, L, E,
+            DC_LAUNCH((hyb_conv_mfma_kernel<false, false>), dim3(gc, (unsigned)G, (unsigned)count), dim3(kHT), 0, s, in, out, ell, ksp, alpha, L, E,
                                N, c.d_mods, c.hyb_up(ell), bup, c.hyb_up_blocks(ell));
         else
-            hipLaunchKernelGGL(hyb_modup_kernel, dim3(gx, (unsigned)G, (unsigned)count), dim3(kHT), 0, s, in, out, ell, ksp, alpha, L, E, N, c.d_mods,
+            DC_LAUNCH(hyb_modup_kernel, dim3(gx, (unsigned)G, (unsigned)count), dim3(kHT), 0, s, in, out, ell, ksp, alpha, L, E, N, c.d_mods,
                                c.hyb_up(ell));
     } else {
         if (mfma && prescaled)
-            hipLaunchKernelGGL((hyb_conv_mfma_kernel<true, true>), dim3(gc, 1, (unsigned)count), dim3(kHT), 0, s, in, out, ell, ksp, alpha, L, E, N,
+            DC_LAUNCH((hyb_conv_mfma_kernel<true, true>), dim3(gc, 1, (unsigned)count), dim3(kHT), 0, s, in, out, ell, ksp, alpha, L, E, N,
                                c.d_mods, c.d_hyb_dn, bdn, c.hyb_dn_blocks(ell));
         else if (mfma)
-            hipLaunchKernelGGL((hyb_conv_mfma_kernel<true, false>), dim3(gc, 1, (unsigned)count), dim3(kHT), 0, s, in, out, ell, ksp, alpha, L, E, N,
+            DC_LAUNCH((hyb_conv_mfma_kernel<true, false>), dim3(gc, 1, (unsigned)count), dim3(kHT), 0, s, in, out, ell, ksp, alpha, L, E, N,
                                c.d_mods, c.d_hyb_dn, bdn, c.hyb_dn_blocks(ell));
         else
-            hipLaunchKernelGGL(hyb_moddown_kernel, dim3(gx, (unsigned)count), dim3(kHT), 0, s, in, out, ell, ksp, L, N, c.d_mods, c.d_hyb_dn);
+            DC_LAUNCH(hyb_moddown_kernel, dim3(gx, (unsigned)count), dim3(kHT), 0, s, in, out, ell, ksp, L, N, c.d_mods, c.d_hyb_dn);
     }
 }
 
@@ -447,7 +447,7 @@ void hyb_launch_mac(Context &c, int mode, const BatchWs &w, const void *items, K
     const dim3 grid((unsigned)(N / (2 * kHT)), (unsigned)B, (unsigned)M);
     u64 *accq = w.acc, *accp = w.acc + (size_t)B * 2 * ell * N;
 #define DC_MAC(MD)                                                                                                                        \
-    hipLaunchKernelGGL(hyb_mac_kernel<MD>, grid, dim3(kHT), 0, s, accq, accp, w.ext, w.target, items, rot_single, key, ell, ksp, alpha, L, K, E, N, \
+    DC_LAUNCH(hyb_mac_kernel<MD>, grid, dim3(kHT), 0, s, accq, accp, w.ext, w.target, items, rot_single, key, ell, ksp, alpha, L, K, E, N, \
                        c.logN, use_slots, c.d_mods, fold_base ? c.d_pmod : (const u64 *)nullptr)
     if (mode == 0)
         DC_MAC(0);
@@ -475,7 +475,7 @@ static void hyb_core(Context &c, const BatchWs &w, const void *items, const u64 
     launch_ntt(c, true, accp, (long)N, 2 * B * ksp, nullptr, L, ksp, s);
     hyb_launch_conv(c, true, false, accp, w.tmp, 2 * B, ell, s);
     launch_ntt(c, false, w.tmp, (long)N, 2 * B * ell, nullptr, 0, ell, s);
-    hipLaunchKernelGGL(hyb_final_kernel<MODE>, dim3(gx, (unsigned)ell, (unsigned)(2 * B)), dim3(kHT), 0, s, accq, w.tmp, items, single, rot_single, ell,
+    DC_LAUNCH(hyb_final_kernel<MODE>, dim3(gx, (unsigned)ell, (unsigned)(2 * B)), dim3(kHT), 0, s, accq, w.tmp, items, single, rot_single, ell,
                        ksp, L, N, c.d_mods, c.d_hyb_dn);
 }
 
@@ -491,7 +491,7 @@ void hyb_rotate_hops(Context &c, const BatchWs &w, const KsItem *d_items, int B,
 {
     if (hyb_fused()) return hybf_rotate_hops(c, w, d_items, B, ell, s, unique);
     const int use_slots = unique > 0 ? 1 : 0, U = use_slots ? unique : B;
-    hipLaunchKernelGGL(hyb_prepare_rot_kernel, dim3((unsigned)(c.N / (2 * kHT)), (unsigned)ell, (unsigned)B), dim3(kHT), 0, s, d_items, KsItem{},
+    DC_LAUNCH(hyb_prepare_rot_kernel, dim3((unsigned)(c.N / (2 * kHT)), (unsigned)ell, (unsigned)B), dim3(kHT), 0, s, d_items, KsItem{},
                        w.digits, ell, c.N, c.logN, use_slots);
     hyb_core<0>(c, w, d_items, nullptr, HybSingle{}, KsItem{}, B, U, use_slots, ell, s);
 }
@@ -501,14 +501,14 @@ void hyb_rotate_hop_single(Context &c, const Workspace &w, CtView dst, CtView sr
     if (hyb_fused()) return hybf_rotate_hop_single(c, w, dst, src, galois_elt, galois_key, ell, s);
     const KsItem it{ src, dst, galois_key, galois_elt, 0 };
     BatchWs bw{ nullptr, w.ks_digits, w.ks_ext, w.ks_acc, w.ks_tmp };
-    hipLaunchKernelGGL(hyb_prepare_rot_kernel, dim3((unsigned)(c.N / (2 * kHT)), (unsigned)ell, 1), dim3(kHT), 0, s, (const KsItem *)nullptr, it,
+    DC_LAUNCH(hyb_prepare_rot_kernel, dim3((unsigned)(c.N / (2 * kHT)), (unsigned)ell, 1), dim3(kHT), 0, s, (const KsItem *)nullptr, it,
                        w.ks_digits, ell, c.N, c.logN, 0);
     hyb_core<0>(c, bw, nullptr, nullptr, HybSingle{}, it, 1, 1, 0, ell, s);
 }
 
 void hyb_mul_relin(Context &c, const BatchWs &w, const MulItem *d_items, const u64 *relin_key, int B, int ell, hipStream_t s)
 {
-    hipLaunchKernelGGL(hyb_prepare_mul_kernel, dim3((unsigned)(c.N / (2 * kHT)), (unsigned)ell, (unsigned)B), dim3(kHT), 0, s, d_items, w.target,
+    DC_LAUNCH(hyb_prepare_mul_kernel, dim3((unsigned)(c.N / (2 * kHT)), (unsigned)ell, (unsigned)B), dim3(kHT), 0, s, d_items, w.target,
                        hyb_fused() ? (u64 *)nullptr : w.digits, ell, c.N, c.d_mods);
     if (hyb_fused()) return hybf_mul_relin_tail(c, w, d_items, relin_key, B, ell, s);
     hyb_core<1>(c, w, d_items, relin_key, HybSingle{}, KsItem{}, B, B, 0, ell, s);
@@ -522,7 +522,7 @@ void hyb_keyswitch(Context &c, const Workspace &w, CtView out, const u64 *base0,
     const size_t N = c.N;
     // the batch scratch of one item: target is read in place, digits / ext / acc / tmp are the workspace's
     BatchWs bw{ const_cast<u64 *>(target), w.ks_digits, w.ks_ext, w.ks_acc, w.ks_tmp };
-    hipLaunchKernelGGL(hyb_copy_kernel, dim3((unsigned)((size_t)ell * N / (2 * kHT))), dim3(kHT), 0, s, w.ks_digits, target);
+    DC_LAUNCH(hyb_copy_kernel, dim3((unsigned)((size_t)ell * N / (2 * kHT))), dim3(kHT), 0, s, w.ks_digits, target);
     hyb_core<2>(c, bw, nullptr, nullptr, HybSingle{ out, base0, base1, key }, KsItem{}, 1, 1, 0, ell, s);
 }
 

@@ -499,16 +499,16 @@ void launch_ntt_full(const Context &c, bool inverse, u64 *data, long limb_stride
     const unsigned grid = (unsigned)(pg > 0 && count > pg ? pg : count);
 #if DC_FULL_PAIRS
     if (!inverse && full_pairs() && c.d_tw2) {
-        hipLaunchKernelGGL((ntt_full15_kernel<false, true>), dim3(grid), dim3(kFullThreads), 0, s, data, limb_stride, d_prime_idx, prime_base,
+        DC_LAUNCH((ntt_full15_kernel<false, true>), dim3(grid), dim3(kFullThreads), 0, s, data, limb_stride, d_prime_idx, prime_base,
                            prime_period, c.d_mods, c.d_tw, c.d_tw2, count);
         return;
     }
 #endif
     if (!inverse)
-        hipLaunchKernelGGL((ntt_full15_kernel<false, false>), dim3(grid), dim3(kFullThreads), 0, s, data, limb_stride, d_prime_idx, prime_base,
+        DC_LAUNCH((ntt_full15_kernel<false, false>), dim3(grid), dim3(kFullThreads), 0, s, data, limb_stride, d_prime_idx, prime_base,
                            prime_period, c.d_mods, c.d_tw, (const u64 *)nullptr, count);
     else
-        hipLaunchKernelGGL((ntt_full15_kernel<true, false>), dim3(grid), dim3(kFullThreads), 0, s, data, limb_stride, d_prime_idx, prime_base,
+        DC_LAUNCH((ntt_full15_kernel<true, false>), dim3(grid), dim3(kFullThreads), 0, s, data, limb_stride, d_prime_idx, prime_base,
                            prime_period, c.d_mods, c.d_itw, (const u64 *)nullptr, count);
 }
 

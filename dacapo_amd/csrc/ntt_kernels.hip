@@ -26,7 +26,7 @@ static void launch_phase(const Context &c, u64 *data, long limb_stride, int coun
                          int prime_period, hipStream_t s, const DModulus *mods)
 {
     dim3 grid((unsigned)(c.N >> TileGeo<LOGE>::LOG), (unsigned)count);
-    hipLaunchKernelGGL((ntt_phase_kernel<K, LOGE, COLS, INV, CANON>), grid, dim3(kTileThreads), 0, s, data, limb_stride,
+    DC_LAUNCH((ntt_phase_kernel<K, LOGE, COLS, INV, CANON>), grid, dim3(kTileThreads), 0, s, data, limb_stride,
                        d_prime_idx, prime_base, prime_period, mods ? mods : c.d_mods, INV ? c.d_itw : c.d_tw, c.logN);
 }
 

@@ -106,6 +106,19 @@ __device__ __forceinline__ void ct_bfly(u64 &x, u64 &y, u64 w, const DModulus &M
     x = xf + t;
     y = xf + (M.q << 2) - t;                  // 4q > t
 }
+#if !DC_GENERIC_WIDTH
+// Cooley-Tukey butterfly on a twiddle PAIR (w, W = w 2^31 mod q) and modarith.hpp's mulmod_pair: 5 mads and one fold per multiply instead of 7
+// and two.  The product comes out below 2q, so with x folded in every butterfly -- xf = fold(x) < 2q, t = w y < 2q, (x, y) <- (xf + t,
+// xf + 2q - t) -- every value stays below 4q < 2^62, mulmod_pair's operand range; a stage whose x is canonical needs no fold (x + t < 3q).
+// Same residues as ct_bfly, hence the same canonical results, bit for bit.
+__device__ __forceinline__ void ct_bfly_pair(u64 &x, u64 &y, u64 w, u64 W, const DModulus &M, bool fold)
+{
+    const u64 xf = fold ? fold60(x, M.delta) : x;
+    const u64 t = mulmod_pair(w, W, y, M.delta);
+    x = xf + t;
+    y = xf + (M.q << 1) - t;
+}
+#endif
 // Gentleman-Sande butterfly, values < 4q (< 2^62) in and out:  (x, y) -> (x + y, (x - y) w)
 // (every value here is a canonical input, a fold60 result or a mulmod_lazy result, all < 4q = 2^62 - 4 delta)
 __device__ __forceinline__ void gs_bfly(u64 &x, u64 &y, u64 w, const DModulus &M)
@@ -143,10 +156,16 @@ __device__ __forceinline__ int cols_tile_of(int bx, int logN)
 //            tile can hand its output to a forward tile in registers (the fused iNTT -> base change -> NTT kernels).
 // wext (latency geometries only): the tile's twiddles as tile_twiddles() fetched them -- a kernel that runs the same tile of the same prime
 // several times (the digits of a key switch) fetches them once, not once per transform behind the exchanges' memory fences.
-template <int K, int LOGE, bool COLS, bool INV, bool CANON, bool PRELOADED, bool KEEP, class Ld, class St>
-__device__ __forceinline__ void ntt_tile_x(u64 (&x)[1 << LOGE], const DModulus M, const u64 *__restrict__ tw, int logN, int tile,
-                                           Ld ld, St st, u64 *__restrict__ lds, const u64 (*wext)[1 << LOGE] = nullptr)
+// PAIRS (forward COLS tiles of the 60-bit build): `tw` is the prime's table of twiddle PAIRS (Context::d_twc2: the first 2^k1 entries of the
+// forward table, 16 bytes each: a COLS phase's twiddles depend on the row group only -- a table of 2^K entries shared by every column of every
+// tile, L1 / L2 resident -- so the pairs' doubled bytes cost nothing, unlike a ROWS phase's per-row tables) and the butterflies are
+// ct_bfly_pair: ~13 % fewer VALU instructions per butterfly.  The phase's inputs must be canonical (a forward transform's first phase: they
+// are); its outputs are below 4q, inside every range the ROWS phase's schedule assumes.
+template <int K, int LOGE, bool COLS, bool INV, bool CANON, bool PRELOADED, bool KEEP, bool PAIRS, class Ld, class St>
+__device__ __forceinline__ void ntt_tile_core(u64 (&x)[1 << LOGE], const DModulus M, const u64 *__restrict__ tw, int logN, int tile,
+                                              Ld ld, St st, u64 *__restrict__ lds, const u64 (*wext)[1 << LOGE] = nullptr)
 {
+    static_assert(!PAIRS || (COLS && !INV && !DC_GENERIC_WIDTH), "twiddle pairs: forward COLS tiles of the 60-bit build");
     constexpr int E = 1 << LOGE, n = 1 << K, LOGB = TileGeo<LOGE>::LOG - K, B = 1 << LOGB, T = kTileThreads, SUBT = n / E;
     constexpr int NP = num_passes<LOGE>(K);
     constexpr int stride = T + kLdsPad;
@@ -182,6 +201,7 @@ __device__ __forceinline__ void ntt_tile_x(u64 (&x)[1 << LOGE], const DModulus M
     // twiddles are a 256-entry table shared by its columns: cache hits, left where they are used.
     constexpr bool PF = (LOGE <= 2) || !COLS; // (radix-8 COLS tiles with the prefetch: 69.8 -> 67.7 us forward, 83.7 -> 82.2 inverse: not worth their fused forms' registers)
     u64 wpre[PF ? NP : 1][E];
+    u64 wpre2[(PF && PAIRS) ? NP : 1][E]; // the pairs' second words
     if (PF && !wext) {
 #pragma unroll
         for (int pp = 0; pp < NP; pp++) {
@@ -194,8 +214,14 @@ __device__ __forceinline__ void ntt_tile_x(u64 (&x)[1 << LOGE], const DModulus M
 #pragma unroll
                 for (int st_ = 0; st_ < r; st_++) {
 #pragma unroll
-                    for (int g = 0; g < (1 << st_); g++)
-                        wpre[pp][(u << r) | ((1 << st_) + g)] = tw[(twroot << (s0 + st_)) + (u32)((hi << st_) | g)];
+                    for (int g = 0; g < (1 << st_); g++) {
+                        const u32 ti = (twroot << (s0 + st_)) + (u32)((hi << st_) | g);
+                        if constexpr (PAIRS) {
+                            const ulonglong2 tp = *reinterpret_cast<const ulonglong2 *>(tw + 2 * (size_t)ti);
+                            wpre[pp][(u << r) | ((1 << st_) + g)] = tp.x, wpre2[PF ? pp : 0][(u << r) | ((1 << st_) + g)] = tp.y;
+                        } else
+                            wpre[pp][(u << r) | ((1 << st_) + g)] = tw[ti];
+                    }
                 }
             }
         }
@@ -234,7 +260,16 @@ __device__ __forceinline__ void ntt_tile_x(u64 (&x)[1 << LOGE], const DModulus M
 #if defined(DC_EXP_NO_TWLOAD) // timing experiment only (wrong results; profiles/r02_experiments.txt): twiddles from registers, not memory
                     const u64 w = M.inv_n + twi;
 #else
-                    const u64 w = PF ? (wext ? wext[PF ? pp : 0][(u << r) | ((1 << st_) + g)] : wpre[PF ? pp : 0][(u << r) | ((1 << st_) + g)]) : tw[twi];
+                    u64 w, W2 = 0;
+                    if constexpr (PAIRS) {
+                        if (PF)
+                            w = wpre[PF ? pp : 0][(u << r) | ((1 << st_) + g)], W2 = wpre2[PF ? pp : 0][(u << r) | ((1 << st_) + g)];
+                        else {
+                            const ulonglong2 tp = *reinterpret_cast<const ulonglong2 *>(tw + 2 * (size_t)twi);
+                            w = tp.x, W2 = tp.y;
+                        }
+                    } else
+                        w = PF ? (wext ? wext[PF ? pp : 0][(u << r) | ((1 << st_) + g)] : wpre[PF ? pp : 0][(u << r) | ((1 << st_) + g)]) : tw[twi];
 #endif
 #pragma unroll
 #if defined(DC_EXP_NO_BFLY) // timing experiment only (wrong results): loads, exchanges and stores without the arithmetic
@@ -243,7 +278,11 @@ __device__ __forceinline__ void ntt_tile_x(u64 (&x)[1 << LOGE], const DModulus M
                     for (int e = 0; e < half; e++) {
 #endif
                         const int j0 = (u << r) | (g << (r - st_)) | e, j1 = j0 | half;
-                        if (!INV)
+                        if constexpr (PAIRS) {
+#if !DC_GENERIC_WIDTH
+                            ct_bfly_pair(x[j0], x[j1], w, W2, M, gs != 0); // (stage 0 of a forward transform: canonical inputs)
+#endif
+                        } else if (!INV)
                             ct_bfly(x[j0], x[j1], w, M, fwd_stage_folds(gs));
                         else if (COLS && gs == 0) { // very last inverse stage: fold N^{-1} in
                             u64 sv = x[j0] + x[j1];
@@ -297,6 +336,27 @@ __device__ __forceinline__ void ntt_tile_x(u64 (&x)[1 << LOGE], const DModulus M
             }
         }
     }
+}
+
+template <int K, int LOGE, bool COLS, bool INV, bool CANON, bool PRELOADED, bool KEEP, class Ld, class St>
+__device__ __forceinline__ void ntt_tile_x(u64 (&x)[1 << LOGE], const DModulus M, const u64 *__restrict__ tw, int logN, int tile,
+                                           Ld ld, St st, u64 *__restrict__ lds, const u64 (*wext)[1 << LOGE] = nullptr)
+{
+    ntt_tile_core<K, LOGE, COLS, INV, CANON, PRELOADED, KEEP, false>(x, M, tw, logN, tile, ld, st, lds, wext);
+}
+// forward COLS tile; tw2 = the prime's pair table when the context has one (60-bit build), else nullptr and `tw` is used on words.
+// (the choice is uniform over the launch; both branches are instantiated)
+template <int K, int LOGE, bool CANON, bool PRELOADED, bool KEEP, class Ld, class St>
+__device__ __forceinline__ void ntt_tile_fcols(u64 (&x)[1 << LOGE], const DModulus M, const u64 *__restrict__ tw, const u64 *__restrict__ tw2,
+                                               int logN, int tile, Ld ld, St st, u64 *__restrict__ lds)
+{
+#if !DC_GENERIC_WIDTH
+    if (tw2) {
+        ntt_tile_core<K, LOGE, true, false, CANON, PRELOADED, KEEP, true>(x, M, tw2, logN, tile, ld, st, lds);
+        return;
+    }
+#endif
+    ntt_tile_core<K, LOGE, true, false, CANON, PRELOADED, KEEP, false>(x, M, tw, logN, tile, ld, st, lds);
 }
 
 // global coefficient index of register j of this thread under pass p (what ld/st are called with): lets a kernel fill

@@ -38,14 +38,16 @@ static const OptDef kDefs[OPT_COUNT] = {
     { "trace", 0 },
     { "step_profile", 0 },
     { "small_tile_wgs", -1 },
-    { "tiny_tile_wgs", 512 },
+    { "tiny_tile_wgs", 2000 },
     { "ntt_full_min_limbs", 640 },
     { "ntt_full_inv_min_limbs", 2048 },
     { "ntt_full_persist", -1 },
     { "ntt_full_inv_persist", -1 },
     { "ntt_full_pairs", 1 },
+    { "cols_pairs", 1 },
     { "ks_merge_special_min_wgs", 2048 },
     { "ks_merge_lift_min_wgs", 1024 },
+    { "ks_items_fast", 1 },
     { "ks_fuse_mac", 1 },
     { "ks_big_tiles", 4096 },
     { "ks_fuse_mac_tiles", 1LL << 40 },
@@ -71,11 +73,50 @@ static void unknown(const char *what, const char *name, size_t len)
     abort();
 }
 
+// value of "name=value": a complete integer (decimal, 0x.., 0..), or one of seal_compr's names; anything else aborts -- "plan=", "max_batch=12abc"
+// and "seal_compr=zlib" used to run as 0, 12 and 0 (a mistyped option must not silently run something else)
+static long long parse_value(int opt, const char *v, size_t len)
+{
+    if (opt == OPT_SEAL_COMPR) {
+        static const char *const names[] = { "none", "zlib", "zstd" };
+        for (int k = 0; k < 3; k++)
+            if (strlen(names[k]) == len && !strncmp(names[k], v, len)) return k;
+    }
+    char buf[32];
+    char *end = nullptr;
+    if (len == 0 || len >= sizeof buf) goto bad;
+    memcpy(buf, v, len), buf[len] = 0;
+    {
+        const long long r = strtoll(buf, &end, 0);
+        if (end != buf && *end == 0) return r;
+    }
+bad:
+    fprintf(stderr, "[dacapo_amd] DACAPO_HEVM_OPTIONS: option \"%s\" needs an integer value%s, got \"%.*s\"\n", kDefs[opt].name,
+            opt == OPT_SEAL_COMPR ? " (or none | zlib | zstd)" : "", (int)len, v);
+    abort();
+}
+
+// Rounds 1-3 read 31 environment variables (DACAPO_HEVM_*, DACAPO_KS_*, DACAPO_NTT_*, ...); they are no longer read.  A script that still
+// sets one would silently run the defaults (N = 2^15, SEAL-mode keys): say so once, naming the replacement.
+extern "C" char **environ;
+static void warn_legacy_environment()
+{
+    for (char **e = environ; e && *e; e++) {
+        if (strncmp(*e, "DACAPO_", 7) != 0) continue;
+        if (!strncmp(*e, "DACAPO_HEVM_OPTIONS=", 20) || !strncmp(*e, "DACAPO_AMD_LIB=", 15) || !strncmp(*e, "DACAPO_FORCE_DIST=", 18)) continue;
+        const char *eq = strchr(*e, '=');
+        fprintf(stderr, "[dacapo_amd] warning: environment variable %.*s is no longer read (round 4 replaced the per-knob variables); use "
+                        "DACAPO_HEVM_OPTIONS=\"name=value,...\" or hevm_set_option() -- names: include/hevm_abi.h, csrc/options.hpp\n",
+                eq ? (int)(eq - *e) : (int)strlen(*e), *e);
+    }
+}
+
 static void init()
 {
     if (g_init) return;
     g_init = true;
     for (int i = 0; i < OPT_COUNT; i++) g_val[i] = kDefs[i].def;
+    warn_legacy_environment();
     const char *e = getenv("DACAPO_HEVM_OPTIONS"); // the only environment variable the library reads
     while (e && *e) {
         const char *end = strchr(e, ',');
@@ -85,7 +126,7 @@ static void init()
             if (!eq) unknown("DACAPO_HEVM_OPTIONS (expected name=value)", e, len);
             const int i = find(e, (size_t)(eq - e));
             if (i < 0) unknown("DACAPO_HEVM_OPTIONS", e, (size_t)(eq - e));
-            g_val[i] = strtoll(eq + 1, nullptr, 0);
+            g_val[i] = parse_value(i, eq + 1, len - (size_t)(eq + 1 - e));
         }
         e = end ? end + 1 : nullptr;
     }

@@ -46,8 +46,10 @@ enum Opt : int {
     OPT_NTT_FULL_PERSIST,        // workgroups of its persistent grid (-1: one per CU; 0: one workgroup per limb)
     OPT_NTT_FULL_INV_PERSIST,    // ... inverse (-1: same as forward)
     OPT_NTT_FULL_PAIRS,          // twiddle pairs in its forward passes A and B
+    OPT_COLS_PAIRS,              // twiddle pairs in the forward COLS tiles of the fused key-switch / rescale phases (60-bit build)
     OPT_KS_MERGE_SPECIAL_MIN_WGS, // fused key-switch middle: one workgroup row for both special-prime accumulators from this many workgroups
     OPT_KS_MERGE_LIFT_MIN_WGS,   // L2 / L6: share the inverse phase among a source limb's targets while this many workgroups remain
+    OPT_KS_ITEMS_FAST,           // fused key-switch middle: items faster than rows in launch order, and a rotation step's items sorted by key (items sharing a key read it out of L2)
     OPT_KS_FUSE_MAC,             // second NTT phase + inner products + first inverse phase in one launch
     OPT_KS_BIG_TILES,            // work (1024-coefficient tiles of lifted digits) from which a key switch takes the large-batch sequence
     OPT_KS_FUSE_MAC_TILES,       // ... and up to which its middle stays one launch

@@ -81,28 +81,52 @@ void HEVM::build_plan()
         cur[i] = v;
     }
     // ---- 1. SSA walk in program order: metadata semantics of the reference, one pseudo-op per kernel sequence ----
-    std::map<std::pair<int, u32>, int> hop_memo; // option rot_compose: (value, Galois element) -> the value that hop produced
+    // option rot_compose: (value, Galois element) -> the value that hop produced.  A memoised value is only ever used as an INTERMEDIATE
+    // or as the buffer behind a register's own view: when a rotate's last hop hits the memo, dst gets a fresh value sharing the buffer
+    // (as modswitch / setscale views do), so that the reference's scale overwrites (addcc / addcp touch ONE register's metadata,
+    // SEAL_HEVM.cpp:301,308) never reach another register that names the same limbs, and a rotation's result carries the scale its
+    // operand has NOW, not the one the memoised hop saw.  memo_base maps such a view back to the value whose hops are memoised.
+    std::map<std::pair<int, u32>, int> hop_memo;
+    std::map<int, int> memo_base;
     for (const WireOp &op : ops) {
         switch (op.opcode) {
         case 1: { // rotate: one key-switch hop per Galois element (direct key or NAF digits)
             int v = need(op.lhs, "rotate");
+            const double in_scale = P.vals[(size_t)v].scale; // (rotate_vector keeps the scale: every hop's result carries the operand's)
+            bool memo_final = false;
             for (u32 elt : rotate_hops((int16_t)op.rhs)) {
                 // option rot_compose (a bounded key set): composed rotations of one value mostly start with the same small offset -- the parts
                 // come in ascending order -- so the hop (value, Galois element) is computed once and its result named again: the same limbs
                 // (a key switch is deterministic), one key switch fewer.  config 4 under the reference HEaaN runtime's 49 keys: 18.7 % of the hops.
+                memo_final = false;
                 if (rot_compose) {
-                    auto it = hop_memo.find({ v, elt });
+                    const auto mb = memo_base.find(v);
+                    auto it = hop_memo.find({ mb != memo_base.end() ? mb->second : v, elt });
                     if (it != hop_memo.end()) {
                         v = it->second;
+                        memo_final = true;
                         continue;
                     }
                 }
                 const Val s = P.vals[(size_t)v];
-                const int nv = new_val(s.level, s.scale);
+                const int nv = new_val(s.level, in_scale);
                 Pop &p = add_pop(P_ROT, s.level, { v }, nv);
                 p.elt = elt, p.key = keys.galois.at(elt);
                 P.n_keyswitch++, P.n_ntt += ks_ntts(s.level);
-                if (rot_compose) hop_memo[{ v, elt }] = nv;
+                if (rot_compose) {
+                    const auto mb = memo_base.find(v);
+                    hop_memo[{ mb != memo_base.end() ? mb->second : v, elt }] = nv;
+                }
+                v = nv;
+            }
+            if (memo_final) { // the last hop came out of the memo: another register may name that value -- dst gets its own view of the buffer
+                const Val s = P.vals[(size_t)v];
+                const int nv = new_val(s.level, in_scale);
+                P.vals[(size_t)nv].root = s.root;
+                P.vals[(size_t)nv].def_pop = P.vals[(size_t)s.root].def_pop;
+                P.vals[(size_t)v].uses++; // the view keeps the memoised value alive and observable
+                const auto mb = memo_base.find(v);
+                memo_base[nv] = mb != memo_base.end() ? mb->second : v;
                 v = nv;
             }
             if (v == cur[op.lhs] && op.dst != op.lhs) { // no hop at all: rotate_vector copies (SEAL_HEVM.cpp:273), so dst gets a value of its
@@ -367,6 +391,13 @@ void HEVM::build_plan()
             buckets[std::make_tuple((int)O[(size_t)pi].kind, O[(size_t)pi].level, O[(size_t)pi].target_level)].push_back(pi);
         for (auto &kv : buckets) {
             const PopKind kind = (PopKind)std::get<0>(kv.first);
+            // A rotation step's items in key order (option ks_items_fast): SEAL's default key set has 28 Galois elements, so the 64 hops of a
+            // convolution's step name each key several times; adjacent in the item table they are adjacent in the fused middle's launch
+            // order and read the key out of L2 (fused_ks.hip f_ks_frows_mac_kernel).  The order of a step's items is free: every item names
+            // its own source and destination, and a linked consumer step is re-ordered to follow its producer below (4b).  Grouped-digit
+            // steps keep program order (their items are grouped by SOURCE, which shares the decomposition).
+            if (kind == P_ROT && !c.hybrid() && option(OPT_KS_ITEMS_FAST))
+                std::stable_sort(kv.second.begin(), kv.second.end(), [&](int x, int y) { return O[(size_t)x].elt < O[(size_t)y].elt; });
             const bool heavy = kind == P_ROT || kind == P_MULCC || kind == P_RESCALE || kind == P_BOOT;
             const size_t chunk = std::max<size_t>(1, (heavy ? (size_t)max_batch : (size_t)4096) / (size_t)S);
             for (size_t off = 0; off < kv.second.size(); off += chunk) {
@@ -1170,13 +1201,13 @@ bool HEVM::capture_plan_dag()
         (void)hipGraphDestroy(g);
         return tail;
     };
-    // head of the run: the zero-encryptions of every opcode-10 item, then the epoch bump (the next run's randomness)
+    // head of the run: the zero-encryptions of every opcode-10 item (the epoch bump -- the next run's randomness -- is the graph's TAIL, behind
+    // both lanes, exactly where issue_plan puts it: any step that samples from d_epoch sees the same epoch in all three execution forms)
     hipGraphNode_t zenc_tail = add_unit([&](hipStream_t s) {
         if (test_zero_enc) {
             if (P.zenc) DC_HIP_CHECK(hipMemsetAsync(P.zenc, 0, P.zenc_bytes, s));
         } else
             for (const Plan::BootChunk &bc : P.boot_chunks) plan_zero_encrypt(bc.first, bc.count, bc.target, s);
-        bump_epoch(s);
     }, {});
     // Every step sits on one of the two scratch lanes, and a lane is a chain (its steps share the batch scratch): a dependency on a step is
     // implied by a dependency on any LATER step of the same lane.  So a step needs at most two edges -- its own lane's tail and the latest
@@ -1212,6 +1243,7 @@ bool HEVM::capture_plan_dag()
         for (const u64 *b : st.reads) reader[st.lane][b] = me;
         for (const u64 *b : st.writes) writer[b] = me;
     }
+    if (ok) (void)add_unit([&](hipStream_t s) { bump_epoch(s); }, { lane_tail[0].node, lane_tail[1].node });
     if (!ok) {
         (void)hipGraphDestroy(main);
         return false;

@@ -39,11 +39,11 @@ void launch_ew(const Context &c, EwOp op, CtView dst, CtView a, CtView b, int po
 {
     dim3 grid((unsigned)(c.N / (2 * kEwThreads)), (unsigned)ell, (unsigned)polys), block(kEwThreads);
     switch (op) {
-    case EwOp::Add: hipLaunchKernelGGL(ew_kernel<0>, grid, block, 0, s, dst, a, b, b_polys, c.N, c.d_mods); break;
-    case EwOp::Sub: hipLaunchKernelGGL(ew_kernel<1>, grid, block, 0, s, dst, a, b, b_polys, c.N, c.d_mods); break;
-    case EwOp::Neg: hipLaunchKernelGGL(ew_kernel<2>, grid, block, 0, s, dst, a, b, b_polys, c.N, c.d_mods); break;
-    case EwOp::Mul: hipLaunchKernelGGL(ew_kernel<3>, grid, block, 0, s, dst, a, b, b_polys, c.N, c.d_mods); break;
-    case EwOp::Copy: hipLaunchKernelGGL(ew_kernel<4>, grid, block, 0, s, dst, a, b, b_polys, c.N, c.d_mods); break;
+    case EwOp::Add: DC_LAUNCH(ew_kernel<0>, grid, block, 0, s, dst, a, b, b_polys, c.N, c.d_mods); break;
+    case EwOp::Sub: DC_LAUNCH(ew_kernel<1>, grid, block, 0, s, dst, a, b, b_polys, c.N, c.d_mods); break;
+    case EwOp::Neg: DC_LAUNCH(ew_kernel<2>, grid, block, 0, s, dst, a, b, b_polys, c.N, c.d_mods); break;
+    case EwOp::Mul: DC_LAUNCH(ew_kernel<3>, grid, block, 0, s, dst, a, b, b_polys, c.N, c.d_mods); break;
+    case EwOp::Copy: DC_LAUNCH(ew_kernel<4>, grid, block, 0, s, dst, a, b, b_polys, c.N, c.d_mods); break;
     }
 }
 
@@ -67,7 +67,7 @@ void launch_add_plain(const Context &c, CtView dst, CtView a, const u64 *pt, int
     // c1 only moves when dst is a different register
     const int polys = (dst.p == a.p && dst.poly_stride == a.poly_stride) ? 1 : 2;
     dim3 grid((unsigned)(c.N / (2 * kEwThreads)), (unsigned)ell, (unsigned)polys);
-    hipLaunchKernelGGL(add_plain_kernel, grid, dim3(kEwThreads), 0, s, dst, a, pt, c.N, c.d_mods);
+    DC_LAUNCH(add_plain_kernel, grid, dim3(kEwThreads), 0, s, dst, a, pt, c.N, c.d_mods);
 }
 
 __global__ __launch_bounds__(kEwThreads) void tensor_kernel(CtView dst, u64 *__restrict__ c2out, CtView a, CtView b,
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(kEwThreads) void tensor_kernel(CtView dst, u64 *__r
 void launch_tensor(const Context &c, CtView dst, u64 *c2out, CtView a, CtView b, int ell, hipStream_t s)
 {
     dim3 grid((unsigned)(c.N / (2 * kEwThreads)), (unsigned)ell);
-    hipLaunchKernelGGL(tensor_kernel, grid, dim3(kEwThreads), 0, s, dst, c2out, a, b, c.N, c.d_mods);
+    DC_LAUNCH(tensor_kernel, grid, dim3(kEwThreads), 0, s, dst, c2out, a, b, c.N, c.d_mods);
 }
 
 // GaloisTool::apply_galois_ntt: out[k] = in[bitrev(((elt * (2*bitrev(k)+1)) >> 1) mod N)].  An aligned block of
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(kEwThreads) void galois_kernel(CtView dst, CtView s
 void launch_galois(const Context &c, CtView dst, CtView src, u32 galois_elt, int polys, int ell, hipStream_t s)
 {
     dim3 grid((unsigned)(c.N / kEwThreads), (unsigned)ell, (unsigned)polys);
-    hipLaunchKernelGGL(galois_kernel, grid, dim3(kEwThreads), 0, s, dst, src, galois_elt, c.logN);
+    DC_LAUNCH(galois_kernel, grid, dim3(kEwThreads), 0, s, dst, src, galois_elt, c.logN);
 }
 
 } // namespace dacapo

@@ -1,6 +1,9 @@
 // SEAL 4.0 serialization (see seal_serial.hpp for the format and the reference call sites it serves).  Host code only.
 #include "seal_serial.hpp"
 
+#include <algorithm>
+#include <stdexcept>
+
 #include "options.hpp"
 
 #include <dlfcn.h>
@@ -88,8 +91,12 @@ ParmsId parms_id(uint64_t N, const uint64_t *primes, size_t count, uint8_t schem
 // ---- reader / writer ---------------------------------------------------------------------------------------------------------
 void Reader::fail(const char *msg) const
 {
+#ifdef DC_PARSE_THROWS // the sanitizer harness (host_fuzz_main.cpp): a rejected input is an outcome there, not the end of the process
+    throw std::runtime_error(what_ + ": " + msg);
+#else
     fprintf(stderr, "[dacapo_amd] SEAL serialization: %s: %s\n", what_.c_str(), msg);
     abort();
+#endif
 }
 void Reader::take(void *dst, size_t n)
 {
@@ -105,11 +112,19 @@ const uint8_t *Reader::skip(size_t n)
     return r;
 }
 
+// What a compressed object may expand to.  Everything SEAL stores in these files is residues mod ~60-bit primes in 64-bit words -- it
+// deflates by a few per cent -- plus headers; a stream that expands beyond 64 x its stored size + 16 MiB (an all-zero ciphertext of the
+// reference's ring still fits the slack) is not a key file, and inflating it on trust is how a few KB of input take down the host
+// (zlib reaches 1032 : 1, Zstandard far more).
+static size_t inflate_limit(size_t stored) { return stored * 64 + ((size_t)16 << 20); }
+static const char *const kBombMsg = "compressed members expand beyond 64 x their stored size + 16 MiB: refusing (not a SEAL key / ciphertext object; decompression bomb?)";
+
 static std::vector<uint8_t> inflate_all(const uint8_t *in, size_t n, const Reader &r)
 {
     z_stream zs;
     memset(&zs, 0, sizeof(zs));
     if (inflateInit(&zs) != Z_OK) r.fail("inflateInit failed");
+    const size_t limit = inflate_limit(n);
     std::vector<uint8_t> out(n * 2 + (1 << 16));
     size_t in_pos = 0, out_pos = 0;
     int rc = Z_OK;
@@ -118,7 +133,13 @@ static std::vector<uint8_t> inflate_all(const uint8_t *in, size_t n, const Reade
             const size_t chunk = n - in_pos < (1u << 30) ? n - in_pos : (1u << 30);
             zs.next_in = const_cast<Bytef *>(in + in_pos), zs.avail_in = (uInt)chunk, in_pos += chunk;
         }
-        if (out_pos == out.size()) out.resize(out.size() * 2);
+        if (out_pos == out.size()) {
+            if (out.size() >= limit) {
+                inflateEnd(&zs);
+                r.fail(kBombMsg);
+            }
+            out.resize(std::min(out.size() * 2, limit));
+        }
         const size_t room = out.size() - out_pos < (1u << 30) ? out.size() - out_pos : (1u << 30);
         zs.next_out = out.data() + out_pos, zs.avail_out = (uInt)room;
         rc = inflate(&zs, Z_NO_FLUSH);
@@ -153,7 +174,13 @@ static std::vector<uint8_t> deflate_all(const uint8_t *in, size_t n)
             const size_t chunk = n - in_pos < (1u << 30) ? n - in_pos : (1u << 30);
             zs.next_in = const_cast<Bytef *>(in + in_pos), zs.avail_in = (uInt)chunk, in_pos += chunk;
         }
-        if (out_pos == out.size()) out.resize(out.size() * 2);
+        if (out_pos == out.size()) {
+            if (out.size() >= limit) {
+                inflateEnd(&zs);
+                r.fail(kBombMsg);
+            }
+            out.resize(std::min(out.size() * 2, limit));
+        }
         const size_t room = out.size() - out_pos < (1u << 30) ? out.size() - out_pos : (1u << 30);
         zs.next_out = out.data() + out_pos, zs.avail_out = (uInt)room;
         rc = deflate(&zs, in_pos >= n ? Z_FINISH : Z_NO_FLUSH);
@@ -206,11 +233,18 @@ static std::vector<uint8_t> zstd_inflate_all(const uint8_t *in, size_t n, const 
     if (!z.ok) r.fail("object is Zstandard-compressed and libzstd.so.1 is not available; re-save it with compr_mode_type::zlib or ::none");
     void *ds = z.createDStream();
     if (!ds) r.fail("ZSTD_createDStream failed");
+    const size_t limit = inflate_limit(n);
     std::vector<uint8_t> out(n * 2 + (1 << 16));
     ZstdApi::InBuf ib{ in, n, 0 };
     size_t out_pos = 0, rc = 1;
     while (ib.pos < ib.size || rc != 0) { // SEAL writes one frame; rc == 0 marks its end
-        if (out_pos == out.size()) out.resize(out.size() * 2);
+        if (out_pos == out.size()) {
+            if (out.size() >= limit) {
+                z.freeDStream(ds);
+                r.fail(kBombMsg);
+            }
+            out.resize(std::min(out.size() * 2, limit));
+        }
         ZstdApi::OutBuf ob{ out.data() + out_pos, out.size() - out_pos, 0 };
         rc = z.decompressStream(ds, &ob, &ib);
         if (z.isError(rc)) {

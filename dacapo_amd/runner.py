@@ -116,7 +116,12 @@ def _option_libs():
     from . import lowlevel
 
     reinit_lw()
-    return list(_vm_libs.values()) + lowlevel.loaded_libs()
+    libs, seen = [], set()
+    for L in list(_vm_libs.values()) + lowlevel.loaded_libs():  # (the VM binding and the kernel-level binding of one build: one table)
+        if L._name not in seen:
+            seen.add(L._name)
+            libs.append(L)
+    return libs
 
 
 def set_option(name: str, value: int):
@@ -148,14 +153,18 @@ def apply_cli_options(argv):
 def options(**kw):
     """set options for the duration of a with-block and put the previous values back: VM options are read when a VM is created, launch
     shapes at every launch -- `with options(plan=0): HEVM(...)`, `with options(sum_pair_min_wgs=0): hevm.run()`"""
-    old = {k: get_option(k) for k in kw}
+    libs = _option_libs()  # each build has its own table: saved and restored per build
+    for L in libs:
+        bind_options(L)
+    old = [{k: int(L.hevm_get_option(k.encode())) for k in kw} for L in libs]
     try:
         for k, v in kw.items():
             set_option(k, v)
         yield
     finally:
-        for k, v in old.items():
-            set_option(k, v)
+        for L, saved in zip(libs, old):
+            for k, v in saved.items():
+                L.hevm_set_option(k.encode(), v)
 
 
 class hevm_ctxt(ctypes.Structure):  # include/hevm_abi.h
@@ -314,7 +323,7 @@ class HEVM:
         self.vm = None
 
     def plaintextBytes(self) -> int:
-        """extension: HBM held for the program's plaintexts (pre-encoded pool, or constants + window with DACAPO_HEVM_ONLINE_ENCODE=1)"""
+        """extension: HBM held for the program's plaintexts (pre-encoded pool, or constants + window with option online_encode = 1)"""
         return int(self.lw.hevm_plaintext_bytes(self.vm))
 
     def addRotationKeys(self, offsets):

@@ -34,7 +34,8 @@ void *initServerVM(char *dir);
  * reader / writer (oracle/seal_format.py), but no file produced by SEAL itself has been read here and none written here has been read
  * by SEAL (SEAL is neither vendored in the reference nor installed; tests/test_seal_diff.py runs where it is).  Keys and all
  * encryption randomness come from ChaCha20 keyed by 512 bits of getrandom(2); the call aborts if that fails.
- * option seal_compr = none (default) | zlib | zstd selects the compr_mode of the written files. */
+ * option seal_compr = 0 none (default) | 1 zlib | 2 zstd selects the compr_mode of the written files (DACAPO_HEVM_OPTIONS also takes
+ * the names: seal_compr=zlib). */
 void create_context(char *dir);
 /* SEAL_HEVM.cpp:424 */
 void load(void *vm, char *constant, char *vmfile);

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Only the headline workload (set-up, then `runs` run() calls of the ResNet-20 HEVM program of bench.py), for rocprofv3 passes whose
-counters should describe the timed step and nothing else:  python3 tools/headline_only.py [runs=3]"""
+counters should describe the timed step and nothing else:  python3 tools/headline_only.py [runs=3] [lowering = b6 | b13] [--opt name=value ...]"""
 import sys
 from pathlib import Path
 
@@ -9,8 +9,13 @@ sys.path.insert(0, str(ROOT))
 from dacapo_amd import hevm_asm as ha  # noqa: E402
 from dacapo_amd import runner  # noqa: E402
 
+sys.argv = runner.apply_cli_options(sys.argv)
 runs = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 fx = ha.read_fixture(ROOT / "tests" / "golden" / "resnet20")
+if len(sys.argv) > 2:  # another lowering of the same trace (same constants)
+    import gzip
+
+    fx["hevm"] = gzip.open(ROOT / "tests" / "golden" / f"resnet20.{sys.argv[2]}.hevm.gz").read()
 hevm = runner.HEVM(seed=0x4845564D, logN=15, num_primes=14)
 hevm.load_mem(fx["cst"], fx["hevm"])
 hevm.setInput(0, fx["packed"])
