@@ -32,7 +32,7 @@ import numpy as np  # noqa: E402
 
 KEY_SEED = 0x4845564D  # every replica expands the same key set from it (bench keys are reproducible, hence NOT secure: hevm_init_seeded)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
-PROF = "r04"  # the round whose profiles/ records this file reads (each is used only when its lib_sha256 is the library being timed)
+PROF = "r05"  # the round whose profiles/ records this file reads (each is used only when its lib_sha256 is the library being timed)
 
 
 def ntt_equivalents(stats_or_counts):
@@ -61,7 +61,9 @@ def roofline_leg(ll, ctx, limbs=4096, iters=10):
     for _ in range(20):
         ctx.ntt(buf, limbs, prime_base=0, prime_period=ctx.K)
     rounds = [(timed(None), timed(0)) for _ in range(3)]
-    ms, two_ms = min(r[0] for r in rounds), min(r[1] for r in rounds)
+    # `achieved` / `frac` come from the MEAN over the rounds (30 launches); the best round is reported beside it, not instead of it
+    ms, two_ms = sum(r[0] for r in rounds) / len(rounds), sum(r[1] for r in rounds) / len(rounds)
+    best_ms = min(r[0] for r in rounds)
     alg_bytes = 2.0 * limbs * N * 8
     gbs = alg_bytes / (ms * 1e-3) / 1e9
     # what a plain device-to-device copy of the same buffer reaches on this GPU (read + write), for scale
@@ -106,8 +108,10 @@ def roofline_leg(ll, ctx, limbs=4096, iters=10):
                       "dacapo_amd/csrc/ntt_full.hip)",
             "launch": {"limbs": limbs, "N": N, "algorithmic_bytes": alg_bytes, "avg_us": round(ms * 1e3, 2),
                        "ntt_per_s": round(limbs / (ms * 1e-3)),
-                       "timing": "HIP events around 10 back-to-back launches; 20 warm-up launches, then best of three alternating rounds",
-                       "rounds_us": [[round(a * 1e3, 1), round(b * 1e3, 1)] for a, b in rounds]},
+                       "timing": "HIP events around 10 back-to-back launches; 20 warm-up launches, then three alternating rounds of the library's "
+                                 "choice and the two-launch transform: avg_us / achieved / frac are the MEAN of the three rounds",
+                       "rounds_us": [[round(a * 1e3, 1), round(b * 1e3, 1)] for a, b in rounds],
+                       "best_round": {"avg_us": round(best_ms * 1e3, 2), "frac": round(alg_bytes / (best_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}},
             # (no measured figure is hard-coded here: the counters of THIS build are in `valu`, reported only when their lib_sha256 matches;
             # the ablations behind the statement are a record of round 3's build of the same kernel source)
             "limiting_resource": "VALU issue and the twiddles' vector-memory path (60-bit modular butterflies on 32-bit ALUs); the HBM fraction is "
@@ -187,6 +191,31 @@ def real_bootstrap_leg(ll, runner, steps=3, resnet=True):
             "rms_vs_torch": float(np.sqrt(np.mean((o[:10] * 32 - fx["torch_result"]) ** 2))),
             "rms_vs_plaintext_evaluation": float(np.sqrt(np.mean((o - fx["expected"]) ** 2)))}
         hevm.close()
+    return out
+
+
+def streams_leg(hevm, cst, hv, image, ntts_per_image, alg_bytes_per_image, steps=3, counts=(1, 2, 4, 8)):
+    """Throughput mode (hevm_set_streams): S independent ciphertext streams of the SAME program in one VM -- every batched step carries the
+    items of all S images, so the launch chain that bounds one image (~5 300 dependent launches of 4-30 us) is shared by S of them.  This is
+    the regime BASELINE config 5 runs in (streams x GPUs); the headline keeps S = 1 like the reference (one image per run())."""
+    out = {"what": "S independent images of the headline program per run() in one VM (extension hevm_set_streams); value of the headline = the S = 1 row's regime",
+           "rows": []}
+    for S in counts:
+        hevm.set_streams(S)
+        hevm.load_mem(cst, hv)
+        for sidx in range(S):
+            hevm.select_stream(sidx)
+            hevm.setInput(0, image if sidx == 0 else np.roll(image, 13 * sidx))
+        hevm.run()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            hevm.run()
+        dt = (time.perf_counter() - t0) / steps
+        gbs = S * alg_bytes_per_image / dt / 1e9
+        out["rows"].append({"streams": S, "ms_per_run": round(dt * 1e3, 3), "ms_per_image": round(dt * 1e3 / S, 3),
+                            "ntt_per_s": round(S * ntts_per_image / dt), "step_algorithmic_gbs": round(gbs, 1),
+                            "step_algorithmic_frac": round(gbs / HBM_PEAK_GBS, 4)})
+    hevm.set_streams(1)
     return out
 
 
@@ -393,6 +422,7 @@ def build_parser():
     ap.add_argument("--layers", type=int, default=20, help="--program shaped: depth (20 = the traced op mix)")
     ap.add_argument("--streams", type=int, default=1, help="independent ciphertext streams per GPU (throughput mode; 1 = the reference's one image per run)")
     ap.add_argument("--no-lowerings", action="store_true", help="skip the other lowerings of the trace (config.lowerings)")
+    ap.add_argument("--no-streams-leg", action="store_true", help="skip the throughput table (1 / 2 / 4 / 8 streams of the headline program in one VM)")
     ap.add_argument("--no-config4", dest="config4", action="store_false",
                     help="skip BASELINE config 4's shape (ResNet-20 traced at nt = 2^16, N = 2^17, real bootstrapping; ~1 min, ~180 GB of HBM); "
                          "it runs by default since round 3, in a child process before this one touches the GPU")
@@ -772,6 +802,10 @@ def main():
                               "algorithmic_bytes": p2["algorithmic_bytes"],
                               "achieved_gbs": round(p2["algorithmic_bytes"] / dt / 1e9, 1),
                               "rms_vs_torch": float(np.sqrt(np.mean((out2[:10] * 32 - fx["torch_result"]) ** 2)))})
+    # ---- throughput mode on the reference's own key set (BEFORE the next leg adds direct rotation keys to this VM) ----------------
+    streams_tab = None
+    if fx is not None and world == 1 and args.streams == 1 and not args.no_streams_leg and not args.hevm_gz:
+        streams_tab = streams_leg(hevm, cst, hv, image, pst["ntt_equivalents"], pst["algorithmic_bytes"], steps=max(2, args.steps))
     # ---- the same headline program with a direct Galois key for each of its rotation offsets (KeyGenerator::create_galois_keys(steps);
     # the reference's HEaaN runtime keeps such a list, HEAAN_HEVM.cpp:58-64): every rotation one key switch.  NOT the headline: the
     # reference's SEAL runtime only has the default key set (SEAL_HEVM.cpp:82-83), which the headline reproduces hop for hop.
@@ -850,6 +884,8 @@ def main():
         "setup_s_untimed": round(t_setup, 1),
         "decrypted_error": rms,
         "roofline": roof,
+        # the fed regime: S images per run() in one VM (what config 5 multiplies by the GPUs); null with --no-streams-leg / --streams > 1
+        "streams": streams_tab,
         "ntt_micro": micro,
         "cfg3_mul_relin": cfg3,
         "per_op_13_primes": per_op,

@@ -387,7 +387,7 @@ class BootstrapEmitter:
             ct = self._op(OP_MULCP, ct, 1, ct.s * 2.0**up, reg)
         delta = ct.s                                             # p = delta * mu ; after ModRaise t = p + q0 I
         ct = self._op(OP_MODRAISE, ct, self.top, 1.0, self.top)  # from here s is relative to z = slots(t)
-        # Noise budget (round 3; measured with the CPU oracle, tools/boot_precision.py).  What a bootstrap must preserve is
+        # Noise budget (round 3; measured with the CPU oracle, tools/experiments/boot_precision.py).  What a bootstrap must preserve is
         # eps_j = p_j / q0 ~ 2^-(10 + msg_bits) / sqrt(N) per coefficient next to I_j ~ 2, so three absolute error sources that a
         # ciphertext at scale 2^40 would never notice decide the result: (a) key-switch noise of the baby-step rotations (~2^17 per slot
         # at N = 2^15, whatever the scale), (b) the integer rounding of the matrix plaintexts (relative 2^-(bits - 7) of |I|), (c) the

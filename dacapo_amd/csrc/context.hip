@@ -145,6 +145,16 @@ Context::Context(int logN_, int K_, int bits, const u64 *primes_or_null, int ksp
             }
         DC_HIP_CHECK(hipMalloc(&d_tw2, pr.size() * 8));
         DC_HIP_CHECK(hipMemcpy(d_tw2, pr.data(), pr.size() * 8, hipMemcpyHostToDevice));
+        std::vector<u64> ipr((size_t)K * 1026 * 2);
+        for (int i = 0; i < K; i++) {
+            const u64 q = primes[(size_t)i];
+            u64 *row = ipr.data() + (size_t)i * 1026 * 2;
+            for (size_t k = 0; k < 1024; k++) row[2 * k] = itw[(size_t)i * N + k], row[2 * k + 1] = h_mulmod(itw[(size_t)i * N + k], 1ull << 31, q);
+            row[2 * 1024] = h_mods[(size_t)i].inv_n, row[2 * 1024 + 1] = h_mulmod(h_mods[(size_t)i].inv_n, 1ull << 31, q);
+            row[2 * 1025] = h_mods[(size_t)i].inv_n_w, row[2 * 1025 + 1] = h_mulmod(h_mods[(size_t)i].inv_n_w, 1ull << 31, q);
+        }
+        DC_HIP_CHECK(hipMalloc(&d_itw2c, ipr.size() * 8));
+        DC_HIP_CHECK(hipMemcpy(d_itw2c, ipr.data(), ipr.size() * 8, hipMemcpyHostToDevice));
     }
 
     if (!DC_GENERIC_WIDTH) {
@@ -261,7 +271,9 @@ Context::Context(int logN_, int K_, int bits, const u64 *primes_or_null, int ksp
         //     sum_t y_t w_t  =  sum_r 2^(8r) [ sum_{t,p} digit_p(y_t) digit_r(V_{t,p}) ]   (mod m)
         // and the bracket is one int8 dot product of length 8 |S| <= 64 = ONE v_mfma_i32_16x16x64_i8 per (16 coefficients, 16 moduli, r).
         // B fragment of lane l: column l & 15, k = 16 (l >> 4) + j in byte j, k = 8 t + p.
-        hyb_mfma = alpha <= 8 && ksp <= 8 && option(OPT_HYB_MFMA) != 0;
+        // (round 5: up to 12 special primes -- the mod-down's inputs 8..11 go through a second, 32-deep MFMA; their B fragments, 8 bytes per
+        // lane, follow the level's main table: [block][plane][lane])
+        hyb_mfma = alpha <= 8 && ksp <= 12 && option(OPT_HYB_MFMA) != 0;
         if (hyb_mfma) {
             auto balanced = [](u64 v, int8_t *out8) {
                 const u64 C = 0x8080808080808080ull, b = (v + C) ^ C;
@@ -296,8 +308,8 @@ Context::Context(int logN_, int K_, int bits, const u64 *primes_or_null, int ksp
                 // mod-down: inputs z_j (j < ksp), outputs q_i (i < ell)
                 const int nd = hyb_dn_blocks(ell);
                 hyb_bdn_off[(size_t)ell] = bdn.size();
-                const size_t bd = bdn.size();
-                bdn.resize(bd + (size_t)nd * 8 * 64 * 16, 0);
+                const size_t bd = bdn.size(), tail = bd + (size_t)nd * 8 * 64 * 16;
+                bdn.resize(tail + (ksp > 8 ? (size_t)nd * 8 * 64 * 8 : 0), 0);
                 for (int i = 0; i < ell; i++) {
                     const u64 m = primes[(size_t)i];
                     for (int j2 = 0; j2 < ksp; j2++) {
@@ -305,8 +317,13 @@ Context::Context(int logN_, int K_, int bits, const u64 *primes_or_null, int ksp
                         for (int pp = 0; pp < 8; pp++) {
                             int8_t d8[8];
                             balanced(V, d8);
-                            const int k = 8 * j2 + pp, lane = (k / 16) * 16 + (i % 16), j = k % 16;
-                            for (int r = 0; r < 8; r++) bdn[bd + ((((size_t)(i / 16)) * 8 + r) * 64 + lane) * 16 + j] = d8[r];
+                            if (j2 < 8) { // main chunk, v_mfma_i32_16x16x64_i8: lane = 16 (k / 16) + column, byte k % 16, k = 8 j + p
+                                const int k = 8 * j2 + pp, lane = (k / 16) * 16 + (i % 16), j = k % 16;
+                                for (int r = 0; r < 8; r++) bdn[bd + ((((size_t)(i / 16)) * 8 + r) * 64 + lane) * 16 + j] = d8[r];
+                            } else {      // tail, v_mfma_i32_16x16x32_i8: lane = 16 (k / 8) + column, byte k % 8, k = 8 (j - 8) + p
+                                const int lane = (j2 - 8) * 16 + (i % 16);
+                                for (int r = 0; r < 8; r++) bdn[tail + ((((size_t)(i / 16)) * 8 + r) * 64 + lane) * 8 + pp] = d8[r];
+                            }
                             V = h_mulmod(V, 256 % m, m);
                         }
                     }
@@ -352,7 +369,7 @@ void Context::ensure_scratch()
 
 Context::~Context()
 {
-    for (void *p : { (void *)d_mods, (void *)d_tw, (void *)d_itw, (void *)d_tw2, (void *)d_twc2, (void *)d_inv_last, (void *)d_half_mod, (void *)d_ks_pidx, (void *)d_pmod,
+    for (void *p : { (void *)d_mods, (void *)d_tw, (void *)d_itw, (void *)d_tw2, (void *)d_itw2c, (void *)d_twc2, (void *)d_inv_last, (void *)d_half_mod, (void *)d_ks_pidx, (void *)d_pmod,
                      (void *)d_hyb_up, (void *)d_hyb_pidx, (void *)d_hyb_dn, (void *)d_hyb_bup, (void *)d_hyb_bdn, (void *)d_hyb_upmods, (void *)d_hyb_dnmods,
                      (void *)d_hyb_hp })
         if (p) (void)hipFree(p);

@@ -117,6 +117,9 @@ struct Context {
     // N = 2^15, 60-bit build: the forward table as pairs (w, w 2^31 mod q), 16 bytes per entry, for the single-crossing kernel's twiddle-pair
     // multiply (ntt_full.hip, modarith.hpp mulmod_pair); nullptr otherwise
     u64 *d_tw2 = nullptr;
+    // ... and entries 0..1023 of the INVERSE table as pairs + (N^-1, N^-1 2^31) + (N^-1 psi^-bitrev(1), . 2^31): [K][1026][2], the twiddles of the
+    // single-crossing kernel's inverse passes B and A (ntt_full.hip full_inv_pass_b_p / full_inv_pass_a_p)
+    u64 *d_itw2c = nullptr;
     // 60-bit build, every ring: the first 2^k1 entries of each prime's forward table as pairs, [K][2^k1][2] -- all the twiddles a forward COLS
     // phase uses (they depend on the row group only), for ntt_tile.hpp's pair butterflies; nullptr in the generic-width build.
     // option cols_pairs = 0 makes twc2() return nullptr: the tiles then run on words (A/B measurements, and a second implementation for the tests)

@@ -285,31 +285,43 @@ constexpr int kConvStrip = 64; // coefficients per wave
 // constants), one 96-bit assembly, ONE fold (T' >> 60 < 2^18, so (T' >> 60) d + (T' mod 2^60) < 2q), one conditional subtraction -- and the
 // constant K0 = 2^20 (2^64 - 1) / 255 that the offsets added leaves with the caller's own final subtraction (k0 = K0 mod m, plus the
 // mod-down's floor(P/2)).  ~23 instructions.  The generic-width build keeps the 128-bit reduction (T' >> b can exceed 32 bits there).
+// (round 5: a conversion with 9..16 inputs -- the mod-down under 9 special primes -- runs TWO K-chunks per tile, 128 byte products per plane:
+// |sum| <= 2^21, so its accumulators start at 2^21 and every plane value is in [0, 2^22]; T' < 2^78.01, T' >> 60 < 2^19: same recombination)
 constexpr int kPlaneBias = 1 << 20;
-__device__ __forceinline__ u64 hyb_recombine(const v4i (&c)[8], int j, const DModulus &M)
+// Round 5: the constant the plane biases add is no longer subtracted per output with two modular steps.  With e = -(K0 + post) mod m (K0 = the
+// biases' sum, post = the mod-down's floor(P/2) mod q_i; one value per output modulus, computed once per block of moduli),
+// T' + e = sum_r c'_r 2^(8r) + e is congruent to the wanted value itself, and the output is ONE fold of it -- below 2q, which is all its only
+// consumer (the first stage of a forward transform, an F stage) asks for.  The conditional subtraction and the modular subtraction of k0
+// (9-10 of the ~25 instructions per output) become one 64-bit add with carry.  (Putting e's base-256 digits into the MFMA's C operand
+// instead was built first: 8 x 4 more live registers, 152 -> 212 per thread, two waves per SIMD instead of three.)
+__device__ __forceinline__ u64 hyb_recombine(const v4i (&c)[8], int j, const DModulus &M, u64 e)
 {
     const u64 slo = mad32((u32)c[3][j], 1u << 24, mad32((u32)c[2][j], 1u << 16, mad32((u32)c[1][j], 1u << 8, (u64)(u32)c[0][j])));
     const u64 shi = mad32((u32)c[7][j], 1u << 24, mad32((u32)c[6][j], 1u << 16, mad32((u32)c[5][j], 1u << 8, (u64)(u32)c[4][j])));
-    const u64 lo = slo + (shi << 32);
-    const u64 hi = (shi >> 32) + (lo < slo ? 1u : 0u);
+    const u64 l0 = slo + (shi << 32);
+    const u64 lo = l0 + e; // (e < 2^60: T' + e < 2^79)
+    const u64 hi = (shi >> 32) + (l0 < slo ? 1u : 0u) + (lo < l0 ? 1u : 0u);
 #if DC_GENERIC_WIDTH
     return reduce128_any(hi, lo, M);
 #else
     const u32 top = (u32)((hi << 4) | (lo >> 60));
-    const u64 r = mad32(top, M.delta, lo & ((1ull << 60) - 1));
-    return r >= M.q ? r - M.q : r;
+    return mad32(top, M.delta, lo & ((1ull << 60) - 1)); // < 2^60 + 2^19 d < 2q: a lazy residue
 #endif
 }
-// K0 mod m, K0 = 2^20 * 0x0101010101010101 (what the plane biases add to every output)
-__device__ __forceinline__ u64 hyb_plane_bias_mod(const DModulus &M)
+// K0 mod m, K0 = 2^(20 + extra) * 0x0101010101010101 (what the plain plane biases add to every output)
+__device__ __forceinline__ u64 hyb_plane_bias_mod(const DModulus &M, int extra = 0)
 {
     const u64 ones = 0x0101010101010101ull;
-    return reduce128_any(ones >> 44, ones << 20, M);
+    return reduce128_any(ones >> (44 - extra), ones << (20 + extra), M);
 }
 
 // PRE: the inputs already carry the conversion's per-input constant -- and, for DOWN, the rounding offset floor(P/2) phat_inv_j -- (the fused
 // sequence folds them into the inverse transform's last stage and store, hybrid_fused.hip)
-template <bool DOWN, bool PRE>
+// CH: K-chunks per tile.  1 everywhere but the mod-down of a context with 9..12 special primes (config 4's 4-digit key shape: digits of 8
+// under 9 special primes), which takes inputs 8..11 through a second, 32-byte-deep MFMA (v_mfma_i32_16x16x32_i8) into the same accumulators.
+// (First version: a second 64-deep MFMA with its operands kept in registers -- 200 registers per thread, two waves per SIMD, 239 us per
+// launch against the 8-input kernel's 146; the short tail with its B operand loaded where it is used: 162 registers, three waves.)
+template <bool DOWN, bool PRE, int CH = 1>
 __global__ __launch_bounds__(kHT) void hyb_conv_mfma_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, int ell, int ksp, int alpha, int L, int E,
                                                              size_t N, const DModulus *__restrict__ mods, const u64 *__restrict__ cst,
                                                              const v4i *__restrict__ btab, int nblk)
@@ -336,35 +348,56 @@ __global__ __launch_bounds__(kHT) void hyb_conv_mfma_kernel(const u64 *__restric
         outp = out + (size_t)z * ell * N;
         bt = btab;
     }
-    // A fragments: this lane's two inputs t = 2 kb, 2 kb + 1 of its row, times the conversion's per-input constant, as balanced bytes
+    // A fragments: this lane's two inputs t = 8 ch + 2 kb, + 1 of its row, times the conversion's per-input constant, as balanced bytes
+    static_assert(CH == 1 || DOWN, "only the mod-down has more than 8 inputs");
+    constexpr int kBias = kPlaneBias << (CH - 1);
     v4i A[kConvStrip / 16];
+    long A2[CH > 1 ? kConvStrip / 16 : 1]; // the tail chunk: input 8 + kb of this lane's row, 8 balanced bytes
     const u64 C8 = 0x8080808080808080ull;
-    u64 mul[2], add[2];
-    DModulus mi[2];
-#pragma unroll
-    for (int h = 0; h < 2; h++) {
-        const int t = 2 * kb + h, tt = t < a ? t : 0;
-        mi[h] = mods[in_prime0 + tt];
-        mul[h] = DOWN ? cst[tt] : cst[lo + tt];          // phat_inv[j] | qhat_inv[i]
-        add[h] = DOWN ? cst[ksp + tt] : 0;               // floor(P/2) mod p_j | -
-    }
-#pragma unroll
-    for (int tile = 0; tile < kConvStrip / 16; tile++) {
-        const size_t n = n0 + (size_t)tile * 16 + col;
-        u64 y[2];
+    {
+        u64 mul[2], add[2];
+        DModulus mi[2];
 #pragma unroll
         for (int h = 0; h < 2; h++) {
-            const int t = 2 * kb + h;
-            if (t < a) {
-                u64 x = inp[(size_t)t * N + n];
-                if (DOWN && !PRE) x = addmod(x, add[h], mi[h].q);
-                if (!PRE) x = mulmod(x, mul[h], mi[h]);
-                y[h] = (x + C8) ^ C8;
-            } else
-                y[h] = 0;
+            const int t = 2 * kb + h, tt = t < a ? t : 0;
+            mi[h] = mods[in_prime0 + tt];
+            mul[h] = DOWN ? cst[tt] : cst[lo + tt];          // phat_inv[j] | qhat_inv[i]
+            add[h] = DOWN ? cst[ksp + tt] : 0;               // floor(P/2) mod p_j | -
         }
-        A[tile] = v4i{ (int)(u32)y[0], (int)(u32)(y[0] >> 32), (int)(u32)y[1], (int)(u32)(y[1] >> 32) };
+#pragma unroll
+        for (int tile = 0; tile < kConvStrip / 16; tile++) {
+            const size_t n = n0 + (size_t)tile * 16 + col;
+            u64 y[2];
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int t = 2 * kb + h;
+                if (t < a && t < 8) {
+                    u64 x = inp[(size_t)t * N + n];
+                    if (DOWN && !PRE) x = addmod(x, add[h], mi[h].q);
+                    if (!PRE) x = mulmod(x, mul[h], mi[h]);
+                    y[h] = (x + C8) ^ C8;
+                } else
+                    y[h] = 0;
+            }
+            A[tile] = v4i{ (int)(u32)y[0], (int)(u32)(y[0] >> 32), (int)(u32)y[1], (int)(u32)(y[1] >> 32) };
+        }
     }
+    if constexpr (CH > 1) {
+        const int t = 8 + kb, tt = t < a ? t : 0;
+        const DModulus mt = mods[in_prime0 + tt];
+        const u64 mulx = cst[tt], addx = cst[ksp + tt];
+#pragma unroll
+        for (int tile = 0; tile < kConvStrip / 16; tile++) {
+            u64 y = 0;
+            if (t < a) {
+                u64 x = inp[(size_t)t * N + n0 + (size_t)tile * 16 + col];
+                if (!PRE) x = mulmod(addmod(x, addx, mt.q), mulx, mt);
+                y = (x + C8) ^ C8;
+            }
+            A2[tile] = (long)y;
+        }
+    }
+    const long *bt2 = reinterpret_cast<const long *>(bt + (size_t)nblk * 8 * 64); // (the tail's B fragments follow the level's main table)
     for (int blk = 0; blk < nblk; blk++) {
         if (blk * 16 >= n_out) break;
         v4i Bf[8];
@@ -382,17 +415,24 @@ __global__ __launch_bounds__(kHT) void hyb_conv_mfma_kernel(const u64 *__restric
             post = valid ? cst[2 * ksp + e] : 0; // floor(P/2) mod q_i
         }
         const DModulus Mo = mods[valid ? pm : 0];
-        const u64 k0 = addmod(hyb_plane_bias_mod(Mo), post, Mo.q); // (once per block of 16 moduli, not per coefficient)
+        // this lane's column = one output modulus: the constant hyb_recombine adds, once per block of 16 moduli
+        const u64 k0 = addmod(hyb_plane_bias_mod(Mo, CH - 1), post, Mo.q);
+        const u64 eb = k0 ? Mo.q - k0 : 0; // -(K0 + post) mod m, < 2^60
 #pragma unroll
         for (int tile = 0; tile < kConvStrip / 16; tile++) {
             v4i c[8];
+            size_t t2 = (size_t)blk * 8 * 64 + lane;
+            if constexpr (CH > 1) asm volatile("" : "+v"(t2)); // (a per-tile value as far as the optimiser can tell: the tail's B operand is loaded
+                                                               // here, out of L1, instead of living in 16 registers across the tiles)
 #pragma unroll
-            for (int r = 0; r < 8; r++)
-                c[r] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[tile], Bf[r], v4i{ kPlaneBias, kPlaneBias, kPlaneBias, kPlaneBias }, 0, 0, 0);
+            for (int r = 0; r < 8; r++) {
+                c[r] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[tile], Bf[r], v4i{ kBias, kBias, kBias, kBias }, 0, 0, 0);
+                if constexpr (CH > 1) c[r] = __builtin_amdgcn_mfma_i32_16x16x32_i8(A2[tile], bt2[t2 + (size_t)r * 64], c[r], 0, 0, 0);
+            }
             if (valid) { // this lane: rows 4 kb .. 4 kb + 3 of the tile, column `col`
                 u64 v[4];
 #pragma unroll
-                for (int j = 0; j < 4; j++) v[j] = submod(hyb_recombine(c, j, Mo), k0, Mo.q);
+                for (int j = 0; j < 4; j++) v[j] = hyb_recombine(c, j, Mo, eb);
                 u64 *o = outp + (size_t)e * N + n0 + (size_t)tile * 16 + 4 * kb;
                 *reinterpret_cast<u64x2 *>(o) = u64x2{ v[0], v[1] };
                 *reinterpret_cast<u64x2 *>(o + 2) = u64x2{ v[2], v[3] };
@@ -427,7 +467,13 @@ void hyb_launch_conv(Context &c, bool down, bool prescaled, const u64 *in, u64 *
             DC_LAUNCH(hyb_modup_kernel, dim3(gx, (unsigned)G, (unsigned)count), dim3(kHT), 0, s, in, out, ell, ksp, alpha, L, E, N, c.d_mods,
                                c.hyb_up(ell));
     } else {
-        if (mfma && prescaled)
+        if (mfma && prescaled && ksp > 8)
+            DC_LAUNCH((hyb_conv_mfma_kernel<true, true, 2>), dim3(gc, 1, (unsigned)count), dim3(kHT), 0, s, in, out, ell, ksp, alpha, L, E, N,
+                               c.d_mods, c.d_hyb_dn, bdn, c.hyb_dn_blocks(ell));
+        else if (mfma && ksp > 8)
+            DC_LAUNCH((hyb_conv_mfma_kernel<true, false, 2>), dim3(gc, 1, (unsigned)count), dim3(kHT), 0, s, in, out, ell, ksp, alpha, L, E, N,
+                               c.d_mods, c.d_hyb_dn, bdn, c.hyb_dn_blocks(ell));
+        else if (mfma && prescaled)
             DC_LAUNCH((hyb_conv_mfma_kernel<true, true>), dim3(gc, 1, (unsigned)count), dim3(kHT), 0, s, in, out, ell, ksp, alpha, L, E, N,
                                c.d_mods, c.d_hyb_dn, bdn, c.hyb_dn_blocks(ell));
         else if (mfma)

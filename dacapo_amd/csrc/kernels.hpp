@@ -28,6 +28,7 @@ void launch_ntt_two_phase(const Context &c, bool inverse, u64 *data, long limb_s
 // at least ntt_full_min_limbs() limbs (option ntt_full_min_limbs / option ntt_full_inv_min_limbs; 0 = never)
 bool ntt_full_supported(const Context &c);
 long ntt_full_min_limbs(bool inverse);
+bool ntt_full_pays(bool inverse, int count); // ... and the launch fills the persistent grid's last round well enough (ntt_full.hip)
 void launch_ntt_full(const Context &c, bool inverse, u64 *data, long limb_stride, int count, const int *d_prime_idx, int prime_base,
                      int prime_period, hipStream_t s);
 

@@ -242,6 +242,78 @@ __device__ __forceinline__ void full_fwd_pass_b_p(u64 (&x)[32], u32 hi, const u6
         }
     }
 }
+
+// ---- inverse passes B and A with twiddle pairs (round 5) ------------------------------------------------------------------------------
+// Gentleman-Sande on a pair: s = x + y, d = x + 2q - y, (x, y) <- (fold(s), w d) with mulmod_pair.  fold60 takes any 64-bit value to < 2q and
+// the pair product is < 2q, so with inputs below 2q every value stays below 2q and d below 4q < 2^62, mulmod_pair's operand range.  The first
+// pair stage follows a word pass, whose outputs are below 4q: it takes d = x + 4q - y (< 8q) through one more fold.  Same residues as
+// gs_bfly, canonical stores: bit-identical results.
+// Round 3 measured pairs in "any prefix" of the inverse's passes as a loss (1 068-1 138 us against 910): every prefix contains pass C, whose
+// 31 per-thread pairs are 16-byte loads of a table that does not fit L2 twice.  The forward kernel's winning set {A, B} is the inverse's
+// SUFFIX {B, A}: pass B's twiddles depend on the 5-bit field a half-wave carries (two addresses per wave instruction, L1 broadcasts) and
+// pass A's on the register index only (scalar loads) -- the pairs' doubled bytes cost nothing there.  Loading every pair where it is used
+// also drops the eight per-thread multiplications by psi^(N/2) that rebuilt the odd twiddles of pass B's widest stage.
+// Table: Context::d_itw2c, per prime [1026][2]: entries 0..1023 of the inverse table as pairs, then (N^-1, .) and (N^-1 psi^-bitrev(1), .).
+constexpr int kFullInvPairStride = 2 * 1026;
+__device__ __forceinline__ void gs_bfly_p(u64 &x, u64 &y, u64 w, u64 W, const DModulus &M, bool after_words)
+{
+    const u64 s = x + y;
+    u64 d = x + (M.q << (after_words ? 2 : 1)) - y;
+    if (after_words) d = fold60(d, M.delta);
+    x = fold60(s, M.delta);
+    y = mulmod_pair(w, W, d, M.delta);
+}
+__device__ __forceinline__ void full_inv_pass_b_p(u64 (&x)[32], u32 hi, const u64 *__restrict__ tw2, const DModulus &M)
+{
+#pragma unroll
+    for (int u = 4; u >= 0; u--) {
+#pragma unroll
+        for (int g = 0; g < (1 << u); g++) {
+            const ulonglong2 tp = *reinterpret_cast<const ulonglong2 *>(tw2 + 2 * ((size_t)(1u << (5 + u)) + (hi << u) + (u32)g));
+            const int half = 16 >> u;
+#pragma unroll
+            for (int e = 0; e < half; e++) {
+                const int j0 = (g << (5 - u)) | e;
+                gs_bfly_p(x[j0], x[j0 | half], tp.x, tp.y, M, u == 4);
+            }
+        }
+    }
+}
+template <int U>
+__device__ __forceinline__ void full_inv_stage_a_p(u64 (&x)[32], const u64 *__restrict__ tw2, const DModulus &M)
+{
+    if constexpr (U == 0) { // the very last inverse stage carries N^-1: both outputs are products
+        const u64 n0 = tw2[2 * 1024], n1 = tw2[2 * 1024 + 1], w0 = tw2[2 * 1025], w1 = tw2[2 * 1025 + 1];
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            const u64 sv = x[e] + x[e | 16], d = x[e] + (M.q << 1) - x[e | 16]; // inputs < 2q: both below 4q
+            x[e] = mulmod_pair(n0, n1, sv, M.delta);
+            x[e | 16] = mulmod_pair(w0, w1, d, M.delta);
+        }
+    } else {
+#pragma unroll
+        for (int g = 0; g < (1 << U); g++) {
+            const u64 w = tw2[2 * ((1u << U) + (u32)g)], W = tw2[2 * ((1u << U) + (u32)g) + 1]; // wave-uniform: scalar loads
+#pragma unroll
+            for (int e = 0; e < (16 >> U); e++) {
+                const int j0 = (g << (5 - U)) | e;
+                gs_bfly_p(x[j0], x[j0 | (16 >> U)], w, W, M, false);
+            }
+        }
+    }
+}
+__device__ __forceinline__ void full_inv_pass_a_p(u64 (&x)[32], const u64 *__restrict__ tw2, const DModulus &M)
+{
+    full_inv_stage_a_p<4>(x, tw2, M);
+    full_inv_stage_a_p<3>(x, tw2, M);
+    full_inv_stage_a_p<2>(x, tw2, M);
+    full_inv_stage_a_p<1>(x, tw2, M);
+    full_inv_stage_a_p<0>(x, tw2, M);
+}
+#endif
+
+#if !DC_FULL_PAIRS
+constexpr int kFullInvPairStride = 2 * 1026;
 #endif
 
 // 32 x 32 transpose between the register index and lane bits 0..4, inside the wavefront: register bit k <-> lane bit k
@@ -377,6 +449,24 @@ __device__ __forceinline__ void full_limb(u64 *__restrict__ d, const u64 *__rest
 #endif
     FullTw t;
     const u64 im = tw[1]; // psi^(N/2) (forward table) or its inverse (inverse table): wave-uniform
+#if DC_FULL_PAIRS
+    if constexpr (PAIRS && INV) { // pass C on words, passes B and A on pairs
+        const u32 hc = (f << 5) | (u32)lo;
+        full_tw_u4<10>(t, hc, tw);
+#pragma unroll
+        for (int j = 0; j < 32; j++) x[j] = d[(int)f * 1024 + j * 32 + lo]; // regs = b, thread = (a = f, c)
+        full_tr(x, lds, tid);                                  // regs = c, lane bits 0..4 = b
+        full_pass_bc<10, true>(x, t, hc, tw, im, M);
+        full_tr(x, lds, tid);                                  // regs = b, lane bits 0..4 = c
+        full_inv_pass_b_p(x, f, tw2, M);
+        full_tr_sync();
+        full_exchange<IN_LOOP>(y, x, lds, tid);                // regs = a, thread = (b = f, c)
+        full_inv_pass_a_p(y, tw2, M);
+#pragma unroll
+        for (int j = 0; j < 32; j++) d[j * 1024 + tid] = canon(y[j], M);
+        return;
+    }
+#endif
     if (!INV) {
 #if defined(DC_FULL_NO_LOAD) // timing experiment only (wrong results)
 #pragma unroll
@@ -458,7 +548,7 @@ __global__ __launch_bounds__(kFullThreads) void ntt_full15_kernel(u64 *__restric
         const int p = prime_idx ? prime_idx[r] : prime_base + r;
         const DModulus M = mods[p];
         full_limb<INV, true, PAIRS>(data + (long)limb * limb_stride, tw_all + ((size_t)p << kFullLogN),
-                                    PAIRS ? tw2_all + ((size_t)p << (kFullLogN + 1)) : nullptr, M, lds, tid);
+                                    PAIRS ? tw2_all + (INV ? (size_t)p * kFullInvPairStride : (size_t)p << (kFullLogN + 1)) : nullptr, M, lds, tid);
         __syncthreads(); // the next limb's exchange / transposes write what the slowest waves may still be reading
     }
 }
@@ -485,6 +575,25 @@ static int full_persist_grid(bool inverse)
     return g < 0 ? cus : g;
 }
 
+// Does the single-crossing kernel beat the two-launch tiles for this launch?  Its persistent grid runs ceil(count / CUs) rounds of one limb
+// per CU, so a launch just above a multiple of the CU count pays a whole round for a few limbs, while the tiles (16 workgroups per limb)
+// scale smoothly -- and got faster in round 4 (COLS placement).  Measured on the round-5 kernels (profiles/r05_ntt_full_check.txt; single
+// crossing / tiles, us): forward 640 limbs 166 / 138, 768 176 / 177, 1 024 214 / 244, 1 536 321 / 438, 2 048 410 / 580; inverse (pairs in
+// passes B and A) 640 163 / 140, 768 170 / 169, 1 024 219 / 222, 1 536 340 / 364, 2 048 448 / 480, 4 096 850 / 939.  So: from the option's
+// limb count on, when the last round is full enough -- or always from 2 048 limbs on, where the tiles' second crossing leaves the caches.
+bool ntt_full_pays(bool inverse, int count)
+{
+    const long m = ntt_full_min_limbs(inverse);
+    if (m <= 0 || count < m) return false;
+    if (count >= 2048) return true;
+    const int pg = full_persist_grid(inverse);
+    if (pg <= 0) return true; // (one workgroup per limb: no rounds)
+    const long rounds = (count + pg - 1) / pg;
+    // (forward: the single-crossing kernel wins from 768 limbs on whatever the last round holds -- 900 limbs 205 / 223 us, 1 300 298 / 368;
+    //  inverse: only when the last round is full -- 900 limbs 214 / 199, 1 300 318 / 315)
+    return !inverse || (long)count * 100 >= rounds * pg * 96;
+}
+
 static bool full_pairs()
 { // option ntt_full_pairs = 0: word butterflies in every forward pass (A/B measurements; the pair tables exist either way)
     return option(OPT_NTT_FULL_PAIRS) != 0;
@@ -501,6 +610,13 @@ void launch_ntt_full(const Context &c, bool inverse, u64 *data, long limb_stride
     if (!inverse && full_pairs() && c.d_tw2) {
         DC_LAUNCH((ntt_full15_kernel<false, true>), dim3(grid), dim3(kFullThreads), 0, s, data, limb_stride, d_prime_idx, prime_base,
                            prime_period, c.d_mods, c.d_tw, c.d_tw2, count);
+        return;
+    }
+#endif
+#if DC_FULL_PAIRS
+    if (inverse && option(OPT_NTT_FULL_INV_PAIRS) != 0 && c.d_itw2c) {
+        DC_LAUNCH((ntt_full15_kernel<true, true>), dim3(grid), dim3(kFullThreads), 0, s, data, limb_stride, d_prime_idx, prime_base,
+                           prime_period, c.d_mods, c.d_itw, c.d_itw2c, count);
         return;
     }
 #endif

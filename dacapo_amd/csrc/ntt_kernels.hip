@@ -89,7 +89,7 @@ void launch_ntt_rows_inv(const Context &c, u64 *data, long limb_stride, int coun
 void launch_ntt(const Context &c, bool inverse, u64 *data, long limb_stride, int count, const int *d_prime_idx,
                 int prime_base, int prime_period, hipStream_t s)
 {
-    if (ntt_full_supported(c) && ntt_full_min_limbs(inverse) > 0 && count >= ntt_full_min_limbs(inverse))
+    if (ntt_full_supported(c) && ntt_full_pays(inverse, count))
         launch_ntt_full(c, inverse, data, limb_stride, count, d_prime_idx, prime_base, prime_period, s);
     else
         launch_ntt_two_phase(c, inverse, data, limb_stride, count, d_prime_idx, prime_base, prime_period, s);

@@ -161,7 +161,8 @@ __device__ __forceinline__ int cols_tile_of(int bx, int logN)
 // tile, L1 / L2 resident -- so the pairs' doubled bytes cost nothing, unlike a ROWS phase's per-row tables) and the butterflies are
 // ct_bfly_pair: ~13 % fewer VALU instructions per butterfly.  The phase's inputs must be canonical (a forward transform's first phase: they
 // are); its outputs are below 4q, inside every range the ROWS phase's schedule assumes.
-template <int K, int LOGE, bool COLS, bool INV, bool CANON, bool PRELOADED, bool KEEP, bool PAIRS, class Ld, class St>
+// FOLD0 (PAIRS only): fold x in stage 0 as well -- for callers whose inputs are residues below 4q but not necessarily canonical
+template <int K, int LOGE, bool COLS, bool INV, bool CANON, bool PRELOADED, bool KEEP, bool PAIRS, bool FOLD0 = false, class Ld, class St>
 __device__ __forceinline__ void ntt_tile_core(u64 (&x)[1 << LOGE], const DModulus M, const u64 *__restrict__ tw, int logN, int tile,
                                               Ld ld, St st, u64 *__restrict__ lds, const u64 (*wext)[1 << LOGE] = nullptr)
 {
@@ -280,7 +281,7 @@ __device__ __forceinline__ void ntt_tile_core(u64 (&x)[1 << LOGE], const DModulu
                         const int j0 = (u << r) | (g << (r - st_)) | e, j1 = j0 | half;
                         if constexpr (PAIRS) {
 #if !DC_GENERIC_WIDTH
-                            ct_bfly_pair(x[j0], x[j1], w, W2, M, gs != 0); // (stage 0 of a forward transform: canonical inputs)
+                            ct_bfly_pair(x[j0], x[j1], w, W2, M, gs != 0 || FOLD0); // (stage 0 of a forward transform: canonical inputs unless FOLD0)
 #endif
                         } else if (!INV)
                             ct_bfly(x[j0], x[j1], w, M, fwd_stage_folds(gs));
@@ -346,13 +347,13 @@ __device__ __forceinline__ void ntt_tile_x(u64 (&x)[1 << LOGE], const DModulus M
 }
 // forward COLS tile; tw2 = the prime's pair table when the context has one (60-bit build), else nullptr and `tw` is used on words.
 // (the choice is uniform over the launch; both branches are instantiated)
-template <int K, int LOGE, bool CANON, bool PRELOADED, bool KEEP, class Ld, class St>
+template <int K, int LOGE, bool CANON, bool PRELOADED, bool KEEP, bool FOLD0 = false, class Ld, class St>
 __device__ __forceinline__ void ntt_tile_fcols(u64 (&x)[1 << LOGE], const DModulus M, const u64 *__restrict__ tw, const u64 *__restrict__ tw2,
                                                int logN, int tile, Ld ld, St st, u64 *__restrict__ lds)
 {
 #if !DC_GENERIC_WIDTH
     if (tw2) {
-        ntt_tile_core<K, LOGE, true, false, CANON, PRELOADED, KEEP, true>(x, M, tw2, logN, tile, ld, st, lds);
+        ntt_tile_core<K, LOGE, true, false, CANON, PRELOADED, KEEP, true, FOLD0>(x, M, tw2, logN, tile, ld, st, lds);
         return;
     }
 #endif

@@ -39,11 +39,12 @@ static const OptDef kDefs[OPT_COUNT] = {
     { "step_profile", 0 },
     { "small_tile_wgs", -1 },
     { "tiny_tile_wgs", 2000 },
-    { "ntt_full_min_limbs", 640 },
-    { "ntt_full_inv_min_limbs", 2048 },
+    { "ntt_full_min_limbs", 768 },
+    { "ntt_full_inv_min_limbs", 768 },
     { "ntt_full_persist", -1 },
     { "ntt_full_inv_persist", -1 },
     { "ntt_full_pairs", 1 },
+    { "ntt_full_inv_pairs", 1 },
     { "cols_pairs", 1 },
     { "ks_merge_special_min_wgs", 2048 },
     { "ks_merge_lift_min_wgs", 1024 },

@@ -46,6 +46,7 @@ enum Opt : int {
     OPT_NTT_FULL_PERSIST,        // workgroups of its persistent grid (-1: one per CU; 0: one workgroup per limb)
     OPT_NTT_FULL_INV_PERSIST,    // ... inverse (-1: same as forward)
     OPT_NTT_FULL_PAIRS,          // twiddle pairs in its forward passes A and B
+    OPT_NTT_FULL_INV_PAIRS,      // twiddle pairs in its inverse passes B and A
     OPT_COLS_PAIRS,              // twiddle pairs in the forward COLS tiles of the fused key-switch / rescale phases (60-bit build)
     OPT_KS_MERGE_SPECIAL_MIN_WGS, // fused key-switch middle: one workgroup row for both special-prime accumulators from this many workgroups
     OPT_KS_MERGE_LIFT_MIN_WGS,   // L2 / L6: share the inverse phase among a source limb's targets while this many workgroups remain

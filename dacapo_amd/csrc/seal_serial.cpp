@@ -174,13 +174,7 @@ static std::vector<uint8_t> deflate_all(const uint8_t *in, size_t n)
             const size_t chunk = n - in_pos < (1u << 30) ? n - in_pos : (1u << 30);
             zs.next_in = const_cast<Bytef *>(in + in_pos), zs.avail_in = (uInt)chunk, in_pos += chunk;
         }
-        if (out_pos == out.size()) {
-            if (out.size() >= limit) {
-                inflateEnd(&zs);
-                r.fail(kBombMsg);
-            }
-            out.resize(std::min(out.size() * 2, limit));
-        }
+        if (out_pos == out.size()) out.resize(out.size() * 2);
         const size_t room = out.size() - out_pos < (1u << 30) ? out.size() - out_pos : (1u << 30);
         zs.next_out = out.data() + out_pos, zs.avail_out = (uInt)room;
         rc = deflate(&zs, in_pos >= n ? Z_FINISH : Z_NO_FLUSH);

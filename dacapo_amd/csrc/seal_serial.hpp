@@ -106,7 +106,8 @@ struct CtHeader { // Ciphertext members before the data array
     double scale = 1.0;
 };
 void put_ciphertext(Writer &w, const CtHeader &h, const uint64_t *data);
-// reads the members of a Ciphertext; `data` points into the reader's storage (size * limbs * N words)
+// reads the members of a Ciphertext; `data` points into the reader's storage (size * limbs * N words).  The array sits behind a 1-byte
+// field, so the pointer is NOT 8-byte aligned: copy from it (memcpy / hipMemcpy, what every caller does), never dereference it as uint64_t
 CtHeader get_ciphertext(Reader &members, const uint64_t *&data);
 
 struct PtHeader {

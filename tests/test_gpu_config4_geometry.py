@@ -29,16 +29,20 @@ def _threads():
     orc_lib().orc_set_threads(min(8, os.cpu_count() or 1))   # OpenMP over limbs: same arithmetic per limb (tests/test_oracle_hybrid.py)
 
 
-def test_rotate_hop_and_mul_relin_at_config4_geometry_match_the_oracle():
+# (8, 7): the shape config 4 has run on since round 3 (5 digits at the top level).  (9, 8): round 5's cheaper key shape -- digits of 8 under 9
+# special primes, 4 digits, P still above a digit -- whose mod-down has 9 inputs: two K-chunks per matrix-core tile (hybrid_ks.hip).
+@pytest.mark.parametrize("KS,ALPHA", [(8, 7), (9, 8)])
+def test_rotate_hop_and_mul_relin_at_config4_geometry_match_the_oracle(KS, ALPHA):
     from dacapo_amd import lowlevel as ll
     from dacapo_amd import runner
 
     _threads()
     N = 1 << LOGN
+    K4 = 31 + KS
     o = Oracle(LOGN, K4)
     o.set_hybrid(KS, ALPHA)
     ctx = ll.Context(LOGN, K4, special=KS, alpha=ALPHA)
-    assert ctx.primes == o.primes and ctx.key_digits == o.dnum == 5 and ctx.max_level == o.max_level == 31
+    assert ctx.primes == o.primes and ctx.key_digits == o.dnum == -(-31 // ALPHA) and ctx.max_level == o.max_level == 31
     pr = np.array(o.primes, dtype=np.uint64)
     # a key is a constant of the key switch: uniform limbs exercise every residue path (a real key's limbs ARE uniform)
     keys = []
@@ -50,7 +54,7 @@ def test_rotate_hop_and_mul_relin_at_config4_geometry_match_the_oracle():
     o.galois[elt], o.relin = keys
     dk, dr = ll.DeviceBuffer.from_host(keys[0]), ll.DeviceBuffer.from_host(keys[1])
     L = ll.lib()
-    for ell in (1, 3, 4, 7, 8, 14, 31):
+    for ell in ((1, 3, 4, 7, 8, 14, 31) if ALPHA == 7 else (3, 4, 8, 9, 14, 31)):  # (alpha = 8: one digit exactly at 8, a one-prime last digit at 9)
         q = pr[:ell, None]
         a = np.stack([np.stack([splitmix_fill(1 + 7 * p + i + 100 * ell, N) for i in range(ell)]) % q for p in range(2)])
         b = np.stack([np.stack([splitmix_fill(99 + 7 * p + i + 100 * ell, N) for i in range(ell)]) % q for p in range(2)])
@@ -69,8 +73,9 @@ def test_rotate_hop_and_mul_relin_at_config4_geometry_match_the_oracle():
                 assert (dd.to_host() == want_mul).all(), ("mul_relin", ell, fuse)
 
 
-@pytest.mark.parametrize("plan,fuse", [(1, 1), (0, 1), (1, 2), (1, 0)])
-def test_hoisted_rotation_batch_at_config4_geometry_matches_the_oracle_vm(tmp_path, plan, fuse):
+@pytest.mark.parametrize("plan,fuse,KS,ALPHA", [(1, 1, 8, 7), (0, 1, 8, 7), (1, 2, 8, 7), (1, 0, 8, 7), (1, 2, 9, 8), (0, 2, 9, 8)])
+def test_hoisted_rotation_batch_at_config4_geometry_matches_the_oracle_vm(tmp_path, plan, fuse, KS, ALPHA):
+    K4 = 31 + KS
     from dacapo_amd import hevm_asm as ha
     from dacapo_amd import lowlevel as ll
     from dacapo_amd import runner
@@ -100,7 +105,7 @@ def test_hoisted_rotation_batch_at_config4_geometry_matches_the_oracle_vm(tmp_pa
     cst, hv, _ = b.assemble()
     runner.set_option("hyb_fuse", fuse)                                # (a launch-shape option: read at every launch, i.e. when the plan's graph is recorded)
     hevm = runner.HEVM(seed=5, logN=LOGN, num_primes=K4, ks_special=KS, ks_alpha=ALPHA, vm_options={"plan": plan})
-    assert hevm.max_level == 31 and hevm.key_digits == 5
+    assert hevm.max_level == 31 and hevm.key_digits == -(-31 // ALPHA)
     hevm.addRotationKeys(direct)
     o = Oracle(LOGN, K4)
     o.set_hybrid(KS, ALPHA)

@@ -848,3 +848,86 @@ def test_bounded_rotation_key_set_serves_every_offset(tmp_path, plan, ks):
     o.rot_compose = False
     assert sum(len(o.rotate_hops(off)) for off in offsets) > total                              # SEAL's NAF over +-2^k takes more hops
     hevm.close()
+
+
+@pytest.mark.parametrize("plan", [1, 0])
+def test_duplicate_rotations_keep_their_own_scale_metadata_under_rot_compose(tmp_path, plan):
+    """option rot_compose memoises a hop (value, Galois element): two rotations of one value by one offset name the same limbs.  The
+    reference's scale overwrites (addcc sets lhs.scale = rhs.scale on ONE register, SEAL_HEVM.cpp:301) must not reach the other register,
+    and a rotation issued after such an overwrite carries its operand's scale, not the memoised value's (round-4 advisor finding on
+    plan_exec.hip hop_memo).  Raw program: r2 = rot(x, 9); r3 = rot(x, 9); r4 = r2 + y (y at another scale: r2's label is overwritten);
+    r5 = rot(x, 9); r6 = r3 + y.  Every result register: level, scale label and limbs == the oracle VM with the same composition rule."""
+    from dacapo_amd import hevm_asm as ha
+    from dacapo_amd import lowlevel as ll
+    from dacapo_amd import runner
+
+    logN, K = 12, 5
+    ROT, ADDCC = ha.OP_ROTATE, ha.OP_ADDCC
+    ops = [(ROT, 2, 0, 9), (ROT, 3, 0, 9), (ADDCC, 4, 2, 1), (ROT, 5, 0, 9), (ADDCC, 6, 3, 1), (ROT, 7, 2, 9)]
+    res = [2, 3, 4, 5, 6, 7]
+    hv = ha.pack_hevm([30, 25], [4, 4], [30] * len(res), [4] * len(res), res, 8, 1, 4, np.array(ops, dtype=np.uint16))
+    cst = ha.pack_cst([np.array([1.0])])
+    hevm = runner.HEVM(seed=17, logN=logN, num_primes=K, vm_options={"plan": plan, "rot_compose": 1})
+    hevm.addRotationKeys([3, 6])  # 9 = 3 + 6 under the bounded set (two hops, the first shared by every rotation here)
+    o = Oracle(logN, K)
+    o.rot_compose = True
+    elts = sorted(set(o.default_galois_elts()) | {o.elt_from_step(s) for s in (3, 6)})
+    _import_keys(o, hevm, ll, elts=elts)
+    assert len(o.rotate_hops(9)) == 2
+    hevm.load_mem(cst, hv)
+    ovm = _mirror_vm(hevm, ll, o, cst, hv, tmp_path)
+    rng = np.random.default_rng(4)
+    for i in range(2):
+        hevm.setInput(i, rng.uniform(-1, 1, 1 << (logN - 1)))
+        ovm.ciphers[i] = _get_ct(hevm, ll, i)
+    hevm.run()
+    ovm.run()
+    for r in res:
+        got, want = _get_ct(hevm, ll, r), ovm.ciphers[r]
+        assert got.ell == want.ell and got.scale == want.scale, (r, got.scale, want.scale)
+        assert (got.data == want.data).all(), r
+    assert _get_ct(hevm, ll, 2).scale == 2.0**25 and _get_ct(hevm, ll, 3).scale == 2.0**25  # both overwritten, each by its own addcc
+    assert _get_ct(hevm, ll, 5).scale == 2.0**30 and _get_ct(hevm, ll, 7).scale == 2.0**25  # operand's scale at the time of the rotation
+    if plan:  # x -> 9 costs two hops once; r7 rotates r2 (another value): two more
+        assert hevm.stats()["keyswitches"] == 4
+    hevm.close()
+
+
+def test_explicit_dag_equals_captured_graph_with_fused_links_and_opcode10(tmp_path):
+    """plan_graph = 2 (the plan's graph built node by node from its own dependencies) against plan_graph = 1 (captured from two streams) on
+    a program with chain-fusion links (ct x ct -> rescale, rescale -> opcode 10) and opcode 10 in it, zero-encryption hook on so that the
+    results are deterministic: identical limbs in every result register, run twice (the epoch bump sits at the graph's tail in both forms,
+    where issue_plan puts it: round-4 advisor finding on capture_plan_dag)."""
+    from dacapo_amd import hevm_asm as ha
+    from dacapo_amd import lowlevel as ll
+    from dacapo_amd import runner
+
+    logN, K = 12, 5
+    slots = 1 << (logN - 1)
+    rng = np.random.default_rng(8)
+    b = ha.Builder(slots=slots, init_level=K - 1, policy="lazy", boot_level=2, shadow=True)
+    x, y = b.input(rng.uniform(-1, 1, slots)), b.input(rng.uniform(-1, 1, slots))
+    p = b.mul(x, y)
+    q = b.mul(b.rotate(p, 3), b.add(p, x))
+    r = b.mul(q, q)
+    r = b.mul(r, b.rotate(r, 5))   # runs out of primes on the way: the lazy policy re-encrypts (opcode 10)
+    b.output(b.finish(b.add(r, b.mul_plain(x, [0.5]))))
+    cst, hv, info = b.assemble()
+    assert info["op_mix"].get("bootstrap", 0) >= 1
+    outs = {}
+    for mode in (1, 2):
+        hevm = runner.HEVM(seed=23, logN=logN, num_primes=K, vm_options={"plan_graph": mode})
+        runner.lw.hevm_test_zero_encryption(hevm.vm, True)
+        hevm.load_mem(cst, hv)
+        for i, a in enumerate(b.args):
+            hevm.setInput(i, a.plain)
+        runs = []
+        for _ in range(2):
+            hevm.run()
+            runs.append(_get_ct(hevm, ll, hevm.res_idx(0) if hasattr(hevm, "res_idx") else int(hevm.lw.getResIdx(hevm.vm, 0))))
+        assert runs[0].ell == runs[1].ell and (runs[0].data == runs[1].data).all()
+        st = hevm.stats()
+        outs[mode] = (runs[1], st["keyswitches"])
+        hevm.close()
+    assert outs[1][1] == outs[2][1]
+    assert outs[1][0].ell == outs[2][0].ell and outs[1][0].scale == outs[2][0].scale and (outs[1][0].data == outs[2][0].data).all()

@@ -84,7 +84,7 @@ timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/po -- p
 cp $(ls $OUT/po/*/*kernel_stats.csv | head -1) $OUT/${R}_per_op_kernel_stats.csv
 rm -rf $OUT/po
 cd $ROOT
-python tools/dag_width.py > /dev/null 2> $OUT/${R}_dag_width.txt
+python tools/experiments/dag_width.py > /dev/null 2> $OUT/${R}_dag_width.txt
 for n in 512 1024 2048 4096; do python tools/ntt_full_check.py $n 20; done > $OUT/${R}_ntt_full_check.txt 2>/dev/null
 python tools/chain_bench.py > $OUT/${R}_chain_latency.txt 2>/dev/null
 for s in 2 4 8; do python bench.py --streams $s --no-cpu-baseline --no-lowerings --no-config4 2>/dev/null | python tools/bench_brief.py; done > $OUT/${R}_streams.txt

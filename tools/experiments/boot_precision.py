@@ -5,10 +5,10 @@ the decrypted polynomials (a bootstrap works on coefficients; a slot error is sq
 the ModRaise overflow I of that coefficient: noise entering before EvalMod's double angles is amplified by 2^r / sin(theta(I)) and shows
 up as a dependence on I; noise of the linear transforms does not.  Round 3 used it to find the three dominant terms (key-switch
 noise of the baby-step rotations, matrix-plaintext rounding, the conjugation's key switch; ckks_boot.BootstrapEmitter.bootstrap).
-    python tools/boot_precision.py logN secret_weight [msg_bits=0] [amplitude=1]      (N = 2^13: 20 s, N = 2^15: 2 min)"""
+    python tools/experiments/boot_precision.py logN secret_weight [msg_bits=0] [amplitude=1]      (N = 2^13: 20 s, N = 2^15: 2 min)"""
 import sys, time, os, tempfile
 from pathlib import Path
-sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))
 import numpy as np
 from dacapo_amd import ckks_boot as cb, hevm_asm as ha
 from oracle.oracle import Oracle, OracleVM

@@ -2,11 +2,11 @@
 """How wide is the headline program's dataflow graph?  Runs the ResNet-20 HEVM program with the plan issued step by step, synchronised
 after every step (option step_profile), and prints (stderr of the library) the sum of all step times next to the sum over waves of each
 wave's LONGEST step: the second number is what a scheduler with unlimited concurrency inside a wave -- more streams, an explicitly
-built HIP graph with the plan's own dependencies -- could reach at best.     python tools/dag_width.py [fixture=resnet20]"""
+built HIP graph with the plan's own dependencies -- could reach at best.     python tools/experiments/dag_width.py [fixture=resnet20]"""
 import sys
 from pathlib import Path
 
-ROOT = Path(__file__).resolve().parent.parent
+ROOT = Path(__file__).resolve().parent.parent.parent
 sys.path.insert(0, str(ROOT))
 from dacapo_amd import hevm_asm as ha  # noqa: E402
 from dacapo_amd import runner  # noqa: E402

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """The single-crossing NTT (ntt_full.hip) against the two-launch tiles on the GPU: bit-exactness (forward, inverse, round trip) and the
-time of both over `limbs` limbs of N = 2^15.   python tools/ntt_full_check.py [limbs=4096] [iters=10]"""
+time of both over `limbs` limbs of N = 2^15.   python tools/ntt_full_check.py [limbs=4096] [iters=10] [--opt name=value ...]"""
 import json
 import sys
 from pathlib import Path
@@ -9,6 +9,9 @@ import numpy as np
 
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from dacapo_amd import lowlevel as ll  # noqa: E402
+from dacapo_amd import runner  # noqa: E402
+
+sys.argv = runner.apply_cli_options(sys.argv)  # --opt name=value (e.g. ntt_full_inv_pairs=0)
 
 limbs = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 10

@@ -149,7 +149,7 @@ rows = [bench_row("r04"), traffic_row("r04"), step_row("r04"), valu_row("r04"),
         f"and the inner products among them: {first_lines('r04_boot_kernel_bytes.txt', 'bootstrap:', 1)}; {kb_rows('r04_boot_kernel_bytes.txt', 'hyb_mac_kernel<0>|b_sum_group_kernel|b_sum_pair_kernel|ntt_phase_kernel<8, 3, true, false, false>', 4)} "
         "(the process = key generation + encoding + 3 runs).  The counter passes run on one bootstrap because rocprofv3's counter mode "
         "crashes or hangs on the whole config-4 program (`r04_experiments.txt` item 12) | three passes of `tools/boot_demo.py 17 5 1 14 8 7` (`--pmc FETCH_SIZE` / `WRITE_SIZE` with `--opt plan_graph=0`), `tools/kernel_bytes.py` |",
-        f"| `r04_dag_width.txt` | the headline program's dataflow graph: {first_lines('r04_dag_width.txt', 'waves,')}; replay times: {first_lines('r04_dag_width.txt', 'graph replay', 4)} | `python tools/dag_width.py` |",
+        f"| `r04_dag_width.txt` | the headline program's dataflow graph: {first_lines('r04_dag_width.txt', 'waves,')}; replay times: {first_lines('r04_dag_width.txt', 'graph replay', 4)} | `python tools/experiments/dag_width.py` |",
         f"| `r04_per_op.json`, `r04_per_op_kernel_stats.csv` | the three expensive opcodes at 13 primes and config 3, kernel by kernel: {stats('r04_per_op_kernel_stats.csv', 3)} | `rocprofv3 --kernel-trace --stats -- python3 tools/per_op_only.py 20` |",
         f"| `r04_kernel_stats.csv`, `r04_by_kernel_and_grid.txt`, `r04_timeline.txt`, `r04_top_kernels.json` | the bench command under the kernel trace: {first_lines('r04_timeline.txt', 'last run', 1)} | `rocprofv3 --kernel-trace --stats … -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-lowerings --no-config4` |",
         "| `r04_experiments.txt` | what was measured on the way and how it came out: the fused sequence's first versions, tile-geometry sweeps per ring, loader vs matrix-core conversions, the explicit graph, mixed chains, bounded key sets | — |",
