@@ -456,22 +456,27 @@ def config4_child():
     About 180 GB of keys and plaintexts: it runs in CHILD processes started before this one touches the GPU (the reference's ABI has no
     destroy symbol, so the other legs' VMs stay resident until exit).  Round 4: the same program also on a mixed 60 / 51-bit chain
     (`chains`) and under bounded rotation-key sets (`key_sets`: the reference HEaaN runtime's 49 offsets, 96 keys, one per offset)."""
-    res = _config4_run([1, "resnet20_nt16", 17, 1, "b14", 8, 7])
+    res = _config4_run([1, "resnet20_nt16", 17, 1, "b14", CONFIG4["ks_special"], CONFIG4["ks_alpha"]])
     if "error" in res:
         return res
     res["program"] = ("tests/golden/resnet20_nt16.b14: bootstraps at the model script's own hints (before every activation), each restoring 14 "
-                      "primes -> 38 real bootstraps (round 2: 541 restoring 3); 31 data + 8 special 60-bit primes")
-    res["keys"] = ("grouped-digit hybrid key switching (extension, hybrid_ks.hip / hybrid_fused.hip): 5 digits of 7 primes, P = 8 primes; one direct "
-                   "Galois key per rotation offset (286 keys x 0.39 GB)")
-    res["security"] = "N = 2^17, log2(QP) = 39 x 60 = 2340 bits, sparse ternary secret (h = 64): inside the 128-bit range for N = 2^17"
-    res["history"] = "round 2: 47.2 s, rms_vs_torch 0.152 (541 bootstraps restoring 3 primes, one-prime-per-digit keys); round 3: 4.0 s"
+                      "primes -> 38 real bootstraps (round 2: 541 restoring 3); 31 data + 9 special 60-bit primes")
+    res["keys"] = ("grouped-digit hybrid key switching (extension, hybrid_ks.hip / hybrid_fused.hip): 4 digits of 8 primes, P = 9 primes (round 5; "
+                   "rounds 3-4: 5 digits of 7 under 8 special primes, `key_shapes`); one direct Galois key per rotation offset (286 keys x 0.34 GB)")
+    res["security"] = "N = 2^17, log2(QP) = 40 x 60 = 2400 bits, sparse ternary secret (h = 64): inside the 128-bit range for N = 2^17"
+    res["history"] = ("round 2: 47.2 s, rms_vs_torch 0.152 (541 bootstraps restoring 3 primes, one-prime-per-digit keys); round 3: 4.0 s; round 4: "
+                      "3.14-3.17 s (digits of 7 under 8 special primes, 117 GB of rotation keys)")
     res["ntt_equivalents_note"] = ("counted per key switch as G (l + k) + 2 k + 2 l; rotations of one ciphertext in a wave share their decomposition "
                                    "(hoisting), so fewer transforms than that are executed")
     res["reference"] = "README.md:131-136: DaCapo's cost model estimates 13.6 s for its 19-bootstrap HEaaN plan (not measured)"
     brief = lambda r: ({k: r.get(k) for k in ("chain", "log2_QP", "primes", "special_primes", "primes_per_digit", "rotation_keys", "rotation_key_bytes",
                                              "rot_compose", "run_s", "key_switches", "ntt_equivalents", "rms_vs_torch", "fixture", "command")}
                        if "error" not in r else r)
-    mixed = _config4_run([1, "resnet20_nt16", 17, 1, "b14r51", 8, 7, "mixed_app"])
+    ks, al = CONFIG4["ks_special"], CONFIG4["ks_alpha"]
+    res["key_shapes"] = {"what": "the same run under rounds 3-4's key shape: 5 digits of 7 primes under 8 special primes (39 primes, 117 GB of rotation "
+                                 "keys).  Round 5's shape needs a 9-input mod-down on the matrix cores (two K-chunks per tile, hybrid_ks.hip)",
+                         "digits_of_8_under_9": brief(res), "digits_of_7_under_8": brief(_config4_run([1, "resnet20_nt16", 17, 1, "b14", 8, 7]))}
+    mixed = _config4_run([1, "resnet20_nt16", 17, 1, "b14r51", ks, al, "mixed_app"])
     res["chains"] = {"what": "the same trace on the 60-bit chain (libSEAL_HEVM.so) and on a HEaaN-style mixed chain -- 60-bit base prime, 51-bit rescale "
                              "primes for the program's 13 levels, 60-bit primes for the bootstrap's 17 levels and the 8 special ones -- through the "
                              "generic-width build (libSEAL_HEVM_gw.so); the program is lowered for the chain's rescale width (b14 / b14r51)",
@@ -482,13 +487,14 @@ def config4_child():
     res["key_sets"] = {"what": "the 60-bit run under bounded rotation-key sets: the reference HEaaN runtime's 49 left-rotation offsets (HEAAN_HEVM.cpp:"
                                "58-64), that list plus the program's most used other offsets up to 96 keys, and one key per offset (286); rotations "
                                "without a direct key are the shortest sum of offsets that have one (option rot_compose)",
-                       "49": brief(_config4_run([49, "resnet20_nt16", 17, 1, "b14", 8, 7])),
-                       "96": brief(_config4_run([96, "resnet20_nt16", 17, 1, "b14", 8, 7])),
+                       "49": brief(_config4_run([49, "resnet20_nt16", 17, 1, "b14", ks, al])),
+                       "96": brief(_config4_run([96, "resnet20_nt16", 17, 1, "b14", ks, al])),
                        "286": brief(res)}
     return res
 
 
-CONFIG4 = {"fixture": "resnet20_nt16", "lowering": "b14", "logN": 17, "ks_special": 8, "ks_alpha": 7, "msg_bits": 1, "secret_hw": 64}
+# (round 5: digits of 8 primes under 9 special primes -- 4 digits at the top level instead of 5, 96 instead of 117 GB of rotation keys, same accuracy)
+CONFIG4 = {"fixture": "resnet20_nt16", "lowering": "b14", "logN": 17, "ks_special": 9, "ks_alpha": 8, "msg_bits": 1, "secret_hw": 64}
 
 
 def config4_program():

@@ -84,7 +84,8 @@ def test_one_real_bootstrap_at_n17():
     hevm.close()
 
 
-def test_config4_resnet20_nt16_with_real_bootstraps_decrypts_to_the_torch_logits(fixture_nt16):
+@pytest.mark.parametrize("ks,alpha", [(9, 8), (8, 7)])   # round 5's key shape (4 digits of 8 under 9 special primes) and rounds 3-4's
+def test_config4_resnet20_nt16_with_real_bootstraps_decrypts_to_the_torch_logits(fixture_nt16, ks, alpha):
     """the nt = 2^16 trace lowered with its bootstraps at the model script's own hints (examples/benchmarks/ResNet.py:65-123: before every
     activation), each restoring 14 primes: 38 REAL bootstraps (round 2: 541 restoring 3), on a chain of 31 data + 8 special primes with
     grouped-digit hybrid key switching (7 primes per digit, rotations of one ciphertext sharing their decomposition; dacapo_amd/csrc/hybrid_ks.hip)
@@ -99,13 +100,12 @@ def test_config4_resnet20_nt16_with_real_bootstraps_decrypts_to_the_torch_logits
     hv0 = gzip.open(str(GOLDEN) + ".b14.hevm.gz").read()
     ops0 = ha.unpack_hevm(hv0)["ops"]
     assert int((ops0[:, 0] == ha.OP_BOOTSTRAP).sum()) == 38 and {int(r) for o, _, _, r in ops0.tolist() if o == ha.OP_BOOTSTRAP} == {14}
-    ks, alpha = 8, 7
     K = 14 + cb.boot_levels() + ks
     hv, cst = cb.lower_bootstraps(hv0, fx["cst"], 17, K, msg_bits=1, ks=ks)    # bootstrapped values are the activations' inputs: |x| <= 1
     ops = ha.unpack_hevm(hv)["ops"]
     assert int((ops[:, 0] == ha.OP_BOOTSTRAP).sum()) == 0 and int((ops[:, 0] == ha.OP_MODRAISE).sum()) == 38
     hevm = runner.HEVM(seed=0x4845564D, logN=17, num_primes=K, ks_special=ks, ks_alpha=alpha, vm_options={"secret_hw": 64})
-    assert hevm.max_level == 31 and hevm.key_digits == 5
+    assert hevm.max_level == 31 and hevm.key_digits == -(-31 // alpha)
     hevm.addRotationKeys(cb.rotation_offsets(hv))
     hevm.load_mem(cst, hv)
     hevm.setInput(0, fx["packed"])

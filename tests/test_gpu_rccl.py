@@ -63,7 +63,7 @@ def test_bench_config5_code_path_through_rccl_at_world_size_1():
     line, _ = _run_bench(["--program", "config4"], 1500)
     assert line["n_gpus"] == 1 and line["measured_on_hardware"] is True and line["dry_run"] is False
     keys = line["config"]["keys"]
-    assert keys["mode"] == "broadcast" and keys["broadcast_bytes"] > 100e9 and len(keys["digest"]) == 16
+    assert keys["mode"] == "broadcast" and keys["broadcast_bytes"] > 90e9 and len(keys["digest"]) == 16
     assert line["config"]["key_switches_per_step"] > 10000 and line["config"]["rotation_keys"] >= 286
     assert line["decrypted_error"]["rms_vs_torch"] < 2e-3
     assert 1.0 < line["hevm_wall_s"] < 10.0

@@ -1,10 +1,10 @@
 #!/bin/bash
 # Everything under profiles/ for one round, collected on the GPU box in one gpurun call:
-#   gpurun --timeout 3000 -- 'bash tools/collect_profiles.sh r04'
+#   gpurun --timeout 3000 -- 'bash tools/collect_profiles.sh r05'
 # Outputs go to gpurun_out/<round>/ (merged back by gpurun); copy the summaries into profiles/ afterwards.
 # rocprofv3 runs with the program directly after `--`, counters (--pmc) in their own passes, kernel-trace / stats only.
 set -u
-R=${1:-r04}
+R=${1:-r05}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/$R
 mkdir -p $OUT
@@ -38,16 +38,16 @@ rm -rf $OUT/hk $OUT/hf $OUT/hw
 # B3. config 4 (N = 2^17, 38 real bootstraps, grouped-digit keys): kernel-time table of the whole run; measured HBM bytes per kernel on ONE
 #     bootstrap of the same geometry (rocprofv3 --pmc on the whole config-4 program crashes or hangs: profiles/r04_experiments.txt item 12)
 cd /tmp
-C4="$ROOT/tools/resnet_real_boot.py 1 resnet20_nt16 17 1 b14 8 7"
+C4="$ROOT/tools/resnet_real_boot.py 1 resnet20_nt16 17 1 b14 9 8"
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c4 -- python3 $C4 > $OUT/${R}_config4_under_profiler.txt 2> $OUT/c4.err
 cp $(ls $OUT/c4/*/*kernel_stats.csv | head -1) $OUT/${R}_config4_kernel_stats.csv
 rm -rf $OUT/c4
-BT="$ROOT/tools/boot_demo.py 17 5 1 14 8 7"
+BT="$ROOT/tools/boot_demo.py 17 5 1 14 9 8"
 timeout 600 rocprofv3 --kernel-trace --output-format csv -d $OUT/bt -- python3 $BT > $OUT/bt.txt 2> $OUT/bt.err
 timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/btf -- python3 $BT --opt plan_graph=0 > /dev/null 2> $OUT/btf.err
 timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/btw -- python3 $BT --opt plan_graph=0 > /dev/null 2> $OUT/btw.err
 cd $ROOT
-{ echo "one real bootstrap at config 4's geometry (N = 2^17, 31 + 8 primes, digits of 7, 1 -> 14 primes): python tools/boot_demo.py 17 5 1 14 8 7"
+{ echo "one real bootstrap at config 4's geometry (N = 2^17, 31 + 9 primes, digits of 8, 1 -> 14 primes): python tools/boot_demo.py 17 5 1 14 9 8"
   echo "the process = key generation + encoding + 3 runs; bytes = FETCH_SIZE x 2 + WRITE_SIZE per kernel (plan run launch by launch for the counters)"
   grep -E "bootstrap:|decrypted" $OUT/bt.txt
   python tools/kernel_bytes.py $(kt $OUT/bt) $(cc $OUT/btf) $(cc $OUT/btw) top=30; } > $OUT/${R}_boot_kernel_bytes.txt
@@ -56,20 +56,22 @@ rm -rf $OUT/bt $OUT/btf $OUT/btw
 #     sequence (default, hyb_fuse = 2), the loader form (1) and round 3's sequence (0); the matrix-core counters of the default
 cd /tmp
 { for f in 2 1 0; do
-    timeout 900 rocprofv3 --kernel-trace --output-format csv -d $OUT/hy$f -- python3 $ROOT/tools/hybrid_ks_bench.py 17 39 8 7 10 31 --opt hyb_fuse=$f > $OUT/hy${f}_hop.json 2> $OUT/hy.err
-    timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/hyf$f -- python3 $ROOT/tools/hybrid_ks_bench.py 17 39 8 7 10 31 --opt hyb_fuse=$f > /dev/null 2>> $OUT/hy.err
-    timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/hyw$f -- python3 $ROOT/tools/hybrid_ks_bench.py 17 39 8 7 10 31 --opt hyb_fuse=$f > /dev/null 2>> $OUT/hy.err
-    echo "== hyb_fuse = $f: one rotation hop at N = 2^17, level 31 (5 digits of 7 primes, 8 special primes); per hop = per launch of hyb_mac_kernel<0>"
+    timeout 900 rocprofv3 --kernel-trace --output-format csv -d $OUT/hy$f -- python3 $ROOT/tools/hybrid_ks_bench.py 17 40 9 8 10 31 --opt hyb_fuse=$f > $OUT/hy${f}_hop.json 2> $OUT/hy.err
+    timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/hyf$f -- python3 $ROOT/tools/hybrid_ks_bench.py 17 40 9 8 10 31 --opt hyb_fuse=$f > /dev/null 2>> $OUT/hy.err
+    timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/hyw$f -- python3 $ROOT/tools/hybrid_ks_bench.py 17 40 9 8 10 31 --opt hyb_fuse=$f > /dev/null 2>> $OUT/hy.err
+    echo "== hyb_fuse = $f: one rotation hop at N = 2^17, level 31 (4 digits of 8 primes, 9 special primes); per hop = per launch of hyb_mac_kernel<0>"
     python3 -c "import json;d=json.loads(open('$OUT/hy${f}_hop.json').read().strip().splitlines()[-1])['levels'][0];print('HIP events, unprofiled loop:', d['hop_us'], 'us per hop;', d['ntt_equivalents'], 'NTT-equivalents; algorithmic bytes (tools/hybrid_ks_bench.py)', d['algorithmic_bytes'])"
     python3 $ROOT/tools/kernel_bytes.py $(kt $OUT/hy$f) $(cc $OUT/hyf$f) $(cc $OUT/hyw$f) per="hyb_mac_kernel<0>" top=16
     echo
     rm -rf $OUT/hy$f $OUT/hyf$f $OUT/hyw$f
   done
-  timeout 900 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_I8 SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/hm -- python3 $ROOT/tools/hybrid_ks_bench.py 17 39 8 7 5 31 > /dev/null 2> $OUT/hm.err
+  timeout 900 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_I8 SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/hm -- python3 $ROOT/tools/hybrid_ks_bench.py 17 40 9 8 5 31 > /dev/null 2> $OUT/hm.err
   echo "== counters of the matrix-core conversions, per launch (rocprofv3 --pmc; tools/pmc_summary.py)"; python3 $ROOT/tools/pmc_summary.py $(cc $OUT/hm) | grep -A7 "hyb_conv_mfma"
   rm -rf $OUT/hm
+  echo; echo "== all levels, HIP events, rounds 3-4's key shape (5 digits of 7 under 8 special primes), hyb_fuse = 2"
+  python3 $ROOT/tools/hybrid_ks_bench.py 17 39 8 7 10 0 2>/dev/null
   echo; echo "== all levels, HIP events: hyb_fuse = 2 / 1 / 0"
-  for f in 2 1 0; do python3 $ROOT/tools/hybrid_ks_bench.py 17 39 8 7 10 0 --opt hyb_fuse=$f 2>/dev/null; done
+  for f in 2 1 0; do python3 $ROOT/tools/hybrid_ks_bench.py 17 40 9 8 10 0 --opt hyb_fuse=$f 2>/dev/null; done
 } > $OUT/${R}_hybrid_ks_kernels.txt
 cd $ROOT
 # B4b. VALU occupancy of the single-crossing NTT
@@ -84,10 +86,15 @@ timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/po -- p
 cp $(ls $OUT/po/*/*kernel_stats.csv | head -1) $OUT/${R}_per_op_kernel_stats.csv
 rm -rf $OUT/po
 cd $ROOT
-python tools/experiments/dag_width.py > /dev/null 2> $OUT/${R}_dag_width.txt
-for n in 512 1024 2048 4096; do python tools/ntt_full_check.py $n 20; done > $OUT/${R}_ntt_full_check.txt 2>/dev/null
+for n in 512 640 768 900 1024 1300 1536 2048 4096; do python tools/ntt_full_check.py $n 20; done > $OUT/${R}_ntt_full_check.txt 2>/dev/null
+# B6 (round 5). kernel-by-kernel budgets: time, HBM bytes, VALU instructions and floors of the single ops and of one run() of the 13-prime lowering / the headline
+bash tools/collect_per_op_budget.sh $R > $OUT/per_op_budget.log 2>&1
+bash tools/collect_run_budget.sh $R b13 > $OUT/run_budget_b13.log 2>&1
+bash tools/collect_run_budget.sh $R headline > $OUT/run_budget_headline.log 2>&1
+python tools/lowering_sweep.py 6 ks_items_fast=0 cols_pairs=0 tiny_tile_wgs=512 ks_items_fast=0,cols_pairs=0,tiny_tile_wgs=512,ntt_full_inv_pairs=0 > $OUT/${R}_lowering_sweep.txt 2>&1
+python tools/per_op_sweep.py 30 ks_items_fast=0 cols_pairs=0 tiny_tile_wgs=512 cols_pairs=0,tiny_tile_wgs=512 > $OUT/${R}_per_op_sweep.txt 2>&1
 python tools/chain_bench.py > $OUT/${R}_chain_latency.txt 2>/dev/null
-for s in 2 4 8; do python bench.py --streams $s --no-cpu-baseline --no-lowerings --no-config4 2>/dev/null | python tools/bench_brief.py; done > $OUT/${R}_streams.txt
+# (round 5: the streams table is a leg of the bench line itself: bench.py streams_leg)
 python tools/profile_backend.py --out $OUT/${R}_profiled_SEAL_MI355X.json > $OUT/profile_backend.log 2>&1
 # E. the bench line itself: it reports the round's sha-gated records (traffic, VALU counters, step kernels) when they were collected on the
 #    library it times -- the ones above were, so they go to profiles/ (of this copy of the repo) first

@@ -67,7 +67,11 @@ def step_row(r):
     if not d:
         return None
     k = d["dominant"]
-    extra = f", algorithmic {k['algorithmic_bytes_in_run'] / 1e9:.1f} GB, traffic ÷ algorithmic {k['traffic_over_algorithmic']}" if k.get("algorithmic_bytes_in_run") else ""
+    if k.get("design_io_budget_bytes_in_run"):  # round 5's fields: 8(d)'s bytes of the ops and the launch's own I/O budget kept apart
+        extra = (f" = {k['hbm_frac_of_peak']} of 8 TB/s; this design's I/O budget for those launches {k['design_io_budget_bytes_in_run'] / 1e9:.1f} GB (traffic ÷ budget "
+                 f"{k['traffic_over_design_io_budget']}), SURVEY 8(d) bytes of the key switches they belong to {k['section_8d_bytes_of_items_in_run'] / 1e9:.1f} GB")
+    else:
+        extra = f", algorithmic {k['algorithmic_bytes_in_run'] / 1e9:.1f} GB, traffic ÷ algorithmic {k['traffic_over_algorithmic']}" if k.get("algorithmic_bytes_in_run") else ""
     return (f"| `{r}_step_kernels.json` | the timed step's own kernels: {d['kernels_in_run']} launches in the last `run()`, {d['kernel_time_ms']:.1f} ms of kernel time in "
             f"{d['wall_ms_under_profiler']:.1f} ms under the profiler, {d['bytes_actually_moved_in_run'] / 1e9:.1f} GB actually moved; dominant `{k['kernel']}` "
             f"{k['calls']} × {k['avg_us']} µs, {k['hbm_bytes_in_run'] / 1e9:.2f} GB from HBM{extra} | three passes of `python3 tools/headline_only.py 3`, `tools/kernel_traffic.py` |")
@@ -78,8 +82,55 @@ def valu_row(r):
     if not d:
         return None
     k = next((v for n, v in d.get("kernels", {}).items() if n.startswith("ntt_full15_kernel<false")), {})
+    ki = next((v for n, v in d.get("kernels", {}).items() if n.startswith("ntt_full15_kernel<true")), {})
+    inv = (f"; inverse kernel: {ki.get('valu_instructions_per_wave_per_limb')} instructions, busy {ki.get('simd_valu_busy_frac')}, {ki.get('avg_us_under_profiler')} µs under the counters"
+           if ki else "")
     return (f"| `{r}_ntt_valu.json` | VALU occupancy of the single-crossing forward kernel: {k.get('valu_instructions_per_wave_per_limb')} vector instructions per wave per limb, "
-            f"SIMD vector ALUs busy {k.get('simd_valu_busy_frac')} of the launch | `tools/collect_profiles.sh` B4b, `tools/ntt_valu.py` |")
+            f"SIMD vector ALUs busy {k.get('simd_valu_busy_frac')} of the launch{inv} | `tools/collect_profiles.sh` B4b, `tools/ntt_valu.py` |")
+
+
+def budget_head(name):
+    """the summary lines (== op / run: ...) of a tools/per_op_budget.py or run_budget.py table"""
+    f = P / name
+    if not f.exists():
+        return "(missing)"
+    return " / ".join(ln[3:].strip() for ln in f.read_text().splitlines() if ln.startswith("== "))
+
+
+def budget_rows(name, pat, n=3):
+    """rows of a tools/run_budget.py table as prose: kernel, calls, ms, share, avg us, GB, TB/s, VALU M, floors, bound, x"""
+    f = P / name
+    if not f.exists():
+        return "(missing)"
+    out = []
+    for ln in f.read_text().splitlines():
+        m = re.match(r"\s*(\S.*?)\s+(\d+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+(valu|bytes)\s+([\d.]+)\s*$", ln)
+        if m and re.search(pat, m.group(1)):
+            k, calls, ms, share, avg, gb, tbs, vm, fb, fv, bound, x = m.groups()
+            out.append(f"`{k}` {calls} × {float(avg):.0f} µs = {float(ms):.1f} ms ({100 * float(share):.1f} %), {float(gb):.0f} GB at {tbs} TB/s, {float(vm) / 1e3:.1f} G VALU instructions: "
+                       f"floors {float(fb):.1f} ms (bytes) / {float(fv):.1f} ms (VALU), {float(x):.2f}× its {bound} floor")
+        if len(out) >= n:
+            break
+    return "; ".join(out) if out else "(no such row)"
+
+
+def sweep_lines(name, n=6):
+    f = P / name
+    if not f.exists():
+        return "(missing)"
+    return " // ".join(re.sub(r"\s+", " ", ln.strip()) for ln in f.read_text().splitlines()[:n])
+
+
+def check_lines(name):
+    f = P / name
+    if not f.exists():
+        return "(missing)"
+    out = []
+    for ln in f.read_text().splitlines():
+        if ln.startswith("{"):
+            d = json.loads(ln)
+            out.append(f"{d['limbs']}: fwd {d['fwd_full_us']:.0f} / {d['fwd_two_phase_us']:.0f}, inv {d['inv_full_us']:.0f} / {d['inv_two_phase_us']:.0f}")
+    return "; ".join(out)
 
 
 def first_lines(name, pat, n=3):
@@ -121,7 +172,7 @@ def seq_totals(name):
     return "; ".join(f"`hyb_fuse` = {f}: {v}" for f, v in zip((2, 1, 0), out))
 
 
-def hop_levels(name):
+def hop_levels(name, labels=("`hyb_fuse` = 2", "`hyb_fuse` = 1", "`hyb_fuse` = 0")):
     f = P / name
     if not f.exists():
         return "(missing)"
@@ -129,12 +180,38 @@ def hop_levels(name):
     for ln in f.read_text().splitlines():
         if ln.startswith('{"N"'):
             d = json.loads(ln)
-            out.append(" / ".join(f"{l['hop_us']:.0f}" for l in d["levels"]))
-    return "; ".join(f"`hyb_fuse` = {f}: {v} µs" for f, v in zip((2, 1, 0), out))
+            out.append(f"({d['special']}, {d['alpha']}) levels " + " / ".join(str(l["level"]) for l in d["levels"]) + ": " + " / ".join(f"{l['hop_us']:.0f}" for l in d["levels"]))
+    return "; ".join(f"{f}: {v} µs" for f, v in zip(labels, out))
 
 
 print("# profiles/ — rocprofv3 evidence (MI355X, ROCm 7.2)\n")
-print("Generated by `python tools/profiles_readme.py > profiles/README.md`: every figure in the round-3 and round-4 tables is read from the file on its row.\n")
+print("Generated by `python tools/profiles_readme.py > profiles/README.md`: every figure in the round-3, round-4 and round-5 tables is read from the file on its row.\n")
+print("## Round 5 (everything `r05_*`; one `gpurun` call of `tools/collect_profiles.sh r05` on the committed build -- the JSON files that `bench.py` reads carry "
+      "the library's sha256)\n")
+print("| file | what (figures read from the file) | command |\n|---|---|---|")
+rows = [bench_row("r05"), traffic_row("r05"), step_row("r05"), valu_row("r05"),
+        f"| `r05_per_op_kernel_bytes.txt`, `r05_per_op_budget_*.json` | the single ops at 13 primes and config 3 KERNEL BY KERNEL: duration, measured HBM bytes (FETCH_SIZE × 2 + WRITE_SIZE), "
+        f"VALU wave-instructions, and three floors per launch (bytes ÷ 5.5 TB/s; VALU × 4 cycles ÷ 1024 SIMDs ÷ 2.05 GHz × CU quantisation; 3.7 µs per dependent launch): "
+        f"{budget_head('r05_per_op_kernel_bytes.txt')} | `tools/collect_per_op_budget.sh r05`: four rocprofv3 passes per op, one op per process, `tools/per_op_budget.py` |",
+        f"| `r05_run_budget_b13.txt` / `.json` | one `run()` of the 13-prime lowering kernel by kernel with the same floors: {budget_head('r05_run_budget_b13.txt')}; "
+        f"{budget_rows('r05_run_budget_b13.txt', 'f_ks_frows_mac_kernel<8, 2, 0, true>|f_ks_lift_fcols_kernel<7, 3>', 2)} | `tools/collect_run_budget.sh r05 b13`, `tools/run_budget.py` |",
+        f"| `r05_run_budget_headline.txt` / `.json` | the same for the headline program: {budget_head('r05_run_budget_headline.txt')}; "
+        f"{budget_rows('r05_run_budget_headline.txt', 'f_ks_frows_mac_kernel<8, 2, 0, true>|f_dr_icols_lift_fcols_kernel<7, 1, false>', 2)} | `tools/collect_run_budget.sh r05 headline` |",
+        f"| `r05_lowering_sweep.txt`, `r05_per_op_sweep.txt` | this round's launch-shape options switched off one at a time on one box (HIP events / best of 6 runs): {sweep_lines('r05_lowering_sweep.txt', 5)} //// {sweep_lines('r05_per_op_sweep.txt', 5)} | `tools/lowering_sweep.py`, `tools/per_op_sweep.py` |",
+        f"| `r05_ntt_full_check.txt` | single-crossing kernel / two-launch tiles, µs, by limb count (bit-exactness checked in the same run): {check_lines('r05_ntt_full_check.txt')} | `tools/ntt_full_check.py <limbs> 20` |",
+        f"| `r05_hybrid_ks_kernels.txt` | one grouped-digit rotation hop at N = 2^17 under round 5's key shape (4 digits of 8 under 9 special primes), kernel by kernel with measured HBM bytes for the three "
+        f"launch sequences, the matrix-core counters, all levels under HIP events: {hop_levels('r05_hybrid_ks_kernels.txt', ('rounds 3-4 shape, `hyb_fuse` = 2', '`hyb_fuse` = 2', '`hyb_fuse` = 1', '`hyb_fuse` = 0'))}. "
+        f"Per hop at level 31 under the trace: {seq_totals('r05_hybrid_ks_kernels.txt')} | `tools/collect_profiles.sh` B4: `tools/hybrid_ks_bench.py 17 40 9 8 10 31 --opt hyb_fuse=f`, `tools/kernel_bytes.py` |",
+        f"| `r05_config4_kernel_stats.csv`, `r05_config4_under_profiler.txt` | BASELINE config 4 under the kernel trace: {stats('r05_config4_kernel_stats.csv')} | "
+        "`rocprofv3 --kernel-trace --stats -- python3 tools/resnet_real_boot.py 1 resnet20_nt16 17 1 b14 9 8` |",
+        f"| `r05_boot_kernel_bytes.txt` | ONE real bootstrap at config 4's geometry, per kernel the measured HBM bytes and GB/s: {first_lines('r05_boot_kernel_bytes.txt', 'bootstrap:', 1)}; "
+        f"{kb_rows('r05_boot_kernel_bytes.txt', 'hyb_mac_kernel<0>|hyb_conv_mfma_kernel<true, true, 2>|hyb_conv_mfma_kernel<false, true, 1>|ntt_phase_kernel<8, 3, true, false, false>', 4)} | three passes of `tools/boot_demo.py 17 5 1 14 9 8`, `tools/kernel_bytes.py` |",
+        f"| `r05_per_op.json`, `r05_per_op_kernel_stats.csv` | the three expensive opcodes at 13 primes and config 3 under `--stats`: {stats('r05_per_op_kernel_stats.csv', 3)} | `rocprofv3 --kernel-trace --stats -- python3 tools/per_op_only.py 20` |",
+        f"| `r05_kernel_stats.csv`, `r05_by_kernel_and_grid.txt`, `r05_timeline.txt`, `r05_top_kernels.json`, `r05_roofline_leg_launches.txt` | the bench command under the kernel trace: {first_lines('r05_timeline.txt', 'last run', 1)} | `rocprofv3 --kernel-trace --stats … -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-lowerings --no-config4` |",
+        "| `r05_experiments.txt` | what was measured on the way and how it came out: the budgets before any change, launch-shape sweeps, key-ordered items, twiddle pairs (COLS tiles, inverse single-crossing passes, LDS twiddle tables), the 9-input mod-down, what was not kept | — |",
+        "| `r05_chain_latency.txt`, `r05_profiled_SEAL_MI355X.json` | as in round 4 on this build (the streams table moved into the bench line: `streams`) | `tools/chain_bench.py`, `tools/profile_backend.py` |"]
+print("\n".join(r for r in rows if r))
+print()
 print("## Round 4 (everything `r04_*`; one `gpurun` call of `tools/collect_profiles.sh r04` on the committed build — the JSON files that `bench.py` reads carry "
       "the library's sha256)\n")
 print("| file | what (figures read from the file) | command |\n|---|---|---|")
