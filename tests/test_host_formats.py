@@ -99,6 +99,16 @@ def test_options_come_from_one_environment_variable(tmp_path):
     env = dict(os.environ, DACAPO_HEVM_OPTIONS="logn=12,primse=4")
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
     assert out.returncode != 0 and "unknown option" in out.stderr and "primes" in out.stderr
+    # a malformed VALUE aborts too (round-4 advisor: "plan=" used to run as 0, "max_batch=12abc" as 12, "seal_compr=zlib" as none)
+    for bad in ("plan=", "max_batch=12abc", "logn=twelve", "primes=4 "):
+        out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, DACAPO_HEVM_OPTIONS=bad), capture_output=True, text=True, timeout=120)
+        assert out.returncode != 0 and "needs an integer value" in out.stderr, (bad, out.stderr[-300:])
+    code2 = code.replace("b'sum_pair_min_wgs'", "b'seal_compr'")
+    out = subprocess.run([sys.executable, "-c", code2], env=dict(os.environ, DACAPO_HEVM_OPTIONS="seal_compr=zstd,plan=0x0"), capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.split() == ["15", "14", "0", "2"], out.stderr[-300:]   # the names of include/hevm_abi.h; hex integers
+    # the per-knob variables of rounds 1-3 are no longer read: setting one is named in a warning instead of silently running the defaults
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, DACAPO_HEVM_LOGN="12", DACAPO_KS_SPECIAL="4"), capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.split()[0] == "15" and "DACAPO_HEVM_LOGN is no longer read" in out.stderr and "DACAPO_KS_SPECIAL" in out.stderr
 
 
 def test_outputs_keep_their_registers_when_used_afterwards():

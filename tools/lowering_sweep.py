@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """The three lowerings of the ResNet-20 trace (opcode 10 -> 3 / 6 / 13 primes) under a list of launch-shape option sets, one VM:
-    python tools/lowering_sweep.py [steps=5] [--only b13] "name=value,name=value" ...
+    python tools/lowering_sweep.py [steps=5] [--only b13] [--new-vm] "name=value,name=value" ...
 Launch shapes are read when a launch is issued, i.e. when load() records the plan's graph: the program is re-loaded per option set.
 Prints best-of-steps ms per run() for each lowering; the first row is the defaults."""
 import gzip
@@ -24,12 +24,18 @@ if "--only" in args:
     del args[i:i + 2]
 fx = ha.read_fixture(ROOT / "tests" / "golden" / "resnet20")
 progs = {t: (fx["hevm"] if not t else gzip.open(ROOT / "tests" / "golden" / f"resnet20{t}.hevm.gz").read()) for t in tags}
-vm = runner.HEVM(seed=0x4845564D, logN=15, num_primes=14)
+new_vm = "--new-vm" in args  # VM options (max_batch, plan_lanes ...) are read when a VM is created: one VM per option set
+args = [a for a in args if a != "--new-vm"]
+vm = None if new_vm else runner.HEVM(seed=0x4845564D, logN=15, num_primes=14)
 for spec in [""] + args:
-    runner.lw.hevm_reset_options()
+    runner.reinit_lw().hevm_reset_options()
     for kv in filter(None, spec.split(",")):
         k, _, v = kv.partition("=")
         runner.set_option(k, int(v, 0))
+    if new_vm:
+        if vm is not None:
+            vm.close()
+        vm = runner.HEVM(seed=0x4845564D, logN=15, num_primes=14)
     row = []
     for t in tags:
         vm.load_mem(fx["cst"], progs[t])
