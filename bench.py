@@ -281,7 +281,7 @@ def ntt_micro_leg(ll, iters=200):
     return {"workload": "single forward NTT, N=2^14, 1 limb", "us_per_ntt_back_to_back": round(us, 2)}
 
 
-def cfg3_leg(ll, iters=5):
+def cfg3_leg(ll, iters=5, grouped=True):
     """BASELINE config 3: one ct x ct multiply + relinearise at N = 2^16, 24 data primes + 1 special (bit-exactness of this
     size is tests/test_gpu_ops.py::test_baseline_config3_...).  Operands are constant-filled canonical residues: timing only.
     Algorithmic bytes per SURVEY.md 8(d): (4l [in] + l [target] + 2l(l+1) [key] + 4l [ct RMW]) * P_limb = 708 MiB."""
@@ -307,6 +307,8 @@ def cfg3_leg(ll, iters=5):
            "ntt_equivalents": ntts, "ntt_per_s": round(ntts / (us * 1e-6)), "algorithmic_bytes": alg,
            "achieved_gbs": round(alg / (us * 1e-6) / 1e9, 1), "frac_of_hbm_peak": round(alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
     del ctx, key
+    if not grouped:  # (the profiler passes of tools/per_op_budget.py: SEAL-mode launches only)
+        return out
     # the same product under grouped-digit keys (EXTENSION, hybrid_ks.hip: not SEAL's scheme): 24 data primes in 3 digits of 8, 8 special primes
     ks = alpha = 8
     ctx2 = ll.Context(logN, ell + ks, special=ks, alpha=alpha)

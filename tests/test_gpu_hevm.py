@@ -781,6 +781,22 @@ def test_merged_and_fine_launch_shapes_of_the_key_switch_match_the_oracle_vm(tmp
             assert res["stats"]["keyswitches"] >= 40
 
 
+@pytest.mark.parametrize("opts", [dict(ks_items_fast=0), dict(cols_pairs=0), dict(tiny_tile_wgs=512), dict(tiny_tile_wgs=100000),
+                                  dict(ks_items_fast=0, cols_pairs=0, tiny_tile_wgs=512, ks_big_tiles=0), dict(ks_big_tiles=0, ks_merge_lift_min_wgs=0)])
+def test_round5_launch_shapes_are_second_implementations_of_the_same_limbs(tmp_path, opts):
+    """round 5's launch-shape options, each switched off (or forced) for every launch of the convolution-shaped program -- 29 rotations whose
+    NAF hops name 7 Galois elements several times each (what ks_items_fast sorts by), a ct x ct product, rescales at several levels: the
+    key-ordered items and the (tiles, items, rows) grid, twiddle pairs in the forward COLS tiles, the one-butterfly tile geometry for every
+    launch / for none, the large-batch sequence (separate inverse COLS + lift launches) forced at every size.  All equal the oracle VM limb for limb."""
+    from dacapo_amd import runner
+    from gpu_helpers import run_conv_shaped_program
+
+    with runner.options(**opts):
+        for logN, K in ((13, 5), (12, 7)):
+            res = run_conv_shaped_program(logN, K, tmp_path)
+            assert res["limbs_identical"] and res["scale_identical"] and res["max_error_vs_cleartext"] < 1e-4, (opts, logN, K)
+
+
 def test_options_table_round_trips_and_rejects_nothing_silently():
     """hevm_set_option / hevm_get_option / hevm_reset_options (include/hevm_abi.h): a value set is the value read, a with-block restores,
     reset returns to the documented defaults -- the reference's ring among them (SEAL_HEVM.cpp:39-40: N = 2^15, 14 primes)"""

@@ -106,7 +106,15 @@ def test_large_batch_uses_the_throughput_tiles_and_matches_oracle(logN, K, limbs
         assert (d.to_host() == a).all()
 
 
-def test_single_crossing_kernel_matches_oracle_and_the_two_launch_tiles():
+@pytest.mark.parametrize("pairs", [(1, 1), (0, 0), (1, 0), (0, 1)])   # (ntt_full_pairs, ntt_full_inv_pairs): word and pair forms of either direction
+def test_single_crossing_kernel_matches_oracle_and_the_two_launch_tiles(pairs):
+    from dacapo_amd import runner
+
+    with runner.options(ntt_full_pairs=pairs[0], ntt_full_inv_pairs=pairs[1]):
+        _single_crossing_body()
+
+
+def _single_crossing_body():
     """ntt_full.hip (one 1024-thread workgroup per limb of N = 2^15, one HBM crossing) through dc_ntt_variant: forward and inverse ==
     oracle bit for bit on an irregular prime pattern and on the edge limbs (zeros, q - 1), with a limb stride, and == the two-launch
     transform on a batch large enough that dc_ntt_forward itself takes the single-crossing kernel (>= 640 limbs)."""

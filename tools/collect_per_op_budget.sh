@@ -28,7 +28,7 @@ for op in rotate_hop mulcc_relin rescale cfg3; do
 import json,sys
 d=json.loads(open('$D/events.json').read().strip().splitlines()[-1])
 print(d['cfg3']['us'] if '$op'=='cfg3' else d['per_op_13_primes']['$op']['us'])" 2>/dev/null || echo 0)
-  IT2=$IT; EX=""; [ $op = cfg3 ] && IT2=10 && EX="exclude=hyb"
+  IT2=$IT; EX=""; [ $op = cfg3 ] && IT2=10
   cp $(kt $D/kt) $D/kernel_trace.csv; cp $(cc $D/pf) $D/fetch.csv; cp $(cc $D/pw) $D/write.csv; cp $(cc $D/pv) $D/valu.csv
   rm -rf $D/kt $D/pf $D/pw $D/pv
   python3 $ROOT/tools/per_op_budget.py $op $IT2 $D/kernel_trace.csv $D/fetch.csv $D/write.csv $D/valu.csv event_us=$EV json=$OUT/${R}_per_op_budget_$op.json $EX >> $TXT 2>> $D/budget.err

@@ -22,5 +22,5 @@ out = {}
 if only != "cfg3":
     out["per_op_13_primes"] = bench.per_op_leg(ll, iters=iters, only=only)
 if only in (None, "cfg3"):
-    out["cfg3"] = bench.cfg3_leg(ll, iters=max(5, iters // 2))
+    out["cfg3"] = bench.cfg3_leg(ll, iters=max(5, iters // 2), grouped=only is None)
 print(json.dumps(out))
