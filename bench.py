@@ -194,7 +194,7 @@ def real_bootstrap_leg(ll, runner, steps=3, resnet=True):
     return out
 
 
-def streams_leg(hevm, cst, hv, image, ntts_per_image, alg_bytes_per_image, steps=3, counts=(1, 2, 4, 8)):
+def streams_leg(hevm, cst, hv, image, ntts_per_image, alg_bytes_per_image, steps=3, counts=(1, 2, 4, 8, 16)):
     """Throughput mode (hevm_set_streams): S independent ciphertext streams of the SAME program in one VM -- every batched step carries the
     items of all S images, so the launch chain that bounds one image (~5 300 dependent launches of 4-30 us) is shared by S of them.  This is
     the regime BASELINE config 5 runs in (streams x GPUs); the headline keeps S = 1 like the reference (one image per run())."""
@@ -424,7 +424,7 @@ def build_parser():
     ap.add_argument("--layers", type=int, default=20, help="--program shaped: depth (20 = the traced op mix)")
     ap.add_argument("--streams", type=int, default=1, help="independent ciphertext streams per GPU (throughput mode; 1 = the reference's one image per run)")
     ap.add_argument("--no-lowerings", action="store_true", help="skip the other lowerings of the trace (config.lowerings)")
-    ap.add_argument("--no-streams-leg", action="store_true", help="skip the throughput table (1 / 2 / 4 / 8 streams of the headline program in one VM)")
+    ap.add_argument("--no-streams-leg", action="store_true", help="skip the throughput table (1 / 2 / 4 / 8 / 16 streams of the headline program in one VM)")
     ap.add_argument("--no-config4", dest="config4", action="store_false",
                     help="skip BASELINE config 4's shape (ResNet-20 traced at nt = 2^16, N = 2^17, real bootstrapping; ~1 min, ~180 GB of HBM); "
                          "it runs by default since round 3, in a child process before this one touches the GPU")
