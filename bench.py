@@ -76,7 +76,7 @@ def roofline_leg(ll, ctx, limbs=4096, iters=10):
     copy_gbs = 2.0 * buf.nbytes / (L.dc_event_elapsed_ms(e0, e1) / iters * 1e-3) / 1e9
     del buf, dst
     # HBM bytes per launch: rocprofv3 --pmc passes cannot run inside this process (they need their own runs with the program directly
-    # after `--`, tools/ntt_variant_only.py).  profiles/<round>_ntt_hbm_traffic.json holds FETCH_SIZE (x2, the gfx950 correction) + WRITE_SIZE
+    # after `--`, tools/legs/ntt_variant_only.py).  profiles/<round>_ntt_hbm_traffic.json holds FETCH_SIZE (x2, the gfx950 correction) + WRITE_SIZE
     # for the same launches; it is reported only when it was collected on exactly this build of the library.
     traffic, traffic_source = None, "not collected for this build (recipe: profiles/README.md, `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE`)"
     tf = ROOT / "profiles" / f"{PROF}_ntt_hbm_traffic.json"
@@ -88,8 +88,8 @@ def roofline_leg(ll, ctx, limbs=4096, iters=10):
             traffic_source = f"profiles/{PROF}_ntt_hbm_traffic.json was collected on another build of the library: not reported"
     floor_us = alg_bytes / (copy_gbs * 1e9) * 1e6
     # what actually bounds the kernel: the vector ALUs' issue rate (profiles/r03_ntt_full.txt).  The counters come from their own rocprofv3
-    # --pmc run (tools/ntt_valu.py) and are reported only for exactly this build of the library.
-    valu = {"source": "not collected for this build (recipe: tools/collect_profiles.sh B4b, tools/ntt_valu.py)"}
+    # --pmc run (tools/summarize/ntt_valu.py) and are reported only for exactly this build of the library.
+    valu = {"source": "not collected for this build (recipe: tools/collect_profiles.sh B4b, tools/summarize/ntt_valu.py)"}
     vf = ROOT / "profiles" / f"{PROF}_ntt_valu.json"
     if vf.exists() and limbs == 4096 and N == 32768:
         rec = json.loads(vf.read_text())
@@ -230,7 +230,7 @@ def lib_sha256():
 def per_op_leg(ll, ell=13, iters=20, only=None):
     """the three expensive opcodes alone at the reference's top level (13 primes, N = 2^15), next to the reference's own
     per-op table for SEAL on a CPU (profiled_SEAL_CPU.json:10-45); algorithmic bytes per SURVEY.md 8(d).  `only`: one op's name
-    (the profiler passes of tools/per_op_budget.py run one op per process)"""
+    (the profiler passes of tools/summarize/per_op_budget.py run one op per process)"""
     L = ll.lib()
     ctx = ll.Context(15, 14)
     N, K = ctx.N, ctx.K
@@ -307,7 +307,7 @@ def cfg3_leg(ll, iters=5, grouped=True):
            "ntt_equivalents": ntts, "ntt_per_s": round(ntts / (us * 1e-6)), "algorithmic_bytes": alg,
            "achieved_gbs": round(alg / (us * 1e-6) / 1e9, 1), "frac_of_hbm_peak": round(alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
     del ctx, key
-    if not grouped:  # (the profiler passes of tools/per_op_budget.py: SEAL-mode launches only)
+    if not grouped:  # (the profiler passes of tools/summarize/per_op_budget.py: SEAL-mode launches only)
         return out
     # the same product under grouped-digit keys (EXTENSION, hybrid_ks.hip: not SEAL's scheme): 24 data primes in 3 digits of 8, 8 special primes
     ks = alpha = 8
@@ -442,19 +442,19 @@ def build_parser():
 def _config4_run(args):
     import subprocess
 
-    cmd = [sys.executable, str(ROOT / "tools" / "resnet_real_boot.py")] + [str(a) for a in args]
+    cmd = [sys.executable, str(ROOT / "tools" / "legs" / "resnet_real_boot.py")] + [str(a) for a in args]
     r = subprocess.run(cmd, capture_output=True, text=True)
     last = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     if r.returncode != 0 or not last:
-        return {"error": f"tools/resnet_real_boot.py exited with {r.returncode}", "stderr_tail": r.stderr[-400:]}
+        return {"error": f"tools/legs/resnet_real_boot.py exited with {r.returncode}", "stderr_tail": r.stderr[-400:]}
     res = json.loads(last[-1])
-    res["command"] = "python tools/resnet_real_boot.py " + " ".join(str(a) for a in args)
+    res["command"] = "python tools/legs/resnet_real_boot.py " + " ".join(str(a) for a in args)
     return res
 
 
 def config4_child():
     """--config4: BASELINE config 4's shape -- ResNet-20 traced at the reference script's own nt = 2^16 slots (examples/benchmarks/
-    ResNet.py:50), run on N = 2^17 (HEAAN_HEVM.cpp:55-56) with a real bootstrap at every bootstrap site (tools/resnet_real_boot.py).
+    ResNet.py:50), run on N = 2^17 (HEAAN_HEVM.cpp:55-56) with a real bootstrap at every bootstrap site (tools/legs/resnet_real_boot.py).
     About 180 GB of keys and plaintexts: it runs in CHILD processes started before this one touches the GPU (the reference's ABI has no
     destroy symbol, so the other legs' VMs stay resident until exit).  Round 4: the same program also on a mixed 60 / 51-bit chain
     (`chains`) and under bounded rotation-key sets (`key_sets`: the reference HEaaN runtime's 49 offsets, 96 keys, one per offset)."""
@@ -840,7 +840,7 @@ def main():
     # the timed step's own place on the byte roofline: SURVEY.md 8(d)'s table walked over the bytecode (progstats.walk)
     step_gbs = pst["algorithmic_bytes"] / (ms_per_step * 1e-3) / 1e9
     # the timed step's own kernels: durations, PMC traffic and (where the grid encodes level and batch) algorithmic bytes per kernel,
-    # collected by tools/kernel_traffic.py on exactly this build of the library (else a note)
+    # collected by tools/summarize/kernel_traffic.py on exactly this build of the library (else a note)
     top, dominant, moved = None, None, None
     tk = ROOT / "profiles" / f"{PROF}_step_kernels.json"
     if tk.exists():
@@ -898,7 +898,7 @@ def main():
         "cfg3_mul_relin": cfg3,
         "per_op_13_primes": per_op,
         "real_bootstrap": real_boot,
-        # BASELINE config 4's shape (run_s, rms_vs_torch, key switches, ...): tools/resnet_real_boot.py in a child process; null under
+        # BASELINE config 4's shape (run_s, rms_vs_torch, key switches, ...): tools/legs/resnet_real_boot.py in a child process; null under
         # --no-config4, --gpus > 1 or an external launcher
         "config4_resnet20_nt65536_N131072": config4,
         "cpu_baseline": cpu,

@@ -565,7 +565,7 @@ def simulate(hevm: bytes, cst: bytes, inputs, logN: int, primes, secret_weight: 
     return (outs, trace) if return_trace else outs
 
 
-# ---- a bootstrap on its own (tools/boot_demo.py, bench.py, tests) ------------------------------------------------------------------
+# ---- a bootstrap on its own (tools/legs/boot_demo.py, bench.py, tests) ------------------------------------------------------------------
 def single_bootstrap_program(logN: int, target: int = 3, r: int = 5, msg_bits: int = 0, ks: int = 1, primes=None):
     """(num_primes, cst, hevm, rotation offsets, emitter) of the program `one ciphertext at 1 prime, scale 2^40 -> bootstrap -> output`;
     ks = number of special primes of the chain (the VM must be created with ks_special = ks); primes: the VM's chain when it is not the

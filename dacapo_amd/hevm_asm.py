@@ -161,7 +161,7 @@ def plain_eval(hevm: bytes, cst: bytes, inputs, slots=1 << 14):
 
 def read_fixture(prefix) -> dict:
     """A traced program committed as data (tests/golden/<name>.{hevm.gz,cst.xz,input.npz,json}; written by
-    tools/trace_reference_model.py): returns the decompressed `.hevm` / `.cst` bytes, the packed input and metadata."""
+    tools/fixtures/trace_reference_model.py): returns the decompressed `.hevm` / `.cst` bytes, the packed input and metadata."""
     import gzip
     import json
     import lzma

@@ -1,5 +1,5 @@
 """GPU: BASELINE config 4's shape -- the reference's ResNet-20 traced at its script's own slot count nt = 2^16
-(examples/benchmarks/ResNet.py:50; fixture tests/golden/resnet20_nt16.*, tools/trace_reference_model.py) on the HEaaN runtime's ring
+(examples/benchmarks/ResNet.py:50; fixture tests/golden/resnet20_nt16.*, tools/fixtures/trace_reference_model.py) on the HEaaN runtime's ring
 N = 2^17 (HEAAN_HEVM.cpp:55-56) -- under test, not only on the builder's lease:
   * the prefix of the program before its first bootstrap (the stem convolution: 27 rotations under the default Galois keys, 25 ct x pt,
     2 rescales) is bit-identical to the oracle VM at N = 2^17 on the same key / plaintext / input limbs;

@@ -1,5 +1,5 @@
 """GPU: the reference's ResNet-20 (examples/benchmarks/ResNet.py traced with its resnet20.silu.model weights; committed
-as data under tests/golden/resnet20.*, see tools/trace_reference_model.py) through the HEVM boundary at the reference's
+as data under tests/golden/resnet20.*, see tools/fixtures/trace_reference_model.py) through the HEVM boundary at the reference's
 parameters (N = 2^15, 14 x 60-bit primes):
   * the first layer (everything before the first opcode 10, whose fresh randomness the oracle cannot reproduce) is
     bit-identical to the oracle VM on the same key/plaintext/input limbs;

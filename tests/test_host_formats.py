@@ -213,7 +213,7 @@ def test_wire_format_against_the_reference_header(tmp_path):
 
 def test_boundary_matches_the_reference_callers_bindings():
     """tests/golden/runner_bindings.json = what the reference's Python driver binds with ctypes (runner.py:34-71, extracted
-    by tools/extract_runner_bindings.py).  Every one of those 18 symbols is exported by the library and declared in
+    by tools/fixtures/extract_runner_bindings.py).  Every one of those 18 symbols is exported by the library and declared in
     include/hevm_abi.h with a parameter list of the same length and compatible C types, result included."""
     import json
 
@@ -237,7 +237,7 @@ def test_boundary_matches_the_reference_callers_bindings():
 
 def test_instruction_encoding_matches_the_reference_emitter():
     """tests/golden/opcode_table.json = opcode number and operand-field kinds per CKKS op as the reference's emitter writes
-    them (CKKSOps.td:60-222, extracted by tools/extract_opcode_table.py); the assembler uses the same numbers and packs the
+    them (CKKSOps.td:60-222, extracted by tools/fixtures/extract_opcode_table.py); the assembler uses the same numbers and packs the
     same fields, and the VM's dispatch (via the op-count statistics of an assembled program) agrees."""
     import json
 

@@ -6,7 +6,7 @@ zlib / Zstandard streams: SEAL_HEVM.cpp:91-180).  `make -C dacapo_amd/csrc host_
 sources, no device code -- with -fsanitize=address,undefined into a harness (host_fuzz_main.cpp) that parses one file and prints
 "ok ..." / "rejected: ..."; any sanitizer report or crash is a non-zero exit.
 
-1. every file of the committed corpus tests/golden/hostile/ (tools/make_hostile_corpus.py: truncations, 2^62 / negative counts, bad magic,
+1. every file of the committed corpus tests/golden/hostile/ (tools/fixtures/make_hostile_corpus.py: truncations, 2^62 / negative counts, bad magic,
    foreign versions, unknown / corrupt / truncated compression, a 200 MiB zlib bomb, a 500 MiB Zstandard bomb) does what manifest.json says;
 2. seeded mutation fuzzing of the valid files: bit flips, truncations, and 8-byte fields overwritten with extreme values -- no outcome is
    asserted except "the sanitizers stay quiet and the process exits 0"."""
@@ -42,9 +42,9 @@ def run(harness, kind, path, constants=None, timeout=120):
 
 
 def test_corpus_matches_its_generator():
-    """the committed files are what tools/make_hostile_corpus.py writes (the corpus is data with a committed recipe)"""
+    """the committed files are what tools/fixtures/make_hostile_corpus.py writes (the corpus is data with a committed recipe)"""
     man = json.loads((HOSTILE / "manifest.json").read_text())
-    assert man["generator"] == "tools/make_hostile_corpus.py" and len(man["files"]) >= 60
+    assert man["generator"] == "tools/fixtures/make_hostile_corpus.py" and len(man["files"]) >= 60
     for e in man["files"]:
         assert (HOSTILE / e["file"]).exists(), e["file"]
     kinds = {e["kind"] for e in man["files"]}

@@ -113,7 +113,7 @@ SUITE = ["SobelFilter", "HarrisCornerDetection", "LinearRegression", "Polynomial
 
 @pytest.mark.parametrize("name", SUITE)
 def test_suite_fixture_cleartext_evaluation(name):
-    """tests/golden/suite/<name>.*: the reference's examples/benchmarks/<name>.py traced (tools/trace_reference_model.py
+    """tests/golden/suite/<name>.*: the reference's examples/benchmarks/<name>.py traced (tools/fixtures/trace_reference_model.py
     --suite), with the inputs its examples/tests/<name>.py script fed and the script's own error figure on cleartext"""
     fx = ha.read_fixture(GOLDEN.parent / "suite" / name)
     meta = fx["meta"]
@@ -172,7 +172,7 @@ def test_other_lowerings_of_the_resnet_trace_share_constants_and_compute_the_sam
 
 def test_resnet20_trace_at_the_reference_scripts_own_slot_count():
     """tests/golden/resnet20_nt16.*: the same model traced at nt = 2^16 (examples/benchmarks/ResNet.py:50, the HEaaN runtime's slot
-    count, HEAAN_HEVM.cpp:55-56) -- the program tools/resnet_real_boot.py runs at N = 2^17 with real bootstrapping (BASELINE config 4)."""
+    count, HEAAN_HEVM.cpp:55-56) -- the program tools/legs/resnet_real_boot.py runs at N = 2^17 with real bootstrapping (BASELINE config 4)."""
     from dacapo_amd import progstats
 
     f16 = ha.read_fixture(GOLDEN.parent / "resnet20_nt16")

@@ -1,6 +1,6 @@
 """Differential test against Microsoft SEAL itself -- SKIPPED unless a SEAL 4.x install is found (none exists in the build image
 or on the GPU box: SURVEY.md 8c).  On a machine that has SEAL (set SEAL_ROOT to its install prefix) it closes the loop that
-"parity unpinned" leaves open: tools/seal_diff_gen.cpp runs SEAL on a fixed scenario and saves keys, inputs and every result in
+"parity unpinned" leaves open: tools/fixtures/seal_diff_gen.cpp runs SEAL on a fixed scenario and saves keys, inputs and every result in
 SEAL's serialization; the oracle (CPU test) and the MI355X runtime (GPU test, through initFullVM / hevm_load_ctxt) replay the
 same evaluator calls on the same keys and inputs and must produce the same limbs, bit for bit."""
 import os
@@ -32,7 +32,7 @@ def scenario(tmp_path_factory):
     inc, lib = found
     d = tmp_path_factory.mktemp("seal_diff")
     exe = d / "seal_diff_gen"
-    base = ["g++", "-std=c++17", "-O2", str(ROOT / "tools" / "seal_diff_gen.cpp"), f"-I{inc}", "-o", str(exe)]
+    base = ["g++", "-std=c++17", "-O2", str(ROOT / "tools" / "fixtures" / "seal_diff_gen.cpp"), f"-I{inc}", "-o", str(exe)]
     for extra in ([str(lib)], [str(lib), "-lzstd", "-lz"], [f"-L{lib.parent}", "-lseal-4.0", "-lzstd", "-lz"]):
         if subprocess.run(base + extra + ["-lpthread"], capture_output=True).returncode == 0:
             break

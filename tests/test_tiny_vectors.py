@@ -1,4 +1,4 @@
-"""CPU: the oracle against hand-auditable vectors (tests/golden/tiny_vectors.json, made by tools/make_tiny_vectors.py from the
+"""CPU: the oracle against hand-auditable vectors (tests/golden/tiny_vectors.json, made by tools/fixtures/make_tiny_vectors.py from the
 integer closed forms of rescale / key switch / multiply on Z[X]/(X^8+1) -- no NTT algorithm, no RNS tricks, no oracle code).
 What SEAL_HEVM.cpp:283 (rescale_to_next), :273 (rotate_vector -> apply_galois + switch_key) and :315-316 (multiply +
 relinearize) compute, small enough to recompute by hand or with any big-integer calculator."""
@@ -25,7 +25,7 @@ def to_u64(nested):
 
 
 def test_committed_vectors_are_what_the_generator_prints():
-    out = subprocess.run([sys.executable, str(ROOT / "tools" / "make_tiny_vectors.py")], capture_output=True, text=True, check=True).stdout
+    out = subprocess.run([sys.executable, str(ROOT / "tools" / "fixtures" / "make_tiny_vectors.py")], capture_output=True, text=True, check=True).stdout
     assert json.loads(out) == V
 
 

@@ -12,7 +12,7 @@ cd /tmp && export TMPDIR=/tmp
 kt() { ls $1/*/*kernel_trace.csv | head -1; }
 cc() { ls $1/*/*counter_collection.csv | head -1; }
 ARG=$LOW; [ $LOW = headline ] && ARG=""
-CMD="python3 $ROOT/tools/headline_only.py 3 $ARG $EXTRA"
+CMD="python3 $ROOT/tools/legs/headline_only.py 3 $ARG $EXTRA"
 D=$OUT/raw_run_$LOW; rm -rf $D; mkdir -p $D
 timeout 600 rocprofv3 --kernel-trace --output-format csv -d $D/kt -- $CMD > /dev/null 2> $D/kt.err
 timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $D/pf -- $CMD > /dev/null 2> $D/pf.err
@@ -22,6 +22,6 @@ cp $(kt $D/kt) $D/kernel_trace.csv; cp $(cc $D/pf) $D/fetch.csv; cp $(cc $D/pw) 
 rm -rf $D/kt $D/pf $D/pw $D/pv
 { echo "One run() of the ResNet-20 trace, lowering $LOW, kernel by kernel: tools/collect_run_budget.sh $R $LOW $EXTRA"
   echo "library sha256: $(sha256sum $ROOT/dacapo_amd/lib/libSEAL_HEVM.so | cut -c1-64)"
-  python3 $ROOT/tools/run_budget.py $D/kernel_trace.csv $D/fetch.csv $D/write.csv $D/valu.csv top=16 label=resnet20.$LOW json=$OUT/${R}_run_budget_$LOW.json; } > $OUT/${R}_run_budget_$LOW.txt 2> $D/budget.err
+  python3 $ROOT/tools/summarize/run_budget.py $D/kernel_trace.csv $D/fetch.csv $D/write.csv $D/valu.csv top=16 label=resnet20.$LOW json=$OUT/${R}_run_budget_$LOW.json; } > $OUT/${R}_run_budget_$LOW.txt 2> $D/budget.err
 gzip -f $D/*.csv
 cat $OUT/${R}_run_budget_$LOW.txt

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Places the kernels of one grouped-digit key switch on the byte roofline:
-    rocprofv3 --kernel-trace --stats --output-format csv -d out -- python3 tools/hybrid_ks_bench.py 17 39 8 7 5 31 > hop.json
+    rocprofv3 --kernel-trace --stats --output-format csv -d out -- python3 tools/legs/hybrid_ks_bench.py 17 39 8 7 5 31 > hop.json
     python tools/experiments/hybrid_ks_summary.py out/*/*kernel_stats.csv hop.json
-per kernel of the sequence: average duration, algorithmic bytes (limbs x 8 N, tools/hybrid_ks_bench.py), GB/s, fraction of 8 TB/s."""
+per kernel of the sequence: average duration, algorithmic bytes (limbs x 8 N, tools/legs/hybrid_ks_bench.py), GB/s, fraction of 8 TB/s."""
 import csv
 import json
 import re

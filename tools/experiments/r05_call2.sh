@@ -8,7 +8,7 @@ for o in tiny_tile_wgs=512 tiny_tile_wgs=1000 tiny_tile_wgs=2000 tiny_tile_wgs=4
   echo "== rotate_hop, $o"; python3 $R/tools/summarize_trace.py $(ls /tmp/kt_$o/*/*kernel_trace.csv | head -1) | grep -v rocclr | head -12
 done > $R/gpurun_out/r05b/rotate_tiny_kernels.txt 2>&1
 cd $R
-python3 tools/lowering_sweep.py 6 tiny_tile_wgs=1000 tiny_tile_wgs=2000 tiny_tile_wgs=4000 tiny_tile_wgs=8000 > gpurun_out/r05b/lowering_sweep.txt 2>&1
-python3 tools/per_op_sweep.py 30 tiny_tile_wgs=2000 tiny_tile_wgs=4000 tiny_tile_wgs=8000 > gpurun_out/r05b/per_op_sweep.txt 2>&1
+python3 tools/legs/lowering_sweep.py 6 tiny_tile_wgs=1000 tiny_tile_wgs=2000 tiny_tile_wgs=4000 tiny_tile_wgs=8000 > gpurun_out/r05b/lowering_sweep.txt 2>&1
+python3 tools/legs/per_op_sweep.py 30 tiny_tile_wgs=2000 tiny_tile_wgs=4000 tiny_tile_wgs=8000 > gpurun_out/r05b/per_op_sweep.txt 2>&1
 python3 -m pytest tests/test_gpu_hevm.py -x -q -m gpu > gpurun_out/r05b/pytest_hevm.txt 2>&1
 tail -5 gpurun_out/r05b/pytest_hevm.txt; cat gpurun_out/r05b/lowering_sweep.txt gpurun_out/r05b/per_op_sweep.txt

@@ -7,7 +7,7 @@ The reference's loaders trust their files (SEAL_HEVM.cpp:182-234: fread into vec
 load()); these are the inputs that trust would trip over: truncation at every field, counts beyond the data, negative and 2^62 counts,
 bad magic, foreign versions, unknown / corrupt / truncated compression, and decompression bombs (zlib and Zstandard).
 
-    python tools/make_hostile_corpus.py        (deterministic; everything is a few KB except the two bombs, ~200 KB and 16 KB)"""
+    python tools/fixtures/make_hostile_corpus.py        (deterministic; everything is a few KB except the two bombs, ~200 KB and 16 KB)"""
 import json
 import struct
 import sys
@@ -16,7 +16,7 @@ from pathlib import Path
 
 import numpy as np
 
-ROOT = Path(__file__).resolve().parent.parent
+ROOT = Path(__file__).resolve().parent.parent.parent
 sys.path.insert(0, str(ROOT))
 from dacapo_amd import hevm_asm as ha  # noqa: E402
 from oracle import seal_format as sf  # noqa: E402
@@ -154,5 +154,5 @@ liar = bytearray(params)
 struct.pack_into("<Q", liar, 1 + 8, 1 << 33)  # coeff_modulus_size
 emit("seal_params_2_33_primes.seal", "seal", sf.wrap(bytes(liar)), "ok", "")
 
-(OUT / "manifest.json").write_text(json.dumps({"generator": "tools/make_hostile_corpus.py", "files": manifest}, indent=1) + "\n")
+(OUT / "manifest.json").write_text(json.dumps({"generator": "tools/fixtures/make_hostile_corpus.py", "files": manifest}, indent=1) + "\n")
 print(len(manifest), "files,", sum((OUT / m["file"]).stat().st_size for m in manifest) >> 10, "KiB ->", OUT)

@@ -20,7 +20,7 @@
 Inputs are produced by a 3-line LCG so that anyone can regenerate them.  The committed output, tests/golden/tiny_vectors.json,
 pins oracle/ckks_oracle.c (tests/test_tiny_vectors.py); nothing here imports the oracle or the product.
 
-    python tools/make_tiny_vectors.py > tests/golden/tiny_vectors.json
+    python tools/fixtures/make_tiny_vectors.py > tests/golden/tiny_vectors.json
 """
 import json
 
@@ -199,7 +199,7 @@ def main():
     ntt_ct = lambda c, mods=q, roots=psi: [[to_ntt(poly[i], mods[i], roots[i]) for i in range(len(poly))] for poly in c]  # noqa: E731
     ntt_key = lambda key: [[[to_ntt(part[i], primes[i], psi[i]) for i in range(4)] for part in digit] for digit in key]  # noqa: E731
     out = {
-        "about": "tools/make_tiny_vectors.py: closed forms over the integers on Z[X]/(X^8+1); all polynomials below are in NTT form "
+        "about": "tools/fixtures/make_tiny_vectors.py: closed forms over the integers on Z[X]/(X^8+1); all polynomials below are in NTT form "
                  "(out[i] = a(psi^(2 brev(i)+1))), limb-major, as decimal strings",
         "logN": LOGN, "primes": primes, "psi": psi, "galois_elt": e_gal,
         "secret_key_coefficients": s,

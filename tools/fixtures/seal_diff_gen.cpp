@@ -2,7 +2,7 @@
 // little scenario and save everything in SEAL's own serialization, so that tests/test_seal_diff.py can feed the same keys
 // and ciphertexts to this repo's runtime (initFullVM / hevm_load_ctxt) and to the oracle, and compare result limbs.
 // Not built by default: SEAL is not installed in the build image.  On a machine that has it:
-//     g++ -std=c++17 -O2 tools/seal_diff_gen.cpp -I$SEAL/include/SEAL-4.0 -L$SEAL/lib -lseal-4.0 -o seal_diff_gen
+//     g++ -std=c++17 -O2 tools/fixtures/seal_diff_gen.cpp -I$SEAL/include/SEAL-4.0 -L$SEAL/lib -lseal-4.0 -o seal_diff_gen
 //     ./seal_diff_gen <outdir> [logN=13] [primes=5]
 // The key directory is written exactly as SEAL_HEVM::create_context writes it (SEAL_HEVM.cpp:44-89: parm / pub / sec /
 // relin / gal .seal, default compr_mode, full -- not seed-compressed -- keys, default Galois key set); the evaluator calls

@@ -6,7 +6,7 @@ nothing here is used at run time on the GPU box.  What it produces is DATA: the 
 reference's own frontend code emits it (rotation offsets, ct*pt / ct*ct / add structure, constant lengths), lowered by
 `dacapo_amd.hevm_asm.Builder` (policy="lazy": rescale-on-demand + automatic bootstrap placement) to `.hevm` bytecode.
 
-    python tools/trace_reference_model.py ResNet --out tests/golden/resnet20
+    python tools/fixtures/trace_reference_model.py ResNet --out tests/golden/resnet20
 
 writes  <out>.hevm.gz    the bytecode (HEVMHeader.h wire format, gzip)
         <out>.cst.xz     the constant file (ElideConstant.cpp:40-53 format, xz): BN-folded weights in packed slot layout
@@ -358,7 +358,7 @@ def trace_suite_program(name, slots_log, waterline, boot_level, out_dir):
     run = hc._state["runner"]
     hops, muls, boots = level_histogram(b)
     meta = {"source": f"examples/benchmarks/{name}.py traced; inputs and error figure from examples/tests/{name}.py run against the "
-                      "cleartext evaluation of the traced program (tools/trace_reference_model.py --suite)",
+                      "cleartext evaluation of the traced program (tools/fixtures/trace_reference_model.py --suite)",
             "slots": slots, "waterline": waterline, "init_level": b.init_level, "boot_level": boot_level, "info": info,
             "num_inputs": len(run.inputs), "num_results": len(b.results), "hops_per_level": {str(k): v for k, v in sorted(hops.items())},
             "mulcc_per_level": {str(k): v for k, v in sorted(muls.items())}, "bootstraps": boots,
@@ -441,7 +441,7 @@ def main():
     hops, muls, boots = level_histogram(b)
     lens = [int(len(c)) for c in b.constants]
     meta = {
-        "source": f"examples/benchmarks/{a.model}.py traced through python/poly with tools/trace_reference_model.py",
+        "source": f"examples/benchmarks/{a.model}.py traced through python/poly with tools/fixtures/trace_reference_model.py",
         "slots": slots, "waterline": a.waterline, "init_level": a.init_level, "boot_level": a.boot_level, "hint_need": a.hint_need,
         "rescale_bits": a.rescale_bits, "headroom": a.headroom,
         "input": {"packed_len": int(len(packed)), "seed": a.seed, "kind": "smooth synthetic 3x32x32 image, CIFAR-normalised"},

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Real CKKS bootstrapping on the MI355X: one ciphertext at 1 prime -> `target` primes, through the extension opcodes and
-dacapo_amd/ckks_boot.py.   python tools/boot_demo.py [logN=15] [r=5] [direct_keys=1] [target=3] [ks_special=1] [ks_alpha=ks_special] [--opt name=value ...]
+dacapo_amd/ckks_boot.py.   python tools/legs/boot_demo.py [logN=15] [r=5] [direct_keys=1] [target=3] [ks_special=1] [ks_alpha=ks_special] [--opt name=value ...]
 ks_special > 1: grouped-digit hybrid key switching (hybrid_ks.hip), the chain gets that many special primes.
-BASELINE config 4's geometry: python tools/boot_demo.py 17 5 1 14 8 7"""
+BASELINE config 4's geometry: python tools/legs/boot_demo.py 17 5 1 14 8 7"""
 import os
 import sys
 import time
@@ -10,7 +10,7 @@ from pathlib import Path
 
 import numpy as np
 
-sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))
 from dacapo_amd import ckks_boot as cb  # noqa: E402
 from dacapo_amd import hevm_asm as ha  # noqa: E402
 from dacapo_amd import runner  # noqa: E402

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Latency of dependent op chains through run() (N = 2^15, 14 primes): what one step of a sequential program section
-costs on the MI355X.  usage: python tools/chain_bench.py"""
+costs on the MI355X.  usage: python tools/legs/chain_bench.py"""
 import sys
 import time
 from pathlib import Path

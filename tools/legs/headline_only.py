@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
 """Only the headline workload (set-up, then `runs` run() calls of the ResNet-20 HEVM program of bench.py), for rocprofv3 passes whose
-counters should describe the timed step and nothing else:  python3 tools/headline_only.py [runs=3] [lowering = b6 | b13] [--opt name=value ...]"""
+counters should describe the timed step and nothing else:  python3 tools/legs/headline_only.py [runs=3] [lowering = b6 | b13] [--opt name=value ...]"""
 import sys
 from pathlib import Path
 
-ROOT = Path(__file__).resolve().parent.parent
+ROOT = Path(__file__).resolve().parent.parent.parent
 sys.path.insert(0, str(ROOT))
 from dacapo_amd import hevm_asm as ha  # noqa: E402
 from dacapo_amd import runner  # noqa: E402

@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
 """One rotation hop with grouped-digit hybrid key switching at N = 2^17 (hybrid_ks.hip), level by level: HIP-event time per hop and the
 algorithmic bytes of each kernel of the sequence, so that a `rocprofv3 --kernel-trace --stats` of this tool (summarised by
-tools/experiments/hybrid_ks_summary.py) places every kernel on the byte roofline.   python3 tools/hybrid_ks_bench.py [logN=17] [K=39] [ks=8] [alpha=7] [iters=5] [only_level=0] [--opt name=value ...]"""
+tools/experiments/hybrid_ks_summary.py) places every kernel on the byte roofline.   python3 tools/legs/hybrid_ks_bench.py [logN=17] [K=39] [ks=8] [alpha=7] [iters=5] [only_level=0] [--opt name=value ...]"""
 import json
 import sys
 from pathlib import Path
 
-sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))
 from dacapo_amd import lowlevel as ll  # noqa: E402
 from dacapo_amd import runner  # noqa: E402
 

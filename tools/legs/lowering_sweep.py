@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """The three lowerings of the ResNet-20 trace (opcode 10 -> 3 / 6 / 13 primes) under a list of launch-shape option sets, one VM:
-    python tools/lowering_sweep.py [steps=5] [--only b13] [--new-vm] "name=value,name=value" ...
+    python tools/legs/lowering_sweep.py [steps=5] [--only b13] [--new-vm] "name=value,name=value" ...
 Launch shapes are read when a launch is issued, i.e. when load() records the plan's graph: the program is re-loaded per option set.
 Prints best-of-steps ms per run() for each lowering; the first row is the defaults."""
 import gzip
@@ -8,7 +8,7 @@ import sys
 import time
 from pathlib import Path
 
-ROOT = Path(__file__).resolve().parent.parent
+ROOT = Path(__file__).resolve().parent.parent.parent
 sys.path.insert(0, str(ROOT))
 from dacapo_amd import hevm_asm as ha  # noqa: E402
 from dacapo_amd import runner  # noqa: E402

@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """The single-crossing NTT (ntt_full.hip) against the two-launch tiles on the GPU: bit-exactness (forward, inverse, round trip) and the
-time of both over `limbs` limbs of N = 2^15.   python tools/ntt_full_check.py [limbs=4096] [iters=10] [--opt name=value ...]"""
+time of both over `limbs` limbs of N = 2^15.   python tools/legs/ntt_full_check.py [limbs=4096] [iters=10] [--opt name=value ...]"""
 import json
 import sys
 from pathlib import Path
 
 import numpy as np
 
-sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))
 from dacapo_amd import lowlevel as ll  # noqa: E402
 from dacapo_amd import runner  # noqa: E402
 

@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""Runs only the batched forward/inverse NTT (for counter collection): python3 tools/ntt_only.py [logN] [limbs] [iters]"""
+"""Runs only the batched forward/inverse NTT (for counter collection): python3 tools/legs/ntt_only.py [logN] [limbs] [iters]"""
 import sys
 from pathlib import Path
 
-sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))
 from dacapo_amd import lowlevel as ll
 
 logN = int(sys.argv[1]) if len(sys.argv) > 1 else 15

@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
-"""Runs one NTT implementation alone, for rocprofv3 (kernel trace / --pmc): python3 tools/ntt_variant_only.py variant [limbs=4096] [iters=3]
+"""Runs one NTT implementation alone, for rocprofv3 (kernel trace / --pmc): python3 tools/legs/ntt_variant_only.py variant [limbs=4096] [iters=3]
 variant 0 = two-launch tiles, 1 = single-crossing kernel (dc_ntt_variant); forward and inverse alternate on N = 2^15."""
 import sys
 from pathlib import Path
 
-sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))
 from dacapo_amd import lowlevel as ll
 
 variant = int(sys.argv[1]) if len(sys.argv) > 1 else 1

@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
 """The per-op leg (13 primes, N = 2^15) and config 3 under a list of launch-shape option sets, HIP events, one process:
-    python tools/per_op_sweep.py [iters=30] "name=value,name=value" "..." ...
+    python tools/legs/per_op_sweep.py [iters=30] "name=value,name=value" "..." ...
 Each argument is one option set (applied on top of the defaults, reset afterwards); the first row is always the defaults.
 Prints one line per set: rotate hop / ct x ct + relinearise / rescale (us), config 3 (us)."""
 import sys
 from pathlib import Path
 
-sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))
 import bench  # noqa: E402
 from dacapo_amd import lowlevel as ll  # noqa: E402
 from dacapo_amd import runner  # noqa: E402

@@ -8,7 +8,7 @@ compiler plan FOR the MI355X backend (e.g. opcode 10 is not free here, and a key
 What is measured is the latency of one op inside a dependent chain through run() (batched plan, one ciphertext): the
 cost a sequential program section pays.  Large independent batches cost far less per op (throughput mode).
 
-    python tools/profile_backend.py [--out profiles/r01_profiled_SEAL_MI355X.json]
+    python tools/legs/profile_backend.py [--out profiles/r01_profiled_SEAL_MI355X.json]
 """
 import argparse
 import json
@@ -85,7 +85,7 @@ def main():
         "latencyTable": table,
         "latencyTable_us_float": {k: [round(x, 2) for x in v] for k, v in lat.items()},
         "noiseTable": {},
-        "_comment": "latency of one op in a dependent chain through run() on one MI355X (tools/profile_backend.py); same arithmetic "
+        "_comment": "latency of one op in a dependent chain through run() on one MI355X (tools/legs/profile_backend.py); same arithmetic "
                     "as SEAL, so profiled_SEAL_CPU.json's noiseTable applies unchanged",
     }
     Path(a.out).write_text(json.dumps(out, indent=1))

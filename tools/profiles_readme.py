@@ -59,7 +59,7 @@ def traffic_row(r):
     b, a = d["forward_ntt_hbm_bytes"], d["forward_ntt_algorithmic_bytes"]
     return (f"| `{r}_ntt_hbm_traffic.json` | FETCH_SIZE (×2) + WRITE_SIZE of the forward transform as `dc_ntt_forward` launches it on {d['limbs']} limbs "
             f"({', '.join('`' + k + '`' for k in d['forward_ntt_kernels'])}): {b / 1e9:.3f} GB = {b / a:.2f} × {a / 1e9:.3f} GB; library sha256 `{d['lib_sha256'][:12]}…` | "
-            "`rocprofv3 --pmc FETCH_SIZE --kernel-trace -- python3 tools/ntt_only.py 15 4096 2` (and `WRITE_SIZE`), `tools/collect_traffic.py` |")
+            "`rocprofv3 --pmc FETCH_SIZE --kernel-trace -- python3 tools/legs/ntt_only.py 15 4096 2` (and `WRITE_SIZE`), `tools/summarize/collect_traffic.py` |")
 
 
 def step_row(r):
@@ -74,7 +74,7 @@ def step_row(r):
         extra = f", algorithmic {k['algorithmic_bytes_in_run'] / 1e9:.1f} GB, traffic ÷ algorithmic {k['traffic_over_algorithmic']}" if k.get("algorithmic_bytes_in_run") else ""
     return (f"| `{r}_step_kernels.json` | the timed step's own kernels: {d['kernels_in_run']} launches in the last `run()`, {d['kernel_time_ms']:.1f} ms of kernel time in "
             f"{d['wall_ms_under_profiler']:.1f} ms under the profiler, {d['bytes_actually_moved_in_run'] / 1e9:.1f} GB actually moved; dominant `{k['kernel']}` "
-            f"{k['calls']} × {k['avg_us']} µs, {k['hbm_bytes_in_run'] / 1e9:.2f} GB from HBM{extra} | three passes of `python3 tools/headline_only.py 3`, `tools/kernel_traffic.py` |")
+            f"{k['calls']} × {k['avg_us']} µs, {k['hbm_bytes_in_run'] / 1e9:.2f} GB from HBM{extra} | three passes of `python3 tools/legs/headline_only.py 3`, `tools/summarize/kernel_traffic.py` |")
 
 
 def valu_row(r):
@@ -86,11 +86,11 @@ def valu_row(r):
     inv = (f"; inverse kernel: {ki.get('valu_instructions_per_wave_per_limb')} instructions, busy {ki.get('simd_valu_busy_frac')}, {ki.get('avg_us_under_profiler')} µs under the counters"
            if ki else "")
     return (f"| `{r}_ntt_valu.json` | VALU occupancy of the single-crossing forward kernel: {k.get('valu_instructions_per_wave_per_limb')} vector instructions per wave per limb, "
-            f"SIMD vector ALUs busy {k.get('simd_valu_busy_frac')} of the launch{inv} | `tools/collect_profiles.sh` B4b, `tools/ntt_valu.py` |")
+            f"SIMD vector ALUs busy {k.get('simd_valu_busy_frac')} of the launch{inv} | `tools/collect_profiles.sh` B4b, `tools/summarize/ntt_valu.py` |")
 
 
 def budget_head(name):
-    """the summary lines (== op / run: ...) of a tools/per_op_budget.py or run_budget.py table"""
+    """the summary lines (== op / run: ...) of a tools/summarize/per_op_budget.py or run_budget.py table"""
     f = P / name
     if not f.exists():
         return "(missing)"
@@ -98,7 +98,7 @@ def budget_head(name):
 
 
 def budget_rows(name, pat, n=3):
-    """rows of a tools/run_budget.py table as prose: kernel, calls, ms, share, avg us, GB, TB/s, VALU M, floors, bound, x"""
+    """rows of a tools/summarize/run_budget.py table as prose: kernel, calls, ms, share, avg us, GB, TB/s, VALU M, floors, bound, x"""
     f = P / name
     if not f.exists():
         return "(missing)"
@@ -142,7 +142,7 @@ def first_lines(name, pat, n=3):
 
 
 def kb_rows(name, pat, n=3):
-    """rows of a tools/kernel_bytes.py table (kernel, calls, avg us, us/unit, share, read MB/unit, write MB/unit, GB/s, fraction of 8 TB/s) as prose"""
+    """rows of a tools/summarize/kernel_bytes.py table (kernel, calls, avg us, us/unit, share, read MB/unit, write MB/unit, GB/s, fraction of 8 TB/s) as prose"""
     f = P / name
     if not f.exists():
         return "(missing)"
@@ -192,24 +192,24 @@ print("| file | what (figures read from the file) | command |\n|---|---|---|")
 rows = [bench_row("r05"), traffic_row("r05"), step_row("r05"), valu_row("r05"),
         f"| `r05_per_op_kernel_bytes.txt`, `r05_per_op_budget_*.json` | the single ops at 13 primes and config 3 KERNEL BY KERNEL: duration, measured HBM bytes (FETCH_SIZE × 2 + WRITE_SIZE), "
         f"VALU wave-instructions, and three floors per launch (bytes ÷ 5.5 TB/s; VALU × 4 cycles ÷ 1024 SIMDs ÷ 2.05 GHz × CU quantisation; 3.7 µs per dependent launch): "
-        f"{budget_head('r05_per_op_kernel_bytes.txt')} | `tools/collect_per_op_budget.sh r05`: four rocprofv3 passes per op, one op per process, `tools/per_op_budget.py` |",
+        f"{budget_head('r05_per_op_kernel_bytes.txt')} | `tools/collect_per_op_budget.sh r05`: four rocprofv3 passes per op, one op per process, `tools/summarize/per_op_budget.py` |",
         f"| `r05_run_budget_b13.txt` / `.json` | one `run()` of the 13-prime lowering kernel by kernel with the same floors: {budget_head('r05_run_budget_b13.txt')}; "
-        f"{budget_rows('r05_run_budget_b13.txt', 'f_ks_frows_mac_kernel<8, 2, 0, true>|f_ks_lift_fcols_kernel<7, 3>', 2)} | `tools/collect_run_budget.sh r05 b13`, `tools/run_budget.py` |",
+        f"{budget_rows('r05_run_budget_b13.txt', 'f_ks_frows_mac_kernel<8, 2, 0, true>|f_ks_lift_fcols_kernel<7, 3>', 2)} | `tools/collect_run_budget.sh r05 b13`, `tools/summarize/run_budget.py` |",
         f"| `r05_run_budget_headline.txt` / `.json` | the same for the headline program: {budget_head('r05_run_budget_headline.txt')}; "
         f"{budget_rows('r05_run_budget_headline.txt', 'f_ks_frows_mac_kernel<8, 2, 0, true>|f_dr_icols_lift_fcols_kernel<7, 1, false>', 2)} | `tools/collect_run_budget.sh r05 headline` |",
-        f"| `r05_lowering_sweep.txt`, `r05_per_op_sweep.txt` | this round's launch-shape options switched off one at a time on one box (HIP events / best of 6 runs): {sweep_lines('r05_lowering_sweep.txt', 5)} //// {sweep_lines('r05_per_op_sweep.txt', 5)} | `tools/lowering_sweep.py`, `tools/per_op_sweep.py` |",
-        f"| `r05_ntt_full_check.txt` | single-crossing kernel / two-launch tiles, µs, by limb count (bit-exactness checked in the same run): {check_lines('r05_ntt_full_check.txt')} | `tools/ntt_full_check.py <limbs> 20` |",
+        f"| `r05_lowering_sweep.txt`, `r05_per_op_sweep.txt` | this round's launch-shape options switched off one at a time on one box (HIP events / best of 6 runs): {sweep_lines('r05_lowering_sweep.txt', 5)} //// {sweep_lines('r05_per_op_sweep.txt', 5)} | `tools/legs/lowering_sweep.py`, `tools/legs/per_op_sweep.py` |",
+        f"| `r05_ntt_full_check.txt` | single-crossing kernel / two-launch tiles, µs, by limb count (bit-exactness checked in the same run): {check_lines('r05_ntt_full_check.txt')} | `tools/legs/ntt_full_check.py <limbs> 20` |",
         f"| `r05_hybrid_ks_kernels.txt` | one grouped-digit rotation hop at N = 2^17 under round 5's key shape (4 digits of 8 under 9 special primes), kernel by kernel with measured HBM bytes for the three "
         f"launch sequences, the matrix-core counters, all levels under HIP events: {hop_levels('r05_hybrid_ks_kernels.txt', ('rounds 3-4 shape, `hyb_fuse` = 2', '`hyb_fuse` = 2', '`hyb_fuse` = 1', '`hyb_fuse` = 0'))}. "
-        f"Per hop at level 31 under the trace: {seq_totals('r05_hybrid_ks_kernels.txt')} | `tools/collect_profiles.sh` B4: `tools/hybrid_ks_bench.py 17 40 9 8 10 31 --opt hyb_fuse=f`, `tools/kernel_bytes.py` |",
+        f"Per hop at level 31 under the trace: {seq_totals('r05_hybrid_ks_kernels.txt')} | `tools/collect_profiles.sh` B4: `tools/legs/hybrid_ks_bench.py 17 40 9 8 10 31 --opt hyb_fuse=f`, `tools/summarize/kernel_bytes.py` |",
         f"| `r05_config4_kernel_stats.csv`, `r05_config4_under_profiler.txt` | BASELINE config 4 under the kernel trace: {stats('r05_config4_kernel_stats.csv')} | "
-        "`rocprofv3 --kernel-trace --stats -- python3 tools/resnet_real_boot.py 1 resnet20_nt16 17 1 b14 9 8` |",
+        "`rocprofv3 --kernel-trace --stats -- python3 tools/legs/resnet_real_boot.py 1 resnet20_nt16 17 1 b14 9 8` |",
         f"| `r05_boot_kernel_bytes.txt` | ONE real bootstrap at config 4's geometry, per kernel the measured HBM bytes and GB/s: {first_lines('r05_boot_kernel_bytes.txt', 'bootstrap:', 1)}; "
-        f"{kb_rows('r05_boot_kernel_bytes.txt', 'hyb_mac_kernel<0>|hyb_conv_mfma_kernel<true, true, 2>|hyb_conv_mfma_kernel<false, true, 1>|ntt_phase_kernel<8, 3, true, false, false>', 4)} | three passes of `tools/boot_demo.py 17 5 1 14 9 8`, `tools/kernel_bytes.py` |",
-        f"| `r05_per_op.json`, `r05_per_op_kernel_stats.csv` | the three expensive opcodes at 13 primes and config 3 under `--stats`: {stats('r05_per_op_kernel_stats.csv', 3)} | `rocprofv3 --kernel-trace --stats -- python3 tools/per_op_only.py 20` |",
+        f"{kb_rows('r05_boot_kernel_bytes.txt', 'hyb_mac_kernel<0>|hyb_conv_mfma_kernel<true, true, 2>|hyb_conv_mfma_kernel<false, true, 1>|ntt_phase_kernel<8, 3, true, false, false>', 4)} | three passes of `tools/legs/boot_demo.py 17 5 1 14 9 8`, `tools/summarize/kernel_bytes.py` |",
+        f"| `r05_per_op.json`, `r05_per_op_kernel_stats.csv` | the three expensive opcodes at 13 primes and config 3 under `--stats`: {stats('r05_per_op_kernel_stats.csv', 3)} | `rocprofv3 --kernel-trace --stats -- python3 tools/legs/per_op_only.py 20` |",
         f"| `r05_kernel_stats.csv`, `r05_by_kernel_and_grid.txt`, `r05_timeline.txt`, `r05_top_kernels.json`, `r05_roofline_leg_launches.txt` | the bench command under the kernel trace: {first_lines('r05_timeline.txt', 'last run', 1)} | `rocprofv3 --kernel-trace --stats … -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-lowerings --no-config4` |",
         "| `r05_experiments.txt` | what was measured on the way and how it came out: the budgets before any change, launch-shape sweeps, key-ordered items, twiddle pairs (COLS tiles, inverse single-crossing passes, LDS twiddle tables), the 9-input mod-down, what was not kept | — |",
-        "| `r05_chain_latency.txt`, `r05_profiled_SEAL_MI355X.json` | as in round 4 on this build (the streams table moved into the bench line: `streams`) | `tools/chain_bench.py`, `tools/profile_backend.py` |"]
+        "| `r05_chain_latency.txt`, `r05_profiled_SEAL_MI355X.json` | as in round 4 on this build (the streams table moved into the bench line: `streams`) | `tools/legs/chain_bench.py`, `tools/legs/profile_backend.py` |"]
 print("\n".join(r for r in rows if r))
 print()
 print("## Round 4 (everything `r04_*`; one `gpurun` call of `tools/collect_profiles.sh r04` on the committed build — the JSON files that `bench.py` reads carry "
@@ -219,24 +219,24 @@ rows = [bench_row("r04"), traffic_row("r04"), step_row("r04"), valu_row("r04"),
         f"| `r04_hybrid_ks_kernels.txt` | one grouped-digit rotation hop at N = 2^17, level 31, kernel by kernel with MEASURED HBM bytes per hop (FETCH_SIZE × 2 + WRITE_SIZE) for the "
         f"three launch sequences, the matrix-core counters, and all levels under HIP events (levels 1 / 7 / 12 / 14 / 31): {hop_levels('r04_hybrid_ks_kernels.txt')}. "
         f"Per hop under the trace: {seq_totals('r04_hybrid_ks_kernels.txt')} | "
-        "`tools/collect_profiles.sh` B4: three passes of `tools/hybrid_ks_bench.py 17 39 8 7 10 31 --opt hyb_fuse=f`, `tools/kernel_bytes.py` |",
+        "`tools/collect_profiles.sh` B4: three passes of `tools/legs/hybrid_ks_bench.py 17 39 8 7 10 31 --opt hyb_fuse=f`, `tools/summarize/kernel_bytes.py` |",
         f"| `r04_config4_kernel_stats.csv`, `r04_config4_under_profiler.txt` | BASELINE config 4 under the kernel trace: {stats('r04_config4_kernel_stats.csv')} | "
-        "`rocprofv3 --kernel-trace --stats -- python3 tools/resnet_real_boot.py 1 resnet20_nt16 17 1 b14 8 7` |",
+        "`rocprofv3 --kernel-trace --stats -- python3 tools/legs/resnet_real_boot.py 1 resnet20_nt16 17 1 b14 8 7` |",
         f"| `r04_boot_kernel_bytes.txt` | ONE real bootstrap at config 4's geometry (38 of them are about nine tenths of config 4), per kernel the measured HBM bytes and GB/s -- the n-ary sums "
         f"and the inner products among them: {first_lines('r04_boot_kernel_bytes.txt', 'bootstrap:', 1)}; {kb_rows('r04_boot_kernel_bytes.txt', 'hyb_mac_kernel<0>|b_sum_group_kernel|b_sum_pair_kernel|ntt_phase_kernel<8, 3, true, false, false>', 4)} "
         "(the process = key generation + encoding + 3 runs).  The counter passes run on one bootstrap because rocprofv3's counter mode "
-        "crashes or hangs on the whole config-4 program (`r04_experiments.txt` item 12) | three passes of `tools/boot_demo.py 17 5 1 14 8 7` (`--pmc FETCH_SIZE` / `WRITE_SIZE` with `--opt plan_graph=0`), `tools/kernel_bytes.py` |",
+        "crashes or hangs on the whole config-4 program (`r04_experiments.txt` item 12) | three passes of `tools/legs/boot_demo.py 17 5 1 14 8 7` (`--pmc FETCH_SIZE` / `WRITE_SIZE` with `--opt plan_graph=0`), `tools/summarize/kernel_bytes.py` |",
         f"| `r04_dag_width.txt` | the headline program's dataflow graph: {first_lines('r04_dag_width.txt', 'waves,')}; replay times: {first_lines('r04_dag_width.txt', 'graph replay', 4)} | `python tools/experiments/dag_width.py` |",
-        f"| `r04_per_op.json`, `r04_per_op_kernel_stats.csv` | the three expensive opcodes at 13 primes and config 3, kernel by kernel: {stats('r04_per_op_kernel_stats.csv', 3)} | `rocprofv3 --kernel-trace --stats -- python3 tools/per_op_only.py 20` |",
+        f"| `r04_per_op.json`, `r04_per_op_kernel_stats.csv` | the three expensive opcodes at 13 primes and config 3, kernel by kernel: {stats('r04_per_op_kernel_stats.csv', 3)} | `rocprofv3 --kernel-trace --stats -- python3 tools/legs/per_op_only.py 20` |",
         f"| `r04_kernel_stats.csv`, `r04_by_kernel_and_grid.txt`, `r04_timeline.txt`, `r04_top_kernels.json` | the bench command under the kernel trace: {first_lines('r04_timeline.txt', 'last run', 1)} | `rocprofv3 --kernel-trace --stats … -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-lowerings --no-config4` |",
         "| `r04_experiments.txt` | what was measured on the way and how it came out: the fused sequence's first versions, tile-geometry sweeps per ring, loader vs matrix-core conversions, the explicit graph, mixed chains, bounded key sets | — |",
-        "| `r04_ntt_full_check.txt`, `r04_roofline_leg_launches.txt`, `r04_chain_latency.txt`, `r04_streams.txt`, `r04_profiled_SEAL_MI355X.json` | as in round 3 on this build | `tools/ntt_full_check.py`, `tools/summarize_trace.py`, `tools/chain_bench.py`, `bench.py --streams S`, `tools/profile_backend.py` |"]
+        "| `r04_ntt_full_check.txt`, `r04_roofline_leg_launches.txt`, `r04_chain_latency.txt`, `r04_streams.txt`, `r04_profiled_SEAL_MI355X.json` | as in round 3 on this build | `tools/legs/ntt_full_check.py`, `tools/summarize/summarize_trace.py`, `tools/legs/chain_bench.py`, `bench.py --streams S`, `tools/legs/profile_backend.py` |"]
 print("\n".join(r for r in rows if r))
 print("\n## Round 3 (everything `r03_*`; `tools/collect_profiles.sh r03` on round 3's committed build)\n")
 print("| file | what (figures read from the file) | command |\n|---|---|---|")
 rows = [bench_row("r03"), traffic_row("r03"), step_row("r03"), valu_row("r03"),
-        f"| `r03_config4_kernel_stats.csv`, `r03_config4_under_profiler.txt` | config 4 on round 3's build: {stats('r03_config4_kernel_stats.csv')} | `rocprofv3 --kernel-trace --stats -- python3 tools/resnet_real_boot.py 1 resnet20_nt16 17 1 b14 8 7` |",
-        "| `r03_step_kernels.json` (note) | its `traffic_over_algorithmic` = 1.52 for `f_ks_frows_mac_kernel<8, 2, 0, true>` is an accounting error of round 3's `tools/kernel_traffic.py` (the merged form's grid has ℓ + 1 rows; the tool priced it one level too low): fixed in round 4, see `r04_step_kernels.json` | — |",
+        f"| `r03_config4_kernel_stats.csv`, `r03_config4_under_profiler.txt` | config 4 on round 3's build: {stats('r03_config4_kernel_stats.csv')} | `rocprofv3 --kernel-trace --stats -- python3 tools/legs/resnet_real_boot.py 1 resnet20_nt16 17 1 b14 8 7` |",
+        "| `r03_step_kernels.json` (note) | its `traffic_over_algorithmic` = 1.52 for `f_ks_frows_mac_kernel<8, 2, 0, true>` is an accounting error of round 3's `tools/summarize/kernel_traffic.py` (the merged form's grid has ℓ + 1 rows; the tool priced it one level too low): fixed in round 4, see `r04_step_kernels.json` | — |",
         "| `r03_hybrid_ks_kernels.txt`, `r03_ntt_full.txt`, `r03_ntt_full_check.txt`, `r03_experiments.txt`, `r03_roofline_leg_launches.txt`, `r03_kernel_stats.csv`, `r03_by_kernel_and_grid.txt`, `r03_timeline.txt`, `r03_top_kernels.json`, `r03_chain_latency.txt`, `r03_streams.txt`, `r03_profiled_SEAL_MI355X.json`, `r03_bench_rccl_world1_broadcast_keys.json` | round 3's records of the grouped-digit hop (matrix-core vs vector conversions), the single-crossing NTT (ablations, counters, variants that lost), its experiments log, traces, chain latency, streams, the per-op table in the reference compiler's schema, the RCCL path at world size 1 | see each file's header |"]
 print("\n".join(r for r in rows if r))
 hist = P / "README.history.md"

@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """HBM traffic of the NTT phase kernels from two rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE do not fit one pass:
-MI355X_MICROARCH.md "rocprofv3 PMC slots") of `python3 tools/ntt_only.py 15 4096 2`:
-    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d out_f -- python3 tools/ntt_only.py 15 4096 2
-    rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d out_w -- python3 tools/ntt_only.py 15 4096 2
-    python tools/collect_traffic.py out_f/*/*counter_collection.csv out_w/*/*counter_collection.csv > profiles/r02_ntt_hbm_traffic.json
+MI355X_MICROARCH.md "rocprofv3 PMC slots") of `python3 tools/legs/ntt_only.py 15 4096 2`:
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d out_f -- python3 tools/legs/ntt_only.py 15 4096 2
+    rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d out_w -- python3 tools/legs/ntt_only.py 15 4096 2
+    python tools/summarize/collect_traffic.py out_f/*/*counter_collection.csv out_w/*/*counter_collection.csv > profiles/r02_ntt_hbm_traffic.json
 Units and corrections as the guide prescribes: both counters are in KB; on gfx950 FETCH_SIZE counts half of the bytes of a wide
 coalesced streaming read (128-B requests tallied at 64 B) and is doubled; WRITE_SIZE is exact."""
 import collections
@@ -14,7 +14,7 @@ import re
 import sys
 from pathlib import Path
 
-ROOT = Path(__file__).resolve().parent.parent
+ROOT = Path(__file__).resolve().parent.parent.parent
 
 
 def per_launch(path, counter):
@@ -38,7 +38,7 @@ hbm = {k: (2.0 * fetch[k] + write.get(k, 0.0)) * 1024.0 for k in fetch}
 # forward transform: the single-crossing kernel ntt_full15_kernel<false, ...> (round 3: what dc_ntt_forward launches on 4096 limbs of N = 2^15),
 # else the two phase kernels with INV = false
 fwd = [k for k in hbm if k.startswith("ntt_full15_kernel<false")] or [k for k in hbm if re.search(r"<\d, \d, (true|false), false, ", k)]
-out = {"command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (separate passes) --kernel-trace -- python3 tools/ntt_only.py 15 4096 2   (dc_ntt_forward / "
+out = {"command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (separate passes) --kernel-trace -- python3 tools/legs/ntt_only.py 15 4096 2   (dc_ntt_forward / "
                   "dc_ntt_inverse: forward = the single-crossing kernel, inverse = the two-launch tiles)",
        "lib_sha256": hashlib.sha256((ROOT / "dacapo_amd" / "lib" / "libSEAL_HEVM.so").read_bytes()).hexdigest(),
        "limbs": 4096, "N": 32768,

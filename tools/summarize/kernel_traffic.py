@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""Per-kernel HBM traffic of ONE run() of the headline program, from three rocprofv3 passes of `python3 tools/headline_only.py 3`:
-    rocprofv3 --kernel-trace --output-format csv -d kt -- python3 tools/headline_only.py 3
-    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d pf -- python3 tools/headline_only.py 3
-    rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d pw -- python3 tools/headline_only.py 3
-    python tools/kernel_traffic.py kt/*/*kernel_trace.csv pf/*/*counter_collection.csv pw/*/*counter_collection.csv > profiles/r04_step_kernels.json
+"""Per-kernel HBM traffic of ONE run() of the headline program, from three rocprofv3 passes of `python3 tools/legs/headline_only.py 3`:
+    rocprofv3 --kernel-trace --output-format csv -d kt -- python3 tools/legs/headline_only.py 3
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d pf -- python3 tools/legs/headline_only.py 3
+    rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d pw -- python3 tools/legs/headline_only.py 3
+    python tools/summarize/kernel_traffic.py kt/*/*kernel_trace.csv pf/*/*counter_collection.csv pw/*/*counter_collection.csv > profiles/r04_step_kernels.json
 Durations come from the counter-free pass; bytes = FETCH_SIZE x 2 (gfx950 counts a 128-byte request of a wide coalesced read as 64:
 MI355X_MICROARCH.md) + WRITE_SIZE, both in KB.  For the kernels whose grid encodes (level l, batch B) two byte counts are recomputed
 (P_limb = 8 N) and kept APART, so that every fraction can be re-derived from this file:
@@ -21,7 +21,7 @@ import re
 import sys
 from pathlib import Path
 
-ROOT = Path(__file__).resolve().parent.parent
+ROOT = Path(__file__).resolve().parent.parent.parent
 N, P_LIMB, PEAK = 32768, 8 * 32768, 8.0e12
 
 
@@ -99,7 +99,7 @@ for n, (calls, t) in sorted(dur.items(), key=lambda kv: -kv[1][1])[:8]:
                                 "measured traffic is hbm_bytes_in_run, its roofline fraction hbm_frac_of_peak")
     kernels.append(e)
 total_hbm = (2.0 * sum(fetch.values()) + sum(write.values())) * 1024.0
-out = {"source": "rocprofv3 passes of `python3 tools/headline_only.py 3` (kernel trace; --pmc FETCH_SIZE; --pmc WRITE_SIZE), the last run()",
+out = {"source": "rocprofv3 passes of `python3 tools/legs/headline_only.py 3` (kernel trace; --pmc FETCH_SIZE; --pmc WRITE_SIZE), the last run()",
        "lib_sha256": hashlib.sha256((ROOT / "dacapo_amd" / "lib" / "libSEAL_HEVM.so").read_bytes()).hexdigest(),
        "note": "gfx950: FETCH_SIZE doubled (128-byte requests tallied at 64), WRITE_SIZE exact, KB -> bytes; durations from the counter-free pass",
        "kernels_in_run": len(kt), "wall_ms_under_profiler": round(wall / 1e6, 3), "kernel_time_ms": round(busy / 1e6, 3),

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""VALU occupancy of the single-crossing NTT from one rocprofv3 --pmc pass of `python3 tools/ntt_variant_only.py 1 4096 2`:
+"""VALU occupancy of the single-crossing NTT from one rocprofv3 --pmc pass of `python3 tools/legs/ntt_variant_only.py 1 4096 2`:
     rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d out -- \\
-        python3 tools/ntt_variant_only.py 1 4096 2
-    python tools/ntt_valu.py out/*/*counter_collection.csv out/*/*kernel_trace.csv > profiles/r03_ntt_valu.json
+        python3 tools/legs/ntt_variant_only.py 1 4096 2
+    python tools/summarize/ntt_valu.py out/*/*counter_collection.csv out/*/*kernel_trace.csv > profiles/r03_ntt_valu.json
 The kernel runs as a persistent grid of one 16-wave workgroup per CU, four waves per SIMD for the whole launch, so a SIMD's VALU is busy for
 sum over its waves of SQ_ACTIVE_INST_VALU out of SQ_WAVE_CYCLES / 4 (both count in units of four cycles): that ratio needs no clock.  The
 clock figure assumes GRBM_GUI_ACTIVE sums the 8 XCDs."""
@@ -14,7 +14,7 @@ import re
 import sys
 from pathlib import Path
 
-ROOT = Path(__file__).resolve().parent.parent
+ROOT = Path(__file__).resolve().parent.parent.parent
 acc, calls, seen = collections.defaultdict(lambda: collections.defaultdict(float)), collections.Counter(), set()
 with open(sys.argv[1]) as f:
     for r in csv.DictReader(f):
@@ -33,7 +33,7 @@ if len(sys.argv) > 2:
             if name.startswith("ntt_full15_kernel"):
                 dur[name].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 out = {"command": "rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -- "
-                  "python3 tools/ntt_variant_only.py 1 4096 2",
+                  "python3 tools/legs/ntt_variant_only.py 1 4096 2",
        "lib_sha256": hashlib.sha256((ROOT / "dacapo_amd" / "lib" / "libSEAL_HEVM.so").read_bytes()).hexdigest(),
        "limbs": 4096, "N": 32768, "kernels": {}}
 for name, cs in acc.items():

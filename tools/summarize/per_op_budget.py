@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Kernel-by-kernel budget of ONE op (a rotation hop, ct x ct + relinearise, a rescale at 13 primes; config 3) from four rocprofv3 passes of
-`python3 tools/per_op_only.py <iters> --only <op>` (durations; FETCH_SIZE; WRITE_SIZE; VALU counters):
-    python tools/per_op_budget.py <op> <iters> kt.csv fetch.csv write.csv valu.csv [json=out.json]
+`python3 tools/legs/per_op_only.py <iters> --only <op>` (durations; FETCH_SIZE; WRITE_SIZE; VALU counters):
+    python tools/summarize/per_op_budget.py <op> <iters> kt.csv fetch.csv write.csv valu.csv [json=out.json]
 Per launch of every kernel of the op, in launch order:
     measured   avg us (kernel trace), HBM bytes = FETCH_SIZE x 2 (the gfx950 correction of MI355X_MICROARCH.md) + WRITE_SIZE, VALU wave-instructions
     floors     bytes / 5.5 TB/s (what a streaming kernel reaches on this part: the copy kernel's 4.7-5.6 TB/s, the n-ary sums' 5.6)

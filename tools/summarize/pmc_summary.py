@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-kernel sums of the counters in a rocprofv3 --pmc counter_collection CSV: python tools/pmc_summary.py <counter_collection.csv>"""
+"""Per-kernel sums of the counters in a rocprofv3 --pmc counter_collection CSV: python tools/summarize/pmc_summary.py <counter_collection.csv>"""
 import collections
 import csv
 import re

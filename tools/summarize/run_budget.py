@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
 """Kernel-by-kernel budget of ONE run() of a program (the headline or one of its lowerings) from four rocprofv3 passes of
-`python3 tools/headline_only.py 3 [b13]` (durations; FETCH_SIZE; WRITE_SIZE; VALU counters):
-    python tools/run_budget.py kt.csv fetch.csv write.csv valu.csv [top=14] [json=out.json] [label=...]
+`python3 tools/legs/headline_only.py 3 [b13]` (durations; FETCH_SIZE; WRITE_SIZE; VALU counters):
+    python tools/summarize/run_budget.py kt.csv fetch.csv write.csv valu.csv [top=14] [json=out.json] [label=...]
 Every kernel NAME of the last complete run (between the last two epoch bumps), all its launches summed:
     measured   total ms, share of kernel time, HBM bytes (FETCH_SIZE x 2 + WRITE_SIZE), VALU wave-instructions (SQ_INSTS_VALU)
-    floors     bytes / 5.5 TB/s;  VALU instructions x 4 cycles / 1024 SIMDs / 2.05 GHz  (tools/per_op_budget.py explains both)
+    floors     bytes / 5.5 TB/s;  VALU instructions x 4 cycles / 1024 SIMDs / 2.05 GHz  (tools/summarize/per_op_budget.py explains both)
     x floor    measured / max(floors): what the launches of that kernel lose to latency, quantisation and stalls together
 A per-launch minimum is not applied here: a program's small launches overlap on the plan's two streams."""
 import collections

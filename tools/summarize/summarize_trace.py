@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-(kernel, grid) average durations from a rocprofv3 --kernel-trace CSV, so that the launches of bench.py's
 roofline leg (4096-limb batches) can be read separately from the small launches of the HEVM run in the same command.
-usage: python tools/summarize_trace.py <..._kernel_trace.csv> [min_grid_y]"""
+usage: python tools/summarize/summarize_trace.py <..._kernel_trace.csv> [min_grid_y]"""
 import collections
 import csv
 import re

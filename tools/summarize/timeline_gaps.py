@@ -2,7 +2,7 @@
 """Busy/idle split of the GPU timeline from a rocprofv3 --kernel-trace CSV: for the last `--tail-ms` of the trace (the
 timed run() calls of bench.py come last, before the roofline leg is excluded by --max-grid-y) print kernel count, summed
 kernel time, summed gaps between consecutive kernels, and the per-kernel-name averages of (duration, gap before).
-usage: python tools/timeline_gaps.py <kernel_trace.csv> [--max-grid-y 2000]"""
+usage: python tools/summarize/timeline_gaps.py <kernel_trace.csv> [--max-grid-y 2000]"""
 import argparse
 import collections
 import csv

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The kernels that dominate the LAST run() in a rocprofv3 --kernel-trace CSV of `python3 bench.py ...`, as JSON for bench.py's
 roofline.step.top_kernels (reported only when `lib_sha256` matches the library being timed).
-usage: python tools/top_kernels.py <kernel_trace.csv> > profiles/r02_top_kernels.json"""
+usage: python tools/summarize/top_kernels.py <kernel_trace.csv> > profiles/r02_top_kernels.json"""
 import collections
 import csv
 import hashlib
@@ -10,7 +10,7 @@ import re
 import sys
 from pathlib import Path
 
-ROOT = Path(__file__).resolve().parent.parent
+ROOT = Path(__file__).resolve().parent.parent.parent
 ev = []
 with open(sys.argv[1]) as f:
     for r in csv.DictReader(f):
