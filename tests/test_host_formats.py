@@ -263,3 +263,27 @@ def test_instruction_encoding_matches_the_reference_emitter():
     assert int(by[ha.OP_ENCODE][3]) >> 10 == 5 and int(by[ha.OP_ROTATE][3]) == 0xFFFD and int(by[ha.OP_MODSWITCH][3]) == 1
     assert int(by[ha.OP_BOOTSTRAP][3]) == 4 and int(by[ha.OP_NEGATE][3]) == 0 and int(by[ha.OP_RESCALE][3]) == 0
     assert int(by[ha.OP_ADDCP][3]) < b.num_plain and int(by[ha.OP_MULCP][3]) < b.num_plain
+
+
+def test_every_tool_a_script_or_document_names_exists():
+    """tools/ is measurement and fixture plumbing in four directories (tools/README.md); the collection scripts, bench.py, the tests and the
+    current documents name its files by path -- every such path must exist (the round-5 reorganisation moved 29 of them)."""
+    import re
+
+    names = set()
+    files = list((ROOT / "tools").glob("*.sh")) + [ROOT / "bench.py", ROOT / "DESIGN.md", ROOT / "INTEGRATION.md", ROOT / "README.md", ROOT / "tools" / "README.md",
+                                                    ROOT / "docs" / "rounds" / "r05.md", ROOT / "tools" / "profiles_readme.py"] + list((ROOT / "tests").glob("*.py"))
+    for f in files:
+        for m in re.finditer(r"tools/(?:[a-z_]+/)?[A-Za-z0-9_]+\.(?:py|sh|cpp|hip)", f.read_text()):
+            names.add(m.group(0))
+    assert len(names) > 30
+    missing = sorted(n for n in names if not (ROOT / n).exists())
+    assert not missing, missing
+    for sub in ("legs", "summarize", "fixtures", "experiments"):
+        assert (ROOT / "tools" / sub).is_dir()
+    # a tool two levels below the root finds the root two levels up (parents[2] / .parent.parent.parent), not one
+    for sub in ("legs", "summarize", "fixtures"):
+        for f in (ROOT / "tools" / sub).glob("*.py"):
+            t = f.read_text()
+            assert not re.search(r"__file__\)\.resolve\(\)\.parents\[1\]", t), f
+            assert not re.search(r"__file__\)\.resolve\(\)\.parent\.parent(?!\.parent)", t), f

@@ -23,6 +23,6 @@ for m in re.finditer(r'def (\w+)\s*:\s*CKKS_Op<"(\w+)".*?op\.opcode = (\d+);\s*o
             return "zero"
         return "imm:" + re.sub(r"\s+", "", e)
     table[mnem] = {"opcode": int(opc), "dst": kind(dst), "lhs": kind(lhs), "rhs": kind(rhs)}
-dst = Path(__file__).resolve().parents[1] / "tests" / "golden" / "opcode_table.json"
+dst = Path(__file__).resolve().parents[2] / "tests" / "golden" / "opcode_table.json"
 dst.write_text(json.dumps({"source": "include/hecate/Dialect/CKKS/IR/CKKSOps.td:60-222", "ops": table}, indent=1))
 print(json.dumps(table, indent=1))

@@ -17,6 +17,6 @@ for m in re.finditer(r"^lw\.(\w+)\.restype\s*=\s*([\w.]+)", src, re.M):
     out.setdefault(m.group(1), {})["restype"] = m.group(2).replace("ctypes.", "")
 for v in out.values():
     v.setdefault("restype", "c_int")  # ctypes' default when the driver sets none (the C functions return void)
-dst = Path(__file__).resolve().parents[1] / "tests" / "golden" / "runner_bindings.json"
+dst = Path(__file__).resolve().parents[2] / "tests" / "golden" / "runner_bindings.json"
 dst.write_text(json.dumps({"source": "python/hecate/hecate/runner.py:34-71", "bindings": out}, indent=1))
 print(len(out), "symbols ->", dst)

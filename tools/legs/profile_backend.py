@@ -18,7 +18,7 @@ from pathlib import Path
 
 import numpy as np
 
-sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+sys.path.insert(0, str(Path(__file__).resolve().parents[2]))
 from dacapo_amd import hevm_asm as ha  # noqa: E402
 from dacapo_amd import runner  # noqa: E402
 
@@ -52,7 +52,7 @@ def chain(hevm, level, n, body, inputs=1):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--out", default=str(Path(__file__).resolve().parents[1] / "profiles" / "r01_profiled_SEAL_MI355X.json"))
+    ap.add_argument("--out", default=str(Path(__file__).resolve().parents[2] / "profiles" / "r01_profiled_SEAL_MI355X.json"))
     a = ap.parse_args()
     hevm = runner.HEVM(seed=3, logN=15, num_primes=14)
     empty = chain(hevm, 2, 1, lambda b, x, xs: b.negate(x)) * 0  # warm
