@@ -944,6 +944,15 @@ void f_dr_icols_lift_fcols(const Context &c, const u64 *last, long last_stride, 
 
 void f_ks_lift_fcols(const Context &c, const u64 *digits, u64 *ext, int B, int ell, hipStream_t s)
 {
+    if ((c.k1 == 7 || c.k1 == 8) && use_wide_tiles(c.N, (long)B * ell * ell) && !use_small_tiles(c.N, (long)B * ell * ell)) { // round 5: radix-16 COLS tiles
+        constexpr int LE = 4;                                                                                               // (ntt_tile.hpp; two phase sizes instantiated)
+        const dim3 grid((unsigned)(c.N >> TileGeo<LE>::LOG), (unsigned)(B * ell * ell));
+        if (c.k1 == 7)
+            DC_LAUNCH((f_ks_lift_fcols_kernel<7, LE>), grid, dim3(kTileThreads), 0, s, digits, ext, ell, c.K - 1, c.d_mods, c.d_tw, c.logN, c.twc2());
+        else
+            DC_LAUNCH((f_ks_lift_fcols_kernel<8, LE>), grid, dim3(kTileThreads), 0, s, digits, ext, ell, c.K - 1, c.d_mods, c.d_tw, c.logN, c.twc2());
+        return;
+    }
     DC_GEO_SWITCH(c.k1, B * ell * ell, DC_LAUNCH((f_ks_lift_fcols_kernel<KK, LE>), grid, dim3(kTileThreads), 0, s, digits, ext, ell,
                                                           c.K - 1, c.d_mods, c.d_tw, c.logN, c.twc2()));
 }

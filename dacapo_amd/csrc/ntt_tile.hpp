@@ -422,6 +422,17 @@ inline long small_tile_threshold(size_t N)
     return N <= ((size_t)1 << 15) ? 5000 : N == ((size_t)1 << 16) ? kSmallTileWgsN16 : 400;
 }
 inline bool use_small_tiles(size_t N, long limbs) { return (long)(N >> kTileLog) * limbs < small_tile_threshold(N); }
+// Round 5: a FOURTH geometry for throughput-bound forward COLS launches, LOGE = 4: 4096-coefficient tiles, 16 coefficients per thread, radix-16
+// passes -- a 128-row phase (N = 2^15) is two passes (4 + 3 stages) with ONE LDS exchange instead of three (3 + 3 + 1) with two, and its row
+// segments are 256 bytes.  Instantiated for the key switch's lift launches at k1 = 7 and 8 only (fused_ks.hip f_ks_lift_fcols; some other
+// (K, direction) instantiations of a radix-16 tile take hipcc tens of minutes): in the 13-prime lowering f_ks_lift_fcols 177.7 -> 160.6 us
+// per launch.  The generic COLS phase kernel at N = 2^17 gained nothing from it (hop at 31 primes 458-466 us either way) and keeps radix 8.
+// option wide_tile_wgs: lift launches of at least this many 4096-coefficient tiles take it (-1: never).
+inline bool use_wide_tiles(size_t N, long limbs)
+{
+    const long o = (long)option(OPT_WIDE_TILE_WGS);
+    return o >= 0 && N >= 4096 && (long)(N >> 12) * limbs >= o;
+}
 // in 512-coefficient workgroups (4 waves each): 256 = one wave on each of the 1024 SIMDs
 inline long tiny_tile_threshold() { return (long)option(OPT_TINY_TILE_WGS); }
 inline bool use_tiny_tiles(size_t N, long limbs) { return (long)(N >> TileGeo<1>::LOG) * limbs <= tiny_tile_threshold(); }

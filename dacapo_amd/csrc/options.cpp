@@ -39,6 +39,7 @@ static const OptDef kDefs[OPT_COUNT] = {
     { "step_profile", 0 },
     { "small_tile_wgs", -1 },
     { "tiny_tile_wgs", 2000 },
+    { "wide_tile_wgs", 2048 },
     { "ntt_full_min_limbs", 768 },
     { "ntt_full_inv_min_limbs", 768 },
     { "ntt_full_persist", -1 },

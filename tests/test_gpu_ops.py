@@ -171,10 +171,20 @@ def test_baseline_config3_mul_relin_n65536_l24():
     assert np.abs(got - x * y).max() < 1e-6
 
 
-def test_reference_size_keyswitch_ops_l13():
+@pytest.mark.parametrize("opts", [{}, {"small_tile_wgs": 0, "wide_tile_wgs": 0}, {"cols_pairs": 0, "tiny_tile_wgs": 512}])
+def test_reference_size_keyswitch_ops_l13(opts):
     """The reference ring and chain (N = 2^15, 14 x 60-bit, SEAL_HEVM.cpp:39-53) at the top level l = 13:
-    rotate hop, mul+relin and rescale bit-exact vs the oracle (210 NTT-equivalents per key switch)."""
+    rotate hop, mul+relin and rescale bit-exact vs the oracle (210 NTT-equivalents per key switch).  Second parameter set: the lift launch
+    forced onto the radix-16 tiles that the 13-prime lowering's batches take by themselves (f_ks_lift_fcols_kernel<7, 4>); third: round 4's
+    launch shapes (word twiddles in the COLS tiles, no one-butterfly tiles for the deep hop's small launches)."""
     from dacapo_amd import lowlevel as ll
+    from dacapo_amd import runner
+
+    with runner.options(**opts):
+        _keyswitch_ops_l13(ll)
+
+
+def _keyswitch_ops_l13(ll):
 
     logN, K = 15, 14
     o = Oracle(logN, K)
