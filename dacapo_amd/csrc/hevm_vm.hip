@@ -479,6 +479,7 @@ void HEVM::init_context(int logN, int K, const u64 *primes, int dir_ksp, int dir
     plan_lanes = option(OPT_PLAN_LANES) >= 2 ? 2 : 1;
     host_encoder = option(OPT_HOST_ENCODER) != 0;
     fold_rescale_into_boot = option(OPT_FOLD_RESCALE_BOOT) != 0;
+    lazy_sums = option(OPT_HYB_LAZY_SUM) != 0;
     max_batch = std::max(1, (int)option(OPT_MAX_BATCH));
     chain_fusion = option(OPT_CHAIN_FUSION) != 0;
     secret_weight = (int)option(OPT_SECRET_HW);
@@ -2044,6 +2045,23 @@ void hevm_last_run_stats(void *vm, int64_t *op_counts, int64_t *keyswitches, int
     if (op_counts) memcpy(op_counts, h->op_counts, sizeof(h->op_counts));
     if (keyswitches) *keyswitches = h->n_keyswitch;
     if (ntts) *ntts = h->n_ntt;
+}
+
+// option hyb_lazy_sum: which rotate instructions of the loaded program the plan of the last run() executed as lazy sums (one division by P
+// per group).  out = [n_0, op, ..., op, n_1, op, ...]: per group its size and the instruction indices of its rotations, ascending.  Returns
+// the number of int32 values the list takes (written only if cap is large enough), 0 without groups, -1 before the first run().
+int64_t hevm_plan_lazy_groups(void *vm, int32_t *out, int64_t cap)
+{
+    auto h = V(vm);
+    if (!h->plan.ready) return -1;
+    std::vector<int32_t> flat;
+    for (const auto &p : h->plan.pops)
+        if (!p.dead && p.kind == HEVM::P_ROTSUM) {
+            flat.push_back((int32_t)p.ops.size());
+            flat.insert(flat.end(), p.ops.begin(), p.ops.end());
+        }
+    if (out && cap >= (int64_t)flat.size()) memcpy(out, flat.data(), flat.size() * sizeof(int32_t));
+    return (int64_t)flat.size();
 }
 
 // the reference never frees a VM (no destroy symbol); a long-lived host that creates many can return one's HBM with this

@@ -134,7 +134,8 @@ class HEVM {
     const CrtTables &crt_tables(int ell);
 
     // ---- batched plan (plan.hpp): built on the first run() of a loaded program -----------------------------
-    enum PopKind { P_ROT, P_MULCC, P_RESCALE, P_SUM, P_NEG, P_MULP, P_ADDP, P_COPY, P_BOOT, P_MODRAISE };
+    enum PopKind { P_ROT, P_MULCC, P_RESCALE, P_SUM, P_NEG, P_MULP, P_ADDP, P_COPY, P_BOOT, P_MODRAISE, P_ROTSUM };
+    static constexpr int kPopKinds = 11;
     struct Val {
         int level = 0;
         double scale = 1.0;
@@ -161,6 +162,13 @@ class HEVM {
         double boot_src_scale = 0.0;  // P_BOOT with boot_drop: scale of the folded rescale's result
         bool dead = false;
         int wave = 0, step = -1;
+        // lazy sums (option hyb_lazy_sum): a P_ROT remembers the instruction it came from and whether it is that instruction's ONLY hop;
+        // a P_ROTSUM (dst = sum of galois_{elts[k]}(srcs[k]) with one division by P, plan.hpp hyb_rotate_sum) lists its rotations
+        int op = -1;
+        bool direct = false;
+        std::vector<u32> elts;
+        std::vector<const u64 *> keys;
+        std::vector<int> ops;
     };
     struct Step {
         PopKind kind;
@@ -169,7 +177,7 @@ class HEVM {
         int wave = 0, lane = 0;             // steps of one wave are independent: lane 1 runs on the auxiliary stream
         Handoff h;                          // link to a fused producer (h.in) / consumer (h.cont, h.out) step, plan.hpp
         int fused_consumer = -1;            // index of the step whose first phase this step's last kernel computes
-        int gfirst = 0, gcount = 0;         // P_SUM: the step's items as groups that share sources (plan.hpp SumGroup), when it runs that way
+        int gfirst = 0, gcount = 0;         // P_SUM: the step's items as groups that share sources (plan.hpp SumGroup), when it runs that way; P_ROTSUM: its groups (in d_ks)
         int unique = 0;                     // P_ROT, grouped-digit mode: distinct source ciphertexts among the items (shared decompositions)
         // what the step's launches read and write, by pool buffer (a value and its modswitch views share one): the edges of the explicitly
         // built graph (option plan_graph = 2, capture_plan_dag)
@@ -246,6 +254,7 @@ class HEVM {
     int secret_weight = 0; // option secret_hw = h: key generation draws a ternary secret with exactly h non-zero coefficients (0: uniform ternary, SEAL's)
     bool chain_fusion = true; // option chain_fusion = 0: every step runs all of its own launches
     hipStream_t aux_stream = nullptr;
+    bool lazy_sums = false; // option hyb_lazy_sum = 1: sums of direct-key rotations share one division by P (plan_exec.hip section 2b)
     bool fold_rescale_into_boot = false; // option fold_rescale_boot = 1: do a rescale that only feeds an opcode 10 inside its re-encoder
     int plan_lanes = 2; // independent steps of a wave also use an auxiliary stream (pays off only inside the graph; option plan_lanes = 1: one stream)
     void bump_epoch(hipStream_t s);

@@ -320,15 +320,14 @@ void hyb_launch_mac(Context &c, int mode, const BatchWs &w, const void *items, K
                     hipStream_t s, bool fold_base);
 void hyb_launch_conv(Context &c, bool down, bool prescaled, const u64 *in, u64 *out, int count, int ell, hipStream_t s);
 
-// everything after F1.  digits [U][ell][N] hold the inverse ROWS phase's output.
+// F2 ... F5: everything between F1 and the accumulators.  digits [U][ell][N] hold the inverse ROWS phase's output.
 template <int MODE>
-static void hybf_core(Context &c, const BatchWs &w, const void *items, KsItem rot_single, HybOut single, const u64 *key, int B, int U, int use_slots,
-                      int ell, hipStream_t s)
+static void hybf_front(Context &c, const BatchWs &w, const void *items, KsItem rot_single, const u64 *key, int B, int U, int use_slots, int ell,
+                       hipStream_t s)
 {
     const size_t N = c.N;
-    const int ksp = c.ksp, L = c.max_level(), E = c.hyb_ext(ell);
+    const int E = c.hyb_ext(ell);
     const bool separate_conv = option(OPT_HYB_FUSE) == 2 && c.hyb_mfma && N >= 512 && ell >= 4;
-    u64 *accq = w.acc, *accp = w.acc + (size_t)B * 2 * ell * N;
     launch_ntt_cols_inv(c, w.digits, (long)N, U * ell, nullptr, 0, ell, s, c.hyb_upmods(ell));                    // F2
     if (separate_conv) {
         hyb_launch_conv(c, false, true, w.digits, w.ext, U, ell, s);
@@ -338,6 +337,15 @@ static void hybf_core(Context &c, const BatchWs &w, const void *items, KsItem ro
         launch_ntt_rows_fwd(c, w.ext, (long)N, U * E, c.hyb_pidx(ell), 0, E, s);                                   // F4
     }
     hyb_launch_mac(c, MODE, w, items, rot_single, key, B, use_slots, ell, s, MODE == 0);                           // F5
+}
+// F6 ... F9: the division by P of `B` accumulator pairs accq [2B][ell][N], accp [2B][ksp][N]; items[b] names where pair b goes
+template <int MODE>
+static void hybf_back(Context &c, const BatchWs &w, const u64 *accq, u64 *accp, const void *items, KsItem rot_single, HybOut single, int B, int ell,
+                      hipStream_t s)
+{
+    const size_t N = c.N;
+    const int ksp = c.ksp, L = c.max_level();
+    const bool separate_conv = option(OPT_HYB_FUSE) == 2 && c.hyb_mfma && N >= 512 && ell >= 4;
     launch_ntt_rows_inv(c, accp, (long)N, 2 * B * ksp, nullptr, L, ksp, s);                                        // F6
     f7_icols_special(c, accp, 2 * B, s);                                                                           // F7
     if (separate_conv) {
@@ -346,6 +354,62 @@ static void hybf_core(Context &c, const BatchWs &w, const void *items, KsItem ro
     } else
         f8_moddown_fcols(c, accp, w.tmp, 2 * B, ell, s);                                                           // F8
     f9_frows_final<MODE>(c, w.tmp, accq, items, rot_single, single, 2 * B, ell, s);                                // F9
+}
+template <int MODE>
+static void hybf_core(Context &c, const BatchWs &w, const void *items, KsItem rot_single, HybOut single, const u64 *key, int B, int U, int use_slots,
+                      int ell, hipStream_t s)
+{
+    hybf_front<MODE>(c, w, items, rot_single, key, B, U, use_slots, ell, s);
+    hybf_back<MODE>(c, w, w.acc, w.acc + (size_t)B * 2 * ell * c.N, items, rot_single, single, B, ell, s);
+}
+
+// ---- lazy sums (option hyb_lazy_sum; oracle/ckks_oracle.c orc_rotate_acc_hybrid / orc_moddown_hybrid) --------------------------------------
+// The rotations of one step whose results are only ever ADDED together (the giant steps of a BSGS matrix-vector product) share ONE division
+// by P: F1 ... F5 run for every item as usual, this kernel adds the accumulators of a group's items (canonical residues, every one of the
+// l + ksp limbs, both polynomials; each item's base term P galois(c0) is already inside its accumulator), and F6 ... F9 run once per GROUP.
+// groups[g]: dst = where the sum goes, elt = the group's first item, slot = its item count (the items of a group are adjacent).
+// grid = (N / 512, l + ksp, 2 G).  Reads 2 (l + ksp) limbs per item once: 16 us per item at l = 31 against the ~140 us of the F6 ... F9 it saves.
+__global__ __launch_bounds__(256) void hybf_group_sum_kernel(const u64 *__restrict__ accq, const u64 *__restrict__ accp, u64 *__restrict__ gq,
+                                                             u64 *__restrict__ gp, const KsItem *__restrict__ groups, int ell, int ksp, int L,
+                                                             size_t N, const DModulus *__restrict__ mods)
+{
+    typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+    const int mi = blockIdx.y, g = blockIdx.z >> 1, c = blockIdx.z & 1;
+    const u32 first = groups[g].elt, count = groups[g].slot;
+    const bool special = mi >= ell;
+    const int limbs = special ? ksp : ell, row = special ? mi - ell : mi;
+    const u64 q = mods[special ? L + row : row].q;
+    const size_t k = ((size_t)blockIdx.x * 256 + threadIdx.x) * 2, stride = (size_t)2 * limbs * N;
+    const u64 *in = (special ? accp : accq) + (((size_t)first * 2 + c) * limbs + row) * N + k;
+    u64x2 a = *reinterpret_cast<const u64x2 *>(in);
+    u32 t = 1;
+    for (; t + 1 < count; t += 2) { // two items' loads in flight
+        const u64x2 v0 = *reinterpret_cast<const u64x2 *>(in + (size_t)t * stride), v1 = *reinterpret_cast<const u64x2 *>(in + (size_t)(t + 1) * stride);
+        a.x = addmod(addmod(a.x, v0.x, q), v1.x, q), a.y = addmod(addmod(a.y, v0.y, q), v1.y, q);
+    }
+    if (t < count) {
+        const u64x2 v = *reinterpret_cast<const u64x2 *>(in + (size_t)t * stride);
+        a.x = addmod(a.x, v.x, q), a.y = addmod(a.y, v.y, q);
+    }
+    *reinterpret_cast<u64x2 *>((special ? gp : gq) + (((size_t)g * 2 + c) * limbs + row) * N + k) = a;
+}
+
+// B rotation items in G groups -> G sums.  The groups' accumulators live in w.ext, free once F5 has read the raised limbs
+// (2 G (l + ksp) <= B E limbs: every group has at least two items).
+void hybf_rotate_sum(Context &c, const BatchWs &w, const KsItem *d_items, int B, const KsItem *d_groups, int G, int ell, hipStream_t s, int unique)
+{
+    const size_t N = c.N;
+    const int use_slots = unique > 0 ? 1 : 0, U = use_slots ? unique : B, ksp = c.ksp;
+    if ((size_t)2 * G * (ell + ksp) > (size_t)B * c.hyb_ext(ell) || N < 512) {
+        fprintf(stderr, "[dacapo_amd] lazy sum: %d groups of %d items do not fit the raised-limb scratch (internal error)\n", G, B);
+        abort();
+    }
+    f1_irows<0>(c, d_items, KsItem{}, nullptr, w.digits, B, ell, use_slots, s);
+    hybf_front<0>(c, w, d_items, KsItem{}, nullptr, B, U, use_slots, ell, s);
+    u64 *gq = w.ext, *gp = w.ext + (size_t)2 * G * ell * N;
+    DC_LAUNCH(hybf_group_sum_kernel, dim3((unsigned)(N / 512), (unsigned)(ell + ksp), (unsigned)(2 * G)), dim3(256), 0, s, w.acc,
+              w.acc + (size_t)B * 2 * ell * N, gq, gp, d_groups, ell, ksp, c.max_level(), N, c.d_mods);
+    hybf_back<0>(c, w, gq, gp, d_groups, KsItem{}, HybOut{}, G, ell, s);
 }
 
 void hybf_rotate_hops(Context &c, const BatchWs &w, const KsItem *d_items, int B, int ell, hipStream_t s, int unique)

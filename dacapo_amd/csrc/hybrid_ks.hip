@@ -531,7 +531,18 @@ void hybf_rotate_hop_single(Context &c, const Workspace &w, CtView dst, CtView s
 void hybf_mul_relin_tail(Context &c, const BatchWs &w, const MulItem *d_items, const u64 *relin_key, int B, int ell, hipStream_t s);
 void hybf_keyswitch(Context &c, const Workspace &w, CtView out, const u64 *base0, const u64 *base1, const u64 *target, const u64 *key, int ell,
                     hipStream_t s);
+void hybf_rotate_sum(Context &c, const BatchWs &w, const KsItem *d_items, int B, const KsItem *d_groups, int G, int ell, hipStream_t s, int unique);
 static bool hyb_fused() { return option(OPT_HYB_FUSE) != 0; }
+bool hyb_lazy_sum_supported(const Context &c) { return c.hybrid() && hyb_fused() && c.N >= 512; }
+
+void hyb_rotate_sum(Context &c, const BatchWs &w, const KsItem *d_items, int B, const KsItem *d_groups, int G, int ell, hipStream_t s, int unique)
+{
+    if (!hyb_lazy_sum_supported(c)) {
+        fprintf(stderr, "[dacapo_amd] lazy sums need the fused grouped-digit sequence (option hyb_fuse != 0)\n");
+        abort();
+    }
+    hybf_rotate_sum(c, w, d_items, B, d_groups, G, ell, s, unique);
+}
 
 void hyb_rotate_hops(Context &c, const BatchWs &w, const KsItem *d_items, int B, int ell, hipStream_t s, int unique)
 {

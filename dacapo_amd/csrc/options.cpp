@@ -34,6 +34,7 @@ static const OptDef kDefs[OPT_COUNT] = {
     { "fold_rescale_boot", 0 },
     { "hyb_mfma", 1 },
     { "hyb_fuse", 2 },
+    { "hyb_lazy_sum", 0 },
     { "seal_compr", 0 },
     { "trace", 0 },
     { "step_profile", 0 },

@@ -105,6 +105,10 @@ void b_rescale(Context &c, const BatchWs &w, const RsItem *d_items, int B, int e
 bool chain_fusion_supported(); // the continuation kernels exist for the default launch sequences only
 // grouped-digit hybrid key switching (hybrid_ks.hip; Context::hybrid()): b_rotate_hops / b_mul_relin / keyswitch route here
 void hyb_rotate_hops(Context &c, const BatchWs &w, const KsItem *d_items, int B, int ell, hipStream_t s, int unique = 0);
+// lazy sums (option hyb_lazy_sum): the B items' accumulators are added group by group and divided by P once per group.  d_groups[g]: dst = the
+// sum's destination, elt = first item of the group, slot = its item count (a group's items are adjacent in d_items; their own dst is unused)
+void hyb_rotate_sum(Context &c, const BatchWs &w, const KsItem *d_items, int B, const KsItem *d_groups, int G, int ell, hipStream_t s, int unique = 0);
+bool hyb_lazy_sum_supported(const Context &c);
 // one rotation hop by value (the one-instruction-at-a-time loop): src must not alias dst
 void hyb_rotate_hop_single(Context &c, const Workspace &w, CtView dst, CtView src, u32 galois_elt, const u64 *galois_key, int ell, hipStream_t s);
 void hyb_mul_relin(Context &c, const BatchWs &w, const MulItem *d_items, const u64 *relin_key, int B, int ell, hipStream_t s);

@@ -94,7 +94,8 @@ void HEVM::build_plan()
             int v = need(op.lhs, "rotate");
             const double in_scale = P.vals[(size_t)v].scale; // (rotate_vector keeps the scale: every hop's result carries the operand's)
             bool memo_final = false;
-            for (u32 elt : rotate_hops((int16_t)op.rhs)) {
+            const std::vector<u32> hops = rotate_hops((int16_t)op.rhs);
+            for (u32 elt : hops) {
                 // option rot_compose (a bounded key set): composed rotations of one value mostly start with the same small offset -- the parts
                 // come in ascending order -- so the hop (value, Galois element) is computed once and its result named again: the same limbs
                 // (a key switch is deterministic), one key switch fewer.  config 4 under the reference HEaaN runtime's 49 keys: 18.7 % of the hops.
@@ -112,6 +113,7 @@ void HEVM::build_plan()
                 const int nv = new_val(s.level, in_scale);
                 Pop &p = add_pop(P_ROT, s.level, { v }, nv);
                 p.elt = elt, p.key = keys.galois.at(elt);
+                p.op = (int)(&op - ops.data()), p.direct = hops.size() == 1;
                 P.n_keyswitch++, P.n_ntt += ks_ntts(s.level);
                 if (rot_compose) {
                     const auto mb = memo_base.find(v);
@@ -358,6 +360,49 @@ void HEVM::build_plan()
         r.dead = true;
     }
 
+    // ---- 2b. lazy sums (option hyb_lazy_sum; grouped-digit mode) ------------------------------------------------------------------
+    // Rotations whose results are only ever added together -- the giant steps of a BSGS matrix-vector product: out = sum_g rot_g(inner_g) --
+    // share ONE division by P ("double hoisting", Bossuat et al. 2021): the accumulators of the group's key switches are added in the raised
+    // basis and F6 ... F9 run once (hybrid_fused.hip hybf_rotate_sum), 1 instead of n roundings.  That is a different -- slightly less noisy --
+    // result than n rotate instructions, limb-wise, which is why the option is off by default and why the rule is narrow and exported
+    // (hevm_plan_lazy_groups; the oracle VM replays exactly these groups): a member is a rotate INSTRUCTION with a direct key (one hop),
+    // whose result nothing else reads, entering the sum as it is (no plaintext factor); a sum needs at least two of them.
+    if (lazy_sums && hyb_lazy_sum_supported(c)) {
+        for (size_t ci = 0; ci < O.size(); ci++) {
+            if (O[ci].dead) continue;
+            if (!(O[ci].kind == P_SUM || ((O[ci].kind == P_RESCALE || O[ci].kind == P_BOOT) && O[ci].rs_sum))) continue;
+            std::vector<size_t> terms; // positions in the consumer's source list
+            for (size_t k = 0; k < O[ci].srcs.size(); k++) {
+                if (!O[ci].src_plain.empty() && O[ci].src_plain[k] >= 0) continue;
+                const int sidx = O[ci].srcs[k];
+                const Val &sv = V[(size_t)sidx];
+                const int dp = sv.root == sidx ? sv.def_pop : -1;
+                if (dp < 0) continue;
+                const Pop &r = O[(size_t)dp];
+                if (r.kind == P_ROT && !r.dead && r.direct && r.dst == sidx && sv.uses == 1 && !sv.pinned && r.level == O[ci].level) terms.push_back(k);
+            }
+            if (terms.size() < 2) continue;
+            // the group takes the place of its LAST member in pop order: every member's source is defined before it, its consumer after it
+            std::sort(terms.begin(), terms.end(), [&](size_t x, size_t y) { return V[(size_t)O[ci].srcs[x]].def_pop < V[(size_t)O[ci].srcs[y]].def_pop; });
+            const size_t keep = terms.back();
+            Pop grp = O[(size_t)V[(size_t)O[ci].srcs[keep]].def_pop];
+            grp.kind = P_ROTSUM, grp.srcs.clear(), grp.direct = false, grp.op = -1;
+            for (size_t k : terms) {
+                Pop &r = O[(size_t)V[(size_t)O[ci].srcs[k]].def_pop];
+                grp.srcs.push_back(r.srcs[0]), grp.elts.push_back(r.elt), grp.keys.push_back(r.key), grp.ops.push_back(r.op);
+                r.dead = true;
+            }
+            O[(size_t)V[(size_t)O[ci].srcs[keep]].def_pop] = grp;
+            std::vector<int> srcs, plain;
+            for (size_t k = 0; k < O[ci].srcs.size(); k++)
+                if (k == keep || std::find(terms.begin(), terms.end(), k) == terms.end()) {
+                    srcs.push_back(O[ci].srcs[k]);
+                    if (!O[ci].src_plain.empty()) plain.push_back(O[ci].src_plain[k]);
+                }
+            O[ci].srcs = srcs, O[ci].src_plain = plain;
+        }
+    }
+
     // ---- 3. dataflow depth ------------------------------------------------------------------------------------------
     int max_wave = 0;
     for (Pop &p : O) {
@@ -398,8 +443,23 @@ void HEVM::build_plan()
             // steps keep program order (their items are grouped by SOURCE, which shares the decomposition).
             if (kind == P_ROT && !c.hybrid() && option(OPT_KS_ITEMS_FAST))
                 std::stable_sort(kv.second.begin(), kv.second.end(), [&](int x, int y) { return O[(size_t)x].elt < O[(size_t)y].elt; });
-            const bool heavy = kind == P_ROT || kind == P_MULCC || kind == P_RESCALE || kind == P_BOOT;
+            const bool heavy = kind == P_ROT || kind == P_MULCC || kind == P_RESCALE || kind == P_BOOT || kind == P_ROTSUM;
             const size_t chunk = std::max<size_t>(1, (heavy ? (size_t)max_batch : (size_t)4096) / (size_t)S);
+            if (kind == P_ROTSUM) { // whole groups, counted by their rotations
+                for (size_t off = 0; off < kv.second.size();) {
+                    size_t end = off, items = 0;
+                    while (end < kv.second.size() && (items == 0 || items + O[(size_t)kv.second[end]].srcs.size() <= chunk))
+                        items += O[(size_t)kv.second[end]].srcs.size(), end++;
+                    Step st;
+                    st.kind = kind, st.level = std::get<1>(kv.first), st.wave = w, st.count = (int)items;
+                    std::vector<int> members(kv.second.begin() + (long)off, kv.second.begin() + (long)end);
+                    for (int pi : members) O[(size_t)pi].step = (int)P.steps.size();
+                    P.steps.push_back(st);
+                    step_pops.push_back(members);
+                    off = end;
+                }
+                continue;
+            }
             for (size_t off = 0; off < kv.second.size(); off += chunk) {
                 Step st;
                 st.kind = kind, st.level = std::get<1>(kv.first), st.target = std::get<2>(kv.first), st.wave = w;
@@ -483,7 +543,7 @@ void HEVM::build_plan()
     // steps of one wave are mutually independent: the costliest stays on the main stream, the rest is balanced over
     // (main, auxiliary) when the auxiliary share is worth a fork/join (>= 3 launches)
     if (plan_lanes >= 2) {
-        auto cost = [](const Step &st) { return st.kind == P_ROT || st.kind == P_MULCC ? 8 : st.kind == P_BOOT ? 5 : st.kind == P_RESCALE ? 3 : 1; };
+        auto cost = [](const Step &st) { return st.kind == P_ROT || st.kind == P_MULCC || st.kind == P_ROTSUM ? 8 : st.kind == P_BOOT ? 5 : st.kind == P_RESCALE ? 3 : 1; };
         for (size_t a = 0; a < P.steps.size();) {
             size_t b = a;
             while (b < P.steps.size() && P.steps[b].wave == P.steps[a].wave) b++;
@@ -661,6 +721,26 @@ void HEVM::build_plan()
                 st.unique = (int)slot_of.size();
             }
             break;
+        case P_ROTSUM: { // the rotations of every group, adjacent; then one entry per group: dst, first item (relative), item count
+            st.first = (int)h_ks.size();
+            std::map<const u64 *, u32> slot_of;
+            std::vector<KsItem> groups;
+            for (int pi : step_pops[s])
+                for (int q = 0; q < S; q++) {
+                    const Pop &rp = O[(size_t)pi];
+                    const CtView dst = view(rp.dst, q);
+                    groups.push_back(KsItem{ dst, dst, nullptr, (u32)(h_ks.size() - (size_t)st.first), (u32)rp.srcs.size() });
+                    for (size_t k = 0; k < rp.srcs.size(); k++) {
+                        const CtView sv = view(rp.srcs[k], q);
+                        const u32 slot = slot_of.emplace(sv.p, (u32)slot_of.size()).first->second;
+                        h_ks.push_back(KsItem{ sv, dst, rp.keys[k], rp.elts[k], slot });
+                    }
+                }
+            st.unique = (int)slot_of.size();
+            st.gfirst = (int)h_ks.size(), st.gcount = (int)groups.size();
+            h_ks.insert(h_ks.end(), groups.begin(), groups.end());
+            break;
+        }
         case P_MULCC:
             st.first = (int)h_mul.size();
             for (int pi : step_pops[s])
@@ -809,7 +889,7 @@ void HEVM::build_plan()
             boot_tmax = std::max(boot_tmax, st.target);
             break;
         }
-        if (st.kind == P_ROT || st.kind == P_MULCC) {
+        if (st.kind == P_ROT || st.kind == P_MULCC || st.kind == P_ROTSUM) {
             need_t = std::max(need_t, B * l), need_d = std::max(need_d, B * std::max<size_t>(l, 2));
             need_e = std::max(need_e, B * (c.hybrid() ? (size_t)c.hyb_ext((int)l) : l * l));
             need_a = std::max(need_a, B * 2 * (l + (size_t)c.ksp)), need_m = std::max(need_m, B * 2 * l);
@@ -959,12 +1039,12 @@ void HEVM::build_plan()
     P.ready = true;
     if (plan_graph) capture_plan(); // part of the (untimed) preparation, like the plan itself
     if (option(OPT_TRACE)) {
-        static const char *kn[] = { "rot", "mulcc", "rescale", "sum", "neg", "mulp", "addp", "copy", "boot", "modraise" };
-        size_t nsteps[10] = { 0 }, nitems[10] = { 0 };
+        static const char *kn[] = { "rot", "mulcc", "rescale", "sum", "neg", "mulp", "addp", "copy", "boot", "modraise", "rotsum" };
+        size_t nsteps[kPopKinds] = { 0 }, nitems[kPopKinds] = { 0 };
         std::map<std::pair<int, int>, std::pair<size_t, size_t>> ks; // (kind, level) -> steps, items
         for (const Step &st : P.steps) {
             nsteps[st.kind]++, nitems[st.kind] += (size_t)st.count;
-            if (st.kind == P_ROT || st.kind == P_MULCC || st.kind == P_RESCALE || st.kind == P_BOOT) {
+            if (st.kind == P_ROT || st.kind == P_MULCC || st.kind == P_RESCALE || st.kind == P_BOOT || st.kind == P_ROTSUM) {
                 auto &e = ks[{ (int)st.kind, st.level }];
                 e.first++, e.second += (size_t)st.count;
             }
@@ -979,7 +1059,7 @@ void HEVM::build_plan()
             }
             fprintf(stderr, "\n");
         }
-        for (int k = 0; k < 10; k++)
+        for (int k = 0; k < kPopKinds; k++)
             if (nsteps[k]) fprintf(stderr, "[dacapo_amd] plan:   %-8s %5zu steps %6zu items\n", kn[k], nsteps[k], nitems[k]);
         {
             size_t gsteps = 0, ggroups = 0, gitems = 0;
@@ -1025,6 +1105,7 @@ void HEVM::issue_step(const Step &st, hipStream_t q)
     const BatchWs &w = P.ws[st.lane];
     switch (st.kind) {
     case P_ROT: b_rotate_hops(c, w, P.d_ks + st.first, st.count, st.level, q, st.h, st.unique); break;
+    case P_ROTSUM: hyb_rotate_sum(c, w, P.d_ks + st.first, st.count, P.d_ks + st.gfirst, st.gcount, st.level, q, st.unique); break;
     case P_MULCC: b_mul_relin(c, w, P.d_mul + st.first, keys.relin, st.count, st.level, q, st.h); break;
     case P_RESCALE: b_rescale(c, w, P.d_rs + st.first, st.count, st.level, q, P.d_sum_srcs, st.h); break;
     case P_SUM:
@@ -1103,7 +1184,7 @@ void HEVM::issue_plan(hipStream_t s)
     }
     bump_epoch(s);
     if (step_profile) {
-        static const char *kn[] = { "rot", "mulcc", "rescale", "sum", "neg", "mulp", "addp", "copy", "boot", "modraise" };
+        static const char *kn[] = { "rot", "mulcc", "rescale", "sum", "neg", "mulp", "addp", "copy", "boot", "modraise", "rotsum" };
         double total = 0;
         for (auto &kv : prof) total += kv.second.second;
         fprintf(stderr, "[dacapo_amd] step profile (synchronised after every step): %.2f ms in %zu steps\n", total * 1e3, P.steps.size());

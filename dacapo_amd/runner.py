@@ -84,6 +84,8 @@ def bind_vm_lib(path):
     L.hevm_load_mem.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_char_p, ctypes.c_uint64]
     L.hevm_last_run_stats.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64),
                                        ctypes.POINTER(ctypes.c_int64)]
+    L.hevm_plan_lazy_groups.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int32), ctypes.c_int64]
+    L.hevm_plan_lazy_groups.restype = ctypes.c_int64
     L.hevm_set_streams.argtypes = [ctypes.c_void_p, ctypes.c_int]
     L.hevm_select_stream.argtypes = [ctypes.c_void_p, ctypes.c_int]
     L.hevm_last_run_bootstrap_seconds.argtypes = [ctypes.c_void_p]
@@ -343,6 +345,19 @@ class HEVM:
 
     def getCtxt(self, reg: int) -> hevm_ctxt:
         return hevm_ctxt.from_address(self.lw.getCtxt(self.vm, reg))
+
+    def lazy_groups(self):
+        """option hyb_lazy_sum: the plan's lazy sums as lists of rotate-instruction indices (hevm_plan_lazy_groups); [] before the first run"""
+        n = self.lw.hevm_plan_lazy_groups(self.vm, None, 0)
+        if n <= 0:
+            return []
+        buf = (ctypes.c_int32 * n)()
+        self.lw.hevm_plan_lazy_groups(self.vm, buf, n)
+        out, i = [], 0
+        while i < n:
+            out.append(list(buf[i + 1 : i + 1 + buf[i]]))
+            i += 1 + buf[i]
+        return out
 
     def stats(self):
         counts = (ctypes.c_int64 * 11)()

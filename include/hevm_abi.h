@@ -105,6 +105,11 @@ const uint64_t *hevm_plain(void *vm, int64_t i, int32_t *level, double *scale);
 void hevm_load_mem(void *vm, const void *cst, uint64_t cst_len, const void *hevm, uint64_t hevm_len);
 /* per-opcode launch statistics of the last run(): counts[11], NTT-equivalents executed */
 void hevm_last_run_stats(void *vm, int64_t *op_counts /*[11]*/, int64_t *keyswitches, int64_t *ntts);
+/* option "hyb_lazy_sum" (grouped-digit mode, off by default): the rotate instructions the last run()'s plan executed as lazy sums -- the
+ * accumulators of a group's key switches added in the raised basis, ONE division by P per group.  out = [n_0, op ...,
+ * n_1, op ...]: per group its size and its rotations' instruction indices.  Returns the length of that list (written if cap suffices), 0 without
+ * groups, -1 before the first run().  Test infrastructure: oracle/oracle.py OracleVM.set_lazy_groups replays exactly these groups. */
+int64_t hevm_plan_lazy_groups(void *vm, int32_t *out, int64_t cap);
 /* Throughput mode: run `n` independent ciphertext streams of the same program side by side (shared keys and
  * plaintexts; every step of the batched plan processes all streams in one launch sequence).  Call before load();
  * encrypt / decrypt / decrypt_result / getCtxt then address the stream chosen with hevm_select_stream. */

@@ -820,6 +820,8 @@ static u64 prod_mod_except(const orc_ctx *c, int lo, int hi, int skip, u64 m)
 }
 
 static void keyswitch_hybrid_perm(const orc_ctx *c, int ell, const u64 *target, const u64 *key, u64 *out0, u64 *out1, const uint32_t *perm);
+static void hybrid_accumulate(const orc_ctx *c, int ell, const u64 *target, const u64 *key, const uint32_t *perm, u64 *prod);
+static void hybrid_moddown(const orc_ctx *c, int ell, u64 *prod, u64 *out0, u64 *out1);
 void orc_keyswitch_hybrid(const orc_ctx *c, int ell, const u64 *target, const u64 *key, u64 *out0, u64 *out1)
 {
     keyswitch_hybrid_perm(c, ell, target, key, out0, out1, NULL);
@@ -837,7 +839,30 @@ void orc_rotate_ks_hybrid(const orc_ctx *c, int ell, const u64 *c1, uint32_t elt
     keyswitch_hybrid_perm(c, ell, c1, key, out0, out1, perm);
     free(perm);
 }
+/* EXTENSION of the extension (the GPU VM's option hyb_lazy_sum): a SUM of grouped-digit rotations with ONE mod-down -- "double hoisting"
+ * (Bossuat, Mouchet, Troncoso-Pastoriza, Hubaux 2021, section 5: the giant steps of a BSGS matrix-vector product).  The inner products of
+ * every rotation of the sum are added in the raised basis, then divided by P once:  sum_r galois_r(c0_r) + moddown(sum_r acc_r).  One
+ * rounding instead of one per rotation, so the limbs differ from the sum of orc_rotate_ks_hybrid results (by the roundings' difference, a
+ * few units) and the noise is, if anything, smaller.  orc_rotate_acc_hybrid adds one rotation's inner products to prod [2][ell + ks][N];
+ * orc_moddown_hybrid adds moddown(prod) to (out0, out1) and destroys prod.  A "sum" of one rotation is orc_rotate_ks_hybrid exactly. */
+void orc_rotate_acc_hybrid(const orc_ctx *c, int ell, const u64 *c1, uint32_t elt, const u64 *key, u64 *prod)
+{
+    uint32_t *perm = (uint32_t *)malloc(c->N * sizeof(uint32_t));
+    orc_galois_table(c, elt, perm);
+    hybrid_accumulate(c, ell, c1, key, perm, prod);
+    free(perm);
+}
+void orc_moddown_hybrid(const orc_ctx *c, int ell, u64 *prod, u64 *out0, u64 *out1) { hybrid_moddown(c, ell, prod, out0, out1); }
+
 static void keyswitch_hybrid_perm(const orc_ctx *c, int ell, const u64 *target, const u64 *key, u64 *out0, u64 *out1, const uint32_t *perm)
+{
+    u64 *prod = (u64 *)calloc((size_t)2 * (ell + c->ks) * c->N, 8); /* [2][ell + ks][N], canonical running sums */
+    hybrid_accumulate(c, ell, target, key, perm, prod);
+    hybrid_moddown(c, ell, prod, out0, out1);
+    free(prod);
+}
+/* prod [2][ell + ks][N] += the inner products of target's digits (read through perm when given) with the key */
+static void hybrid_accumulate(const orc_ctx *c, int ell, const u64 *target, const u64 *key, const uint32_t *perm, u64 *prod)
 {
     size_t N = c->N;
     int K = c->K, ks = c->ks, al = c->alpha, L = K - ks, M = ell + ks;
@@ -846,7 +871,6 @@ static void keyswitch_hybrid_perm(const orc_ctx *c, int ell, const u64 *target, 
     u64 *coef = (u64 *)malloc((size_t)ell * N * 8);
     u64 *y = (u64 *)malloc((size_t)al * N * 8);
     u64 *t = (u64 *)malloc(N * 8);
-    u64 *prod = (u64 *)calloc((size_t)2 * M * N, 8); /* [2][ell + ks][N], canonical running sums */
     memcpy(coef, target, (size_t)ell * N * 8);
     for (int j = 0; j < ell; j++) orc_ntt_inv(c, j, coef + (size_t)j * N);
     for (int g = 0; g < G; g++) {
@@ -883,6 +907,16 @@ static void keyswitch_hybrid_perm(const orc_ctx *c, int ell, const u64 *target, 
             }
         }
     }
+    free(coef);
+    free(y);
+    free(t);
+}
+/* (out0, out1) += prod / P, rounded (prod's special limbs are overwritten) */
+static void hybrid_moddown(const orc_ctx *c, int ell, u64 *prod, u64 *out0, u64 *out1)
+{
+    size_t N = c->N;
+    int K = c->K, ks = c->ks, L = K - ks, M = ell + ks;
+    u64 *t = (u64 *)malloc(N * 8);
     /* mod-down by P with rounding */
     u64 *z = (u64 *)malloc((size_t)ks * N * 8);
     for (int kc = 0; kc < 2; kc++) {
@@ -921,10 +955,7 @@ static void keyswitch_hybrid_perm(const orc_ctx *c, int ell, const u64 *target, 
             }
         }
     }
-    free(coef);
-    free(y);
     free(t);
-    free(prod);
     free(z);
 }
 

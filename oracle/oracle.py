@@ -101,6 +101,30 @@ class Plaintext:
         return self.data.shape[0]
 
 
+@dataclass
+class LazySum:
+    """EXTENSION (the GPU VM's option hyb_lazy_sum, orc_rotate_acc_hybrid): a partial sum some of whose terms are grouped-digit rotations
+    still in the raised basis.  base = the ordinary terms and the rotations' galois(c0); acc [2][ell + ks][N] = the rotations' inner products
+    with their keys, not yet divided by P; have = rotations merged so far, of the group's `size`."""
+    base: "Ciphertext"
+    acc: np.ndarray
+    group: int
+    have: int
+    size: int
+
+    @property
+    def ell(self) -> int:
+        return self.base.ell
+
+    @property
+    def scale(self) -> float:
+        return self.base.scale
+
+    @scale.setter
+    def scale(self, v):
+        self.base.scale = v
+
+
 class Oracle:
     def __init__(self, logN: int = 15, K: int = 14, bit_size: int = 60, primes=None):
         self.L = lib()
@@ -428,6 +452,36 @@ class Oracle:
         self.keyswitch(temp, self.galois[elt], c0, c1)
         return Ciphertext(np.stack([c0, c1]), a.scale)
 
+    def rotate_lazy(self, a: Ciphertext, steps: int, group: int, size: int) -> "LazySum":
+        """one single-hop rotation as a term of a lazy sum: (galois(c0), 0) and its inner products in the raised basis"""
+        assert (self.ks, self.alpha) != (1, 1), "lazy sums exist in grouped-digit mode only"
+        hops = self.rotate_hops(steps)
+        assert len(hops) == 1, "only rotations with a direct key join a lazy sum"
+        elt = hops[0]
+        c0 = self.galois_ntt(a.data[0], elt)
+        acc = np.zeros((2, a.ell + self.ks, self.N), dtype=np.uint64)
+        key = self.galois[elt]
+        self.L.orc_rotate_acc_hybrid(self.ctx, a.ell, _p(np.ascontiguousarray(a.data[1])), C.c_uint32(elt), _p(key), _p(acc))
+        return LazySum(Ciphertext(np.stack([c0, np.zeros_like(c0)]), a.scale), acc, group, 1, size)
+
+    def lazy_add(self, a, b):
+        """a + b where either may be a LazySum of the same group; finished (one mod-down) when the group's last rotation has joined"""
+        if not isinstance(a, LazySum):
+            a, b = b, a
+        if isinstance(b, LazySum):
+            assert a.group == b.group, "two lazy sums met in one addition"
+            ell = a.ell
+            q = np.array(list(self.primes[:ell]) + list(self.primes[self.K - self.ks :]), dtype=np.uint64)[None, :, None]
+            out = LazySum(self.add(a.base, b.base), (a.acc + b.acc) % q, a.group, a.have + b.have, a.size)
+        else:
+            out = LazySum(self.add(a.base, b), a.acc, a.group, a.have, a.size)
+        if out.have < out.size:
+            return out
+        c0, c1 = out.base.data[0].copy(), out.base.data[1].copy()
+        acc = np.ascontiguousarray(out.acc)
+        self.L.orc_moddown_hybrid(self.ctx, out.ell, _p(acc), _p(c0), _p(c1))
+        return Ciphertext(np.stack([c0, c1]), out.base.scale)
+
     rot_compose = False  # EXTENSION (the GPU VM's option rot_compose): see compose_rotation
 
     def compose_rotation(self, steps: int):
@@ -581,9 +635,30 @@ class OracleVM:
     def decrypt_result(self, i):
         return self.decrypt(self.prog.res_dst[i])
 
-    def step(self, op):
+    def set_lazy_groups(self, groups):
+        """EXTENSION: the GPU plan's lazy sums (hevm_plan_lazy_groups): per group the instruction indices of the rotations whose mod-down
+        is shared.  The fusion DECISION is the plan's; the arithmetic here is the oracle's own (Oracle.rotate_lazy / lazy_add)."""
+        self.lazy = {}
+        for g, ops in enumerate(groups):
+            for i in ops:
+                self.lazy[int(i)] = (g, len(ops))
+
+    def step(self, op, index=None):
         o, c, p = self.o, self.ciphers, self.plains
         opcode, dst, lhs, rhs = (int(x) for x in op)
+        lazy = getattr(self, "lazy", None)
+        if lazy:
+            if opcode == 1 and index in lazy:
+                g, size = lazy[index]
+                c[dst] = o.rotate_lazy(c[lhs], struct.unpack("<h", struct.pack("<H", rhs))[0], g, size)
+                return
+            if opcode == 6 and (isinstance(c[lhs], LazySum) or isinstance(c[rhs], LazySum)):
+                c[lhs].scale = c[rhs].scale
+                c[dst] = o.lazy_add(c[lhs], c[rhs])
+                return
+            for r in ((lhs,) if opcode in (1, 2, 3, 4, 7, 9, 10, 17, 18, 19) else (lhs, rhs) if opcode in (6, 8) else ()):
+                if r < len(c) and isinstance(c[r], LazySum):
+                    raise RuntimeError(f"op {index} (opcode {opcode}) reads an unfinished lazy sum: the plan's groups and the program disagree")
         if opcode == 1:
             c[dst] = o.rotate(c[lhs], struct.unpack("<h", struct.pack("<H", rhs))[0])
         elif opcode == 2:
@@ -621,6 +696,6 @@ class OracleVM:
         for op in self.prog.ops:
             if max_ops is not None and n >= max_ops:
                 break
-            self.step(op)
+            self.step(op, n)
             n += 1
         return n

@@ -130,6 +130,68 @@ def test_hoisted_rotation_batch_at_config4_geometry_matches_the_oracle_vm(tmp_pa
     runner.set_option("hyb_fuse", 2)
 
 
+def test_lazy_sums_at_config4_geometry_match_the_oracle_vm(tmp_path):
+    """option hyb_lazy_sum at config 4's shape (N = 2^17, digits of 8 under 9 special primes): the giant steps of a BSGS product -- three
+    rotations of three different inner sums added to a fourth -- at 31 primes (4 digits) and at 12 (2 digits, a partial one), one division
+    by P per sum (hybrid_fused.hip hybf_rotate_sum) == the oracle VM replaying the plan's groups (orc_rotate_acc_hybrid / orc_moddown_hybrid)"""
+    KS, ALPHA = 9, 8
+    K4 = 31 + KS
+    from dacapo_amd import hevm_asm as ha
+    from dacapo_amd import lowlevel as ll
+    from dacapo_amd import runner
+
+    _threads()
+    slots = 1 << (LOGN - 1)
+    rng = np.random.default_rng(23)
+    b = ha.Builder(slots=slots, init_level=31, policy="lazy", boot_level=31, shadow=True)
+    x, y = b.input(rng.uniform(-1, 1, slots)), b.input(rng.uniform(-1, 1, slots))
+    giants = (16, 32, 48)                                              # 48 gets a direct key
+
+    def bsgs(u, v):
+        out = b.add(b.mul_plain(u, [0.5]), b.mul_plain(v, [0.25]))
+        for g, k in enumerate(giants):
+            inner = b.add(b.mul_plain(u, [0.1 * (g + 1)]), b.mul_plain(v, [-0.2 * (g + 1)]))
+            out = b.add(out, b.rotate(inner, k))
+        return out
+
+    top = bsgs(x, y)
+    low = bsgs(b.modswitch(x, 19), b.modswitch(y, 19))
+    # (eight temporaries alive at once: every register a rotation result sat in is written again, so none of them is a register's FINAL value --
+    # architectural state the plan keeps observable, which would keep that rotation out of its group)
+    ts = [b.mul_plain(x, [0.01 * (i + 1)]) for i in range(8)]
+    pad = ts[0]
+    for t in ts[1:]:
+        pad = b.add(pad, t)
+    b.output(b.finish(top))
+    b.output(b.finish(low))
+    b.output(b.finish(pad))
+    cst, hv, _ = b.assemble()
+    hevm = runner.HEVM(seed=5, logN=LOGN, num_primes=K4, ks_special=KS, ks_alpha=ALPHA, vm_options={"plan": 1, "hyb_lazy_sum": 1})
+    hevm.addRotationKeys([48])
+    o = Oracle(LOGN, K4)
+    o.set_hybrid(KS, ALPHA)
+    _import_keys(o, hevm, ll, elts=sorted({o.elt_from_step(s) for s in giants}), relin=False)
+    hevm.load_mem(cst, hv)
+    ovm = _mirror_vm(hevm, ll, o, cst, hv, tmp_path)
+    for i, a in enumerate(b.args):
+        hevm.setInput(i, a.plain)
+        ovm.ciphers[i] = _get_ct(hevm, ll, i)
+    hevm.run()
+    groups = hevm.lazy_groups()
+    assert [len(g) for g in groups] == [3, 3], groups
+    ovm.set_lazy_groups(groups)
+    ovm.run()
+    for i in range(2):
+        r = ovm.prog.res_dst[i]
+        got, want = _get_ct(hevm, ll, r), ovm.ciphers[r]
+        assert got.ell == want.ell and got.scale == want.scale
+        assert (got.data == want.data).all(), i
+    out = hevm.getOutput()
+    for i in range(2):
+        assert np.abs(out[i] - b.expected()[i]).max() < 5e-4
+    hevm.close()
+
+
 def test_nt16_prefix_bit_exact_at_n17_on_grouped_digit_keys(tmp_path):
     """tests/test_gpu_config4.py::test_nt16_prefix_bit_exact_at_n17 with ks_special = 8, ks_alpha = 7: the stem convolution of the nt = 2^16
     trace as config 4 runs it (the .b14 lowering: 27 rotations at 14 primes as NAF hops of the default Galois keys, 25 ct x pt, 2 rescales) through the grouped-digit sequence, rotations of one

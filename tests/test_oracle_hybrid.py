@@ -122,3 +122,36 @@ def test_hybrid_key_switch_closed_form_on_a_small_ring():
                     want[i, n] = (acc[kc][i][n] - t) * pow(P, -1, q[i]) % q[i]
             got = o.ntt_inv(out, list(range(ell)))
             assert (got == want).all(), (ell, kc)
+
+
+@pytest.mark.parametrize("K,ks,alpha", [(7, 2, 2), (9, 3, 2)])
+def test_lazy_sum_of_rotations_shares_one_mod_down(K, ks, alpha):
+    """orc_rotate_acc_hybrid / orc_moddown_hybrid (the GPU VM's option hyb_lazy_sum): a "sum" of ONE rotation is the eager rotation limb
+    for limb; a sum of three decrypts to the sum of the rotated messages and differs from the eager sum by the roundings only (at most the
+    three eager roundings against the single lazy one: 2 units plus the conversions' overshoot, |d| <= 2 + 2 ks per limb)."""
+    logN = 10
+    o = Oracle(logN, K)
+    o.set_hybrid(ks, alpha)
+    steps = [1, -3, 8]
+    o.keygen(seed=5, galois_elts=[o.elt_from_step(s) for s in steps])
+    rng = np.random.default_rng(3)
+    for ell in (o.max_level, 3):
+        xs = [rng.uniform(-1, 1, o.slots) for _ in steps]
+        cts = [o.encrypt(o.encode(x, 2.0**40, ell)) for x in xs]
+        one = o.lazy_add(o.rotate_lazy(cts[0], steps[0], 0, 1), cts[1])
+        ref = o.add(o.rotate(cts[0], steps[0]), cts[1])
+        assert isinstance(one, Ciphertext) and (one.data == ref.data).all()
+        lazy = o.rotate_lazy(cts[0], steps[0], 0, 3)
+        lazy = o.lazy_add(lazy, cts[1])                                  # an ordinary term joins the base
+        lazy = o.lazy_add(o.rotate_lazy(cts[1], steps[1], 0, 3), lazy)
+        assert not isinstance(lazy, Ciphertext)
+        lazy = o.lazy_add(lazy, o.rotate_lazy(cts[2], steps[2], 0, 3))
+        assert isinstance(lazy, Ciphertext)
+        eager = o.add(o.add(o.add(o.rotate(cts[0], steps[0]), cts[1]), o.rotate(cts[1], steps[1])), o.rotate(cts[2], steps[2]))
+        want = sum(np.roll(x, -s) for x, s in zip(xs, steps)) + xs[1]
+        assert np.abs(o.decode(o.decrypt(lazy)) - want).max() < 1e-6
+        q = np.array(o.primes[:ell], dtype=np.int64)[None, :, None]
+        diff = np.stack([o.ntt_inv(o.poly_sub(lazy.data[k], eager.data[k]), list(range(ell))) for k in range(2)])   # coefficient domain
+        d = diff.astype(np.int64) % q
+        d = np.where(d > q // 2, d - q, d)
+        assert np.abs(d).max() <= 2 + 2 * ks and np.abs(d).max() > 0
