@@ -458,7 +458,8 @@ def config4_child():
     About 180 GB of keys and plaintexts: it runs in CHILD processes started before this one touches the GPU (the reference's ABI has no
     destroy symbol, so the other legs' VMs stay resident until exit).  Round 4: the same program also on a mixed 60 / 51-bit chain
     (`chains`) and under bounded rotation-key sets (`key_sets`: the reference HEaaN runtime's 49 offsets, 96 keys, one per offset)."""
-    res = _config4_run([1, "resnet20_nt16", 17, 1, "b14", CONFIG4["ks_special"], CONFIG4["ks_alpha"]])
+    lazy = ["--opt", f"hyb_lazy_sum={CONFIG4['lazy_sums']}"]
+    res = _config4_run([1, "resnet20_nt16", 17, 1, "b14", CONFIG4["ks_special"], CONFIG4["ks_alpha"]] + lazy)
     if "error" in res:
         return res
     res["program"] = ("tests/golden/resnet20_nt16.b14: bootstraps at the model script's own hints (before every activation), each restoring 14 "
@@ -467,7 +468,8 @@ def config4_child():
                    "rounds 3-4: 5 digits of 7 under 8 special primes, `key_shapes`); one direct Galois key per rotation offset (286 keys x 0.34 GB)")
     res["security"] = "N = 2^17, log2(QP) = 40 x 60 = 2400 bits, sparse ternary secret (h = 64): inside the 128-bit range for N = 2^17"
     res["history"] = ("round 2: 47.2 s, rms_vs_torch 0.152 (541 bootstraps restoring 3 primes, one-prime-per-digit keys); round 3: 4.0 s; round 4: "
-                      "3.14-3.17 s (digits of 7 under 8 special primes, 117 GB of rotation keys)")
+                      "3.14-3.17 s (digits of 7 under 8 special primes, 117 GB of rotation keys); round 5: 3.06-3.08 s on digits of 8 under 9, and "
+                      "`lazy_sums_ab` for this run's lazy sums")
     res["ntt_equivalents_note"] = ("counted per key switch as G (l + k) + 2 k + 2 l; rotations of one ciphertext in a wave share their decomposition "
                                    "(hoisting), so fewer transforms than that are executed")
     res["reference"] = "README.md:131-136: DaCapo's cost model estimates 13.6 s for its 19-bootstrap HEaaN plan (not measured)"
@@ -475,10 +477,17 @@ def config4_child():
                                              "rot_compose", "run_s", "key_switches", "ntt_equivalents", "rms_vs_torch", "fixture", "command")}
                        if "error" not in r else r)
     ks, al = CONFIG4["ks_special"], CONFIG4["ks_alpha"]
+    res["lazy_sums_ab"] = {"what": "option hyb_lazy_sum (round 5): direct-key rotations whose results are only added together -- the giant steps of the "
+                                   "bootstraps' matrix products, a convolution's shifted partial sums -- are key-switched into one accumulator in "
+                                   "the raised basis and divided by P once per sum (plan_exec.hip section 2b; limbs == the oracle VM replaying the "
+                                   "plan's groups, tests/test_gpu_config4_geometry.py).  One rounding instead of n: not the limbs of n rotate "
+                                   "instructions, which is why the option is off unless asked for; this run asks for it",
+                           "on": dict(brief(res), lazy_sums=res.get("lazy_sums")),
+                           "off": brief(_config4_run([1, "resnet20_nt16", 17, 1, "b14", ks, al]))}
     res["key_shapes"] = {"what": "the same run under rounds 3-4's key shape: 5 digits of 7 primes under 8 special primes (39 primes, 117 GB of rotation "
                                  "keys).  Round 5's shape needs a 9-input mod-down on the matrix cores (two K-chunks per tile, hybrid_ks.hip)",
-                         "digits_of_8_under_9": brief(res), "digits_of_7_under_8": brief(_config4_run([1, "resnet20_nt16", 17, 1, "b14", 8, 7]))}
-    mixed = _config4_run([1, "resnet20_nt16", 17, 1, "b14r51", ks, al, "mixed_app"])
+                         "digits_of_8_under_9": brief(res), "digits_of_7_under_8": brief(_config4_run([1, "resnet20_nt16", 17, 1, "b14", 8, 7] + lazy))}
+    mixed = _config4_run([1, "resnet20_nt16", 17, 1, "b14r51", ks, al, "mixed_app"] + lazy)
     res["chains"] = {"what": "the same trace on the 60-bit chain (libSEAL_HEVM.so) and on a HEaaN-style mixed chain -- 60-bit base prime, 51-bit rescale "
                              "primes for the program's 13 levels, 60-bit primes for the bootstrap's 17 levels and the 8 special ones -- through the "
                              "generic-width build (libSEAL_HEVM_gw.so); the program is lowered for the chain's rescale width (b14 / b14r51)",
@@ -489,14 +498,14 @@ def config4_child():
     res["key_sets"] = {"what": "the 60-bit run under bounded rotation-key sets: the reference HEaaN runtime's 49 left-rotation offsets (HEAAN_HEVM.cpp:"
                                "58-64), that list plus the program's most used other offsets up to 96 keys, and one key per offset (286); rotations "
                                "without a direct key are the shortest sum of offsets that have one (option rot_compose)",
-                       "49": brief(_config4_run([49, "resnet20_nt16", 17, 1, "b14", ks, al])),
-                       "96": brief(_config4_run([96, "resnet20_nt16", 17, 1, "b14", ks, al])),
+                       "49": brief(_config4_run([49, "resnet20_nt16", 17, 1, "b14", ks, al] + lazy)),
+                       "96": brief(_config4_run([96, "resnet20_nt16", 17, 1, "b14", ks, al] + lazy)),
                        "286": brief(res)}
     return res
 
 
 # (round 5: digits of 8 primes under 9 special primes -- 4 digits at the top level instead of 5, 96 instead of 117 GB of rotation keys, same accuracy)
-CONFIG4 = {"fixture": "resnet20_nt16", "lowering": "b14", "logN": 17, "ks_special": 9, "ks_alpha": 8, "msg_bits": 1, "secret_hw": 64}
+CONFIG4 = {"fixture": "resnet20_nt16", "lowering": "b14", "logN": 17, "ks_special": 9, "ks_alpha": 8, "msg_bits": 1, "secret_hw": 64, "lazy_sums": 1}
 
 
 def config4_program():
@@ -548,7 +557,7 @@ def main_config4(args, grp):
 
     t_setup = time.time()
     hevm = runner.HEVM(seed=KEY_SEED + (rank if args.broadcast_keys else 0), logN=CONFIG4["logN"], num_primes=K, ks_special=CONFIG4["ks_special"],
-                       ks_alpha=CONFIG4["ks_alpha"], vm_options={"secret_hw": CONFIG4["secret_hw"]})
+                       ks_alpha=CONFIG4["ks_alpha"], vm_options={"secret_hw": CONFIG4["secret_hw"], "hyb_lazy_sum": CONFIG4["lazy_sums"]})
     hevm.addRotationKeys(offs)  # (before the digest: the direct keys are part of the replicated key set)
 
     def _copy_out(ptr, words):
@@ -603,7 +612,8 @@ def config4_line(args, world, elapsed, total, ntts_per_step, ks_per_step, key_in
             "measured_on_hardware": not dry,
             "config": {"workload": f"BASELINE config {5 if world > 1 else 4}: ResNet-20 (SiLU) traced at nt = 2^16 slots, N = 2^17, {K} x 60-bit primes "
                                    f"({K - CONFIG4['ks_special']} data + {CONFIG4['ks_special']} special), 38 real bootstraps each restoring 14 primes, "
-                                   "grouped-digit hybrid key switching, one independent ciphertext stream per GPU",
+                                   "grouped-digit hybrid key switching" + (", lazy sums (option hyb_lazy_sum)" if CONFIG4["lazy_sums"] else "")
+                                   + ", one independent ciphertext stream per GPU",
                        "ntt_equivalents_per_step": ntts_per_step, "key_switches_per_step": ks_per_step, "rotation_keys": n_keys,
                        "key_bytes_per_gpu": key_bytes, "streams_per_gpu": 1,
                        "parallelism": f"replicas x{world} (no collective in the op path)", "keys": key_info},

@@ -319,11 +319,12 @@ static void f9_frows_final(const Context &c, const u64 *tmp, const u64 *accq, co
 void hyb_launch_mac(Context &c, int mode, const BatchWs &w, const void *items, KsItem rot_single, const u64 *key, int B, int use_slots, int ell,
                     hipStream_t s, bool fold_base);
 void hyb_launch_conv(Context &c, bool down, bool prescaled, const u64 *in, u64 *out, int count, int ell, hipStream_t s);
+void hyb_launch_mac_groups(Context &c, const BatchWs &w, const KsItem *items, const KsItem *groups, int G, int use_slots, int ell, hipStream_t s);
 
 // F2 ... F5: everything between F1 and the accumulators.  digits [U][ell][N] hold the inverse ROWS phase's output.
 template <int MODE>
 static void hybf_front(Context &c, const BatchWs &w, const void *items, KsItem rot_single, const u64 *key, int B, int U, int use_slots, int ell,
-                       hipStream_t s)
+                       hipStream_t s, bool with_mac = true)
 {
     const size_t N = c.N;
     const int E = c.hyb_ext(ell);
@@ -336,7 +337,7 @@ static void hybf_front(Context &c, const BatchWs &w, const void *items, KsItem r
         f3_modup_fcols(c, w.digits, w.ext, U, ell, s);                                                             // F3
         launch_ntt_rows_fwd(c, w.ext, (long)N, U * E, c.hyb_pidx(ell), 0, E, s);                                   // F4
     }
-    hyb_launch_mac(c, MODE, w, items, rot_single, key, B, use_slots, ell, s, MODE == 0);                           // F5
+    if (with_mac) hyb_launch_mac(c, MODE, w, items, rot_single, key, B, use_slots, ell, s, MODE == 0);             // F5
 }
 // F6 ... F9: the division by P of `B` accumulator pairs accq [2B][ell][N], accp [2B][ksp][N]; items[b] names where pair b goes
 template <int MODE>
@@ -394,18 +395,26 @@ __global__ __launch_bounds__(256) void hybf_group_sum_kernel(const u64 *__restri
     *reinterpret_cast<u64x2 *>((special ? gp : gq) + (((size_t)g * 2 + c) * limbs + row) * N + k) = a;
 }
 
-// B rotation items in G groups -> G sums.  The groups' accumulators live in w.ext, free once F5 has read the raised limbs
-// (2 G (l + ksp) <= B E limbs: every group has at least two items).
+// B rotation items in G groups -> G sums.  Default: the inner-product kernel itself walks a group's items (hyb_mac_group_kernel: no item's
+// accumulator is ever stored).  option hyb_lazy_sum = 2 -- a second implementation of the same sums, kept for the parity tests: every item's
+// accumulators as for an ordinary step, added by hybf_group_sum_kernel into w.ext (free once F5 has read the raised limbs; 2 G (l + ksp) <= B E
+// limbs: every group has at least two items).
 void hybf_rotate_sum(Context &c, const BatchWs &w, const KsItem *d_items, int B, const KsItem *d_groups, int G, int ell, hipStream_t s, int unique)
 {
     const size_t N = c.N;
     const int use_slots = unique > 0 ? 1 : 0, U = use_slots ? unique : B, ksp = c.ksp;
-    if ((size_t)2 * G * (ell + ksp) > (size_t)B * c.hyb_ext(ell) || N < 512) {
-        fprintf(stderr, "[dacapo_amd] lazy sum: %d groups of %d items do not fit the raised-limb scratch (internal error)\n", G, B);
+    const bool separate_sum = option(OPT_HYB_LAZY_SUM) == 2;
+    if ((size_t)2 * G * (ell + ksp) > (size_t)B * c.hyb_ext(ell) || N < 512 || 2 * G > B) {
+        fprintf(stderr, "[dacapo_amd] lazy sum: %d groups of %d items do not fit the step's scratch (internal error)\n", G, B);
         abort();
     }
     f1_irows<0>(c, d_items, KsItem{}, nullptr, w.digits, B, ell, use_slots, s);
-    hybf_front<0>(c, w, d_items, KsItem{}, nullptr, B, U, use_slots, ell, s);
+    hybf_front<0>(c, w, d_items, KsItem{}, nullptr, B, U, use_slots, ell, s, separate_sum);
+    if (!separate_sum) {
+        hyb_launch_mac_groups(c, w, d_items, d_groups, G, use_slots, ell, s);
+        hybf_back<0>(c, w, w.acc, w.acc + (size_t)G * 2 * ell * N, d_groups, KsItem{}, HybOut{}, G, ell, s);
+        return;
+    }
     u64 *gq = w.ext, *gp = w.ext + (size_t)2 * G * ell * N;
     DC_LAUNCH(hybf_group_sum_kernel, dim3((unsigned)(N / 512), (unsigned)(ell + ksp), (unsigned)(2 * G)), dim3(256), 0, s, w.acc,
               w.acc + (size_t)B * 2 * ell * N, gq, gp, d_groups, ell, ksp, c.max_level(), N, c.d_mods);

@@ -199,6 +199,71 @@ __global__ __launch_bounds__(kHT) void hyb_mac_kernel(u64 *__restrict__ accq, u6
     }
 }
 
+// lazy sums (option hyb_lazy_sum; hybrid_fused.hip hybf_rotate_sum): the inner products of ALL rotations of a group into ONE accumulator pair.
+// grid = (N/512, groups, M); groups[g]: elt = first item, slot = item count.  Per item exactly hyb_mac_kernel<0>'s arithmetic (its own key,
+// Galois map, decomposition slot and base term P galois(c0)), reduced to the canonical residue and added to the running sum -- so the sum equals
+// the sum of the items' accumulators limb for limb, and no item's accumulator crosses HBM (2 (l + ksp) limbs written and read again per
+// item otherwise: a third of this kernel's traffic at 12 primes, where a convolution's sums run).
+__global__ __launch_bounds__(kHT) void hyb_mac_group_kernel(u64 *__restrict__ accq, u64 *__restrict__ accp, const u64 *__restrict__ ext,
+                                                            const KsItem *__restrict__ items, const KsItem *__restrict__ groups, int ell, int ksp,
+                                                            int alpha, int L, int K, int E, size_t N, int logN, int use_slots,
+                                                            const DModulus *__restrict__ mods, const u64 *__restrict__ pmod)
+{
+    const int mi = blockIdx.z, gr = blockIdx.y, M = ell + ksp, pm = mi < ell ? mi : L + (mi - ell);
+    const DModulus Md = mods[pm];
+    const u32 first = groups[gr].elt, count = groups[gr].slot;
+    const size_t k = ((size_t)blockIdx.x * kHT + threadIdx.x) * 2;
+    const int G = (ell + alpha - 1) / alpha;
+    const u64 P = mi < ell ? pmod[pm] : 0;
+    u64x2 s0{ 0, 0 }, s1{ 0, 0 };
+    for (u32 t = 0; t < count; t++) {
+        const KsItem it = items[first + t];
+        const size_t slot = use_slots ? it.slot : (size_t)(first + t);
+        const u32 gsrc = hyb_galois_src((u32)k, it.elt, logN);
+        Acc128 a0[2], a1[2];
+#pragma unroll
+        for (int e = 0; e < 2; e++) a0[e].clear(), a1[e].clear();
+        auto fetch = [&](int g, u64x2 &x, u64x2 &y0, u64x2 &y1) {
+            const int lo = g * alpha, hi = min(lo + alpha, ell);
+            const bool own = mi >= lo && mi < hi;
+            const u64 *op = own ? it.src.limb(1, mi, N) : ext + (slot * E + (size_t)g * (M - alpha) + (mi < lo ? mi : mi - (hi - lo))) * N;
+            x = *reinterpret_cast<const u64x2 *>(op + (gsrc & ~1u));
+            y0 = *reinterpret_cast<const u64x2 *>(it.key + (((size_t)g * 2 + 0) * K + pm) * N + k);
+            y1 = *reinterpret_cast<const u64x2 *>(it.key + (((size_t)g * 2 + 1) * K + pm) * N + k);
+        };
+        u64x2 xn, y0n, y1n;
+        fetch(0, xn, y0n, y1n);
+        for (int g = 0; g < G; g++) {
+            u64x2 x = xn;
+            const u64x2 y0 = y0n, y1 = y1n;
+            if (g + 1 < G) fetch(g + 1, xn, y0n, y1n);
+            if (gsrc & 1u) x = u64x2{ x.y, x.x };
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                a0[e].mac(x[e], y0[e]);
+                a1[e].mac(x[e], y1[e]);
+            }
+        }
+        u64x2 o0, o1;
+#pragma unroll
+        for (int e = 0; e < 2; e++) o0[e] = a0[e].reduce(Md), o1[e] = a1[e].reduce(Md);
+        if (mi < ell) { // the rotation's base term P galois(c0), as in hyb_mac_kernel<0>
+            const u64x2 v = *reinterpret_cast<const u64x2 *>(it.src.limb(0, mi, N) + (gsrc & ~1u));
+            o0.x = addmod(o0.x, mulmod((gsrc & 1u) ? v.y : v.x, P, Md), Md.q);
+            o0.y = addmod(o0.y, mulmod((gsrc & 1u) ? v.x : v.y, P, Md), Md.q);
+        }
+        s0.x = addmod(s0.x, o0.x, Md.q), s0.y = addmod(s0.y, o0.y, Md.q);
+        s1.x = addmod(s1.x, o1.x, Md.q), s1.y = addmod(s1.y, o1.y, Md.q);
+    }
+    if (mi < ell) {
+        *reinterpret_cast<u64x2 *>(accq + (((size_t)gr * 2 + 0) * ell + mi) * N + k) = s0;
+        *reinterpret_cast<u64x2 *>(accq + (((size_t)gr * 2 + 1) * ell + mi) * N + k) = s1;
+    } else {
+        *reinterpret_cast<u64x2 *>(accp + (((size_t)gr * 2 + 0) * ksp + (mi - ell)) * N + k) = s0;
+        *reinterpret_cast<u64x2 *>(accp + (((size_t)gr * 2 + 1) * ksp + (mi - ell)) * N + k) = s1;
+    }
+}
+
 // mod-down base conversion: accp [2B][ksp][N] (coefficient domain) -> tmp [2B][l][N].  grid = (N/512, 2B)
 __global__ __launch_bounds__(kHT) void hyb_moddown_kernel(const u64 *__restrict__ accp, u64 *__restrict__ tmp, int ell, int ksp, int L, size_t N,
                                                            const DModulus *__restrict__ mods, const u64 *__restrict__ dn)
@@ -482,6 +547,16 @@ void hyb_launch_conv(Context &c, bool down, bool prescaled, const u64 *in, u64 *
         else
             DC_LAUNCH(hyb_moddown_kernel, dim3(gx, (unsigned)count), dim3(kHT), 0, s, in, out, ell, ksp, L, N, c.d_mods, c.d_hyb_dn);
     }
+}
+
+// lazy sums: G groups of rotation items -> accq = w.acc [2G][ell][N], accp behind it [2G][ksp][N]
+void hyb_launch_mac_groups(Context &c, const BatchWs &w, const KsItem *items, const KsItem *groups, int G, int use_slots, int ell, hipStream_t s)
+{
+    const size_t N = c.N;
+    const int ksp = c.ksp, M = ell + ksp;
+    DC_LAUNCH(hyb_mac_group_kernel, dim3((unsigned)(N / (2 * kHT)), (unsigned)G, (unsigned)M), dim3(kHT), 0, s, w.acc,
+              w.acc + (size_t)G * 2 * ell * N, w.ext, items, groups, ell, ksp, c.alpha, c.max_level(), c.K, c.hyb_ext(ell), N, c.logN, use_slots, c.d_mods,
+              c.d_pmod);
 }
 
 // inner products with the key: w.ext [U][E][N] (NTT form), w.target (modes 1, 2) -> accq = w.acc [2B][ell][N], accp behind it [2B][ksp][N]

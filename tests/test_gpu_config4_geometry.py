@@ -130,7 +130,8 @@ def test_hoisted_rotation_batch_at_config4_geometry_matches_the_oracle_vm(tmp_pa
     runner.set_option("hyb_fuse", 2)
 
 
-def test_lazy_sums_at_config4_geometry_match_the_oracle_vm(tmp_path):
+@pytest.mark.parametrize("mode", [1, 2])
+def test_lazy_sums_at_config4_geometry_match_the_oracle_vm(tmp_path, mode):
     """option hyb_lazy_sum at config 4's shape (N = 2^17, digits of 8 under 9 special primes): the giant steps of a BSGS product -- three
     rotations of three different inner sums added to a fourth -- at 31 primes (4 digits) and at 12 (2 digits, a partial one), one division
     by P per sum (hybrid_fused.hip hybf_rotate_sum) == the oracle VM replaying the plan's groups (orc_rotate_acc_hybrid / orc_moddown_hybrid)"""
@@ -176,7 +177,8 @@ def test_lazy_sums_at_config4_geometry_match_the_oracle_vm(tmp_path):
     for i, a in enumerate(b.args):
         hevm.setInput(i, a.plain)
         ovm.ciphers[i] = _get_ct(hevm, ll, i)
-    hevm.run()
+    with runner.options(hyb_lazy_sum=mode):                            # 1: hyb_mac_group_kernel; 2: per-item accumulators + hybf_group_sum_kernel
+        hevm.run()
     groups = hevm.lazy_groups()
     assert [len(g) for g in groups] == [3, 3], groups
     ovm.set_lazy_groups(groups)

@@ -1,12 +1,9 @@
-set -u
-cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r05v
-python3 -m pytest tests/test_gpu_ntt.py -x -q -m gpu > gpurun_out/r05v/pytest.txt 2>&1; tail -2 gpurun_out/r05v/pytest.txt
-for rep in 1 2; do
-for v in 3 0 2 4; do
-  L=""; [ $v != 3 ] && L=$GRAFT_REPO_ROOT/tools/experiments/lib_c$v/libSEAL_HEVM.so
-  echo "pair stages in forward pass C = $v"
-  DACAPO_AMD_LIB=$L python3 tools/legs/ntt_full_check.py 4096 20 | python3 -c "import sys,json; d=json.loads(sys.stdin.readline()); print(d['forward'], d['round_trip'], 'fwd', d['fwd_full_us'], 'inv', d['inv_full_us'], 'two-phase fwd', d['fwd_two_phase_us'])"
-  DACAPO_AMD_LIB=$L python3 tools/legs/ntt_full_check.py 1024 20 | python3 -c "import sys,json; d=json.loads(sys.stdin.readline()); print(d['forward'], '1024: fwd', d['fwd_full_us'], 'inv', d['inv_full_us'])"
-done; done > gpurun_out/r05v/c_pairs.txt 2>&1
-cat gpurun_out/r05v/c_pairs.txt
+#!/bin/bash
+# round 5, call 16: lazy sums through the group-walking inner-product kernel: parity, then config 4 (modes 1 / 2 / off)
+mkdir -p gpurun_out/r05q
+timeout 1500 python -m pytest tests/test_gpu_hybrid.py tests/test_gpu_config4_geometry.py -q -m gpu -k "lazy" > gpurun_out/r05q/pytest3.txt 2>&1
+tail -8 gpurun_out/r05q/pytest3.txt
+for lz in 1 2 0 1; do
+  timeout 900 python tools/legs/resnet_real_boot.py 1 resnet20_nt16 17 1 b14 9 8 --opt hyb_lazy_sum=$lz > gpurun_out/r05q/c4_mode$lz.txt 2> gpurun_out/r05q/c4_mode$lz.err
+  echo "mode $lz: $(tail -1 gpurun_out/r05q/c4_mode$lz.txt | python3 -c 'import json,sys; r=json.loads(sys.stdin.read()); print(r["run_s"], r["rms_vs_torch"], r.get("lazy_sums"))')"
+done

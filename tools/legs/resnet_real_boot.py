@@ -132,4 +132,6 @@ if streams > 1:  # throughput mode: the other streams' logits are finite and dif
         others.append([round(float(v), 4) for v in o])
     hevm.select_stream(0)
     res.update(streams=streams, images_per_s=round(streams / dt, 3), s_per_image=round(dt / streams, 3), other_streams_logits=others)
+groups = hevm.lazy_groups()  # option hyb_lazy_sum (--opt hyb_lazy_sum=1): sums of direct-key rotations with one division by P
+res["lazy_sums"] = {"groups": len(groups), "rotations": sum(len(g) for g in groups)}
 print(json.dumps(res))
