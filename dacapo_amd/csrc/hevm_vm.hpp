@@ -162,7 +162,7 @@ class HEVM {
         double boot_src_scale = 0.0;  // P_BOOT with boot_drop: scale of the folded rescale's result
         bool dead = false;
         int wave = 0, step = -1;
-        // lazy sums (option hyb_lazy_sum): a P_ROT remembers the instruction it came from and whether it is that instruction's ONLY hop;
+        // lazy sums (option hyb_lazy_sum): a P_ROT remembers the instruction it came from and whether it is that instruction's LAST hop;
         // a P_ROTSUM (dst = sum of galois_{elts[k]}(srcs[k]) with one division by P, plan.hpp hyb_rotate_sum) lists its rotations
         int op = -1;
         bool direct = false;

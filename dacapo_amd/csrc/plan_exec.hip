@@ -95,7 +95,7 @@ void HEVM::build_plan()
             const double in_scale = P.vals[(size_t)v].scale; // (rotate_vector keeps the scale: every hop's result carries the operand's)
             bool memo_final = false;
             const std::vector<u32> hops = rotate_hops((int16_t)op.rhs);
-            for (u32 elt : hops) {
+            for (const u32 &elt : hops) {
                 // option rot_compose (a bounded key set): composed rotations of one value mostly start with the same small offset -- the parts
                 // come in ascending order -- so the hop (value, Galois element) is computed once and its result named again: the same limbs
                 // (a key switch is deterministic), one key switch fewer.  config 4 under the reference HEaaN runtime's 49 keys: 18.7 % of the hops.
@@ -113,7 +113,7 @@ void HEVM::build_plan()
                 const int nv = new_val(s.level, in_scale);
                 Pop &p = add_pop(P_ROT, s.level, { v }, nv);
                 p.elt = elt, p.key = keys.galois.at(elt);
-                p.op = (int)(&op - ops.data()), p.direct = hops.size() == 1;
+                p.op = (int)(&op - ops.data()), p.direct = &elt == &hops.back(); // (the LAST hop of the instruction: the one whose result the program sees)
                 P.n_keyswitch++, P.n_ntt += ks_ntts(s.level);
                 if (rot_compose) {
                     const auto mb = memo_base.find(v);
@@ -365,8 +365,8 @@ void HEVM::build_plan()
     // share ONE division by P ("double hoisting", Bossuat et al. 2021): the accumulators of the group's key switches are added in the raised
     // basis and F6 ... F9 run once (hybrid_fused.hip hybf_rotate_sum), 1 instead of n roundings.  That is a different -- slightly less noisy --
     // result than n rotate instructions, limb-wise, which is why the option is off by default and why the rule is narrow and exported
-    // (hevm_plan_lazy_groups; the oracle VM replays exactly these groups): a member is a rotate INSTRUCTION with a direct key (one hop),
-    // whose result nothing else reads, entering the sum as it is (no plaintext factor); a sum needs at least two of them.
+    // (hevm_plan_lazy_groups; the oracle VM replays exactly these groups): a member is the LAST hop of a rotate instruction (the only one under a
+    // direct key) whose result nothing else reads, entering the sum as it is (no plaintext factor); a sum needs at least two of them.
     if (lazy_sums && hyb_lazy_sum_supported(c)) {
         for (size_t ci = 0; ci < O.size(); ci++) {
             if (O[ci].dead) continue;

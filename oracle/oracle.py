@@ -453,11 +453,14 @@ class Oracle:
         return Ciphertext(np.stack([c0, c1]), a.scale)
 
     def rotate_lazy(self, a: Ciphertext, steps: int, group: int, size: int) -> "LazySum":
-        """one single-hop rotation as a term of a lazy sum: (galois(c0), 0) and its inner products in the raised basis"""
+        """one rotation as a term of a lazy sum: every hop but the last as usual, the last one left as (galois(c0), 0) and its inner products
+        in the raised basis"""
         assert (self.ks, self.alpha) != (1, 1), "lazy sums exist in grouped-digit mode only"
         hops = self.rotate_hops(steps)
-        assert len(hops) == 1, "only rotations with a direct key join a lazy sum"
-        elt = hops[0]
+        assert hops, "a rotation by zero has no key switch to share"
+        for e in hops[:-1]:
+            a = self.apply_galois(a, e)
+        elt = hops[-1]
         c0 = self.galois_ntt(a.data[0], elt)
         acc = np.zeros((2, a.ell + self.ks, self.N), dtype=np.uint64)
         key = self.galois[elt]

@@ -38,16 +38,16 @@ rm -rf $OUT/hk $OUT/hf $OUT/hw
 # B3. config 4 (N = 2^17, 38 real bootstraps, grouped-digit keys): kernel-time table of the whole run; measured HBM bytes per kernel on ONE
 #     bootstrap of the same geometry (rocprofv3 --pmc on the whole config-4 program crashes or hangs: profiles/r04_experiments.txt item 12)
 cd /tmp
-C4="$ROOT/tools/legs/resnet_real_boot.py 1 resnet20_nt16 17 1 b14 9 8"
+C4="$ROOT/tools/legs/resnet_real_boot.py 1 resnet20_nt16 17 1 b14 9 8 --opt hyb_lazy_sum=1"   # as bench.py runs it (CONFIG4["lazy_sums"])
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c4 -- python3 $C4 > $OUT/${R}_config4_under_profiler.txt 2> $OUT/c4.err
 cp $(ls $OUT/c4/*/*kernel_stats.csv | head -1) $OUT/${R}_config4_kernel_stats.csv
 rm -rf $OUT/c4
-BT="$ROOT/tools/legs/boot_demo.py 17 5 1 14 9 8"
+BT="$ROOT/tools/legs/boot_demo.py 17 5 1 14 9 8 --opt hyb_lazy_sum=1"
 timeout 600 rocprofv3 --kernel-trace --output-format csv -d $OUT/bt -- python3 $BT > $OUT/bt.txt 2> $OUT/bt.err
 timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/btf -- python3 $BT --opt plan_graph=0 > /dev/null 2> $OUT/btf.err
 timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/btw -- python3 $BT --opt plan_graph=0 > /dev/null 2> $OUT/btw.err
 cd $ROOT
-{ echo "one real bootstrap at config 4's geometry (N = 2^17, 31 + 9 primes, digits of 8, 1 -> 14 primes): python tools/legs/boot_demo.py 17 5 1 14 9 8"
+{ echo "one real bootstrap at config 4's geometry (N = 2^17, 31 + 9 primes, digits of 8, 1 -> 14 primes): python tools/legs/boot_demo.py 17 5 1 14 9 8 --opt hyb_lazy_sum=1 (lazy sums, as config 4 runs)"
   echo "the process = key generation + encoding + 3 runs; bytes = FETCH_SIZE x 2 + WRITE_SIZE per kernel (plan run launch by launch for the counters)"
   grep -E "bootstrap:|decrypted" $OUT/bt.txt
   python tools/summarize/kernel_bytes.py $(kt $OUT/bt) $(cc $OUT/btf) $(cc $OUT/btw) top=30; } > $OUT/${R}_boot_kernel_bytes.txt

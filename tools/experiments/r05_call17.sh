@@ -1,6 +1,7 @@
-set -u
-cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r05ac
-python3 tools/legs/per_op_sweep.py 30 wide_tile_wgs=0 wide_tile_wgs=1024 wide_tile_wgs=4096 > gpurun_out/r05ac/per_op.txt 2>&1
-python3 tools/legs/lowering_sweep.py 6 wide_tile_wgs=0 wide_tile_wgs=512 wide_tile_wgs=2048 wide_tile_wgs=8192 > gpurun_out/r05ac/low.txt 2>&1
-cat gpurun_out/r05ac/per_op.txt gpurun_out/r05ac/low.txt gpurun_out/r05ac/hop.txt
+#!/bin/bash
+# round 5, call 17: the whole GPU suite + smoke on the lazy-sums build
+mkdir -p gpurun_out/r05p
+timeout 3000 python -m pytest tests -q -m gpu > gpurun_out/r05p/pytest_gpu.txt 2>&1
+tail -6 gpurun_out/r05p/pytest_gpu.txt
+timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/r05p/smoke.txt 2>&1; tail -3 gpurun_out/r05p/smoke.txt
+sha256sum dacapo_amd/lib/*.so

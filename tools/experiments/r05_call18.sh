@@ -1,13 +1,9 @@
-set -u
-cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
-mkdir -p $R/gpurun_out/r05ae
-for w in -1 0; do
-  rm -rf /tmp/kt_$w
-  timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/kt_$w -- python3 $R/tools/legs/per_op_only.py 20 --only rotate_hop --opt wide_tile_wgs=$w > /dev/null 2>/tmp/kt.err
-  echo "== rotate_hop, wide_tile_wgs=$w"; python3 $R/tools/summarize/summarize_trace.py $(ls /tmp/kt_$w/*/*kernel_trace.csv | head -1) | grep -v rocclr | head -9
-  rm -rf /tmp/kb_$w
-  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kb_$w -- python3 $R/tools/legs/headline_only.py 3 b13 --opt wide_tile_wgs=$w > /dev/null 2>/tmp/kb.err
-  echo "== b13, wide_tile_wgs=$w"; head -6 $(ls /tmp/kb_$w/*/*kernel_stats.csv | head -1) | cut -c1-60,200-330
-done > $R/gpurun_out/r05ae/wide_kernels.txt 2>&1
-cat $R/gpurun_out/r05ae/wide_kernels.txt
+#!/bin/bash
+# round 5, call 18: lazy sums also for the last hop of a composed rotation: parity, then config 4 under 49 / 96 / 286 keys, lazy on / off
+mkdir -p gpurun_out/r05q
+timeout 1500 python -m pytest tests/test_gpu_hybrid.py tests/test_gpu_config4_geometry.py tests/test_gpu_config4.py -q -m gpu > gpurun_out/r05q/pytest4.txt 2>&1
+tail -5 gpurun_out/r05q/pytest4.txt
+for keys in 49 96 1; do for lz in 1 0; do
+  timeout 900 python tools/legs/resnet_real_boot.py $keys resnet20_nt16 17 1 b14 9 8 --opt hyb_lazy_sum=$lz > gpurun_out/r05q/c4_k${keys}_lazy$lz.txt 2> gpurun_out/r05q/c4_k${keys}_lazy$lz.err
+  echo "keys $keys lazy $lz: $(tail -1 gpurun_out/r05q/c4_k${keys}_lazy$lz.txt | python3 -c 'import json,sys; r=json.loads(sys.stdin.read()); print(r["run_s"], r["rms_vs_torch"], r["key_switches"], r.get("lazy_sums"))')"
+done; done
