@@ -101,7 +101,12 @@ def bind_vm_lib(path):
     L.hevm_init_seeded_primes.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_uint64), ctypes.c_int, ctypes.c_uint64]
     L.hevm_init_seeded_primes.restype = ctypes.c_void_p
     bind_options(L)
+    for name, value in _cli_options.items():  # `--opt` pairs given before this build was loaded (each build has its own option table)
+        L.hevm_set_option(name.encode(), int(value))
     return L
+
+
+_cli_options: dict = {}
 
 
 def bind_options(L):
@@ -144,6 +149,7 @@ def apply_cli_options(argv):
         if argv[i] == "--opt" and i + 1 < len(argv):
             name, _, value = argv[i + 1].partition("=")
             set_option(name, int(value, 0))
+            _cli_options[name] = int(value, 0)  # ... and on builds loaded later (bind_vm_lib)
             i += 2
         else:
             out.append(argv[i])

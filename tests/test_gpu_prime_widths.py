@@ -172,3 +172,55 @@ def test_vm_program_on_a_51_bit_chain_matches_the_oracle_vm(tmp_path):
     assert np.abs(hevm.getOutput()[0] - b.expected()[0]).max() < 1e-5
     assert info["op_mix"]["rescale"] >= 2 and info["op_mix"]["mulcc"] == 2
     hevm.close()
+
+
+def test_lazy_sums_on_a_51_bit_grouped_digit_chain_match_the_oracle_vm(tmp_path):
+    """option hyb_lazy_sum on the generic-width build (libSEAL_HEVM_gw.so): nine 51-bit primes, three of them special, digits of three -- sums of
+    rotations divided by P once (hyb_mac_group_kernel, plan_exec.hip section 2b) == the oracle VM replaying the plan's groups on the same
+    primes, limb for limb (tests/test_gpu_hybrid.py has the 60-bit build's version of this test, and what is eligible)"""
+    from dacapo_amd import hevm_asm as ha
+    from dacapo_amd import lowlevel as ll
+    from dacapo_amd import runner
+    from gpu_helpers import _get_ct, _import_keys, _mirror_vm
+
+    logN, K, ks, bits = 12, 9, 3, 51
+    slots = 1 << (logN - 1)
+    rng = np.random.default_rng(31)
+    b = ha.Builder(slots=slots, init_level=K - ks, policy="lazy", boot_level=K - ks, rescale_bits=bits, shadow=True)
+    x, y = b.input(rng.uniform(-1, 1, slots)), b.input(rng.uniform(-1, 1, slots))
+    z = b.add(b.add(b.rotate(x, 4), y), b.rotate(y, -2))
+    out = None
+    for g in range(4):
+        inner = b.add(b.mul_plain(x, rng.uniform(-1, 1, slots)), b.mul_plain(y, rng.uniform(-1, 1, slots)))
+        if g:
+            inner = b.rotate(inner, (8, 16, 40)[g - 1])          # 40 = 32 + 8: its second hop joins the sum
+        out = inner if out is None else b.add(out, inner)
+    ts = [b.mul_plain(x, [0.01 * (i + 1)]) for i in range(8)]   # (eight temporaries alive at once: no rotation result stays a register's FINAL
+    pad = ts[0]                                                 # value -- architectural state, which would keep it out of its group)
+    for t in ts[1:]:
+        pad = b.add(pad, t)
+    b.output(b.finish(out))
+    b.output(b.finish(z))
+    b.output(b.finish(pad))
+    cst, hv, _ = b.assemble()
+    hevm = runner.HEVM(seed=13, logN=logN, num_primes=K, ks_special=ks, vm_options={"prime_bits": bits, "hyb_lazy_sum": 1})
+    assert hevm.lw is runner.bind_vm_lib(__import__("dacapo_amd").LIB_PATH_GW)
+    o = Oracle(logN, K, bit_size=bits)
+    o.set_hybrid(ks)
+    _import_keys(o, hevm, ll)
+    hevm.load_mem(cst, hv)
+    ovm = _mirror_vm(hevm, ll, o, cst, hv, tmp_path)
+    for i, a in enumerate(b.args):
+        hevm.setInput(i, a.plain)
+        ovm.ciphers[i] = _get_ct(hevm, ll, i)
+    hevm.run()
+    groups = hevm.lazy_groups()
+    assert sorted(len(g) for g in groups) == [2, 3], groups
+    ovm.set_lazy_groups(groups)
+    ovm.run()
+    for k in range(2):
+        r = ovm.prog.res_dst[k]
+        got, want = _get_ct(hevm, ll, r), ovm.ciphers[r]
+        assert got.ell == want.ell and got.scale == want.scale and (got.data == want.data).all(), k
+        assert np.abs(hevm.getOutput()[k] - b.expected()[k]).max() < 1e-5
+    hevm.close()
