@@ -108,7 +108,7 @@ void hevm_last_run_stats(void *vm, int64_t *op_counts /*[11]*/, int64_t *keyswit
 /* option "hyb_lazy_sum" (grouped-digit mode, off by default): the rotate instructions the last run()'s plan executed as lazy sums -- the
  * accumulators of a group's key switches added in the raised basis, ONE division by P per group.  out = [n_0, op ...,
  * n_1, op ...]: per group its size and its rotations' instruction indices.  Returns the length of that list (written if cap suffices), 0 without
- * groups, -1 before the first run().  Test infrastructure: oracle/oracle.py OracleVM.set_lazy_groups replays exactly these groups. */
+ * groups, -1 before the first run() and under option "plan" = 0 (the loop executes every rotate on its own).  Test infrastructure: oracle/oracle.py OracleVM.set_lazy_groups replays exactly these groups. */
 int64_t hevm_plan_lazy_groups(void *vm, int32_t *out, int64_t cap);
 /* Throughput mode: run `n` independent ciphertext streams of the same program side by side (shared keys and
  * plaintexts; every step of the batched plan processes all streams in one launch sequence).  Call before load();
