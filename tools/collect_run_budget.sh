@@ -1,6 +1,6 @@
 #!/bin/bash
 # Kernel-by-kernel budget of one run() of a lowering of the ResNet-20 trace (durations, HBM bytes, VALU instructions, floors):
-#   gpurun --timeout 1500 -- 'bash tools/collect_run_budget.sh r05 b13 [--opt name=value ...]'      (lowering: headline | b6 | b13)
+#   gpurun --timeout 1500 -- 'bash tools/collect_run_budget.sh r05 b13 [--opt name=value ...]'      (lowering: headline | headline_s<streams> | b6 | b13)
 # -> gpurun_out/<round>/<round>_run_budget_<lowering>.txt / .json (+ raw CSVs, gzipped)
 set -u
 R=${1:-r05}; LOW=${2:-b13}; shift; shift || true
@@ -12,6 +12,7 @@ cd /tmp && export TMPDIR=/tmp
 kt() { ls $1/*/*kernel_trace.csv | head -1; }
 cc() { ls $1/*/*counter_collection.csv | head -1; }
 ARG=$LOW; [ $LOW = headline ] && ARG=""
+case $LOW in headline_s*) ARG=""; EXTRA="--streams ${LOW#headline_s} $EXTRA";; esac   # headline_s16: 16 images per run() in one VM
 CMD="python3 $ROOT/tools/legs/headline_only.py 3 $ARG $EXTRA"
 D=$OUT/raw_run_$LOW; rm -rf $D; mkdir -p $D
 timeout 600 rocprofv3 --kernel-trace --output-format csv -d $D/kt -- $CMD > /dev/null 2> $D/kt.err
