@@ -208,7 +208,8 @@ rows = [bench_row("r05"), traffic_row("r05"), step_row("r05"), valu_row("r05"),
         f"{kb_rows('r05_boot_kernel_bytes.txt', 'hyb_mac_kernel<0>|hyb_conv_mfma_kernel<true, true, 2>|hyb_conv_mfma_kernel<false, true, 1>|ntt_phase_kernel<8, 3, true, false, false>', 4)} | three passes of `tools/legs/boot_demo.py 17 5 1 14 9 8`, `tools/summarize/kernel_bytes.py` |",
         f"| `r05_per_op.json`, `r05_per_op_kernel_stats.csv` | the three expensive opcodes at 13 primes and config 3 under `--stats`: {stats('r05_per_op_kernel_stats.csv', 3)} | `rocprofv3 --kernel-trace --stats -- python3 tools/legs/per_op_only.py 20` |",
         f"| `r05_kernel_stats.csv`, `r05_by_kernel_and_grid.txt`, `r05_timeline.txt`, `r05_top_kernels.json`, `r05_roofline_leg_launches.txt` | the bench command under the kernel trace: {first_lines('r05_timeline.txt', 'last run', 1)} | `rocprofv3 --kernel-trace --stats … -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-lowerings --no-config4` |",
-        "| `r05_experiments.txt` | what was measured on the way and how it came out: the budgets before any change, launch-shape sweeps, key-ordered items, twiddle pairs (COLS tiles, inverse single-crossing passes, LDS twiddle tables), the 9-input mod-down, what was not kept | — |",
+        "| `r05_experiments.txt` | what was measured on the way and how it came out: the budgets before any change, launch-shape sweeps, key-ordered items, twiddle pairs (COLS tiles, inverse single-crossing passes, LDS twiddle tables), the 9-input mod-down, lazy sums, what was not kept | — |",
+        "| `r05_streams16_top_kernels.txt` | the headline program with 16 images per run() in one VM, kernel trace of one run: which kernels the fed regime spends its time in (the counter passes did not survive this run: durations only) | `rocprofv3 --kernel-trace -- python3 tools/legs/headline_only.py 3 --streams 16` |",
         "| `r05_chain_latency.txt`, `r05_profiled_SEAL_MI355X.json` | as in round 4 on this build (the streams table moved into the bench line: `streams`) | `tools/legs/chain_bench.py`, `tools/legs/profile_backend.py` |"]
 print("\n".join(r for r in rows if r))
 print()
