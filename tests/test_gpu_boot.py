@@ -83,11 +83,14 @@ def test_sparse_secret_and_extension_opcodes_against_the_oracle(tmp_path):
     assert (o.ntt_inv(o.decrypt(ovm.ciphers[1]).data[:1], [0])[0] == m1).all()
 
 
-@pytest.mark.parametrize("plan,chain,ks", [(1, "60", 1), (0, "60", 1), (1, "mixed", 1), (1, "mixed", 3), (0, "mixed", 3)])
-def test_bootstrap_limbs_bit_identical_to_the_oracle(tmp_path, plan, chain, ks):
+@pytest.mark.parametrize("plan,chain,ks,lazy", [(1, "60", 1, 0), (0, "60", 1, 0), (1, "mixed", 1, 0), (1, "mixed", 3, 0), (0, "mixed", 3, 0),
+                                                (1, "60", 3, 1), (1, "mixed", 3, 1)])
+def test_bootstrap_limbs_bit_identical_to_the_oracle(tmp_path, plan, chain, ks, lazy):
     """chain "mixed" (round 4): a HEaaN-style chain -- 60-bit base prime, 51-bit rescale primes, 60-bit special primes (HEAAN_HEVM.cpp:55-56,
     profiled_HEAAN_GPU.json: rescalingFactor 51) -- on the generic-width build of the library, with SEAL-style (ks = 1) and grouped-digit
-    (ks = 3) keys: the whole bootstrap, ~1 100 instructions incl. ModRaise from the 60-bit base into 51-bit primes, limb for limb."""
+    (ks = 3) keys: the whole bootstrap, ~1 100 instructions incl. ModRaise from the 60-bit base into 51-bit primes, limb for limb.
+    lazy = 1 (round 5, option hyb_lazy_sum): the giant steps of the bootstrap's matrix products share one division by P per product; the
+    oracle VM replays the plan's groups (hevm_plan_lazy_groups) with orc_rotate_acc_hybrid / orc_moddown_hybrid -- still limb for limb."""
     from dacapo_amd import ckks_boot as cb
     from dacapo_amd import lowlevel as ll
 
@@ -97,7 +100,7 @@ def test_bootstrap_limbs_bit_identical_to_the_oracle(tmp_path, plan, chain, ks):
         K0 = 3 + cb.boot_levels() + ks
         primes = cb.mixed_prime_chain(logN, [60] + [51] * (K0 - 1 - ks) + [60] * ks)
     K, cst, hv, offs = _program(logN, ks=ks, primes=primes)
-    hevm = _vm(logN, K, 32, offs, {"plan": plan}, ks=ks, primes=primes)
+    hevm = _vm(logN, K, 32, offs, {"plan": plan, "hyb_lazy_sum": lazy}, ks=ks, primes=primes)
     o = Oracle(logN, K, primes=primes)
     if ks > 1:
         o.set_hybrid(ks)
@@ -113,6 +116,10 @@ def test_bootstrap_limbs_bit_identical_to_the_oracle(tmp_path, plan, chain, ks):
     hevm.setInput(0, msg)
     ovm.ciphers[0] = _get_ct(hevm, ll, 0)
     hevm.run()
+    if lazy:
+        groups = hevm.lazy_groups()
+        assert len(groups) >= 4 and sum(len(g) for g in groups) >= 12, groups   # every matrix product of CoeffToSlot / SlotToCoeff has giant steps
+        ovm.set_lazy_groups(groups)
     ovm.run()
     r = ovm.prog.res_dst[0]
     got, want = _get_ct(hevm, ll, r), ovm.ciphers[r]
