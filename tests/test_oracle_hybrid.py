@@ -155,3 +155,53 @@ def test_lazy_sum_of_rotations_shares_one_mod_down(K, ks, alpha):
         d = diff.astype(np.int64) % q
         d = np.where(d > q // 2, d - q, d)
         assert np.abs(d).max() <= 2 + 2 * ks and np.abs(d).max() > 0
+
+
+def test_oracle_vm_replays_lazy_groups(tmp_path):
+    """OracleVM.set_lazy_groups (what the GPU parity tests feed with hevm_plan_lazy_groups): a program Sum_g rot_g(inner_g) run eagerly and
+    with its three rotations named as one group decrypts to the same values, the limbs differ (one rounding instead of three), a group of ONE
+    rotation reproduces the eager limbs exactly, and a group that the program's dataflow contradicts -- one of its rotations is multiplied
+    by a plaintext before anything adds it -- is reported, not silently computed."""
+    from dacapo_amd import hevm_asm as ha
+    from oracle.oracle import OracleVM
+
+    logN, K, ks = 10, 7, 2
+    slots = 1 << (logN - 1)
+    rng = np.random.default_rng(4)
+    b = ha.Builder(slots=slots, init_level=K - ks, policy="lazy", boot_level=K - ks, shadow=True)
+    x, y = b.input(rng.uniform(-1, 1, slots)), b.input(rng.uniform(-1, 1, slots))
+    out = b.add(x, y)
+    for g, k in enumerate((4, 8, 16)):
+        out = b.add(out, b.rotate(b.add(b.mul_plain(x, [0.1 * (g + 1)]), b.mul_plain(y, [0.2])), k))
+    bad = b.mul_plain(b.rotate(x, 2), [0.5])
+    b.output(b.finish(out))
+    b.output(b.finish(bad))
+    cst, hv, _ = b.assemble()
+    (tmp_path / "p.cst").write_bytes(cst)
+    (tmp_path / "p.hevm").write_bytes(hv)
+    o = Oracle(logN, K)
+    o.set_hybrid(ks)
+    o.keygen(seed=3)
+
+    def run(groups):
+        vm = OracleVM(o)
+        vm.load(tmp_path / "p.cst", tmp_path / "p.hevm")
+        vm.preprocess()
+        o.rng.value = 99                                        # same encryption randomness in every run
+        for i, a in enumerate(b.args):
+            vm.encrypt(i, a.plain)
+        if groups is not None:
+            vm.set_lazy_groups(groups)
+        vm.run()
+        return vm
+
+    ops = ha.unpack_hevm(hv)["ops"].tolist()
+    rots = [i for i, op in enumerate(ops) if op[0] == ha.OP_ROTATE]
+    assert len(rots) == 4                                       # the three giant steps, then the rotation by 2
+    eager, lazy, single = run(None), run([rots[:3]]), run([[rots[0]]])
+    r = eager.prog.res_dst[0]
+    assert np.abs(lazy.decrypt(r) - b.expected()[0]).max() < 1e-6 and np.abs(eager.decrypt(r) - b.expected()[0]).max() < 1e-6
+    assert (lazy.ciphers[r].data != eager.ciphers[r].data).any()
+    assert (single.ciphers[r].data == eager.ciphers[r].data).all()
+    with pytest.raises(RuntimeError, match="unfinished lazy sum"):
+        run([[rots[2], rots[3]]])
