@@ -471,7 +471,8 @@ def config4_child():
                       "3.14-3.17 s (digits of 7 under 8 special primes, 117 GB of rotation keys); round 5: 3.06-3.08 s on digits of 8 under 9, and "
                       "`lazy_sums_ab` for this run's lazy sums")
     res["ntt_equivalents_note"] = ("counted per key switch as G (l + k) + 2 k + 2 l; rotations of one ciphertext in a wave share their decomposition "
-                                   "(hoisting), so fewer transforms than that are executed")
+                                   "(hoisting) and, with lazy sums, rotations that are only added together share their division by P, so fewer "
+                                   "transforms than that are executed: the figure to compare is run_s, seconds per inference")
     res["reference"] = "README.md:131-136: DaCapo's cost model estimates 13.6 s for its 19-bootstrap HEaaN plan (not measured)"
     brief = lambda r: ({k: r.get(k) for k in ("chain", "log2_QP", "primes", "special_primes", "primes_per_digit", "rotation_keys", "rotation_key_bytes",
                                              "rot_compose", "run_s", "key_switches", "ntt_equivalents", "rms_vs_torch", "fixture", "command")}
