@@ -81,10 +81,13 @@ __device__ __forceinline__ bool hf_first_of_slot(const KsItem *__restrict__ item
 template <int K, int LOGE, int MODE>
 __global__ __launch_bounds__(kTileThreads) void hybf_irows_kernel(const KsItem *__restrict__ items, KsItem single, const u64 *__restrict__ target,
                                                                    u64 *__restrict__ digits, int ell, int use_slots,
-                                                                   const DModulus *__restrict__ mods, const u64 *__restrict__ itw, int logN)
+                                                                   const DModulus *__restrict__ mods, const u64 *__restrict__ itw, int logN,
+                                                                   int prime_major)
 {
     __shared__ __attribute__((aligned(16))) u64 lds[TileGeo<LOGE>::LDS_ELEMS];
-    const int z = blockIdx.y, i = z % ell, b = z / ell;
+    // (prime_major: the B limbs of one prime adjacent in launch order -- their twiddle tiles come out of L2, ntt_kernels.hip)
+    const int B = gridDim.y / ell;
+    const int i = prime_major ? blockIdx.y / B : blockIdx.y % ell, b = prime_major ? blockIdx.y % B : blockIdx.y / ell, z = b * ell + i;
     const size_t N = (size_t)1 << logN;
     const u64 *in;
     size_t slot = (size_t)b;
@@ -244,15 +247,18 @@ template <int K, int LOGE, int MODE>
 __global__ __launch_bounds__(kTileThreads) void hybf_frows_final_kernel(const u64 *__restrict__ tmp, const u64 *__restrict__ accq,
                                                                          const void *__restrict__ items, KsItem rot_single, HybOut single, int ell,
                                                                          int ksp, int L, const DModulus *__restrict__ mods,
-                                                                         const u64 *__restrict__ dn, const u64 *__restrict__ tw, int logN)
+                                                                         const u64 *__restrict__ dn, const u64 *__restrict__ tw, int logN,
+                                                                         int prime_major)
 {
     __shared__ __attribute__((aligned(16))) u64 lds[TileGeo<LOGE>::LDS_ELEMS];
     constexpr int EC = 1 << LOGE, NP = num_passes<LOGE>(K);
     const size_t N = (size_t)1 << logN;
-    const int i = blockIdx.y % ell, z = blockIdx.y / ell, b = z >> 1, c = z & 1;
+    // (prime_major: the 2 B limbs of one prime adjacent in launch order -- their twiddle tiles come out of L2, ntt_kernels.hip)
+    const int polys = gridDim.y / ell;
+    const int i = prime_major ? blockIdx.y / polys : blockIdx.y % ell, z = prime_major ? blockIdx.y % polys : blockIdx.y / ell, b = z >> 1, c = z & 1;
     const DModulus M = mods[i];
     const u64 pinv = dn[2 * ksp + L + i];
-    const u64 *in = tmp + (size_t)blockIdx.y * N, *ac = accq + (size_t)blockIdx.y * N;
+    const u64 *in = tmp + ((size_t)z * ell + i) * N, *ac = accq + ((size_t)z * ell + i) * N;
     u64 *dst;
     const u64 *base = nullptr;
     if (MODE == 0) {
@@ -289,7 +295,7 @@ template <int MODE>
 static void f1_irows(const Context &c, const KsItem *items, KsItem single, const u64 *target, u64 *digits, int B, int ell, int use_slots, hipStream_t s)
 {
     DC_GEO_SWITCH(c.k2, B * ell, DC_LAUNCH((hybf_irows_kernel<KK, LE, MODE>), grid, dim3(kTileThreads), 0, s, items, single, target, digits, ell,
-                                                    use_slots, c.d_mods, c.d_itw, c.logN));
+                                                    use_slots, c.d_mods, c.d_itw, c.logN, (int)(B > 1 && rows_prime_major(c))));
 }
 static void f3_modup_fcols(const Context &c, const u64 *digits, u64 *ext, int U, int ell, hipStream_t s)
 {
@@ -312,7 +318,8 @@ static void f9_frows_final(const Context &c, const u64 *tmp, const u64 *accq, co
                            hipStream_t s)
 {
     DC_GEO_SWITCH(c.k2, polys * ell, DC_LAUNCH((hybf_frows_final_kernel<KK, LE, MODE>), grid, dim3(kTileThreads), 0, s, tmp, accq, items,
-                                                        rot_single, single, ell, c.ksp, c.max_level(), c.d_mods, c.d_hyb_dn, c.d_tw, c.logN));
+                                                        rot_single, single, ell, c.ksp, c.max_level(), c.d_mods, c.d_hyb_dn, c.d_tw, c.logN,
+                                                        (int)rows_prime_major(c)));
 }
 
 // hybrid_ks.hip

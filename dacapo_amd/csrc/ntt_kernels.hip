@@ -10,10 +10,19 @@ template <int K, int LOGE, bool COLS, bool INV, bool CANON>
 __global__ __launch_bounds__(kTileThreads) void ntt_phase_kernel(u64 *__restrict__ data, long limb_stride,
                                                                   const int *__restrict__ prime_idx, int prime_base,
                                                                   int prime_period, const DModulus *__restrict__ mods,
-                                                                  const u64 *__restrict__ tw, int logN)
+                                                                  const u64 *__restrict__ tw, int logN, int prime_major)
 {
     __shared__ __attribute__((aligned(16))) u64 lds[TileGeo<LOGE>::LDS_ELEMS];
-    const int limb = blockIdx.y;
+    // prime_major (ROWS phases on large rings, option rows_prime_major): row y of the grid is limb (y mod batches) * period + y / batches --
+    // the `batches` limbs that share a prime are adjacent in launch order.  A ROWS tile's twiddles are its own 2^K-entry slice of the prime's
+    // table, so a limb's transform reads as many twiddle bytes as data bytes; at N = 2^17 a table is 1 MiB per prime and 40 of them do not
+    // stay in a 4 MiB L2 from one limb of a prime to the next one `period` limbs later.  Adjacent, tile t of the next limb (same XCD: the
+    // tile count is a multiple of 8) finds them there.
+    int limb = blockIdx.y;
+    if (prime_major) {
+        const int batches = gridDim.y / prime_period;
+        limb = (int)(blockIdx.y % batches) * prime_period + (int)(blockIdx.y / batches);
+    }
     const int p = prime_idx ? prime_idx[limb % prime_period] : prime_base + (limb % prime_period);
     u64 *a = data + (long)limb * limb_stride;
     const DModulus M = mods[p];
@@ -27,7 +36,8 @@ static void launch_phase(const Context &c, u64 *data, long limb_stride, int coun
 {
     dim3 grid((unsigned)(c.N >> TileGeo<LOGE>::LOG), (unsigned)count);
     DC_LAUNCH((ntt_phase_kernel<K, LOGE, COLS, INV, CANON>), grid, dim3(kTileThreads), 0, s, data, limb_stride,
-                       d_prime_idx, prime_base, prime_period, mods ? mods : c.d_mods, INV ? c.d_itw : c.d_tw, c.logN);
+                       d_prime_idx, prime_base, prime_period, mods ? mods : c.d_mods, INV ? c.d_itw : c.d_tw, c.logN,
+                       (int)(!COLS && rows_prime_major(c) && count > prime_period && count % prime_period == 0));
 }
 
 template <bool COLS, bool INV, bool CANON>

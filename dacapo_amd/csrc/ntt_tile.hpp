@@ -161,6 +161,9 @@ __device__ __forceinline__ int cols_tile_of(int bx, int logN)
 // tile, L1 / L2 resident -- so the pairs' doubled bytes cost nothing, unlike a ROWS phase's per-row tables) and the butterflies are
 // ct_bfly_pair: ~13 % fewer VALU instructions per butterfly.  The phase's inputs must be canonical (a forward transform's first phase: they
 // are); its outputs are below 4q, inside every range the ROWS phase's schedule assumes.
+// (Round 5, measured and not kept: pairs in the generic forward ROWS phase at N = 2^17 -- a 16-byte-per-twiddle copy of the whole table, both
+// operands folded in the first stage -- with rows_prime_major supplying L2 hits for the doubled table bytes: config 4 2.789 / 2.798 s against
+// 2.797 / 2.767 without, a single hop at 31 primes 475 against 466 us; profiles/r05_experiments.txt item 21.)
 // FOLD0 (PAIRS only): fold x in stage 0 as well -- for callers whose inputs are residues below 4q but not necessarily canonical
 template <int K, int LOGE, bool COLS, bool INV, bool CANON, bool PRELOADED, bool KEEP, bool PAIRS, bool FOLD0 = false, class Ld, class St>
 __device__ __forceinline__ void ntt_tile_core(u64 (&x)[1 << LOGE], const DModulus M, const u64 *__restrict__ tw, int logN, int tile,
@@ -432,6 +435,14 @@ inline bool use_wide_tiles(size_t N, long limbs)
 {
     const long o = (long)option(OPT_WIDE_TILE_WGS);
     return o >= 0 && N >= 4096 && (long)(N >> 12) * limbs >= o;
+}
+// Round 5: ROWS-phase launches on rings whose twiddle tables outgrow the L2 walk their limbs prime by prime (ntt_kernels.hip ntt_phase_kernel,
+// hybrid_fused.hip F1 / F9).  option rows_prime_major = log2 of the smallest such ring (16; 0 = never).
+template <class Ctx>
+inline bool rows_prime_major(const Ctx &c)
+{
+    const long o = (long)option(OPT_ROWS_PRIME_MAJOR);
+    return o > 0 && c.logN >= o;
 }
 // in 512-coefficient workgroups (4 waves each): 256 = one wave on each of the 1024 SIMDs
 inline long tiny_tile_threshold() { return (long)option(OPT_TINY_TILE_WGS); }

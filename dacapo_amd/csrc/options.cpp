@@ -41,6 +41,7 @@ static const OptDef kDefs[OPT_COUNT] = {
     { "small_tile_wgs", -1 },
     { "tiny_tile_wgs", 2000 },
     { "wide_tile_wgs", 2048 },
+    { "rows_prime_major", 16 },
     { "ntt_full_min_limbs", 768 },
     { "ntt_full_inv_min_limbs", 768 },
     { "ntt_full_persist", -1 },

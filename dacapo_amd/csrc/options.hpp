@@ -43,6 +43,7 @@ enum Opt : int {
     OPT_SMALL_TILE_WGS,          // launches below this many 2048-coefficient tiles take the 1024-coefficient (radix-4) geometry (-1: the per-ring table of ntt_tile.hpp)
     OPT_TINY_TILE_WGS,           // launches of at most this many 512-coefficient tiles take the one-butterfly geometry
     OPT_WIDE_TILE_WGS,           // the key switch's lift launches (base change + forward COLS phase) of at least this many 4096-coefficient tiles take the radix-16 geometry (-1: never)
+    OPT_ROWS_PRIME_MAJOR,        // rings of at least 2^this: a ROWS-phase launch walks its limbs prime by prime (limbs of one prime adjacent in launch order: the prime's twiddle tiles, as large as the data at N >= 2^16, are read out of L2 by all but the first); 0 = never
     OPT_NTT_FULL_MIN_LIMBS,      // N = 2^15: forward launches of at least this many limbs take the single-crossing kernel (0 = never)
     OPT_NTT_FULL_INV_MIN_LIMBS,  // ... inverse launches
     OPT_NTT_FULL_PERSIST,        // workgroups of its persistent grid (-1: one per CU; 0: one workgroup per limb)

@@ -81,11 +81,17 @@ def test_linearity_and_convolution_at_full_size():
     assert (dp.to_host() == shifted).all()
 
 
-@pytest.mark.parametrize("logN,K,limbs", [(15, 14, 520), (17, 3, 136)])
-def test_large_batch_uses_the_throughput_tiles_and_matches_oracle(logN, K, limbs):
+@pytest.mark.parametrize("logN,K,limbs,prime_major", [(15, 14, 520, 16), (17, 3, 136, 16), (17, 3, 135, 16), (17, 3, 135, 0), (16, 4, 160, 16)])
+def test_large_batch_uses_the_throughput_tiles_and_matches_oracle(logN, K, limbs, prime_major, request):
     """>= 5000 workgroups per launch: the radix-8 (2048-coefficient) tile geometry (round 3: at N = 2^15 the roofline leg's forward
     transform takes the single-crossing kernel from 640 limbs on; this batch of 520 stays on the tiles, and N = 2^17 always does).
-    Forward == oracle on a spread of limbs, repeated launches agree, forward/inverse round trips are exact."""
+    Forward == oracle on a spread of limbs, repeated launches agree, forward/inverse round trips are exact.
+    Round 5 (option rows_prime_major): from N = 2^16 a ROWS phase over whole periods of the prime pattern (135 = 45 x 3, 160 = 40 x 4) walks its
+    limbs prime by prime -- the same transforms in another launch order; 136 limbs (not a multiple of the period) and option 0 keep limb order."""
+    from dacapo_amd import runner
+
+    runner.set_option("rows_prime_major", prime_major)
+    request.addfinalizer(lambda: runner.set_option("rows_prime_major", 16))
     ll, ctx = _ctx(logN, K)
     o = Oracle(logN, K)
     N = 1 << logN
