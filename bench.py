@@ -30,9 +30,9 @@ sys.path.insert(0, str(ROOT))
 
 import numpy as np  # noqa: E402
 
-KEY_SEED = 0x4845564D  # every replica expands the same key set from it (bench keys are reproducible, hence NOT secure: hevm_init_seeded)
+KEY_SEED = 0x4845564D  # --dry-run only (stand-in key buffers expanded with numpy): a real run generates keys from the OS's randomness (hevm_init_fresh)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
-PROF = "r05"  # the round whose profiles/ records this file reads (each is used only when its lib_sha256 is the library being timed)
+PROF = "r06"  # the round whose profiles/ records this file reads (each is used only when its lib_sha256 is the library being timed)
 
 
 def ntt_equivalents(stats_or_counts):
@@ -142,7 +142,7 @@ def real_bootstrap_leg(ll, runner, steps=3, resnet=True):
            "reference": "profiled_HEAAN_GPU.json earth.bootstrap_single: 0.29-0.46 s at N = 2^17 on HEaaN (its GPU unstated)", "single": []}
     for logN in (15, 17):
         K, cst, hv, offs, _ = cb.single_bootstrap_program(logN)
-        hevm = runner.HEVM(seed=5, logN=logN, num_primes=K, vm_options=sparse)
+        hevm = runner.HEVM(fresh=True, logN=logN, num_primes=K, vm_options=sparse)
         hevm.addRotationKeys(offs)
         hevm.load_mem(cst, hv)
         msg = np.random.default_rng(3).uniform(-1, 1, hevm.slots)
@@ -172,7 +172,7 @@ def real_bootstrap_leg(ll, runner, steps=3, resnet=True):
         t0 = time.time()
         fx["hevm"], fx["cst"] = cb.lower_bootstraps(fx["hevm"], fx["cst"], 15, KB, msg_bits=4)  # every opcode 10 -> real bootstrapping
         t_lower = time.time() - t0
-        hevm = runner.HEVM(seed=0x4845564D, logN=15, num_primes=KB, vm_options=sparse)
+        hevm = runner.HEVM(fresh=True, logN=15, num_primes=KB, vm_options=sparse)
         hevm.addRotationKeys(cb.rotation_offsets(fx["hevm"]))
         hevm.load_mem(fx["cst"], fx["hevm"])
         hevm.setInput(0, fx["packed"])
@@ -372,7 +372,7 @@ def _cpu_prefix(o, cst: bytes, hv: bytes, image, budget_s: float, threads: int):
     return ntts, spent, n_ops, ks
 
 
-def cpu_baseline_leg(cst: bytes, hv: bytes, image, budget_s=15.0, hv_b13: bytes | None = None):
+def cpu_baseline_leg(cst: bytes, hv: bytes, image, budget_s=15.0, hv_b13: bytes | None = None, openmp=True):
     """The CPU path timed beside the GPU: the oracle VM (oracle/: a restatement of SEAL's algorithms, the reference's arithmetic being
     unbuildable here) on a PREFIX of the same program.  `value` = 1 thread, like SEAL's evaluator and the reference's HEVM loop; beside it
     the 8-thread OpenMP-over-limbs variant BASELINE.md names, and both again on the b13 lowering (key switches at up to 13 primes: the
@@ -393,7 +393,7 @@ def cpu_baseline_leg(cst: bytes, hv: bytes, image, budget_s=15.0, hv_b13: bytes 
                      f"{spent:.1f} s of single-thread work (+{setup_s:.0f} s untimed keygen)",
            "seconds": round(spent, 2), "ntt_equivalents": ntts, "host_cpus": ncpu,
            "reference_published": "README.md:176-188: 53.73 s for the DaCapo-compiled ResNet-20 on SEAL CPU (hardware unstated)"}
-    if o.L.orc_has_openmp() and th > 1:
+    if openmp and o.L.orc_has_openmp() and th > 1:
         _cpu_prefix(o, cst, hv, image, 0.5, th)  # thread-pool warm-up
         n2, s2, ops2, ks2 = _cpu_prefix(o, cst, hv, image, budget_s / 2, th)
         out["openmp"] = {"value": round(n2 / s2, 1), "unit": "NTT/s", "cores": th,
@@ -410,6 +410,92 @@ def cpu_baseline_leg(cst: bytes, hv: bytes, image, budget_s=15.0, hv_b13: bytes 
     return out
 
 
+def ks_traffic_record(per_op, cfg3):
+    """measured HBM bytes (FETCH_SIZE x 2 + WRITE_SIZE, summed over an op's launches) over SURVEY 8(d)'s algorithmic bytes, for the rotation hop
+    at 13 primes and config 3: from profiles/<round>_per_op_budget_<op>.json (tools/collect_per_op_budget.sh), reported only when those passes ran
+    on exactly the library being timed"""
+    out = {}
+    for name, op, alg in (("hop13", "rotate_hop", per_op.get("rotate_hop", {}).get("algorithmic_bytes")), ("cfg3", "cfg3", cfg3.get("algorithmic_bytes"))):
+        f = ROOT / "profiles" / f"{PROF}_per_op_budget_{op}.json"
+        if not f.exists() or not alg:
+            continue
+        rec = json.loads(f.read_text())
+        if rec.get("lib_sha256") != lib_sha256():
+            continue
+        moved = sum((k["read_MB"] + k["write_MB"]) * 1e6 * k.get("launches_per_op", 1) for k in rec["kernels"])
+        out[name] = {"hbm_bytes": moved, "algorithmic_bytes": alg, "traffic_over_algorithmic": round(moved / alg, 3),
+                     "source": f"profiles/{PROF}_per_op_budget_{op}.json"}
+    return out or None
+
+
+LINE_LIMIT = 4096  # bytes of the final stdout line: the driver's parser reads the tail of stdout (round 5's 22.5 KB line did not parse)
+
+
+def compact_line(full: dict) -> dict:
+    """The ONE line the driver parses: the contract's fields + roofline + cpu_baseline + a handful of scalars; numbers and short names only.
+    Everything else (legs, tables, prose) is the full record (--out).  tests/test_bench_line.py holds it to LINE_LIMIT on a full-size stub."""
+    g = lambda d, *ks: (g(d.get(ks[0]), *ks[1:]) if len(ks) > 1 else d.get(ks[0])) if isinstance(d, dict) else None
+    cfg = full.get("config") or {}
+    line = {k: full.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                                    "dtype", "data")}
+    line["config"] = {"workload": str(cfg.get("workload", ""))[:300], "key_switches_per_step": cfg.get("key_switches_per_step"),
+                      "ntt_equivalents_per_step": cfg.get("ntt_equivalents_per_step"), "streams_per_gpu": cfg.get("streams_per_gpu"),
+                      "parallelism": cfg.get("parallelism")}
+    r = full.get("roofline")
+    if r:
+        dom = g(r, "step", "dominant") or {}
+        moved, alg = g(r, "step", "bytes_actually_moved"), g(r, "step", "algorithmic_bytes")
+        line["roofline"] = {"bound": r.get("bound"), "achieved": r.get("achieved"), "peak": r.get("peak"), "unit": r.get("unit"), "frac": r.get("frac"),
+                            "traffic": r.get("traffic"), "kernel": str(r.get("kernel", "")).split(" ")[0], "avg_us": g(r, "launch", "avg_us"),
+                            "algorithmic_bytes": g(r, "launch", "algorithmic_bytes"),
+                            "step_frac": g(r, "step", "frac"), "step_achieved": g(r, "step", "achieved_gbs"),
+                            "step_traffic_over_algorithmic": (round(moved / alg, 3) if moved and alg else None),
+                            "dominant_kernel": (str(dom.get("kernel"))[:80] if dom else None), "dominant_frac": dom.get("hbm_frac_of_peak")}
+    c = full.get("cpu_baseline")
+    if c:
+        line["cpu_baseline"] = {k: c.get(k) for k in ("value", "unit", "cores", "kind", "sample", "seconds")}
+        line["cpu_baseline"]["sample"] = str(c.get("sample", ""))[:200]
+        line["speedup_vs_cpu_port"] = full.get("speedup_vs_cpu_port")
+    line["rms_vs_torch"] = g(full, "decrypted_error", "rms_vs_torch")
+    c4 = full.get("config4_resnet20_nt65536_N131072")
+    if c4:
+        line["config4"] = ({"error": str(c4["error"])[:120]} if "error" in c4 else
+                           {"run_s": c4.get("run_s"), "rms_vs_torch": c4.get("rms_vs_torch"), "bootstraps": c4.get("real_bootstraps"),
+                            "bootstraps_reference_plan": c4.get("bootstraps_reference_plan"), "key_switches": c4.get("key_switches"),
+                            "lazy_sums_run_s": g(c4, "lazy_sums", "run_s"), "lazy_sums_rms_vs_torch": g(c4, "lazy_sums", "rms_vs_torch")})
+    line["cfg3_us"], line["cfg3_frac"] = g(full, "cfg3_mul_relin", "us"), g(full, "cfg3_mul_relin", "frac_of_hbm_peak")
+    po = full.get("per_op_13_primes") or {}
+    line["per_op_13_us"] = {k: g(po, k, "us") for k in ("rotate_hop", "mulcc_relin", "rescale") if k in po} or None
+    kt = full.get("ks_traffic") or {}
+    line["ks_traffic_over_algorithmic"] = {k: v.get("traffic_over_algorithmic") for k, v in kt.items()} or None
+    line["ntt_micro_us"] = g(full, "ntt_micro", "us_per_ntt_back_to_back")
+    line["full_record"] = full.get("full_record")
+    # belt and braces: should a field ever grow, drop the optional ones (last first) rather than emit a line the driver cannot parse
+    for k in ("full_record", "ntt_micro_us", "ks_traffic_over_algorithmic", "per_op_13_us", "cfg3_frac", "cfg3_us", "config4", "rms_vs_torch"):
+        if len(json.dumps(line)) <= LINE_LIMIT:
+            break
+        line.pop(k, None)
+    return line
+
+
+def emit(full: dict, out=None):
+    """write the full record to `out` (default gpurun_out/bench_full.json: merged back by gpurun, git-ignored), then print the compact line as the
+    LAST line of stdout"""
+    path = Path(out) if out else ROOT / "gpurun_out" / "bench_full.json"
+    try:
+        path.parent.mkdir(parents=True, exist_ok=True)
+        full["full_record"] = str(path.relative_to(ROOT)) if path.is_relative_to(ROOT) else str(path)
+        path.write_text(json.dumps(full, indent=1))
+    except OSError as e:  # a read-only tree must not cost the line
+        full["full_record"] = None
+        print(f"[bench] full record not written: {e}", file=sys.stderr)
+    text = json.dumps(compact_line(full))
+    assert len(text) <= LINE_LIMIT, len(text)
+    sys.stdout.flush()
+    print(text, flush=True)
+    return path
+
+
 def build_parser():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -423,16 +509,25 @@ def build_parser():
     ap.add_argument("--hevm-gz", default=None, help="--program resnet20: another lowering of the same trace (same constants)")
     ap.add_argument("--layers", type=int, default=20, help="--program shaped: depth (20 = the traced op mix)")
     ap.add_argument("--streams", type=int, default=1, help="independent ciphertext streams per GPU (throughput mode; 1 = the reference's one image per run)")
-    ap.add_argument("--no-lowerings", action="store_true", help="skip the other lowerings of the trace (config.lowerings)")
-    ap.add_argument("--no-streams-leg", action="store_true", help="skip the throughput table (1 / 2 / 4 / 8 / 16 streams of the headline program in one VM)")
+    ap.add_argument("--full", action="store_true",
+                    help="also run the A/B legs that only the full record carries: the b6 / b13 lowerings, direct rotation keys, the streams table, "
+                         "real bootstrapping at N = 2^15, config 3 under grouped-digit keys, config 4's key shapes / chains / key sets, the CPU "
+                         "baseline with OpenMP and on the b13 lowering (several minutes more)")
+    ap.add_argument("--out", default=None,
+                    help="where the FULL record goes (default gpurun_out/bench_full.json); stdout's last line is the compact line (<= 4 KB)")
+    ap.add_argument("--no-lowerings", action="store_true", help="--full: skip the other lowerings of the trace (config.lowerings)")
+    ap.add_argument("--no-streams-leg", action="store_true", help="--full: skip the throughput table (1 / 2 / 4 / 8 / 16 streams of the headline program in one VM)")
+    ap.add_argument("--config4-lazy-sums", type=int, default=0,
+                    help="--program config4: VM option hyb_lazy_sum for the timed stream (0 = the library's default: every rotate instruction "
+                         "rounds on its own, the reference's semantics; 1 = one division by P per sum of rotations)")
     ap.add_argument("--no-config4", dest="config4", action="store_false",
                     help="skip BASELINE config 4's shape (ResNet-20 traced at nt = 2^16, N = 2^17, real bootstrapping; ~1 min, ~180 GB of HBM); "
                          "it runs by default since round 3, in a child process before this one touches the GPU")
     ap.add_argument("--config4", dest="config4", action="store_true", help="(default)")
     ap.set_defaults(config4=True)
     ap.add_argument("--broadcast-keys", action="store_true",
-                    help="--gpus > 1: every rank generates its own key set, then rank 0's is shipped to the others (one flat RCCL broadcast "
-                         "per key buffer) instead of every rank expanding the same seed; either way the ranks compare key digests")
+                    help="every rank generates its own key set, then rank 0's is shipped to the others (one flat RCCL broadcast per key "
+                         "buffer) and the ranks compare key digests: the default with more than one rank (the flag forces the path at world size 1)")
     ap.add_argument("--dry-run", action="store_true",
                     help="exercise the launch / rank / aggregation path without a GPU: no kernel runs, the step is a sleep, the process "
                          "group uses gloo (tests/test_dist_gloo.py)")
@@ -452,61 +547,45 @@ def _config4_run(args):
     return res
 
 
-def config4_child():
-    """--config4: BASELINE config 4's shape -- ResNet-20 traced at the reference script's own nt = 2^16 slots (examples/benchmarks/
-    ResNet.py:50), run on N = 2^17 (HEAAN_HEVM.cpp:55-56) with a real bootstrap at every bootstrap site (tools/legs/resnet_real_boot.py).
-    About 180 GB of keys and plaintexts: it runs in CHILD processes started before this one touches the GPU (the reference's ABI has no
-    destroy symbol, so the other legs' VMs stay resident until exit).  Round 4: the same program also on a mixed 60 / 51-bit chain
-    (`chains`) and under bounded rotation-key sets (`key_sets`: the reference HEaaN runtime's 49 offsets, 96 keys, one per offset)."""
-    lazy = ["--opt", f"hyb_lazy_sum={CONFIG4['lazy_sums']}"]
-    res = _config4_run([1, "resnet20_nt16", 17, 1, "b14", CONFIG4["ks_special"], CONFIG4["ks_alpha"]] + lazy)
+def config4_child(full=False):
+    """BASELINE config 4's shape -- ResNet-20 traced at the reference script's own nt = 2^16 slots (examples/benchmarks/ResNet.py:50), run
+    on N = 2^17 (HEAAN_HEVM.cpp:55-56) with a real bootstrap at every bootstrap site (tools/legs/resnet_real_boot.py).  About 180 GB of keys
+    and plaintexts: it runs in a CHILD process started before this one touches the GPU.  One child, two VMs one after the other: the
+    library's default options first (`run_s`: every rotate instruction rounds on its own, the reference's semantics), then the same lowered
+    program with VM option hyb_lazy_sum = 1 (`lazy_sums.run_s`: one division by P per sum of rotations -- other limbs, replayed by the
+    oracle VM in tests/test_gpu_config4_geometry.py -- a labelled extension, never the like-for-like figure).  --full adds rounds 3-5's
+    A/B children (key shapes, chains, bounded key sets)."""
+    ks, al = CONFIG4["ks_special"], CONFIG4["ks_alpha"]
+    res = _config4_run([1, CONFIG4["fixture"], CONFIG4["logN"], CONFIG4["msg_bits"], CONFIG4["lowering"], ks, al, "--also-opt", "hyb_lazy_sum=1"])
     if "error" in res:
         return res
+    lazy = res.pop("also", None)
     res["program"] = ("tests/golden/resnet20_nt16.b14: bootstraps at the model script's own hints (before every activation), each restoring 14 "
-                      "primes -> 38 real bootstraps (round 2: 541 restoring 3); 31 data + 9 special 60-bit primes")
-    res["keys"] = ("grouped-digit hybrid key switching (extension, hybrid_ks.hip / hybrid_fused.hip): 4 digits of 8 primes, P = 9 primes (round 5; "
-                   "rounds 3-4: 5 digits of 7 under 8 special primes, `key_shapes`); one direct Galois key per rotation offset (286 keys x 0.34 GB)")
+                      "primes -> 38 real bootstraps; 31 data + 9 special 60-bit primes")
+    res["bootstraps_reference_plan"] = 19  # README.md:131-136: DaCapo's own plan for HEaaN places 19 (placement is the compiler's, out of scope)
+    res["keys"] = ("grouped-digit hybrid key switching (extension, hybrid_ks.hip / hybrid_fused.hip): 4 digits of 8 primes, P = 9 primes; one "
+                   "direct Galois key per rotation offset (286 keys x 0.34 GB)")
     res["security"] = "N = 2^17, log2(QP) = 40 x 60 = 2400 bits, sparse ternary secret (h = 64): inside the 128-bit range for N = 2^17"
-    res["history"] = ("round 2: 47.2 s, rms_vs_torch 0.152 (541 bootstraps restoring 3 primes, one-prime-per-digit keys); round 3: 4.0 s; round 4: "
-                      "3.14-3.17 s (digits of 7 under 8 special primes, 117 GB of rotation keys); round 5: 3.06-3.08 s on digits of 8 under 9, and "
-                      "`lazy_sums_ab` for this run's lazy sums")
-    res["ntt_equivalents_note"] = ("counted per key switch as G (l + k) + 2 k + 2 l; rotations of one ciphertext in a wave share their decomposition "
-                                   "(hoisting) and, with lazy sums, rotations that are only added together share their division by P, so fewer "
-                                   "transforms than that are executed: the figure to compare is run_s, seconds per inference")
     res["reference"] = "README.md:131-136: DaCapo's cost model estimates 13.6 s for its 19-bootstrap HEaaN plan (not measured)"
     brief = lambda r: ({k: r.get(k) for k in ("chain", "log2_QP", "primes", "special_primes", "primes_per_digit", "rotation_keys", "rotation_key_bytes",
-                                             "rot_compose", "run_s", "key_switches", "ntt_equivalents", "rms_vs_torch", "fixture", "command")}
+                                             "rot_compose", "run_s", "key_switches", "ntt_equivalents", "rms_vs_torch", "fixture", "command", "lazy_sums")}
                        if "error" not in r else r)
-    ks, al = CONFIG4["ks_special"], CONFIG4["ks_alpha"]
-    res["lazy_sums_ab"] = {"what": "option hyb_lazy_sum (round 5): direct-key rotations whose results are only added together -- the giant steps of the "
-                                   "bootstraps' matrix products, a convolution's shifted partial sums -- are key-switched into one accumulator in "
-                                   "the raised basis and divided by P once per sum (plan_exec.hip section 2b; limbs == the oracle VM replaying the "
-                                   "plan's groups, tests/test_gpu_config4_geometry.py).  One rounding instead of n: not the limbs of n rotate "
-                                   "instructions, which is why the option is off unless asked for; this run asks for it",
-                           "on": dict(brief(res), lazy_sums=res.get("lazy_sums")),
-                           "off": brief(_config4_run([1, "resnet20_nt16", 17, 1, "b14", ks, al]))}
-    res["key_shapes"] = {"what": "the same run under rounds 3-4's key shape: 5 digits of 7 primes under 8 special primes (39 primes, 117 GB of rotation "
-                                 "keys).  Round 5's shape needs a 9-input mod-down on the matrix cores (two K-chunks per tile, hybrid_ks.hip)",
-                         "digits_of_8_under_9": brief(res), "digits_of_7_under_8": brief(_config4_run([1, "resnet20_nt16", 17, 1, "b14", 8, 7] + lazy))}
-    mixed = _config4_run([1, "resnet20_nt16", 17, 1, "b14r51", ks, al, "mixed_app"] + lazy)
-    res["chains"] = {"what": "the same trace on the 60-bit chain (libSEAL_HEVM.so) and on a HEaaN-style mixed chain -- 60-bit base prime, 51-bit rescale "
-                             "primes for the program's 13 levels, 60-bit primes for the bootstrap's 17 levels and the 8 special ones -- through the "
-                             "generic-width build (libSEAL_HEVM_gw.so); the program is lowered for the chain's rescale width (b14 / b14r51)",
-                     "chain_60": brief(res), "chain_mixed": brief(mixed),
-                     "note": "the mixed chain has the same number of limbs: it buys modulus bits (2223 instead of 2340), not speed, and the "
-                             "generic-width build's run-time shifts and third fold cost ~13 % (DESIGN.md section 3).  With EVERY rescale prime at 51 "
-                             "bits the bootstraps run at a 2^51 scale: rms vs torch 1.2e-2 (measured, profiles/r04_experiments.txt)"}
-    res["key_sets"] = {"what": "the 60-bit run under bounded rotation-key sets: the reference HEaaN runtime's 49 left-rotation offsets (HEAAN_HEVM.cpp:"
-                               "58-64), that list plus the program's most used other offsets up to 96 keys, and one key per offset (286); rotations "
-                               "without a direct key are the shortest sum of offsets that have one (option rot_compose)",
-                       "49": brief(_config4_run([49, "resnet20_nt16", 17, 1, "b14", ks, al] + lazy)),
-                       "96": brief(_config4_run([96, "resnet20_nt16", 17, 1, "b14", ks, al] + lazy)),
-                       "286": brief(res)}
+    res["lazy_sums"] = brief(lazy) if lazy else None  # (the extension's figure, beside -- not instead of -- run_s)
+    if not full:
+        return res
+    lz = ["--opt", "hyb_lazy_sum=1"]
+    res["key_shapes"] = {"digits_of_8_under_9": brief(res), "digits_of_7_under_8": brief(_config4_run([1, "resnet20_nt16", 17, 1, "b14", 8, 7]))}
+    res["chains"] = {"chain_60": brief(res), "chain_mixed": brief(_config4_run([1, "resnet20_nt16", 17, 1, "b14r51", ks, al, "mixed_app"]))}
+    res["key_sets"] = {"49": brief(_config4_run([49, "resnet20_nt16", 17, 1, "b14", ks, al])),
+                       "96": brief(_config4_run([96, "resnet20_nt16", 17, 1, "b14", ks, al])),
+                       "286": brief(res),
+                       "96_lazy_sums": brief(_config4_run([96, "resnet20_nt16", 17, 1, "b14", ks, al] + lz))}
     return res
 
 
-# (round 5: digits of 8 primes under 9 special primes -- 4 digits at the top level instead of 5, 96 instead of 117 GB of rotation keys, same accuracy)
-CONFIG4 = {"fixture": "resnet20_nt16", "lowering": "b14", "logN": 17, "ks_special": 9, "ks_alpha": 8, "msg_bits": 1, "secret_hw": 64, "lazy_sums": 1}
+# digits of 8 primes under 9 special primes (round 5: 4 digits at the top level, 96 GB of rotation keys).  lazy_sums = VM option hyb_lazy_sum of
+# `--program config4` (BASELINE config 5's stream): the library's default, 0, unless --config4-lazy-sums asks for the extension
+CONFIG4 = {"fixture": "resnet20_nt16", "lowering": "b14", "logN": 17, "ks_special": 9, "ks_alpha": 8, "msg_bits": 1, "secret_hw": 64, "lazy_sums": 0}
 
 
 def config4_program():
@@ -548,6 +627,7 @@ def main_config4(args, grp):
     from dacapo_amd import runner
 
     rank, local_rank, world = grp.rank, grp.local_rank, grp.world
+    CONFIG4["lazy_sums"] = int(args.config4_lazy_sums)
     fx, cst, hv, K, offs = config4_program()
     L = ll.lib()
     L.dc_set_device(local_rank)
@@ -557,7 +637,7 @@ def main_config4(args, grp):
         L.dc_device_sync()
 
     t_setup = time.time()
-    hevm = runner.HEVM(seed=KEY_SEED + (rank if args.broadcast_keys else 0), logN=CONFIG4["logN"], num_primes=K, ks_special=CONFIG4["ks_special"],
+    hevm = runner.HEVM(fresh=True, logN=CONFIG4["logN"], num_primes=K, ks_special=CONFIG4["ks_special"],
                        ks_alpha=CONFIG4["ks_alpha"], vm_options={"secret_hw": CONFIG4["secret_hw"], "hyb_lazy_sum": CONFIG4["lazy_sums"]})
     hevm.addRotationKeys(offs)  # (before the digest: the direct keys are part of the replicated key set)
 
@@ -576,9 +656,9 @@ def main_config4(args, grp):
         L.dc_memcpy_d2d(ptr, t.data_ptr(), 8 * t.numel(), None)
         L.dc_device_sync()
 
-    key_info = grp.share_keys(hevm.keyDigest, buffers_fn=hevm.keyBuffers, copy_out=_copy_out, copy_in=_copy_in,
-                              mode="broadcast" if args.broadcast_keys else "seed")
-    if args.broadcast_keys and rank != 0:
+    share = args.broadcast_keys or world > 1  # every rank generated its own set; rank 0's is shipped to the others (RCCL broadcasts out of HBM)
+    key_info = grp.share_keys(hevm.keyDigest, buffers_fn=hevm.keyBuffers, copy_out=_copy_out, copy_in=_copy_in, mode="broadcast" if share else "local")
+    if share and rank != 0:
         hevm.keysReplaced()
     image = fx["packed"] if rank == 0 else np.roll(fx["packed"], 17 * rank) * (1.0 - 0.01 * rank)
     hevm.load_mem(cst, hv)
@@ -656,11 +736,12 @@ def dry_run(args, grp):
 
     import torch
 
-    seed = KEY_SEED + (grp.rank if args.broadcast_keys else 0)  # broadcast mode starts from DIFFERENT per-rank sets
+    share = args.broadcast_keys or grp.world > 1  # as in the real run: per-rank sets, rank 0's broadcast whenever there is more than one rank
+    seed = KEY_SEED + (grp.rank if share else 0)
     fake = [torch.from_numpy(np.random.default_rng([seed, i]).integers(0, 1 << 62, 4096, dtype=np.int64)) for i in range(3)]
     keys = grp.share_keys(lambda: int.from_bytes(hashlib.sha256(b"".join(t.numpy().tobytes() for t in fake)).digest()[:8], "little"),
                           buffers_fn=lambda: [(i, 4096) for i in range(3)], copy_out=lambda i, w: fake[i].clone(),
-                          copy_in=lambda i, t: fake[i].copy_(t), mode="broadcast" if args.broadcast_keys else "seed")
+                          copy_in=lambda i, t: fake[i].copy_(t), mode="broadcast" if share else "local")
     for _ in range(args.warmup):
         time.sleep(0.001)
     grp.barrier()
@@ -690,7 +771,7 @@ def main():
         sys.exit(spawn_ranks(args, argv))
 
     # rank 0 of a 1-GPU run only: the other legs of the line are N = 1 figures as well
-    config4 = config4_child() if (args.config4 and args.gpus == 1 and not args.dry_run and "RANK" not in os.environ
+    config4 = config4_child(args.full) if (args.config4 and args.gpus == 1 and not args.dry_run and "RANK" not in os.environ
                                   and args.program != "config4") else None
 
     from dacapo_amd.dist import Group
@@ -717,9 +798,9 @@ def main():
 
     # ---- set-up (untimed, like hc-test: context/keys, load, preprocess, encrypt) ---------------------------------
     t_setup = time.time()
-    # replicas serve ONE client: every rank holds the same key set.  Default: all ranks expand the same seed on their own
-    # GPU; --broadcast-keys: per-rank sets, then rank 0's is broadcast.  The inputs (and the encryption randomness) differ per rank.
-    hevm = runner.HEVM(seed=KEY_SEED + (rank if args.broadcast_keys else 0), logN=15, num_primes=14)
+    # replicas serve ONE client: every rank holds the same key set.  Every rank generates a set on its own GPU, then rank 0's
+    # is broadcast (one flat RCCL broadcast per key buffer) and the ranks compare device-side digests.  Inputs and encryption randomness differ per rank.
+    hevm = runner.HEVM(fresh=True, logN=15, num_primes=14)  # (hevm_init_fresh: keys from the OS's randomness -- the release build has no seeded keygen)
     if args.streams > 1:
         hevm.set_streams(args.streams)
 
@@ -738,9 +819,9 @@ def main():
         L.dc_memcpy_d2d(ptr, t.data_ptr(), 8 * t.numel(), None)
         L.dc_device_sync()
 
-    key_info = grp.share_keys(hevm.keyDigest, buffers_fn=hevm.keyBuffers, copy_out=_copy_out, copy_in=_copy_in,
-                              mode="broadcast" if args.broadcast_keys else "seed")
-    if args.broadcast_keys and rank != 0:
+    share = args.broadcast_keys or world > 1  # every rank generated its own set; rank 0's is shipped to the others (RCCL broadcasts out of HBM)
+    key_info = grp.share_keys(hevm.keyDigest, buffers_fn=hevm.keyBuffers, copy_out=_copy_out, copy_in=_copy_in, mode="broadcast" if share else "local")
+    if share and rank != 0:
         hevm.keysReplaced()
     fx = None
     if args.program == "resnet20":
@@ -798,7 +879,7 @@ def main():
                   "ntt_per_s": round(ntts_per_step * 1e3 / ms_per_step), "ntt_equivalents": pst["ntt_equivalents"],
                   "key_switch_level_histogram": pst["key_switch_level_histogram"], "opcode10": pst["opcode10_histogram"],
                   "algorithmic_bytes": pst["algorithmic_bytes"]}]
-    if fx is not None and world == 1 and args.streams == 1 and not args.no_lowerings and not args.hevm_gz:
+    if args.full and fx is not None and world == 1 and args.streams == 1 and not args.no_lowerings and not args.hevm_gz:
         import gzip
 
         for tag in ("b6", "b13"):
@@ -823,13 +904,13 @@ def main():
                               "rms_vs_torch": float(np.sqrt(np.mean((out2[:10] * 32 - fx["torch_result"]) ** 2)))})
     # ---- throughput mode on the reference's own key set (BEFORE the next leg adds direct rotation keys to this VM) ----------------
     streams_tab = None
-    if fx is not None and world == 1 and args.streams == 1 and not args.no_streams_leg and not args.hevm_gz:
+    if args.full and fx is not None and world == 1 and args.streams == 1 and not args.no_streams_leg and not args.hevm_gz:
         streams_tab = streams_leg(hevm, cst, hv, image, pst["ntt_equivalents"], pst["algorithmic_bytes"], steps=max(2, args.steps))
     # ---- the same headline program with a direct Galois key for each of its rotation offsets (KeyGenerator::create_galois_keys(steps);
     # the reference's HEaaN runtime keeps such a list, HEAAN_HEVM.cpp:58-64): every rotation one key switch.  NOT the headline: the
     # reference's SEAL runtime only has the default key set (SEAL_HEVM.cpp:82-83), which the headline reproduces hop for hop.
     direct = None
-    if fx is not None and world == 1 and args.streams == 1 and not args.no_lowerings and not args.hevm_gz:
+    if args.full and fx is not None and world == 1 and args.streams == 1 and not args.no_lowerings and not args.hevm_gz:
         offs = sorted({(int(r) - 65536 if r >= 32768 else int(r)) for o, _, _, r in ha.unpack_hevm(hv)["ops"].tolist() if o == ha.OP_ROTATE} - {0})
         t1 = time.time()
         hevm.addRotationKeys(offs)
@@ -873,9 +954,10 @@ def main():
                             "section-8(d) bytes are never moved -- the plan folds those ops into their consumers' loaders -- which is why "
                             "bytes_actually_moved (FETCH_SIZE x 2 + WRITE_SIZE over one run) is the honest numerator"}
     micro = ntt_micro_leg(ll)
-    cfg3 = cfg3_leg(ll)
+    cfg3 = cfg3_leg(ll, grouped=args.full)
     per_op = per_op_leg(ll)
-    real_boot = real_bootstrap_leg(ll, runner) if (world == 1 and not args.no_lowerings) else None
+    ks_traffic = ks_traffic_record(per_op, cfg3)
+    real_boot = real_bootstrap_leg(ll, runner) if (args.full and world == 1 and not args.no_lowerings) else None
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
         hv13 = None
@@ -883,7 +965,7 @@ def main():
             import gzip
 
             hv13 = gzip.open(ROOT / "tests" / "golden" / "resnet20.b13.hevm.gz").read()
-        cpu = cpu_baseline_leg(cst, hv, image, hv_b13=hv13)
+        cpu = cpu_baseline_leg(cst, hv, image, hv_b13=hv13 if args.full else None, openmp=args.full)
 
     line = {
         "metric": "NTT/s (NTT-equivalents over one run() of the ResNet HEVM program, nt=2^14)",
@@ -914,9 +996,11 @@ def main():
         "config4_resnet20_nt65536_N131072": config4,
         "cpu_baseline": cpu,
     }
+    line["ks_traffic"] = ks_traffic
     if cpu:
         line["speedup_vs_cpu_port"] = round(value / cpu["value"], 1)
-    print(json.dumps(line))
+    out_path = emit(line, args.out)
+    print(f"[bench] full record: {out_path}", file=sys.stderr)
     grp.close()
 
 

@@ -13,7 +13,13 @@ a GPU, fails loudly.
 import os
 from pathlib import Path
 
+_LIB_DIR = Path(__file__).resolve().parent / "lib"
+# The RELEASE builds -- what a maintainer deploys, what bench.py and __graft_entry__.smoke() run: the reference's 18 symbols + the safe extensions.
+LIB_PATH_RELEASE, LIB_PATH_GW_RELEASE = _LIB_DIR / "libSEAL_HEVM.so", _LIB_DIR / "libSEAL_HEVM_gw.so"
+# The HOOKS builds: the same objects + csrc/test_hooks.hip (seeded keys, secret-key pointer, zero encryptions).  tests/conftest.py selects them
+# with DACAPO_AMD_HOOKS=1 before this package is imported; nothing else does.
+HOOKS = os.environ.get("DACAPO_AMD_HOOKS") == "1"
 # DACAPO_AMD_LIB: another build of the same library (kernel-tuning sweeps: tools/experiments/sweep_lds_pad.sh); never a different backend
-LIB_PATH = Path(os.environ.get("DACAPO_AMD_LIB") or Path(__file__).resolve().parent / "lib" / "libSEAL_HEVM.so")
+LIB_PATH = Path(os.environ.get("DACAPO_AMD_LIB") or (_LIB_DIR / "libSEAL_HEVM_hooks.so" if HOOKS else LIB_PATH_RELEASE))
 # the generic-width build of the same sources (csrc/modarith.hpp DC_GENERIC_WIDTH = 1): primes of 45..60 bits, mixed chains
-LIB_PATH_GW = Path(__file__).resolve().parent / "lib" / "libSEAL_HEVM_gw.so"
+LIB_PATH_GW = _LIB_DIR / "libSEAL_HEVM_gw_hooks.so" if HOOKS else LIB_PATH_GW_RELEASE

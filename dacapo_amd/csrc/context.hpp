@@ -27,9 +27,13 @@ namespace dacapo {
 // Every kernel launch of the library goes through this: hipLaunchKernelGGL + a check of the launch itself (a grid or block the device
 // refuses, too much LDS or too many registers for the block size, an invalid function) at the launch site, not at some later synchronise.
 // hipGetLastError is a host-side read of the thread's last error: free outside a capture, and inside a stream capture it still reports
-// what the record-time validation of the launch found.
+// what the record-time validation of the launch found.  The thread's error state is read (and thereby cleared) BEFORE the launch too: on
+// runtimes where the last error is sticky, an unrelated earlier failure on this thread -- PyTorch and RCCL share it in bench.py and
+// tests/test_gpu_rccl.py, and a benign hipErrorInvalidValue from a pointer-attribute probe is enough -- would otherwise be reported as this
+// launch's and abort the process at the wrong site (round-5 advisor).
 #define DC_LAUNCH(...)                                                                                          \
     do {                                                                                                       \
+        (void)hipGetLastError();                                                                               \
         hipLaunchKernelGGL(__VA_ARGS__);                                                                       \
         DC_HIP_CHECK(hipGetLastError());                                                                       \
     } while (0)

@@ -423,21 +423,6 @@ RngKeys rng_keys_from_os()
     return k;
 }
 
-RngKeys rng_keys_from_test_seed(uint64_t seed)
-{ // splitmix64 expansion: reproducible, NOT secret (64 bits of entropy at most)
-    RngKeys k;
-    uint32_t *w = reinterpret_cast<uint32_t *>(&k);
-    u64 z = seed;
-    for (size_t i = 0; i < sizeof(RngKeys) / 4; i += 2) {
-        z += 0x9E3779B97F4A7C15ull;
-        u64 x = z;
-        x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
-        x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
-        x ^= x >> 31;
-        w[i] = (uint32_t)x, w[i + 1] = (uint32_t)(x >> 32);
-    }
-    return k;
-}
 
 static u64 *dalloc(size_t elems)
 {
@@ -1818,20 +1803,20 @@ void setToGPU(void *vm, bool ongpu)
 void printMem(void *vm) { (void)vm; } // O(1): it sits inside the caller's timed region (runner.py:223-225)
 
 // ---- extensions -----------------------------------------------------------------------------------------
-void *hevm_init_seeded(int logN, int num_primes, uint64_t seed)
-{
+void *hevm_init_fresh(int logN, int num_primes)
+{ // create_context + initFullVM without the files: parameters and the reference's key set generated in HBM from the OS's randomness
     int dl, dk;
     env_params(dl, dk);
     auto vm = new HEVM();
     vm->init_context(logN > 0 ? logN : dl, num_primes > 0 ? num_primes : dk, nullptr);
-    vm->generate_keys(dacapo::rng_keys_from_test_seed(seed), true, true, true); // reproducible and therefore insecure: tests / bench only
+    vm->generate_keys(dacapo::rng_keys_from_os(), true, true, true);
     return vm;
 }
-void *hevm_init_seeded_primes(int logN, const uint64_t *primes, int num_primes, uint64_t seed)
+void *hevm_init_fresh_primes(int logN, const uint64_t *primes, int num_primes)
 { // the same on an explicit chain (each prime = 1 mod 2N, 45..60 bits; other than 60: the generic-width build), e.g. a HEaaN-style mixed one
     auto vm = new HEVM();
     vm->init_context(logN, num_primes, primes);
-    vm->generate_keys(dacapo::rng_keys_from_test_seed(seed), true, true, true);
+    vm->generate_keys(dacapo::rng_keys_from_os(), true, true, true);
     return vm;
 }
 void *hevm_context(void *vm)
@@ -1847,7 +1832,6 @@ const uint64_t *hevm_galois_key(void *vm, uint32_t elt)
     auto it = g.find(elt);
     return it == g.end() ? nullptr : it->second;
 }
-const uint64_t *hevm_secret_key(void *vm) { return V(vm)->keys.sk; }
 const uint64_t *hevm_public_key(void *vm) { return V(vm)->keys.pk; }
 const uint64_t *hevm_plain(void *vm, int64_t i, int32_t *level, double *scale)
 {
@@ -1954,12 +1938,6 @@ void hevm_keys_replaced(void *vm)
     DC_HIP_CHECK(hipStreamSynchronize(h->S()));
     h->plan.ready = false;
     h->drop_plan_graph();
-}
-void hevm_test_zero_encryption(void *vm, bool on)
-{
-    if (on) fprintf(stderr, "[dacapo_amd] TEST HOOK: encryptions of zero are (0, 0) from now on -- this VM offers NO security\n");
-    V(vm)->test_zero_enc = on;
-    V(vm)->drop_plan_graph(); // the recorded launch sequence contains (or lacks) the zero-encryption launches
 }
 void hevm_save_ctxt(void *vm, int64_t reg, const char *path) { V(vm)->save_ctxt((size_t)reg, path); }
 void hevm_load_ctxt(void *vm, int64_t reg, const char *path) { V(vm)->load_ctxt((size_t)reg, path); }

@@ -508,6 +508,12 @@ __global__ __launch_bounds__(kHT) void hyb_conv_mfma_kernel(const u64 *__restric
 
 // the two base conversions (matrix cores when the context has their operand tables and the level is high enough, else the vector kernels).
 // `prescaled`: inputs already multiplied by the per-input constant (fused sequence).  count = decompositions (up) / polynomials (down).
+// OUTPUT RANGE (contract): the matrix-core form of the 60-bit build writes LAZY residues -- congruent to the converted value, one fold, below
+// 2q, NOT canonical (hyb_recombine); the vector kernels and the generic-width build write canonical ones.  Every consumer must therefore
+// fold its input before anything that needs x < q: a forward transform's first stage does (launch_ntt / launch_ntt_cols_fwd fold at stage 0,
+// with and without twiddle pairs; ntt_full's pair pass takes x < 2q).  ntt_tile_core<PAIRS> without FOLD0, submod-based epilogues and
+// anything that compares limbs (tests reading w.ext / w.tmp) are NOT valid consumers.  tests/test_gpu_hybrid.py
+// test_lazy_conversion_outputs_feed_every_forward_transform runs each forward path behind it against the oracle.
 void hyb_launch_conv(Context &c, bool down, bool prescaled, const u64 *in, u64 *out, int count, int ell, hipStream_t s)
 {
     const size_t N = c.N;

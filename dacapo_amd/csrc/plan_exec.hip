@@ -391,8 +391,10 @@ void HEVM::build_plan()
                 Pop &r = O[(size_t)V[(size_t)O[ci].srcs[k]].def_pop];
                 grp.srcs.push_back(r.srcs[0]), grp.elts.push_back(r.elt), grp.keys.push_back(r.key), grp.ops.push_back(r.op);
                 r.dead = true;
+                if (k != keep) V[(size_t)O[ci].srcs[k]].uses = 0, V[(size_t)O[ci].srcs[k]].def_pop = -1; // (no pop defines or reads this value any more)
             }
-            O[(size_t)V[(size_t)O[ci].srcs[keep]].def_pop] = grp;
+            const int gi = V[(size_t)O[ci].srcs[keep]].def_pop;
+            O[(size_t)gi] = grp;
             std::vector<int> srcs, plain;
             for (size_t k = 0; k < O[ci].srcs.size(); k++)
                 if (k == keep || std::find(terms.begin(), terms.end(), k) == terms.end()) {
@@ -400,6 +402,17 @@ void HEVM::build_plan()
                     if (!O[ci].src_plain.empty()) plain.push_back(O[ci].src_plain[k]);
                 }
             O[ci].srcs = srcs, O[ci].src_plain = plain;
+            // A plain sum whose terms were ALL grouped (rot(x, a) + rot(y, b)) is now a one-source sum without a plaintext: a copy of the group's
+            // result.  The group writes the sum's destination itself and the sum goes away (round-5 advisor: one launch and one buffer less).
+            if (O[ci].kind == P_SUM && O[ci].srcs.size() == 1 && (O[ci].src_plain.empty() || O[ci].src_plain[0] < 0)) {
+                const int old = O[(size_t)gi].dst, dst = O[ci].dst;
+                if (V[(size_t)dst].root == dst && V[(size_t)dst].level == V[(size_t)old].level) { // (its own buffer, same number of limbs)
+                    O[(size_t)gi].dst = dst;
+                    V[(size_t)dst].def_pop = gi;
+                    V[(size_t)old].uses = 0, V[(size_t)old].def_pop = -1;
+                    O[ci].dead = true;
+                }
+            }
         }
     }
 

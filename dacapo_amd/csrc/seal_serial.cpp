@@ -113,11 +113,12 @@ const uint8_t *Reader::skip(size_t n)
 }
 
 // What a compressed object may expand to.  Everything SEAL stores in these files is residues mod ~60-bit primes in 64-bit words -- it
-// deflates by a few per cent -- plus headers; a stream that expands beyond 64 x its stored size + 16 MiB (an all-zero ciphertext of the
-// reference's ring still fits the slack) is not a key file, and inflating it on trust is how a few KB of input take down the host
-// (zlib reaches 1032 : 1, Zstandard far more).
-static size_t inflate_limit(size_t stored) { return stored * 64 + ((size_t)16 << 20); }
-static const char *const kBombMsg = "compressed members expand beyond 64 x their stored size + 16 MiB: refusing (not a SEAL key / ciphertext object; decompression bomb?)";
+// deflates by a few per cent -- plus headers; the one legitimate exception is a transparent / all-zero ciphertext, which deflates ~1000 : 1.
+// The largest object this library supports is a ciphertext of N = 2^17 at 40 primes: 2 x 40 x 2^17 x 8 = 80 MiB (round-5 advisor: the 16 MiB
+// slack argued for the reference's ring refused an all-zero N = 2^17 ciphertext).  A stream that expands beyond 64 x its stored size + 128 MiB is
+// not a key file, and inflating it on trust is how a few KB of input take down the host (zlib reaches 1032 : 1, Zstandard far more).
+static size_t inflate_limit(size_t stored) { return stored * 64 + ((size_t)128 << 20); }
+static const char *const kBombMsg = "compressed members expand beyond 64 x their stored size + 128 MiB: refusing (not a SEAL key / ciphertext object; decompression bomb?)";
 
 static std::vector<uint8_t> inflate_all(const uint8_t *in, size_t n, const Reader &r)
 {

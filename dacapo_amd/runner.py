@@ -66,11 +66,22 @@ def bind_vm_lib(path):
     L.setToGPU.argtypes = [ctypes.c_void_p, ctypes.c_bool]
     L.printMem.argtypes = [ctypes.c_void_p]
     # extensions of include/hevm_abi.h
-    L.hevm_init_seeded.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_uint64]
-    L.hevm_init_seeded.restype = ctypes.c_void_p
+    L.hevm_init_fresh.argtypes = [ctypes.c_int, ctypes.c_int]
+    L.hevm_init_fresh.restype = ctypes.c_void_p
+    L.hevm_init_fresh_primes.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_uint64), ctypes.c_int]
+    L.hevm_init_fresh_primes.restype = ctypes.c_void_p
+    L.has_test_hooks = hasattr(L, "hevm_init_seeded")  # the *_hooks.so builds only (csrc/test_hooks.hip; DACAPO_AMD_HOOKS=1)
+    if L.has_test_hooks:
+        L.hevm_init_seeded.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_uint64]
+        L.hevm_init_seeded.restype = ctypes.c_void_p
+        L.hevm_init_seeded_primes.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_uint64), ctypes.c_int, ctypes.c_uint64]
+        L.hevm_init_seeded_primes.restype = ctypes.c_void_p
+        L.hevm_secret_key.argtypes = [ctypes.c_void_p]
+        L.hevm_secret_key.restype = ctypes.c_void_p
+        L.hevm_test_zero_encryption.argtypes = [ctypes.c_void_p, ctypes.c_bool]
     L.hevm_context.argtypes = [ctypes.c_void_p]
     L.hevm_context.restype = ctypes.c_void_p
-    for f in (L.hevm_relin_key, L.hevm_secret_key, L.hevm_public_key):
+    for f in (L.hevm_relin_key, L.hevm_public_key):
         f.argtypes = [ctypes.c_void_p]
         f.restype = ctypes.c_void_p
     L.hevm_key_buffers.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
@@ -95,11 +106,8 @@ def bind_vm_lib(path):
     L.hevm_destroy.argtypes = [ctypes.c_void_p]
     L.hevm_destroy.restype = None
     L.hevm_add_rotation_keys.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64), ctypes.c_int]
-    L.hevm_test_zero_encryption.argtypes = [ctypes.c_void_p, ctypes.c_bool]
     L.hevm_save_ctxt.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_char_p]
     L.hevm_load_ctxt.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_char_p]
-    L.hevm_init_seeded_primes.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_uint64), ctypes.c_int, ctypes.c_uint64]
-    L.hevm_init_seeded_primes.restype = ctypes.c_void_p
     bind_options(L)
     for name, value in _cli_options.items():  # `--opt` pairs given before this build was loaded (each build has its own option table)
         L.hevm_set_option(name.encode(), int(value))
@@ -205,8 +213,10 @@ def close_all():
 
 class HEVM:
     def __init__(self, path=str((Path.home() / ".hevm" / "seal").absolute()), option="full", seed=None, logN=0, num_primes=0,
-                 ks_special=1, ks_alpha=None, vm_options=None, primes=None):
-        """ks_special / ks_alpha (extension): grouped-digit hybrid key switching -- the last ks_special primes are special, a digit is
+                 ks_special=1, ks_alpha=None, vm_options=None, primes=None, fresh=False):
+        """fresh (extension): parameters and keys generated in HBM from the OS's randomness, nothing on disk (hevm_init_fresh); `primes`
+        implies it.  seed (TEST HOOK, the *_hooks.so builds only): the same with every key expanded from the seed -- reproducible, not secret.
+        ks_special / ks_alpha (extension): grouped-digit hybrid key switching -- the last ks_special primes are special, a digit is
         ks_alpha (default ks_special) data primes.  1 / 1 = the reference's SEAL scheme.  vm_options: further VM options of
         csrc/options.hpp (plan, plan_graph, secret_hw, logn, primes, ...), in force while this VM is created; the previous values are put
         back afterwards (a VM keeps what it was created with).  primes (extension, seeded VMs): an explicit chain, e.g. a HEaaN-style
@@ -223,11 +233,19 @@ class HEVM:
         if ks_special != 1 or (ks_alpha or 1) != 1:
             opts.update(ks_special=ks_special, ks_alpha=ks_alpha or ks_special)
         with options(**opts):
+            if seed is not None and not lw_.has_test_hooks:
+                raise RuntimeError("HEVM(seed=...) needs the hooks build of the library (DACAPO_AMD_HOOKS=1 before importing dacapo_amd: "
+                                   "tests/conftest.py); the release build generates keys from the OS's randomness only -- HEVM(fresh=True)")
             if seed is not None and primes is not None:
                 arr = (ctypes.c_uint64 * len(primes))(*[int(q) for q in primes])
                 self.vm = lw_.hevm_init_seeded_primes(logN, arr, len(primes), seed)
-            elif seed is not None:  # extension: keys generated in HBM, nothing on disk
+            elif seed is not None:  # test hook: keys generated in HBM from a seed, nothing on disk
                 self.vm = lw_.hevm_init_seeded(logN, num_primes, seed)
+            elif primes is not None:
+                arr = (ctypes.c_uint64 * len(primes))(*[int(q) for q in primes])
+                self.vm = lw_.hevm_init_fresh_primes(logN, arr, len(primes))
+            elif fresh:  # extension: keys generated in HBM, nothing on disk
+                self.vm = lw_.hevm_init_fresh(logN, num_primes)
             else:
                 if not Path(path).is_dir():  # runner.py:185-192 (the reference also waits for a key press)
                     Path(path).mkdir(parents=True)

@@ -76,21 +76,34 @@ struct hevm_ctxt {
     double scale;
 };
 
-/* ---- extensions (not in the reference) used by this repo's tests and bench ------------------------------- */
-/* Generate parameters + the reference's key set in HBM without touching disk.  logN/num_primes = 0 take the
- * reference's hard-coded N = 2^15, 14 primes (SEAL_HEVM.cpp:39-40).  TEST / BENCH ONLY: all randomness is expanded from
- * the 64-bit `seed` so that runs are reproducible -- such keys are NOT secure.  create_context() is the secure path. */
-void *hevm_init_seeded(int logN, int num_primes, uint64_t seed);
+/* ---- extensions (not in the reference) ------------------------------------------------------------------ */
+/* create_context + initFullVM without the files: parameters and the reference's key set (secret, public, relinearisation, default
+ * Galois keys) generated in HBM from the operating system's randomness (getrandom), nothing written to disk.  logN / num_primes = 0 take
+ * the reference's hard-coded N = 2^15, 14 primes (SEAL_HEVM.cpp:39-40). */
+void *hevm_init_fresh(int logN, int num_primes);
 /* ... on an explicit prime chain (every prime = 1 mod 2N, 45..60 bits, the last `ks_special` of them special): e.g. a HEaaN-style mixed
  * chain, 60-bit base and special primes around 51-bit rescale primes (HEAAN_HEVM.cpp:55-56, profiled_HEAAN_GPU.json).  Primes narrower
  * than 60 bits need the generic-width build of the library (libSEAL_HEVM_gw.so); the default build aborts with a message. */
+void *hevm_init_fresh_primes(int logN, const uint64_t *primes, int num_primes);
+#ifdef DC_TEST_HOOKS
+/* TEST HOOKS -- exported by libSEAL_HEVM_hooks.so / libSEAL_HEVM_gw_hooks.so only (csrc/test_hooks.hip; the builds tests/ load).  The
+ * release libraries do not contain them: seeded keys are not secret, the secret-key pointer and zero encryptions have no place in a
+ * deployment.
+ * hevm_init_seeded(_primes): hevm_init_fresh(_primes) with all randomness expanded from the 64-bit `seed` (reproducible runs). */
+void *hevm_init_seeded(int logN, int num_primes, uint64_t seed);
 void *hevm_init_seeded_primes(int logN, const uint64_t *primes, int num_primes, uint64_t seed);
+/* device pointer to the secret key [K][N] */
+const uint64_t *hevm_secret_key(void *vm);
+/* INSECURE: while on, every encryption of zero (encrypt(), opcode 10) is the pair (0, 0), so a ciphertext is
+ * (plaintext, 0) and opcode 10's deterministic half -- decrypt, decode, re-encode (SEAL_HEVM.cpp:328-333) -- can be compared
+ * limb by limb with the oracle.  Prints a warning when switched on. */
+void hevm_test_zero_encryption(void *vm, bool on);
+#endif
 /* the kernel-level context (dc_context*, include/dacapo_ckks.h) behind a VM */
 void *hevm_context(void *vm);
-/* device pointers to key material: relin key, galois key for `elt` (NULL if absent), secret/public key */
+/* device pointers to PUBLIC key material: relin key, galois key for `elt` (NULL if absent), public key */
 const uint64_t *hevm_relin_key(void *vm);
 const uint64_t *hevm_galois_key(void *vm, uint32_t elt);
-const uint64_t *hevm_secret_key(void *vm);
 const uint64_t *hevm_public_key(void *vm);
 /* Key replication over VM replicas (one VM per GPU): the VM's key buffers in a canonical order (secret, public,
  * relinearisation, Galois keys by ascending element) -- device pointers and sizes in 64-bit words; returns their number (call with
@@ -130,10 +143,6 @@ void hevm_destroy(void *vm);
  * direct key when it exists).  Needs the secret key; call before load()/preprocess() or re-run preprocess() afterwards.
  * The reference's SEAL runtime only ever has the default set (SEAL_HEVM.cpp:82-83): programs run identically without this. */
 void hevm_add_rotation_keys(void *vm, const int64_t *offsets, int count);
-/* TEST HOOK, INSECURE: while on, every encryption of zero (encrypt(), opcode 10) is the pair (0, 0), so a ciphertext is
- * (plaintext, 0) and opcode 10's deterministic half -- decrypt, decode, re-encode (SEAL_HEVM.cpp:328-333) -- can be compared
- * limb by limb with the oracle.  Prints a warning when switched on. */
-void hevm_test_zero_encryption(void *vm, bool on);
 /* seal::Ciphertext::save / ::load of cipher register `reg` (the reference hands out seal::Ciphertext* through getCtxt "to
  * implement communication", SEAL_HEVM.cpp:463-473): SEAL 4.0 bytes, parms_id of the register's level, its scale. */
 void hevm_save_ctxt(void *vm, int64_t reg, const char *path);

@@ -4,6 +4,12 @@ from pathlib import Path
 
 import pytest
 
+# tests/ run on the HOOKS builds of the library (libSEAL_HEVM_hooks.so, libSEAL_HEVM_gw_hooks.so: the release builds' objects + csrc/test_hooks.hip --
+# seeded keys, the secret-key pointer, zero encryptions).  Must be set before dacapo_amd is imported; child processes inherit it.  The release
+# builds' own checks -- export lists, and the reference's call sequence through the library a maintainer deploys -- name them explicitly
+# (tests/test_host_formats.py, tests/test_gpu_release_lib.py: a child process with DACAPO_AMD_HOOKS unset).
+os.environ.setdefault("DACAPO_AMD_HOOKS", "1")
+
 ROOT = Path(__file__).resolve().parent.parent
 if str(ROOT) not in sys.path:
     sys.path.insert(0, str(ROOT))

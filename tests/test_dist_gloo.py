@@ -81,19 +81,19 @@ def test_bench_gpus_flag_starts_the_ranks_itself():
     assert abs(r["value"] - 2 * per_step * r["steps"] / (r["ms_per_step"] * r["steps"] * 1e-3)) / r["value"] < 1e-3
 
 
-def test_replicas_hold_one_key_set_seeded_or_broadcast():
-    """keys are replicated over the GPUs.  Default: every rank expands the same seed -> identical digests, nothing moved.
-    --broadcast-keys: the ranks start from DIFFERENT sets, rank 0's is broadcast buffer by buffer, the digests then agree (the run would
-    abort otherwise) and the line reports the bytes shipped.  --streams S rides along on the multi-rank path (config 5 = 8 GPUs x S)."""
+def test_replicas_hold_one_key_set_by_broadcast():
+    """keys are replicated over the GPUs.  The release library has no seeded key generation (round 6), so with more than one
+    rank the ranks always start from DIFFERENT sets, rank 0's is broadcast buffer by buffer, the digests then agree (the run would abort
+    otherwise) and the line reports the bytes shipped.  --streams S rides along on the multi-rank path (config 5 = 8 GPUs x S)."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
-    seeded = _bench_lines(["--gpus", "2", "--steps", "1", "--warmup", "0", "--dry-run", "--streams", "3"], env)[0]
-    assert seeded["keys"]["keys"] == "shared" and seeded["keys"]["mode"] == "seed" and seeded["keys"]["broadcast_bytes"] == 0
-    assert seeded["config"]["streams_per_gpu"] == 3
+    two = _bench_lines(["--gpus", "2", "--steps", "1", "--warmup", "0", "--dry-run", "--streams", "3"], env)[0]
+    assert two["keys"]["keys"] == "shared" and two["keys"]["mode"] == "broadcast" and two["keys"]["broadcast_bytes"] == 3 * 4096 * 8
+    assert two["config"]["streams_per_gpu"] == 3
     single = _bench_lines(["--dry-run"], env)[0]
-    assert single["keys"]["digest"] == seeded["keys"]["digest"]          # the same key set at every world size
+    assert single["keys"]["mode"] == "local" and single["keys"]["broadcast_bytes"] == 0
+    assert single["keys"]["digest"] == two["keys"]["digest"]              # rank 0's set is the one every replica ends up with
     bc = _bench_lines(["--gpus", "2", "--steps", "1", "--warmup", "0", "--dry-run", "--broadcast-keys"], env)[0]
-    assert bc["keys"]["keys"] == "shared" and bc["keys"]["mode"] == "broadcast" and bc["keys"]["broadcast_bytes"] == 3 * 4096 * 8
-    assert bc["keys"]["digest"] == seeded["keys"]["digest"]               # rank 0's set is the seed's set
+    assert bc["keys"] == two["keys"]                                      # the flag only forces the path at world size 1
 
 
 def test_share_keys_refuses_replicas_with_different_keys(tmp_path):

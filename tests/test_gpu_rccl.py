@@ -24,14 +24,24 @@ def _run_bench(extra, timeout):
         sk.bind(("127.0.0.1", 0))
         port = str(sk.getsockname()[1])
     env = dict(os.environ, DACAPO_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    env.pop("DACAPO_AMD_HOOKS", None)  # bench.py runs on the RELEASE build of the library, like the driver's own run of it
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this pool (RCCL needs it)
-    cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0", "--broadcast-keys", "--no-cpu-baseline",
-           "--no-lowerings", "--no-config4"] + extra
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=str(ROOT))
-    assert r.returncode == 0, (r.stdout[-500:], r.stderr[-2000:])
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, r.stdout[-1000:]
-    return json.loads(lines[0]), r.stderr
+    import tempfile
+
+    with tempfile.TemporaryDirectory() as d:
+        full = Path(d) / "bench_full.json"
+        cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0", "--broadcast-keys", "--no-cpu-baseline",
+               "--no-config4", "--out", str(full)] + extra
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=str(ROOT))
+        assert r.returncode == 0, (r.stdout[-500:], r.stderr[-2000:])
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1 and len(lines[0]) <= 4096, r.stdout[-1000:]  # the line the driver parses
+        line = json.loads(lines[0])
+        if full.exists():  # the headline program: the compact line + the full record (keys, decrypted error, legs)
+            rec = json.loads(full.read_text())
+            assert rec["value"] == line["value"] and line["roofline"]["frac"] == rec["roofline"]["frac"]
+            return rec, r.stderr
+        return line, r.stderr  # --program config4 prints its (small) record itself
 
 
 def test_bench_headline_through_rccl_at_world_size_1():
@@ -46,14 +56,7 @@ def test_bench_headline_through_rccl_at_world_size_1():
     assert keys["broadcast_bytes"] == 8 * (K * N + 2 * K * N + 29 * (K - 1) * 2 * K * N)
     assert line["value"] > 1e5 and line["ms_per_step"] > 0 and line["decrypted_error"]["rms_vs_torch"] < 2e-3
     assert line["roofline"]["frac"] > 0.05 and line["config"]["parallelism"].startswith("replicas x1")
-    # rank 0 of a broadcast run starts from seed KEY_SEED + 0: its digest is the one a VM seeded the same way computes
-    sys.path.insert(0, str(ROOT))
-    import bench
-    from dacapo_amd import runner
-
-    vm = runner.HEVM(seed=bench.KEY_SEED, logN=15, num_primes=14)
-    assert keys["digest"] == f"{vm.keyDigest() & 0xFFFFFFFFFFFFFFFF:016x}"
-    vm.close()
+    assert len(keys["digest"]) == 16 and int(keys["digest"], 16) != 0  # (fresh keys from the OS's randomness: nothing to recompute it from)
 
 
 def test_bench_config5_code_path_through_rccl_at_world_size_1():

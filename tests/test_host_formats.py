@@ -51,20 +51,35 @@ def test_resnet_shaped_program_has_the_traced_op_mix():
     assert 50 <= mix["bootstrap"] <= 200 and info["num_ctxt"] < 32  # SEAL-VM "bootstrap" = cheap re-encryption, used often
 
 
-@pytest.mark.parametrize("which", ["default", "generic_width"])
+HOOKS = {"hevm_init_seeded", "hevm_init_seeded_primes", "hevm_secret_key", "hevm_test_zero_encryption"}  # csrc/test_hooks.hip
+
+
+@pytest.mark.parametrize("which", ["default", "generic_width", "default_hooks", "generic_width_hooks"])
 def test_library_exports_every_declared_symbol(which):
     """the C-ABI library loads without a GPU and exports everything include/*.h declares -- the default build (the reference's 60-bit chain)
-    and the generic-width build of the same sources (libSEAL_HEVM_gw.so: 45..60-bit primes)"""
-    from dacapo_amd import LIB_PATH, LIB_PATH_GW
+    and the generic-width build of the same sources (libSEAL_HEVM_gw.so: 45..60-bit primes).  The RELEASE builds, which a maintainer copies
+    next to the reference's runner, export the 18 reference symbols (SEAL_HEVM.cpp:404-504) and the safe extensions: none of the test hooks
+    (the header declares those under DC_TEST_HOOKS).  The *_hooks.so builds tests/ load export exactly the four hooks more."""
+    import dacapo_amd as pkg
 
-    lib = ctypes.CDLL(str(LIB_PATH if which == "default" else LIB_PATH_GW))
-    names = set()
-    for h in ("hevm_abi.h", "dacapo_ckks.h"):
-        text = (ROOT / "include" / h).read_text()
-        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-        text = re.sub(r"^\s*#.*$", "", text, flags=re.M)          # preprocessor lines (#pragma GCC visibility push(default))
-        names |= set(re.findall(r"\b(\w+)\s*\([^;{]*\)\s*;", text))
-    names -= {"defined"}
+    hooks = which.endswith("_hooks")
+    path = {"default": pkg.LIB_PATH_RELEASE, "generic_width": pkg.LIB_PATH_GW_RELEASE,
+            "default_hooks": pkg._LIB_DIR / "libSEAL_HEVM_hooks.so", "generic_width_hooks": pkg._LIB_DIR / "libSEAL_HEVM_gw_hooks.so"}[which]
+    lib = ctypes.CDLL(str(path))
+
+    def declared(with_hooks):
+        names = set()
+        for h in ("hevm_abi.h", "dacapo_ckks.h"):
+            text = (ROOT / "include" / h).read_text()
+            text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+            if not with_hooks:
+                text = re.sub(r"#ifdef DC_TEST_HOOKS.*?#endif", "", text, flags=re.S)
+            text = re.sub(r"^\s*#.*$", "", text, flags=re.M)          # preprocessor lines (#pragma GCC visibility push(default))
+            names |= set(re.findall(r"\b(\w+)\s*\([^;{]*\)\s*;", text))
+        return names - {"defined"}
+
+    names = declared(hooks)
+    assert declared(True) - declared(False) == HOOKS
     reference_18 = {"initFullVM", "initClientVM", "initServerVM", "create_context", "load", "loadClient", "encrypt", "decrypt",
                     "decrypt_result", "getResIdx", "getCtxt", "preprocess", "run", "getArgLen", "getResLen", "setDebug",
                     "setToGPU", "printMem"}
@@ -74,12 +89,29 @@ def test_library_exports_every_declared_symbol(which):
     # ... and NOTHING else: -fvisibility=hidden + csrc/exports.map (round 3's library exported ~250 dacapo:: C++ symbols next to these)
     import subprocess
 
-    path = LIB_PATH if which == "default" else LIB_PATH_GW
     nm = subprocess.run(["nm", "-D", "--defined-only", str(path)], capture_output=True, text=True, check=True).stdout
     exported = {ln.split()[-1] for ln in nm.splitlines() if ln.strip()}
     assert exported == names, (sorted(exported - names), sorted(names - exported))
+    assert bool(exported & HOOKS) == hooks and (not hooks or HOOKS <= exported)
     listed = set(re.findall(r"^\s+(\w+);", (ROOT / "dacapo_amd" / "csrc" / "exports.map").read_text(), flags=re.M))
-    assert listed == names
+    assert listed == declared(False) and not (listed & HOOKS)  # exports.map is the release list; the Makefile derives the hooks list from it
+
+
+def test_tests_run_on_the_hooks_build_and_everything_else_on_the_release_build():
+    """tests/conftest.py selects the hooks builds for this process; a process without DACAPO_AMD_HOOKS -- bench.py, smoke(), a maintainer's
+    runner -- binds the release build, where HEVM(seed=...) fails loudly instead of falling back"""
+    import os
+    import subprocess
+    import sys
+
+    import dacapo_amd as pkg
+
+    assert pkg.HOOKS and pkg.LIB_PATH.name == "libSEAL_HEVM_hooks.so" and pkg.LIB_PATH_GW.name == "libSEAL_HEVM_gw_hooks.so"
+    env = {k: v for k, v in os.environ.items() if k != "DACAPO_AMD_HOOKS"}
+    code = ("import sys; sys.path.insert(0, %r); import dacapo_amd as p; from dacapo_amd import runner; L = runner.reinit_lw();"
+            "print(p.LIB_PATH.name, p.LIB_PATH_GW.name, L.has_test_hooks)" % str(ROOT))
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.split() == ["libSEAL_HEVM.so", "libSEAL_HEVM_gw.so", "False"], out.stderr[-500:]
 
 
 def test_options_come_from_one_environment_variable(tmp_path):
@@ -148,7 +180,7 @@ def test_headers_are_plain_c_and_link_against_the_library(tmp_path):
         pytest.skip("library not built or no gcc")
     names = []
     for h in ("hevm_abi.h", "dacapo_ckks.h"):
-        text = (root / "include" / h).read_text()
+        text = re.sub(r"#ifdef DC_TEST_HOOKS.*?#endif", "", (root / "include" / h).read_text(), flags=re.S)  # the release library: no test hooks
         names += re.findall(r"^[A-Za-z_][\w \*]*?\b(\w+)\s*\(", re.sub(r"/\*.*?\*/", "", text, flags=re.S), flags=re.M)
     names = sorted({n for n in names if n not in ("defined", "if", "sizeof")})
     assert len(names) >= 50 and "initFullVM" in names and "dc_ntt_forward" in names

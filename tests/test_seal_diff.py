@@ -1,6 +1,7 @@
-"""Differential test against Microsoft SEAL itself -- SKIPPED unless a SEAL 4.x install is found (none exists in the build image
-or on the GPU box: SURVEY.md 8c).  On a machine that has SEAL (set SEAL_ROOT to its install prefix) it closes the loop that
-"parity unpinned" leaves open: tools/fixtures/seal_diff_gen.cpp runs SEAL on a fixed scenario and saves keys, inputs and every result in
+"""Differential test against Microsoft SEAL itself.  It runs on COMMITTED SEAL output when tests/golden/seal_vectors/ exists (written once, on
+any machine that has SEAL 4.x, by `SEAL_ROOT=... bash tools/fixtures/make_seal_vectors.sh`: from then on no SEAL is needed, here or on the GPU
+box); otherwise on a scenario generated on the spot when a SEAL 4.x install is found (SEAL_ROOT); otherwise it is SKIPPED (no SEAL exists in
+the build image or on the GPU box: SURVEY.md 8c).  It closes the loop that "parity unpinned" leaves open: tools/fixtures/seal_diff_gen.cpp runs SEAL on a fixed scenario and saves keys, inputs and every result in
 SEAL's serialization; the oracle (CPU test) and the MI355X runtime (GPU test, through initFullVM / hevm_load_ctxt) replay the
 same evaluator calls on the same keys and inputs and must produce the same limbs, bit for bit."""
 import os
@@ -24,8 +25,19 @@ def _find_seal():
     return None
 
 
+VECTORS = ROOT / "tests" / "golden" / "seal_vectors"
+
+
 @pytest.fixture(scope="module")
 def scenario(tmp_path_factory):
+    if (VECTORS / "MANIFEST.json").exists() and (VECTORS / "parm.seal").exists():  # SEAL's own output, committed: preferred, needs no SEAL
+        import hashlib
+        import json
+
+        man = json.loads((VECTORS / "MANIFEST.json").read_text())
+        for name, rec in man["files"].items():
+            assert hashlib.sha256((VECTORS / name).read_bytes()).hexdigest() == rec["sha256"], f"{name} differs from what SEAL wrote"
+        return VECTORS
     found = _find_seal()
     if found is None or shutil.which("g++") is None:
         pytest.skip("Microsoft SEAL 4.x not installed (set SEAL_ROOT): the SEAL-side pin of the arithmetic cannot run here")

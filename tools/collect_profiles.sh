@@ -1,10 +1,10 @@
 #!/bin/bash
 # Everything under profiles/ for one round, collected on the GPU box in one gpurun call:
-#   gpurun --timeout 3000 -- 'bash tools/collect_profiles.sh r05'
+#   gpurun --timeout 3000 -- 'bash tools/collect_profiles.sh r06'
 # Outputs go to gpurun_out/<round>/ (merged back by gpurun); copy the summaries into profiles/ afterwards.
 # rocprofv3 runs with the program directly after `--`, counters (--pmc) in their own passes, kernel-trace / stats only.
 set -u
-R=${1:-r05}
+R=${1:-r06}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/$R
 mkdir -p $OUT
@@ -98,6 +98,7 @@ python tools/legs/chain_bench.py > $OUT/${R}_chain_latency.txt 2>/dev/null
 python tools/legs/profile_backend.py --out $OUT/${R}_profiled_SEAL_MI355X.json > $OUT/profile_backend.log 2>&1
 # E. the bench line itself: it reports the round's sha-gated records (traffic, VALU counters, step kernels) when they were collected on the
 #    library it times -- the ones above were, so they go to profiles/ (of this copy of the repo) first
-for f in ntt_hbm_traffic ntt_valu step_kernels; do [ -s $OUT/${R}_$f.json ] && cp $OUT/${R}_$f.json $ROOT/profiles/; done
-python bench.py > $OUT/${R}_bench.json 2> $OUT/bench.err
-tail -c 400 $OUT/${R}_bench.json
+for f in ntt_hbm_traffic ntt_valu step_kernels per_op_budget_rotate_hop per_op_budget_cfg3; do [ -s $OUT/${R}_$f.json ] && cp $OUT/${R}_$f.json $ROOT/profiles/; done
+# (round 6) stdout's last line = the compact line the driver parses (<= 4 KB); the full record -- every leg, with --full the A/B legs too -- is its own file
+python bench.py --full --out $OUT/${R}_bench_full.json > $OUT/${R}_bench_line.json 2> $OUT/bench.err
+tail -c 2500 $OUT/${R}_bench_line.json

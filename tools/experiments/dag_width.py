@@ -14,7 +14,7 @@ from dacapo_amd import runner  # noqa: E402
 name = sys.argv[1] if len(sys.argv) > 1 else "resnet20"
 fx = ha.read_fixture(ROOT / "tests" / "golden" / name)
 runner.set_option("step_profile", 1)
-vm = runner.HEVM(seed=0x4845564D, logN=15, num_primes=14, vm_options={"plan_graph": 0, "plan_lanes": 1})
+vm = runner.HEVM(fresh=True, logN=15, num_primes=14, vm_options={"plan_graph": 0, "plan_lanes": 1})
 vm.load_mem(fx["cst"], fx["hevm"])
 vm.setInput(0, fx["packed"])
 runner.set_option("step_profile", 0)
@@ -27,7 +27,7 @@ import time
 
 runner.set_option("step_profile", 0)
 for lanes, graph in ((1, 1), (2, 1), (2, 2), (1, 2)):
-    vm = runner.HEVM(seed=0x4845564D, logN=15, num_primes=14, vm_options={"plan_graph": graph, "plan_lanes": lanes})
+    vm = runner.HEVM(fresh=True, logN=15, num_primes=14, vm_options={"plan_graph": graph, "plan_lanes": lanes})
     vm.load_mem(fx["cst"], fx["hevm"])
     vm.setInput(0, fx["packed"])
     vm.run()
@@ -42,7 +42,7 @@ for lanes, graph in ((1, 1), (2, 1), (2, 2), (1, 2)):
 
 # the fork / join threshold of the two-stream capture (option plan_aux_min_cost)
 for cost in (1, 3, 5, 8, 11, 16):
-    vm = runner.HEVM(seed=0x4845564D, logN=15, num_primes=14, vm_options={"plan_aux_min_cost": cost})
+    vm = runner.HEVM(fresh=True, logN=15, num_primes=14, vm_options={"plan_aux_min_cost": cost})
     vm.load_mem(fx["cst"], fx["hevm"])
     vm.setInput(0, fx["packed"])
     vm.run()

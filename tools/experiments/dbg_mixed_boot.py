@@ -1,4 +1,7 @@
-import sys, tempfile
+import os
+import sys
+import tempfile
+os.environ.setdefault("DACAPO_AMD_HOOKS", "1")  # seeded keys: the hooks build (csrc/test_hooks.hip)
 from pathlib import Path
 sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
 import numpy as np

@@ -1,4 +1,6 @@
+import os
 import sys
+os.environ.setdefault("DACAPO_AMD_HOOKS", "1")  # seeded keys: the hooks build (csrc/test_hooks.hip)
 sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
 import numpy as np
 from dacapo_amd import ckks_boot as cb, lowlevel as ll, runner

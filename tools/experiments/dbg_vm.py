@@ -1,4 +1,6 @@
-import sys, os
+import os
+import sys
+os.environ.setdefault("DACAPO_AMD_HOOKS", "1")  # seeded keys: the hooks build (csrc/test_hooks.hip)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from dacapo_amd import runner, hevm_asm as ha

@@ -18,7 +18,7 @@ fx = ha.read_fixture(ROOT / "tests" / "golden" / "resnet20")
 if len(sys.argv) > 2 and sys.argv[2] != "resnet20":  # another lowering of the same trace: same constants, other bytecode
     import gzip
     fx["hevm"] = gzip.open(ROOT / "tests" / "golden" / (sys.argv[2] + ".hevm.gz")).read()
-vm = runner.HEVM(seed=0x4845564D, logN=15, num_primes=14)
+vm = runner.HEVM(fresh=True, logN=15, num_primes=14)
 vm.load_mem(fx["cst"], fx["hevm"])
 vm.setInput(0, fx["packed"])
 vm.run()

@@ -28,7 +28,7 @@ def free_bytes():
 
 
 fx = ha.read_fixture(ROOT / "tests" / "golden" / "resnet20")
-vm = runner.HEVM(seed=0x4845564D, logN=15, num_primes=14)
+vm = runner.HEVM(fresh=True, logN=15, num_primes=14)
 vm.load_mem(fx["cst"], fx["hevm"])
 vm.setInput(0, fx["packed"])
 vm.run()

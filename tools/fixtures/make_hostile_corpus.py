@@ -125,7 +125,12 @@ z = zlib.compress(ct)
 emit("seal_zlib_corrupt.seal", "seal", sf.header(16 + len(z), sf.COMPR_ZLIB) + z[:20] + bytes(b ^ 0x5A for b in z[20:60]) + z[60:], "rejected", "zlib")
 emit("seal_zlib_truncated.seal", "seal", sf.header(16 + len(z) - 9, sf.COMPR_ZLIB) + z[:-9], "rejected", "zlib")
 emit("seal_zlib_garbage.seal", "seal", sf.header(16 + 64, sf.COMPR_ZLIB) + bytes(range(64)), "rejected", "zlib")
-bomb = zlib.compress(bytes(200 << 20), 9)  # 200 MiB of zeros -> ~200 KB: 1030 : 1, far beyond the 64 x + 16 MiB a key object may expand to
+# the one legitimate object that deflates ~1000 : 1: an all-zero ciphertext.  At the largest ring the library runs (N = 2^17, here 31 limbs: 62 MiB
+# -> ~62 KB) it must load (round-5 advisor: the limit sized for the reference's ring refused it)
+big_pid = sf.parms_id(1 << 17, list(range(3, 3 + 31)))
+zero_ct = sf.ciphertext_members(big_pid, np.zeros((2, 31, 1 << 17), dtype=np.uint64), scale=2.0**40)
+emit("seal_ciphertext_all_zero_N131072_zlib.seal", "seal", sf.header(16 + len(zlib.compress(zero_ct, 9)), sf.COMPR_ZLIB) + zlib.compress(zero_ct, 9), "ok", "ciphertext")
+bomb = zlib.compress(bytes(200 << 20), 9)  # 200 MiB of zeros -> ~200 KB: 1030 : 1, far beyond the 64 x + 128 MiB a key object may expand to
 emit("seal_zlib_bomb_200MiB.seal", "seal", sf.header(16 + len(bomb), sf.COMPR_ZLIB) + bomb, "rejected", "expand")
 # Zstandard, hand-assembled (RFC 8878): magic | frame header descriptor 0x00 (no content size, windowed) | window descriptor (128 KiB) |
 # 4 000 RLE blocks of 128 KiB each (3-byte block header: last | type 1 << 1 | size << 3, + the byte) = 16 KB -> 500 MiB

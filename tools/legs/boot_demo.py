@@ -30,7 +30,7 @@ msg = np.random.default_rng(3).uniform(-1, 1, slots)
 sim = cb.simulate(hv, cst, [msg], logN, em.primes)[0]
 print("cleartext simulation: max error", np.abs(sim - msg).max())
 t0 = time.time()
-hevm = runner.HEVM(seed=5, logN=logN, num_primes=K, ks_special=ks, ks_alpha=alpha, vm_options={"secret_hw": 64})
+hevm = runner.HEVM(fresh=True, logN=logN, num_primes=K, ks_special=ks, ks_alpha=alpha, vm_options={"secret_hw": 64})
 print(f"context + keys: {time.time()-t0:.1f} s")
 if direct:
     offs = offs_all

@@ -24,7 +24,7 @@ def timed(hevm, b, reps=5):
 
 
 def main():
-    hevm = runner.HEVM(seed=1, logN=15, num_primes=14)
+    hevm = runner.HEVM(fresh=True, logN=15, num_primes=14)
     rows = []
     for lvl in (1, 2, 3, 4):
         n = 120

@@ -21,7 +21,7 @@ if len(sys.argv) > 2:  # another lowering of the same trace (same constants)
     import gzip
 
     fx["hevm"] = gzip.open(ROOT / "tests" / "golden" / f"resnet20.{sys.argv[2]}.hevm.gz").read()
-hevm = runner.HEVM(seed=0x4845564D, logN=15, num_primes=14)
+hevm = runner.HEVM(fresh=True, logN=15, num_primes=14)
 if streams > 1:
     hevm.set_streams(streams)
 hevm.load_mem(fx["cst"], fx["hevm"])

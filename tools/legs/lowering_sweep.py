@@ -26,7 +26,7 @@ fx = ha.read_fixture(ROOT / "tests" / "golden" / "resnet20")
 progs = {t: (fx["hevm"] if not t else gzip.open(ROOT / "tests" / "golden" / f"resnet20{t}.hevm.gz").read()) for t in tags}
 new_vm = "--new-vm" in args  # VM options (max_batch, plan_lanes ...) are read when a VM is created: one VM per option set
 args = [a for a in args if a != "--new-vm"]
-vm = None if new_vm else runner.HEVM(seed=0x4845564D, logN=15, num_primes=14)
+vm = None if new_vm else runner.HEVM(fresh=True, logN=15, num_primes=14)
 for spec in [""] + args:
     runner.reinit_lw().hevm_reset_options()
     for kv in filter(None, spec.split(",")):
@@ -35,7 +35,7 @@ for spec in [""] + args:
     if new_vm:
         if vm is not None:
             vm.close()
-        vm = runner.HEVM(seed=0x4845564D, logN=15, num_primes=14)
+        vm = runner.HEVM(fresh=True, logN=15, num_primes=14)
     row = []
     for t in tags:
         vm.load_mem(fx["cst"], progs[t])

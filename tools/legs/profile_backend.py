@@ -54,7 +54,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=str(Path(__file__).resolve().parents[2] / "profiles" / "r01_profiled_SEAL_MI355X.json"))
     a = ap.parse_args()
-    hevm = runner.HEVM(seed=3, logN=15, num_primes=14)
+    hevm = runner.HEVM(fresh=True, logN=15, num_primes=14)
     empty = chain(hevm, 2, 1, lambda b, x, xs: b.negate(x)) * 0  # warm
     lat = {k: [] for k in ("earth.rotate_single", "earth.rescale_single", "earth.modswitch_single", "earth.add_single", "earth.add_double",
                            "earth.mul_single", "earth.mul_double", "earth.negate_single", "earth.bootstrap_single")}

@@ -124,4 +124,9 @@ for r in rows:
           f"{r['read_MB']:7.1f} {r['write_MB']:7.1f} {r['hbm_TBps']:5.2f} {r['valu_wave_instructions'] / 1e6:10.3f} {(r['valu_busy_frac'] or 0):5.2f} "
           f"{r['floor_bytes_us']:7.1f} {r['floor_valu_us']:6.1f} {r['floor_valu_quantised_us']:6.1f} {r['floor_us']:6.1f} {(r['x_floor'] or 0):5.2f}")
 if "json" in opts:
+    import hashlib
+    from pathlib import Path
+
+    lib = Path(__file__).resolve().parent.parent.parent / "dacapo_amd" / "lib" / "libSEAL_HEVM.so"
+    out["lib_sha256"] = hashlib.sha256(lib.read_bytes()).hexdigest() if lib.exists() else None  # bench.py reports a record only for the build it times
     json.dump(out, open(opts["json"], "w"), indent=1)

@@ -85,4 +85,9 @@ for r in rows[:top]:
     print(f"{r['kernel'][:52]:52s} {r['calls']:6d} {r['total_ms']:8.2f} {r['share']:6.3f} {r['avg_us']:8.1f} {r['hbm_GB']:8.2f} {r['hbm_TBps']:5.2f} {r['valu_Minst']:9.1f} "
           f"{r['floor_bytes_ms']:8.2f} {r['floor_valu_ms']:8.2f} {r['bound']:>5s} {(r['x_floor'] or 0):5.2f}")
 if "json" in opts:
+    import hashlib
+    from pathlib import Path
+
+    lib = Path(__file__).resolve().parent.parent.parent / "dacapo_amd" / "lib" / "libSEAL_HEVM.so"
+    out["lib_sha256"] = hashlib.sha256(lib.read_bytes()).hexdigest() if lib.exists() else None  # bench.py reports a record only for the build it times
     json.dump(out, open(opts["json"], "w"), indent=1)
