@@ -462,7 +462,9 @@ def compact_line(full: dict) -> dict:
         line["config4"] = ({"error": str(c4["error"])[:120]} if "error" in c4 else
                            {"run_s": c4.get("run_s"), "rms_vs_torch": c4.get("rms_vs_torch"), "bootstraps": c4.get("real_bootstraps"),
                             "bootstraps_reference_plan": c4.get("bootstraps_reference_plan"), "key_switches": c4.get("key_switches"),
-                            "lazy_sums_run_s": g(c4, "lazy_sums", "run_s"), "lazy_sums_rms_vs_torch": g(c4, "lazy_sums", "rms_vs_torch")})
+                            "lazy_sums_run_s": g(c4, "lazy_sums", "run_s"), "lazy_sums_rms_vs_torch": g(c4, "lazy_sums", "rms_vs_torch"),
+                            "double_hoist_run_s": g(c4, "lazy_sums_double_hoist", "run_s"),
+                            "double_hoist_rms_vs_torch": g(c4, "lazy_sums_double_hoist", "rms_vs_torch")})
     line["cfg3_us"], line["cfg3_frac"] = g(full, "cfg3_mul_relin", "us"), g(full, "cfg3_mul_relin", "frac_of_hbm_peak")
     po = full.get("per_op_13_primes") or {}
     line["per_op_13_us"] = {k: g(po, k, "us") for k in ("rotate_hop", "mulcc_relin", "rescale") if k in po} or None
@@ -556,10 +558,12 @@ def config4_child(full=False):
     oracle VM in tests/test_gpu_config4_geometry.py -- a labelled extension, never the like-for-like figure).  --full adds rounds 3-5's
     A/B children (key shapes, chains, bounded key sets)."""
     ks, al = CONFIG4["ks_special"], CONFIG4["ks_alpha"]
-    res = _config4_run([1, CONFIG4["fixture"], CONFIG4["logN"], CONFIG4["msg_bits"], CONFIG4["lowering"], ks, al, "--also-opt", "hyb_lazy_sum=1"])
+    res = _config4_run([1, CONFIG4["fixture"], CONFIG4["logN"], CONFIG4["msg_bits"], CONFIG4["lowering"], ks, al, "--also-opt", "hyb_lazy_sum=1",
+                        "--also-opt", "hyb_lazy_sum=1,hyb_double_hoist=1"])
     if "error" in res:
         return res
-    lazy = res.pop("also", None)
+    also = res.pop("also", None) or [None, None]
+    lazy, dh = also[0], (also[1] if len(also) > 1 else None)
     res["program"] = ("tests/golden/resnet20_nt16.b14: bootstraps at the model script's own hints (before every activation), each restoring 14 "
                       "primes -> 38 real bootstraps; 31 data + 9 special 60-bit primes")
     res["bootstraps_reference_plan"] = 19  # README.md:131-136: DaCapo's own plan for HEaaN places 19 (placement is the compiler's, out of scope)
@@ -571,6 +575,7 @@ def config4_child(full=False):
                                              "rot_compose", "run_s", "key_switches", "ntt_equivalents", "rms_vs_torch", "fixture", "command", "lazy_sums")}
                        if "error" not in r else r)
     res["lazy_sums"] = brief(lazy) if lazy else None  # (the extension's figure, beside -- not instead of -- run_s)
+    res["lazy_sums_double_hoist"] = brief(dh) if dh else None  # (option hyb_double_hoist on top: taps times a plaintext join the sums)
     if not full:
         return res
     lz = ["--opt", "hyb_lazy_sum=1"]

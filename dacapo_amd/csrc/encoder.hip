@@ -51,8 +51,9 @@ __global__ __launch_bounds__(kEncThreads) void enc_stage_kernel(double2 *__restr
 }
 
 // round the real parts, reduce into the first `level` primes: out[p][k][j].  grid = (N/256, P)
+// (prime_base: the limbs are those of primes prime_base ... prime_base + level - 1 -- 0 everywhere but the special-prime limbs of double hoisting)
 __global__ __launch_bounds__(kEncThreads) void enc_round_lift_kernel(u64 *__restrict__ out, const double2 *__restrict__ v, int level, size_t N,
-                                                                      const DModulus *__restrict__ mods, int *__restrict__ overflow)
+                                                                      const DModulus *__restrict__ mods, int *__restrict__ overflow, int prime_base)
 {
     const size_t j = (size_t)blockIdx.x * kEncThreads + threadIdx.x;
     const double c = round(v[(size_t)blockIdx.y * N + j].x);
@@ -76,7 +77,7 @@ __global__ __launch_bounds__(kEncThreads) void enc_round_lift_kernel(u64 *__rest
     }
     u64 *o = out + (size_t)blockIdx.y * level * N + j;
     for (int k = 0; k < level; k++) {
-        const DModulus M = mods[k];
+        const DModulus M = mods[prime_base + k];
         const u64 r = reduce128_any(h, l, M);
         o[(size_t)k * N] = (neg && r) ? M.q - r : r;
     }
@@ -113,7 +114,7 @@ void dec_fft(const Context &c, const EncTables &tb, double2 *v, double *out, hip
 }
 
 void enc_batch(const Context &c, const EncTables &tb, const double *d_consts, const EncItem *d_items, int P, int level, double2 *scratch,
-               u64 *out, int *d_overflow, hipStream_t s)
+               u64 *out, int *d_overflow, hipStream_t s, int prime_base)
 {
     const size_t N = c.N;
     DC_LAUNCH(enc_scatter_kernel, dim3((unsigned)(N / 2 / kEncThreads), (unsigned)P), dim3(kEncThreads), 0, s, scratch, d_consts, d_items,
@@ -122,8 +123,8 @@ void enc_batch(const Context &c, const EncTables &tb, const double *d_consts, co
         DC_LAUNCH(enc_stage_kernel, dim3((unsigned)(N / 2 / kEncThreads), (unsigned)P), dim3(kEncThreads), 0, s, scratch, tb.roots, d_items,
                            N, (unsigned)lg, lg == c.logN - 1 ? 1 : 0);
     DC_LAUNCH(enc_round_lift_kernel, dim3((unsigned)(N / kEncThreads), (unsigned)P), dim3(kEncThreads), 0, s, out, scratch, level, N,
-                       c.d_mods, d_overflow);
-    launch_ntt(c, false, out, (long)N, P * level, nullptr, 0, level, s);
+                       c.d_mods, d_overflow, prime_base);
+    launch_ntt(c, false, out, (long)N, P * level, nullptr, prime_base, level, s);
 }
 
 } // namespace dacapo

@@ -16,9 +16,10 @@ struct EncTables {
 };
 
 // P plaintexts of `level` primes: scratch [P][N] complex, out [P][level][N] (NTT form on return).  *d_overflow is set if a
-// coefficient does not fit 120 bits.
+// coefficient does not fit 120 bits.  prime_base: the `level` limbs are those of primes prime_base ... (the special-prime limbs of a plaintext
+// that multiplies a rotation inside a lazy sum, option hyb_double_hoist: prime_base = the chain's first special prime, level = their number)
 void enc_batch(const Context &c, const EncTables &tb, const double *d_consts, const EncItem *d_items, int P, int level, double2 *scratch,
-               u64 *out, int *d_overflow, hipStream_t s);
+               u64 *out, int *d_overflow, hipStream_t s, int prime_base = 0);
 
 // decode: v [N] complex (real parts = plaintext coefficients / scale) -> out [N/2] slot values (real parts), on the device
 void dec_fft(const Context &c, const EncTables &tb, double2 *v, double *out, hipStream_t s);

@@ -465,6 +465,7 @@ void HEVM::init_context(int logN, int K, const u64 *primes, int dir_ksp, int dir
     host_encoder = option(OPT_HOST_ENCODER) != 0;
     fold_rescale_into_boot = option(OPT_FOLD_RESCALE_BOOT) != 0;
     lazy_sums = option(OPT_HYB_LAZY_SUM) != 0;
+    double_hoist = lazy_sums && option(OPT_HYB_DOUBLE_HOIST) != 0;
     max_batch = std::max(1, (int)option(OPT_MAX_BATCH));
     chain_fusion = option(OPT_CHAIN_FUSION) != 0;
     secret_weight = (int)option(OPT_SECRET_HW);
@@ -958,6 +959,8 @@ void HEVM::free_plains()
 {
     if (online.d_consts) (void)vm_free(online.d_consts);
     online.d_consts = nullptr, online.items.clear();
+    if (dh_consts) (void)vm_free(dh_consts);
+    dh_consts = nullptr, dh_items.clear();
     for (auto &pl : plains)
         if (pl.d && !pl.arena) (void)vm_free(pl.d);
     for (u64 *a : plain_arenas) (void)vm_free(a);
@@ -1028,6 +1031,7 @@ void HEVM::preprocess_device()
         pl.level = level, pl.scale = pow(2.0, (double)scale_bits), pl.arena = true;
         by_level[level].push_back({ (int)op.dst, it });
         if (online_encode) online.items[(int)op.dst] = it;
+        if (double_hoist) dh_items[(int)op.dst] = it;
     }
     if (by_level.empty()) return;
     double *d_consts = nullptr;
@@ -1067,7 +1071,59 @@ void HEVM::preprocess_device()
     }
     int overflow = 0;
     DC_HIP_CHECK(hipMemcpy(&overflow, d_overflow, sizeof(int), hipMemcpyDeviceToHost));
-    (void)vm_free(d_consts), (void)vm_free(scratch), (void)vm_free(d_items), (void)vm_free(d_overflow);
+    if (double_hoist) // (build_plan encodes special-prime limbs from the same constants: they stay until the plaintexts go)
+        dh_consts = d_consts;
+    else
+        (void)vm_free(d_consts);
+    (void)vm_free(scratch), (void)vm_free(d_items), (void)vm_free(d_overflow);
+    if (overflow) {
+        fprintf(stderr, "[dacapo_amd] encode: coefficient does not fit 120 bits (scale too large)\n");
+        abort();
+    }
+}
+
+// option hyb_double_hoist: the limbs over the chain's SPECIAL primes of the plaintext registers the plan multiplies rotations by inside its lazy sums
+// (plan_exec.hip section 2b).  The same encoding as preprocess_device's -- same items, same constants, same FFT, hence the same integer
+// coefficients -- reduced into primes max_level ... max_level + ksp - 1; registers that already have them are skipped.
+void HEVM::ensure_special_limbs(const std::vector<int> &plain_regs)
+{
+    Context &c = *ctx;
+    const size_t N = c.N;
+    std::vector<int> todo;
+    for (int r : plain_regs)
+        if (!plains.at((size_t)r).dsp) todo.push_back(r);
+    std::sort(todo.begin(), todo.end());
+    todo.erase(std::unique(todo.begin(), todo.end()), todo.end());
+    if (todo.empty()) return;
+    if (!dh_consts) {
+        fprintf(stderr, "[dacapo_amd] double hoisting: the program's constants are gone (option hyb_double_hoist was off, or host_encoder / online_encode is on, when the program was preprocessed)\n");
+        abort();
+    }
+    ensure_enc_tables();
+    const int ksp = c.ksp, chunk = 256;
+    u64 *arena = dalloc(todo.size() * (size_t)ksp * N);
+    plain_arenas.push_back(arena);
+    double2 *scratch = nullptr;
+    EncItem *d_items = nullptr;
+    int *d_overflow = nullptr;
+    DC_HIP_CHECK(vm_malloc(&scratch, (size_t)chunk * N * sizeof(double2)));
+    DC_HIP_CHECK(vm_malloc(&d_items, (size_t)chunk * sizeof(EncItem)));
+    DC_HIP_CHECK(vm_malloc(&d_overflow, sizeof(int)));
+    DC_HIP_CHECK(hipMemset(d_overflow, 0, sizeof(int)));
+    std::vector<EncItem> items(todo.size());
+    for (size_t k = 0; k < todo.size(); k++) {
+        items[k] = dh_items.at(todo[k]);
+        plains.at((size_t)todo[k]).dsp = arena + k * (size_t)ksp * N;
+    }
+    for (size_t k = 0; k < todo.size(); k += (size_t)chunk) {
+        const int cnt = (int)std::min<size_t>((size_t)chunk, todo.size() - k);
+        DC_HIP_CHECK(hipMemcpyAsync(d_items, items.data() + k, (size_t)cnt * sizeof(EncItem), hipMemcpyHostToDevice, S()));
+        enc_batch(c, enc_tables, dh_consts, d_items, cnt, ksp, scratch, arena + k * (size_t)ksp * N, d_overflow, S(), c.max_level());
+        DC_HIP_CHECK(hipStreamSynchronize(S()));
+    }
+    int overflow = 0;
+    DC_HIP_CHECK(hipMemcpy(&overflow, d_overflow, sizeof(int), hipMemcpyDeviceToHost));
+    (void)vm_free(scratch), (void)vm_free(d_items), (void)vm_free(d_overflow);
     if (overflow) {
         fprintf(stderr, "[dacapo_amd] encode: coefficient does not fit 120 bits (scale too large)\n");
         abort();
@@ -1840,6 +1896,7 @@ const uint64_t *hevm_plain(void *vm, int64_t i, int32_t *level, double *scale)
     if (scale) *scale = p.scale;
     return p.d;
 }
+const uint64_t *hevm_plain_special(void *vm, int64_t i) { return V(vm)->plains.at((size_t)i).dsp; }
 void hevm_load_mem(void *vm, const void *cst, uint64_t cst_len, const void *hevm, uint64_t hevm_len)
 {
     auto h = V(vm);

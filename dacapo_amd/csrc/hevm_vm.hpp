@@ -68,6 +68,7 @@ struct Plain {
     int level = 0;
     double scale = 1.0;
     bool arena = false; // d points into HEVM::plain_arenas (batched device encoder): not freed individually
+    u64 *dsp = nullptr; // option hyb_double_hoist: the same plaintext's limbs over the special primes [ksp][N] (NTT form; in an arena), or null
 };
 
 struct KeySet {
@@ -169,6 +170,7 @@ class HEVM {
         std::vector<u32> elts;
         std::vector<const u64 *> keys;
         std::vector<int> ops;
+        std::vector<int> plains; // P_ROTSUM, option hyb_double_hoist: the plaintext register multiplying rotation k before it joins the sum, or -1
     };
     struct Step {
         PopKind kind;
@@ -254,6 +256,12 @@ class HEVM {
     int secret_weight = 0; // option secret_hw = h: key generation draws a ternary secret with exactly h non-zero coefficients (0: uniform ternary, SEAL's)
     bool chain_fusion = true; // option chain_fusion = 0: every step runs all of its own launches
     hipStream_t aux_stream = nullptr;
+    // option hyb_double_hoist = 1 (with hyb_lazy_sum): rotations multiplied by a plaintext join the lazy sums; the plaintexts' special-prime limbs
+    // are encoded when the plan first names them (the program's constants and encode items stay resident for that)
+    bool double_hoist = false;
+    double *dh_consts = nullptr;
+    std::map<int, EncItem> dh_items; // plaintext register -> its encode item (preprocess_device)
+    void ensure_special_limbs(const std::vector<int> &plain_regs);
     bool lazy_sums = false; // option hyb_lazy_sum = 1: sums of direct-key rotations share one division by P (plan_exec.hip section 2b)
     bool fold_rescale_into_boot = false; // option fold_rescale_boot = 1: do a rescale that only feeds an opcode 10 inside its re-encoder
     int plan_lanes = 2; // independent steps of a wave also use an auxiliary stream (pays off only inside the graph; option plan_lanes = 1: one stream)

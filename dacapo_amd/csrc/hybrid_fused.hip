@@ -378,25 +378,36 @@ static void hybf_core(Context &c, const BatchWs &w, const void *items, KsItem ro
 // groups[g]: dst = where the sum goes, elt = the group's first item, slot = its item count (the items of a group are adjacent).
 // grid = (N / 512, l + ksp, 2 G).  Reads 2 (l + ksp) limbs per item once: 16 us per item at l = 31 against the ~140 us of the F6 ... F9 it saves.
 __global__ __launch_bounds__(256) void hybf_group_sum_kernel(const u64 *__restrict__ accq, const u64 *__restrict__ accp, u64 *__restrict__ gq,
-                                                             u64 *__restrict__ gp, const KsItem *__restrict__ groups, int ell, int ksp, int L,
-                                                             size_t N, const DModulus *__restrict__ mods)
+                                                             u64 *__restrict__ gp, const KsItem *__restrict__ items, const KsItem *__restrict__ groups,
+                                                             int ell, int ksp, int L, size_t N, const DModulus *__restrict__ mods)
 {
     typedef u64 u64x2 __attribute__((ext_vector_type(2)));
     const int mi = blockIdx.y, g = blockIdx.z >> 1, c = blockIdx.z & 1;
     const u32 first = groups[g].elt, count = groups[g].slot;
     const bool special = mi >= ell;
     const int limbs = special ? ksp : ell, row = special ? mi - ell : mi;
-    const u64 q = mods[special ? L + row : row].q;
+    const DModulus M = mods[special ? L + row : row];
+    const u64 q = M.q;
     const size_t k = ((size_t)blockIdx.x * 256 + threadIdx.x) * 2, stride = (size_t)2 * limbs * N;
     const u64 *in = (special ? accp : accq) + (((size_t)first * 2 + c) * limbs + row) * N + k;
-    u64x2 a = *reinterpret_cast<const u64x2 *>(in);
+    // an item's accumulator, times its plaintext when it has one (double hoisting: hyb_mac_group_kernel's rule, hybrid_ks.hip)
+    auto term = [&](u32 t) {
+        u64x2 v = *reinterpret_cast<const u64x2 *>(in + (size_t)t * stride);
+        const KsItem &it = items[first + t];
+        if (it.plain) {
+            const u64x2 w = *reinterpret_cast<const u64x2 *>((special ? it.plain_sp : it.plain) + (size_t)row * N + k);
+            v.x = mulmod(v.x, w.x, M), v.y = mulmod(v.y, w.y, M);
+        }
+        return v;
+    };
+    u64x2 a = term(0);
     u32 t = 1;
     for (; t + 1 < count; t += 2) { // two items' loads in flight
-        const u64x2 v0 = *reinterpret_cast<const u64x2 *>(in + (size_t)t * stride), v1 = *reinterpret_cast<const u64x2 *>(in + (size_t)(t + 1) * stride);
+        const u64x2 v0 = term(t), v1 = term(t + 1);
         a.x = addmod(addmod(a.x, v0.x, q), v1.x, q), a.y = addmod(addmod(a.y, v0.y, q), v1.y, q);
     }
     if (t < count) {
-        const u64x2 v = *reinterpret_cast<const u64x2 *>(in + (size_t)t * stride);
+        const u64x2 v = term(t);
         a.x = addmod(a.x, v.x, q), a.y = addmod(a.y, v.y, q);
     }
     *reinterpret_cast<u64x2 *>((special ? gp : gq) + (((size_t)g * 2 + c) * limbs + row) * N + k) = a;
@@ -424,7 +435,7 @@ void hybf_rotate_sum(Context &c, const BatchWs &w, const KsItem *d_items, int B,
     }
     u64 *gq = w.ext, *gp = w.ext + (size_t)2 * G * ell * N;
     DC_LAUNCH(hybf_group_sum_kernel, dim3((unsigned)(N / 512), (unsigned)(ell + ksp), (unsigned)(2 * G)), dim3(256), 0, s, w.acc,
-              w.acc + (size_t)B * 2 * ell * N, gq, gp, d_groups, ell, ksp, c.max_level(), N, c.d_mods);
+              w.acc + (size_t)B * 2 * ell * N, gq, gp, d_items, d_groups, ell, ksp, c.max_level(), N, c.d_mods);
     hybf_back<0>(c, w, gq, gp, d_groups, KsItem{}, HybOut{}, G, ell, s);
 }
 

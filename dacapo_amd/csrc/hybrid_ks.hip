@@ -252,6 +252,12 @@ __global__ __launch_bounds__(kHT) void hyb_mac_group_kernel(u64 *__restrict__ ac
             o0.x = addmod(o0.x, mulmod((gsrc & 1u) ? v.y : v.x, P, Md), Md.q);
             o0.y = addmod(o0.y, mulmod((gsrc & 1u) ? v.x : v.y, P, Md), Md.q);
         }
+        if (it.plain) { // double hoisting: pt * rot(x) enters the sum in the raised basis -- (P galois(c0) + <digits, key>) * pt limb by limb over
+                        // Q and P, so that ModDown(sum) = sum_k pt_k galois(c0_k) + ModDown(sum_k pt_k <digits_k, key_k>): one division by P
+            const u64x2 w = *reinterpret_cast<const u64x2 *>((mi < ell ? it.plain + (size_t)mi * N : it.plain_sp + (size_t)(mi - ell) * N) + k);
+            o0.x = mulmod(o0.x, w.x, Md), o0.y = mulmod(o0.y, w.y, Md);
+            o1.x = mulmod(o1.x, w.x, Md), o1.y = mulmod(o1.y, w.y, Md);
+        }
         s0.x = addmod(s0.x, o0.x, Md.q), s0.y = addmod(s0.y, o0.y, Md.q);
         s1.x = addmod(s1.x, o1.x, Md.q), s1.y = addmod(s1.y, o1.y, Md.q);
     }

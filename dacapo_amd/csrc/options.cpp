@@ -35,6 +35,7 @@ static const OptDef kDefs[OPT_COUNT] = {
     { "hyb_mfma", 1 },
     { "hyb_fuse", 2 },
     { "hyb_lazy_sum", 0 },
+    { "hyb_double_hoist", 0 },
     { "seal_compr", 0 },
     { "trace", 0 },
     { "step_profile", 0 },
@@ -107,7 +108,9 @@ static void warn_legacy_environment()
 {
     for (char **e = environ; e && *e; e++) {
         if (strncmp(*e, "DACAPO_", 7) != 0) continue;
-        if (!strncmp(*e, "DACAPO_HEVM_OPTIONS=", 20) || !strncmp(*e, "DACAPO_AMD_LIB=", 15) || !strncmp(*e, "DACAPO_FORCE_DIST=", 18)) continue;
+        if (!strncmp(*e, "DACAPO_HEVM_OPTIONS=", 20) || !strncmp(*e, "DACAPO_AMD_LIB=", 15) || !strncmp(*e, "DACAPO_FORCE_DIST=", 18) ||
+            !strncmp(*e, "DACAPO_AMD_HOOKS=", 17)) // (read by the Python package: which build of the library it loads)
+            continue;
         const char *eq = strchr(*e, '=');
         fprintf(stderr, "[dacapo_amd] warning: environment variable %.*s is no longer read (round 4 replaced the per-knob variables); use "
                         "DACAPO_HEVM_OPTIONS=\"name=value,...\" or hevm_set_option() -- names: include/hevm_abi.h, csrc/options.hpp\n",

@@ -36,6 +36,7 @@ enum Opt : int {
     OPT_HYB_MFMA,          // grouped-digit base conversions on the matrix cores (0: vector kernels)
     OPT_HYB_FUSE,          // grouped-digit key switch: 2 (default) fused sequence, base conversions as pre-scaled matrix-core launches; 1 fused, conversions in the transforms' loaders; 0 round 3's sequence
     OPT_HYB_LAZY_SUM,      // grouped-digit plan: rotations (the last hop of a rotate instruction) whose single-use results are bare terms of one sum share ONE mod-down (changes the rounding: off; hevm_plan_lazy_groups names the groups; 2: same sums through per-item accumulators and a separate adding kernel)
+    OPT_HYB_DOUBLE_HOIST,  // with hyb_lazy_sum: a rotation multiplied by a plaintext before it joins the sum is a member too -- the product is taken in the raised basis (the plaintext's special-prime limbs are encoded at preprocess) and the group still has ONE mod-down (changes the rounding like hyb_lazy_sum: off)
     OPT_SEAL_COMPR,        // compression of written .seal files: 0 none, 1 zlib, 2 zstd
     OPT_TRACE,             // plan statistics on stderr (2: per wave)
     OPT_STEP_PROFILE,      // per-step timing of an un-graphed plan on stderr

@@ -22,6 +22,9 @@ struct KsItem {   // one key-switch hop of a rotation: dst = apply_galois(src)
     const u64 *key;
     u32 elt;
     u32 slot;     // grouped-digit mode: which decomposition of the batch this hop reads (hops of one source ciphertext share one); else 0
+    // double hoisting (option hyb_double_hoist; items of a lazy sum only): the plaintext that multiplies this rotation's result before it joins
+    // the sum -- its limbs over the data primes [level][N] and over the special primes [ksp][N] (both NTT form) -- or null
+    const u64 *plain = nullptr, *plain_sp = nullptr;
 };
 struct MulItem {  // dst = relinearize(a * b)
     CtView a, b, dst;

@@ -373,7 +373,11 @@ void HEVM::build_plan()
             if (!(O[ci].kind == P_SUM || ((O[ci].kind == P_RESCALE || O[ci].kind == P_BOOT) && O[ci].rs_sum))) continue;
             std::vector<size_t> terms; // positions in the consumer's source list
             for (size_t k = 0; k < O[ci].srcs.size(); k++) {
-                if (!O[ci].src_plain.empty() && O[ci].src_plain[k] >= 0) continue;
+                // a term times a plaintext joins only under option hyb_double_hoist: its product is then taken in the raised basis, which needs
+                // the plaintext over the special primes too (encoded below, from the resident constants)
+                if (!O[ci].src_plain.empty() && O[ci].src_plain[k] >= 0 &&
+                    !(double_hoist && !online_encode && !host_encoder && dh_items.count(O[ci].src_plain[k]) && plains.at((size_t)O[ci].src_plain[k]).level >= O[ci].level))
+                    continue;
                 const int sidx = O[ci].srcs[k];
                 const Val &sv = V[(size_t)sidx];
                 const int dp = sv.root == sidx ? sv.def_pop : -1;
@@ -390,6 +394,7 @@ void HEVM::build_plan()
             for (size_t k : terms) {
                 Pop &r = O[(size_t)V[(size_t)O[ci].srcs[k]].def_pop];
                 grp.srcs.push_back(r.srcs[0]), grp.elts.push_back(r.elt), grp.keys.push_back(r.key), grp.ops.push_back(r.op);
+                grp.plains.push_back(O[ci].src_plain.empty() ? -1 : O[ci].src_plain[k]);
                 r.dead = true;
                 if (k != keep) V[(size_t)O[ci].srcs[k]].uses = 0, V[(size_t)O[ci].srcs[k]].def_pop = -1; // (no pop defines or reads this value any more)
             }
@@ -399,7 +404,7 @@ void HEVM::build_plan()
             for (size_t k = 0; k < O[ci].srcs.size(); k++)
                 if (k == keep || std::find(terms.begin(), terms.end(), k) == terms.end()) {
                     srcs.push_back(O[ci].srcs[k]);
-                    if (!O[ci].src_plain.empty()) plain.push_back(O[ci].src_plain[k]);
+                    if (!O[ci].src_plain.empty()) plain.push_back(k == keep ? -1 : O[ci].src_plain[k]); // (the group applies its members' plaintexts itself)
                 }
             O[ci].srcs = srcs, O[ci].src_plain = plain;
             // A plain sum whose terms were ALL grouped (rot(x, a) + rot(y, b)) is now a one-source sum without a plaintext: a copy of the group's
@@ -414,6 +419,15 @@ void HEVM::build_plan()
                 }
             }
         }
+    }
+
+    if (double_hoist) { // the special-prime limbs of every plaintext a group multiplies by (encoded once; a rebuilt plan finds them in place)
+        std::vector<int> need_sp;
+        for (const Pop &p : O)
+            if (!p.dead && p.kind == P_ROTSUM)
+                for (int pl : p.plains)
+                    if (pl >= 0) need_sp.push_back(pl);
+        ensure_special_limbs(need_sp);
     }
 
     // ---- 3. dataflow depth ------------------------------------------------------------------------------------------
@@ -746,7 +760,9 @@ void HEVM::build_plan()
                     for (size_t k = 0; k < rp.srcs.size(); k++) {
                         const CtView sv = view(rp.srcs[k], q);
                         const u32 slot = slot_of.emplace(sv.p, (u32)slot_of.size()).first->second;
-                        h_ks.push_back(KsItem{ sv, dst, rp.keys[k], rp.elts[k], slot });
+                        const int pl = rp.plains.empty() ? -1 : rp.plains[k];
+                        h_ks.push_back(KsItem{ sv, dst, rp.keys[k], rp.elts[k], slot, pl >= 0 ? plains.at((size_t)pl).d : nullptr,
+                                               pl >= 0 ? plains.at((size_t)pl).dsp : nullptr });
                     }
                 }
             st.unique = (int)slot_of.size();

@@ -92,6 +92,8 @@ def bind_vm_lib(path):
     L.hevm_galois_key.restype = ctypes.c_void_p
     L.hevm_plain.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_double)]
     L.hevm_plain.restype = ctypes.c_void_p
+    L.hevm_plain_special.argtypes = [ctypes.c_void_p, ctypes.c_int64]
+    L.hevm_plain_special.restype = ctypes.c_void_p
     L.hevm_load_mem.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_uint64, ctypes.c_char_p, ctypes.c_uint64]
     L.hevm_last_run_stats.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64),
                                        ctypes.POINTER(ctypes.c_int64)]

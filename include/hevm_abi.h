@@ -114,6 +114,9 @@ uint64_t hevm_key_digest(void *vm);
 void hevm_keys_replaced(void *vm);
 /* device pointer + level + scale of plaintext register i after preprocess() */
 const uint64_t *hevm_plain(void *vm, int64_t i, int32_t *level, double *scale);
+/* option "hyb_double_hoist": device pointer to plaintext register i's limbs over the chain's special primes [ks_special][N] (NTT form) once
+ * the plan has encoded them -- the registers that multiply a rotation inside a lazy sum -- else NULL.  Test infrastructure, like hevm_plain. */
+const uint64_t *hevm_plain_special(void *vm, int64_t i);
 /* load a program from memory images of the .cst / .hevm files */
 void hevm_load_mem(void *vm, const void *cst, uint64_t cst_len, const void *hevm, uint64_t hevm_len);
 /* per-opcode launch statistics of the last run(): counts[11], NTT-equivalents executed */

@@ -511,6 +511,15 @@ void orc_poly_mul(const orc_ctx *c, int ell, const u64 *a, const u64 *b, u64 *ou
         for (size_t j = 0; j < c->N; j++) out[i * c->N + j] = mulmod(a[i * c->N + j], b[i * c->N + j], m);
     }
 }
+/* EXTENSION (the GPU VM's option hyb_double_hoist): the same dyadic product on limbs of primes first ... first + count - 1 -- the special-prime
+ * limbs of an accumulator in the raised basis times a plaintext's limbs over those primes */
+void orc_poly_mul_at(const orc_ctx *c, int first, int count, const u64 *a, const u64 *b, u64 *out)
+{
+    for (int i = 0; i < count; i++) {
+        const orc_mod *m = &c->mod[first + i];
+        for (size_t j = 0; j < c->N; j++) out[i * c->N + j] = mulmod(a[i * c->N + j], b[i * c->N + j], m);
+    }
+}
 /* same with % (cross-check) */
 void orc_poly_mul_simple(const orc_ctx *c, int ell, const u64 *a, const u64 *b, u64 *out)
 {

@@ -467,6 +467,21 @@ class Oracle:
         self.L.orc_rotate_acc_hybrid(self.ctx, a.ell, _p(np.ascontiguousarray(a.data[1])), C.c_uint32(elt), _p(key), _p(acc))
         return LazySum(Ciphertext(np.stack([c0, np.zeros_like(c0)]), a.scale), acc, group, 1, size)
 
+    def lazy_mul_plain(self, a: "LazySum", p: Plaintext, p_special: np.ndarray) -> "LazySum":
+        """EXTENSION (the GPU VM's option hyb_double_hoist): a rotation still in the raised basis times a plaintext -- galois(c0) * p on the data
+        primes as usual, the inner products * p limb by limb over the data primes AND the special primes (p_special [ks][N]: the same encoded
+        polynomial reduced into them), so that the sum it joins is divided by P once"""
+        assert a.ell == p.ell and p_special.shape == (self.ks, self.N) and a.have == 1
+        ell = a.ell
+        acc = np.empty_like(a.acc)
+        sp = np.ascontiguousarray(p_special, dtype=np.uint64)
+        for c in range(2):
+            acc[c, :ell] = self.poly_mul(a.acc[c, :ell], p.data)
+            hi, out = np.ascontiguousarray(a.acc[c, ell:]), np.empty((self.ks, self.N), dtype=np.uint64)
+            self.L.orc_poly_mul_at(self.ctx, self.K - self.ks, self.ks, _p(hi), _p(sp), _p(out))
+            acc[c, ell:] = out
+        return LazySum(self.mul_plain(a.base, p), acc, a.group, a.have, a.size)
+
     def lazy_add(self, a, b):
         """a + b where either may be a LazySum of the same group; finished (one mod-down) when the group's last rotation has joined"""
         if not isinstance(a, LazySum):
@@ -658,6 +673,9 @@ class OracleVM:
             if opcode == 6 and (isinstance(c[lhs], LazySum) or isinstance(c[rhs], LazySum)):
                 c[lhs].scale = c[rhs].scale
                 c[dst] = o.lazy_add(c[lhs], c[rhs])
+                return
+            if opcode == 9 and isinstance(c[lhs], LazySum) and c[lhs].have == 1 and rhs in getattr(self, "plains_special", {}):
+                c[dst] = o.lazy_mul_plain(c[lhs], p[rhs], self.plains_special[rhs])  # (double hoisting: the plan multiplied inside the group)
                 return
             for r in ((lhs,) if opcode in (1, 2, 3, 4, 7, 9, 10, 17, 18, 19) else (lhs, rhs) if opcode in (6, 8) else ()):
                 if r < len(c) and isinstance(c[r], LazySum):

@@ -136,4 +136,11 @@ def _mirror_vm(hevm, ll, o, cst, hv, tmp_path):
         p = hevm.lw.hevm_plain(hevm.vm, i, ctypes.byref(lvl), ctypes.byref(sc))
         if p:
             ovm.plains[i] = Plaintext(ll.read_device(p, (lvl.value, o.N)), sc.value)
+    # option hyb_double_hoist: the special-prime limbs the plan encoded for the plaintexts that multiply rotations inside its lazy sums
+    ovm.plains_special = {}
+    if hasattr(hevm.lw, "hevm_plain_special") and getattr(o, "ks", 1) > 1:
+        for i in range(ovm.prog.num_ptxt):
+            p = hevm.lw.hevm_plain_special(hevm.vm, i)
+            if p:
+                ovm.plains_special[i] = ll.read_device(p, (o.ks, o.N))
     return ovm

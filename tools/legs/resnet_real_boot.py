@@ -24,13 +24,13 @@ from dacapo_amd import hevm_asm as ha  # noqa: E402
 from dacapo_amd import ckks_boot as cb  # noqa: E402
 from dacapo_amd import runner  # noqa: E402
 
-# --also-opt name=value: after the run, destroy the VM and run the same lowered program once more in a second VM created with that VM
-# option set (bench.py: hyb_lazy_sum off and on in ONE process -- the program is lowered and the fixture read once)
-also = {}
+# --also-opt name=value[,name=value...] (repeatable): after the run, destroy the VM and run the same lowered program once more in another VM
+# created with those VM options set (bench.py: hyb_lazy_sum off / on / on with hyb_double_hoist in ONE process -- the program is lowered and
+# the fixture read once)
+also = []
 while "--also-opt" in sys.argv:
     i = sys.argv.index("--also-opt")
-    k_, _, v_ = sys.argv[i + 1].partition("=")
-    also[k_] = int(v_, 0)
+    also.append({kv.partition("=")[0]: int(kv.partition("=")[2], 0) for kv in sys.argv[i + 1].split(",")})
     del sys.argv[i:i + 2]
 sys.argv = runner.apply_cli_options(sys.argv)  # --opt name=value (csrc/options.hpp)
 
@@ -153,5 +153,5 @@ def one_run(extra_vm_options):
 
 res = one_run({})
 if also:
-    res["also"] = dict(one_run(also), vm_options=also)
+    res["also"] = [dict(one_run(opts), vm_options=opts) for opts in also]
 print(json.dumps(res))
