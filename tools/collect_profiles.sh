@@ -38,16 +38,16 @@ rm -rf $OUT/hk $OUT/hf $OUT/hw
 # B3. config 4 (N = 2^17, 38 real bootstraps, grouped-digit keys): kernel-time table of the whole run; measured HBM bytes per kernel on ONE
 #     bootstrap of the same geometry (rocprofv3 --pmc on the whole config-4 program crashes or hangs: profiles/r04_experiments.txt item 12)
 cd /tmp
-C4="$ROOT/tools/legs/resnet_real_boot.py 1 resnet20_nt16 17 1 b14 9 8 --opt hyb_lazy_sum=1"   # as bench.py runs it (CONFIG4["lazy_sums"])
+C4="$ROOT/tools/legs/resnet_real_boot.py 1 resnet20_nt16 17 1 b14 9 8"   # as bench.py's config-4 leg runs it: the library's default options (round 6)
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c4 -- python3 $C4 > $OUT/${R}_config4_under_profiler.txt 2> $OUT/c4.err
 cp $(ls $OUT/c4/*/*kernel_stats.csv | head -1) $OUT/${R}_config4_kernel_stats.csv
 rm -rf $OUT/c4
-BT="$ROOT/tools/legs/boot_demo.py 17 5 1 14 9 8 --opt hyb_lazy_sum=1"
+BT="$ROOT/tools/legs/boot_demo.py 17 5 1 14 9 8"
 timeout 600 rocprofv3 --kernel-trace --output-format csv -d $OUT/bt -- python3 $BT > $OUT/bt.txt 2> $OUT/bt.err
 timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/btf -- python3 $BT --opt plan_graph=0 > /dev/null 2> $OUT/btf.err
 timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/btw -- python3 $BT --opt plan_graph=0 > /dev/null 2> $OUT/btw.err
 cd $ROOT
-{ echo "one real bootstrap at config 4's geometry (N = 2^17, 31 + 9 primes, digits of 8, 1 -> 14 primes): python tools/legs/boot_demo.py 17 5 1 14 9 8 --opt hyb_lazy_sum=1 (lazy sums, as config 4 runs)"
+{ echo "one real bootstrap at config 4's geometry (N = 2^17, 31 + 9 primes, digits of 8, 1 -> 14 primes): python tools/legs/boot_demo.py 17 5 1 14 9 8 (default options, as config 4's headline runs)"
   echo "the process = key generation + encoding + 3 runs; bytes = FETCH_SIZE x 2 + WRITE_SIZE per kernel (plan run launch by launch for the counters)"
   grep -E "bootstrap:|decrypted" $OUT/bt.txt
   python tools/summarize/kernel_bytes.py $(kt $OUT/bt) $(cc $OUT/btf) $(cc $OUT/btw) top=30; } > $OUT/${R}_boot_kernel_bytes.txt
@@ -101,4 +101,8 @@ python tools/legs/profile_backend.py --out $OUT/${R}_profiled_SEAL_MI355X.json >
 for f in ntt_hbm_traffic ntt_valu step_kernels per_op_budget_rotate_hop per_op_budget_cfg3; do [ -s $OUT/${R}_$f.json ] && cp $OUT/${R}_$f.json $ROOT/profiles/; done
 # (round 6) stdout's last line = the compact line the driver parses (<= 4 KB); the full record -- every leg, with --full the A/B legs too -- is its own file
 python bench.py --full --out $OUT/${R}_bench_full.json > $OUT/${R}_bench_line.json 2> $OUT/bench.err
+# F. the default run exactly as the driver starts it (timed), and the perf guard's figures by the guard's own code
+S0=$(date +%s); python bench.py --gpus 1 --steps 20 --warmup 5 --out $OUT/${R}_bench_default_full.json > $OUT/${R}_bench_default_line.json 2> $OUT/bench_default.err
+echo "default bench.py run: $(( $(date +%s) - S0 )) s" > $OUT/${R}_bench_default_seconds.txt
+DACAPO_AMD_HOOKS= python tests/test_gpu_perf_guard.py --record $OUT/perf_guard.json $R > $OUT/perf_guard.log 2>&1
 tail -c 2500 $OUT/${R}_bench_line.json
