@@ -194,6 +194,67 @@ def test_lazy_sums_at_config4_geometry_match_the_oracle_vm(tmp_path, mode):
     hevm.close()
 
 
+def test_double_hoisting_at_config4_geometry_matches_the_oracle_vm(tmp_path):
+    """option hyb_double_hoist at config 4's shape (N = 2^17, digits of 8 under 9 special primes): a convolution's taps -- three rotations, each
+    times its own plaintext, added to an unrotated tap -- at 31 primes (4 digits) and at 12 (2 digits, a partial one): the products are taken in
+    the raised basis on the plaintexts' special-prime limbs (encoded by the plan, hevm_plain_special), one division by P per sum == the oracle VM
+    replaying the plan's groups with Oracle.lazy_mul_plain on the same plaintext limbs"""
+    KS, ALPHA = 9, 8
+    K4 = 31 + KS
+    from dacapo_amd import hevm_asm as ha
+    from dacapo_amd import lowlevel as ll
+    from dacapo_amd import runner
+
+    _threads()
+    slots = 1 << (LOGN - 1)
+    rng = np.random.default_rng(29)
+    b = ha.Builder(slots=slots, init_level=31, policy="lazy", boot_level=31, shadow=True)
+    x, y = b.input(rng.uniform(-1, 1, slots)), b.input(rng.uniform(-1, 1, slots))
+    taps = (16, 32, 48)                                                # 48 gets a direct key
+
+    def conv(u, v):
+        out = b.mul_plain(u, rng.uniform(-1, 1, slots))
+        for k, src in zip(taps, (u, v, u)):
+            out = b.add(out, b.mul_plain(b.rotate(src, k), rng.uniform(-1, 1, slots)))
+        return out
+
+    top = conv(x, y)
+    low = conv(b.modswitch(x, 19), b.modswitch(y, 19))
+    ts = [b.mul_plain(x, [0.01 * (i + 1)]) for i in range(8)]          # (no rotation result is a register's final value: see the test above)
+    pad = ts[0]
+    for t in ts[1:]:
+        pad = b.add(pad, t)
+    b.output(b.finish(top))
+    b.output(b.finish(low))
+    b.output(b.finish(pad))
+    cst, hv, _ = b.assemble()
+    hevm = runner.HEVM(seed=5, logN=LOGN, num_primes=K4, ks_special=KS, ks_alpha=ALPHA, vm_options={"plan": 1, "hyb_lazy_sum": 1, "hyb_double_hoist": 1})
+    hevm.addRotationKeys([48])
+    o = Oracle(LOGN, K4)
+    o.set_hybrid(KS, ALPHA)
+    _import_keys(o, hevm, ll, elts=sorted({o.elt_from_step(s) for s in taps}), relin=False)
+    hevm.load_mem(cst, hv)
+    ovm = _mirror_vm(hevm, ll, o, cst, hv, tmp_path)
+    assert len(ovm.plains_special) == 6                                # the six taps' plaintexts, nothing else
+    for i, a in enumerate(b.args):
+        hevm.setInput(i, a.plain)
+        ovm.ciphers[i] = _get_ct(hevm, ll, i)
+    hevm.run()
+    groups = hevm.lazy_groups()
+    assert [len(g) for g in groups] == [3, 3], groups
+    ovm.set_lazy_groups(groups)
+    ovm.run()
+    for i in range(2):
+        r = ovm.prog.res_dst[i]
+        got, want = _get_ct(hevm, ll, r), ovm.ciphers[r]
+        assert got.ell == want.ell and got.scale == want.scale
+        assert (got.data == want.data).all(), i
+    out = hevm.getOutput()
+    for i in range(2):
+        assert np.abs(out[i] - b.expected()[i]).max() < 5e-4
+    hevm.close()
+
+
 def test_nt16_prefix_bit_exact_at_n17_on_grouped_digit_keys(tmp_path):
     """tests/test_gpu_config4.py::test_nt16_prefix_bit_exact_at_n17 with ks_special = 8, ks_alpha = 7: the stem convolution of the nt = 2^16
     trace as config 4 runs it (the .b14 lowering: 27 rotations at 14 primes as NAF hops of the default Galois keys, 25 ct x pt, 2 rescales) through the grouped-digit sequence, rotations of one

@@ -52,6 +52,35 @@ def bench_row(r):
     return f"| `{r}_bench.json` | {txt} | `python bench.py` |"
 
 
+def bench_row6(r):
+    d = J(f"{r}_bench_full.json")
+    if not d:
+        return f"| `{r}_bench_full.json` | (missing) | `python bench.py --full` |"
+    roof, c4, per = d["roofline"], d.get("config4_resnet20_nt65536_N131072") or {}, d["per_op_13_primes"]
+    traffic = roof.get("traffic")
+    line = (P / f"{r}_bench_default_line.json").read_text().strip().splitlines()[-1] if (P / f"{r}_bench_default_line.json").exists() else ""
+    secs = (P / f"{r}_bench_default_seconds.txt").read_text().strip() if (P / f"{r}_bench_default_seconds.txt").exists() else ""
+    lz, dh = c4.get("lazy_sums") or {}, c4.get("lazy_sums_double_hoist") or {}
+    txt = (f"the full record of `python bench.py --full`: headline {d['ms_per_step']:.1f} ms / {d['value'] / 1e6:.2f} M NTT/s, roofline leg {roof['launch']['avg_us']:.0f} µs = {roof['frac']:.3f} "
+           f"(two-launch transform on the same buffer: {roof['two_launch_transform']['avg_us']:.0f} µs)"
+           + (f", `roofline.traffic` {traffic / 1e9:.2f} GB = {traffic / roof['launch']['algorithmic_bytes']:.2f}× algorithmic" if traffic else ", `roofline.traffic` null (counter file of another build)")
+           + f", config 4 with default options {c4.get('run_s')} s / rms {c4.get('rms_vs_torch', 0):.1e}, with lazy sums {lz.get('run_s')} s, with lazy sums + double hoisting {dh.get('run_s')} s"
+           f" ({(dh.get('lazy_sums') or {}).get('rotations')} rotations in {(dh.get('lazy_sums') or {}).get('groups')} groups), cfg3 {d['cfg3_mul_relin']['us']:.0f} µs"
+           + (f" ({d['cfg3_mul_relin']['grouped_digit_keys']['us']:.0f} µs under grouped-digit keys)" if d['cfg3_mul_relin'].get('grouped_digit_keys') else "")
+           + f", per op at 13 primes {per['rotate_hop']['us']:.0f} / {per['mulcc_relin']['us']:.0f} / {per['rescale']['us']:.0f} µs, CPU baseline {d['cpu_baseline']['value']:.0f} NTT/s on 1 thread")
+    kt = d.get("ks_traffic") or {}
+    if kt:
+        txt += "; measured HBM bytes ÷ SURVEY 8(d) bytes: " + ", ".join(f"{k} {v['traffic_over_algorithmic']}" for k, v in kt.items())
+    if c4.get("key_sets"):
+        ks = c4["key_sets"]
+        txt += "; key sets (default options) " + ", ".join(f"{k}: {v.get('run_s')} s / {v.get('rotation_key_bytes', 0) / 1e9:.0f} GB" for k, v in ks.items() if isinstance(v, dict))
+    row = f"| `{r}_bench_full.json` | {txt} | `python bench.py --full --out …` |"
+    if line:
+        row += (f"\n| `{r}_bench_default_line.json`, `{r}_bench_default_full.json` | the DEFAULT run as the driver starts it (`--gpus 1 --steps 20 --warmup 5`): last stdout line = {len(line)} bytes "
+                f"(limit 4 096), {secs}; `value` {json.loads(line)['value'] / 1e6:.3f} M NTT/s, `ms_per_step` {json.loads(line)['ms_per_step']} | `python bench.py --gpus 1 --steps 20 --warmup 5` |")
+    return row
+
+
 def traffic_row(r):
     d = J(f"{r}_ntt_hbm_traffic.json")
     if not d:
@@ -185,7 +214,23 @@ def hop_levels(name, labels=("`hyb_fuse` = 2", "`hyb_fuse` = 1", "`hyb_fuse` = 0
 
 
 print("# profiles/ — rocprofv3 evidence (MI355X, ROCm 7.2)\n")
-print("Generated by `python tools/profiles_readme.py > profiles/README.md`: every figure in the round-3, round-4 and round-5 tables is read from the file on its row.\n")
+print("Generated by `python tools/profiles_readme.py > profiles/README.md`: every figure in the round-3 ... round-6 tables is read from the file on its row.\n")
+print("## Round 6 (everything `r06_*`; one `gpurun` call of `tools/collect_profiles.sh r06` on the committed build -- the JSON files that `bench.py` reads carry "
+      "the library's sha256)\n")
+print("| file | what (figures read from the file) | command |\n|---|---|---|")
+rows = [bench_row6("r06"), traffic_row("r06"), step_row("r06"), valu_row("r06"),
+        f"| `r06_per_op_kernel_bytes.txt`, `r06_per_op_budget_*.json` | the single ops at 13 primes and config 3 kernel by kernel (duration, measured HBM bytes, VALU wave-instructions, three floors per launch): "
+        f"{budget_head('r06_per_op_kernel_bytes.txt')} | `tools/collect_per_op_budget.sh r06` |",
+        f"| `r06_run_budget_headline.txt` / `.json`, `r06_run_budget_b13.txt` / `.json` | one `run()` kernel by kernel with the same floors: {budget_head('r06_run_budget_headline.txt')} /// {budget_head('r06_run_budget_b13.txt')} | `tools/collect_run_budget.sh r06 headline` / `b13` |",
+        "| `r06_cluster_barrier.txt` | XCD-local / cross-XCD / device-wide barrier costs beside a dependent launch chain, with what they mean for fusing the headline's launch-floor-sized chains (negative) | `tools/experiments/cluster_barrier_bench.hip` |",
+        "| `r06_headline_step_profile.txt` | the headline plan step by step (kind, level, batch bucket: steps, total and mean time with a synchronise after every step), the plan's edges by kind, the dataflow graph's width | `DACAPO_HEVM_OPTIONS=plan_graph=0,step_profile=1,trace=1 python tools/legs/headline_only.py 2` |",
+        "| `r06_experiments.txt` | what was measured on the way: the barriers, opcode 10's inverse phase folded into the re-encoding kernel (no gain), table indirection (no cost), double hoisting at config 4 | — |",
+        f"| `r06_config4_kernel_stats.csv`, `r06_config4_under_profiler.txt` | BASELINE config 4 (default options) under the kernel trace: {stats('r06_config4_kernel_stats.csv')} | `rocprofv3 --kernel-trace --stats -- python3 tools/legs/resnet_real_boot.py 1 resnet20_nt16 17 1 b14 9 8` |",
+        f"| `r06_ntt_full_check.txt` | single-crossing kernel / two-launch tiles, µs, by limb count: {check_lines('r06_ntt_full_check.txt')} | `tools/legs/ntt_full_check.py <limbs> 20` |",
+        f"| `r06_kernel_stats.csv`, `r06_by_kernel_and_grid.txt`, `r06_timeline.txt`, `r06_top_kernels.json`, `r06_roofline_leg_launches.txt` | the bench command under the kernel trace: {first_lines('r06_timeline.txt', 'last run', 1)} | `rocprofv3 --kernel-trace --stats … -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-config4` |",
+        "| `r06_hybrid_ks_kernels.txt`, `r06_boot_kernel_bytes.txt`, `r06_per_op.json`, `r06_per_op_kernel_stats.csv`, `r06_lowering_sweep.txt`, `r06_per_op_sweep.txt`, `r06_chain_latency.txt`, `r06_profiled_SEAL_MI355X.json` | as in round 5 on this build | see round 5's rows |"]
+print("\n".join(r for r in rows if r))
+print()
 print("## Round 5 (everything `r05_*`; one `gpurun` call of `tools/collect_profiles.sh r05` on the committed build -- the JSON files that `bench.py` reads carry "
       "the library's sha256)\n")
 print("| file | what (figures read from the file) | command |\n|---|---|---|")
