@@ -439,16 +439,8 @@ __device__ __forceinline__ void full_limb(u64 *__restrict__ d, const u64 *__rest
         full_exchange<IN_LOOP>(y, x, lds, tid);                // regs = b, thread = (a = f, c)
         full_tr_sync();
         full_fwd_pass_b_p(y, f, tw2, M);
-#if defined(DC_FULL_FWD_C_PIPELINED)
-        FullTw tc;
-        const u32 hcf = (f << 5) | (u32)lo;
-        full_tw_small<10>(tc, hcf, tw);                        // (requested before the transpose: they travel under it)
-        full_tr(y, lds, tid);
-        full_pass_bc<10, false>(y, tc, hcf, tw, tw[1], M);
-#else
         full_tr(y, lds, tid);                                  // regs = c, lane bits 0..4 = b
         full_fwd_pass_simple<10>(y, (f << 5) | (u32)lo, tw, M);
-#endif
         full_tr(y, lds, tid);                                  // regs = b, lane bits 0..4 = c
 #pragma unroll
         for (int j = 0; j < 32; j++) d[(int)f * 1024 + j * 32 + lo] = canon(y[j], M);
